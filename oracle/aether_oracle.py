@@ -1,0 +1,205 @@
+"""CPU oracle for the Aether state2state step.  TEST INFRASTRUCTURE ONLY.
+
+This is a restatement (not a copy) of the reference algorithm for the hot path
+named by BASELINE.json, written as plain functions over a ``state_dict``.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it; the product path (``aether_amd``) never does.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every stage of
+this file against ``tests/golden/*.npz``, which ``oracle/make_golden.py``
+produced by importing and running the reference itself in the build container.
+
+Reference lines followed, stage by stage (paths relative to the reference root):
+
+* field net ............ nn/state2state/aether.py:108-134
+* node frames .......... nn/utils/geometry.py:7-73, nn/state2state/aether.py:33-50
+* edge features ........ nn/state2state/aether.py:52-100, nn/utils/geometry.py:76-105
+* GNN layer x4 ......... nn/state2state/locs/locs.py:197-243 (scatter-mean :236-238)
+* out MLP, globalise ... nn/state2state/locs/locs.py:160-168,193; nn/utils/local_to_global.py:7-13
+* glue / residual ...... nn/state2state/aether.py:169-186
+
+The functions are dtype-generic (fp32 for parity and the CPU baseline, fp64 for
+the noise-floor figure) and differentiable, so ``torch.autograd`` provides the
+gradient oracle for the backward kernels.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+TWO_PI = 2.0 * math.pi
+EPS = 1e-7
+
+
+def _linear(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+# ---------------------------------------------------------------- field net
+def field_net(sd, x, vel, charges):
+    """aether.py:108-134.  ``charges`` [Nn,1] float in {-1,0,+1}."""
+    idx = (charges + 1).long().squeeze(1)                       # :122-124 truncation
+    emb = sd["field_net.class_embedding.weight"][idx]
+    z = torch.cat([x, vel, emb], dim=-1)
+    z = F.silu(_linear(sd, "field_net.net.0", z))
+    z = F.silu(_linear(sd, "field_net.net.2", z))
+    return _linear(sd, "field_net.net.4", z)
+
+
+# ------------------------------------------------------------------ geometry
+def spherical_angles(v, symmetric_theta):
+    """geometry.py:37-66 -> (rho, theta[, phi]) each [...,1]."""
+    D = v.shape[-1]
+    rho = torch.linalg.vector_norm(v, ord=2, dim=-1, keepdim=True)
+    theta = torch.atan2(v[..., 1:2], v[..., 0:1])
+    if not symmetric_theta:
+        theta = theta + (theta < 0).to(theta.dtype) * TWO_PI      # :51-53
+    if D == 2:
+        return rho, theta, None
+    phi = torch.acos(torch.clamp(v[..., 2:3] / (rho + EPS), min=-1.0, max=1.0))  # :63-64
+    return rho, theta, phi
+
+
+def frame_from_velocity(vel):
+    """geometry.py:7-34,69-73 -> R [...,D,D] (un-transposed)."""
+    D = vel.shape[-1]
+    _, theta, phi = spherical_angles(vel, symmetric_theta=False)
+    c, s = torch.cos(theta), torch.sin(theta)
+    if D == 2:
+        return torch.stack([torch.cat([c, -s], -1), torch.cat([s, c], -1)], -2)
+    cp, sp = torch.cos(phi), torch.sin(phi)
+    return torch.stack(
+        [
+            torch.cat([cp * c, -s, sp * c], -1),
+            torch.cat([cp * s, c, sp * s], -1),
+            torch.cat([-sp, torch.zeros_like(c), cp], -1),
+        ],
+        -2,
+    )
+
+
+def apply_rot(R, x):
+    """geometry.py:104-105: einsum('...ij,...j->...i')."""
+    return torch.einsum("...ij,...j->...i", R, x)
+
+
+def euler_from_matrix(M, D):
+    """geometry.py:76-101, normalised by pi (the default the localizer uses)."""
+    if D == 2:
+        e = torch.atan2(M[..., 1, 0:1], M[..., 0, 0:1])
+    else:
+        e = torch.stack(
+            [
+                torch.atan2(M[..., 1, 0], M[..., 0, 0]),
+                torch.asin(-M[..., 2, 0]),                        # no clamp (:93)
+                torch.atan2(M[..., 2, 1], M[..., 2, 2]),
+            ],
+            -1,
+        )
+    return e / math.pi
+
+
+def canonical_nodes(ext, D):
+    """aether.py:33-50: ext=[p|v|f] -> rel_feat [Nn,3D], R [Nn,D,D]."""
+    vel = ext[..., D:2 * D]
+    f = ext[..., 2 * D:3 * D]
+    R = frame_from_velocity(vel)
+    Rt = R.transpose(-1, -2)
+    cv = apply_rot(Rt, vel)
+    cf = apply_rot(Rt, f)
+    return torch.cat([torch.zeros_like(cv), cv, cf], dim=-1), R
+
+
+def edge_features(ext, send, recv, D):
+    """aether.py:52-92: 4D + D(D-1)/2 local-frame columns per edge j->i."""
+    xj, xi = ext[send], ext[recv]
+    Ri = frame_from_velocity(xi[..., D:2 * D])
+    Rit = Ri.transpose(-1, -2)
+    rel = xj[..., :D] - xi[..., :D]
+    rrel = apply_rot(Rit, rel)
+    Rj = frame_from_velocity(xj[..., D:2 * D])
+    euler = euler_from_matrix(Rit @ Rj, D)
+    dist = torch.linalg.vector_norm(rel, ord=2, dim=-1, keepdim=True)
+    _, th, ph = spherical_angles(rrel, symmetric_theta=True)
+    sph = th if D == 2 else torch.cat([th, ph], -1)
+    rv = apply_rot(Rit, xj[..., D:2 * D])
+    rf = apply_rot(Rit, xj[..., 2 * D:3 * D])
+    return torch.cat([rrel, euler, dist, sph, rv, rf], -1)
+
+
+# ----------------------------------------------------------------------- GNN
+def scatter_mean(e, recv, n_rows):
+    """pytorch-scatter ``reduce='mean'`` as called at locs.py:236-238:
+    sum over edges with that receiver / in-degree (clamped to >=1); rows with no
+    in-edge are 0.  (The reference infers n_rows = max(recv)+1; the caller
+    passes the node count, which is equal whenever the reference itself runs.)
+    Summed sequentially in edge order via index_add_ on one thread."""
+    out = torch.zeros(n_rows, e.shape[1], dtype=e.dtype, device=e.device)
+    out = out.index_add(0, recv, e)
+    deg = torch.zeros(n_rows, dtype=e.dtype, device=e.device)
+    deg = deg.index_add(0, recv, torch.ones_like(recv, dtype=e.dtype))
+    return out / deg.clamp(min=1).unsqueeze(1)
+
+
+def gnn_layer(sd, prefix, x, e_in, send, recv, first):
+    """locs.py:227-243."""
+    if not first:
+        e_in = torch.cat([x[send], x[recv], e_in], dim=-1)        # :233
+    m = F.silu(_linear(sd, prefix + ".message_fn.0", e_in))
+    m = F.silu(_linear(sd, prefix + ".message_fn.2", m))
+    aggr = scatter_mean(m, recv, x.shape[0])
+    x = (_linear(sd, prefix + ".res", x) if first else x) + aggr   # :214-218,240
+    u = F.silu(_linear(sd, prefix + ".update_fn.0", x))
+    x = x + _linear(sd, prefix + ".update_fn.2", u)                # :241
+    return x, m
+
+
+def out_mlp(sd, x):
+    """locs.py:160-168 with Dropout p=0 (runner: main.py:143)."""
+    x = F.silu(_linear(sd, "gnn.out_mlp.0", x))
+    x = F.silu(_linear(sd, "gnn.out_mlp.3", x))
+    return _linear(sd, "gnn.out_mlp.6", x)
+
+
+# --------------------------------------------------------------------- whole
+def aether_forward(sd, x, vel, edges, edge_attr_orig, charges, return_all=False):
+    """aether.py:169-186.  ``sd`` maps reference state_dict keys to tensors."""
+    D = x.shape[-1]
+    send, recv = edges
+    inputs = torch.cat([x, vel], dim=-1)
+    field = field_net(sd, x, vel, charges)
+    ext = torch.cat([inputs, field], dim=-1)
+    rel_feat, R = canonical_nodes(ext, D)
+    ea = edge_features(ext, send, recv, D)
+    ea_local = torch.cat([ea, rel_feat[recv]], -1)                  # aether.py:99
+    ea_full = torch.cat([ea_local, edge_attr_orig], -1)             # aether.py:177
+    res = {"field": field, "rel_feat": rel_feat, "R": R, "edge_attr_local": ea_local}
+    h, e = rel_feat, ea_full
+    for k in range(1, 5):
+        h, e = gnn_layer(sd, f"gnn.layer_{k}", h, e, send, recv, first=(k == 1))
+        res[f"x{k}"], res[f"e{k}"] = h, e
+    pred = out_mlp(sd, h)
+    res["pred_local"] = pred
+    pred = apply_rot(R, pred)                                       # local_to_global.py:12-13
+    res["pred_global"] = pred
+    out = x + pred
+    res["out"] = out
+    return res if return_all else out
+
+
+def rollout(sd, x, vel, edges, charges, steps, dt=1.0):
+    """SURVEY.md 8(d) metric 2 for the state2state module:
+    x_{t+1} = Aether(x_t, v_t); v_{t+1} = (x_{t+1} - x_t) / dt."""
+    rows, cols = edges
+    qprod = charges[rows] * charges[cols]
+    traj = []
+    for _ in range(steps):
+        dist = torch.sqrt(torch.sum((x[rows] - x[cols]) ** 2, 1)).unsqueeze(1)
+        ea = torch.cat([qprod, dist], 1)
+        xn = aether_forward(sd, x, vel, edges, ea, charges)
+        vel = (xn - x) / dt
+        x = xn
+        traj.append(x)
+    return torch.stack(traj)

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_case(name):
+    """Load one golden fixture -> (inputs dict of torch tensors, ref dict, meta)."""
+    d = np.load(os.path.join(GOLDEN, name))
+    inp = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("in.")}
+    if "send" in inp:
+        inp["edges"] = [inp.pop("send"), inp.pop("recv")]
+    ref = {k[4:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("ref.")}
+    ref64 = {k[6:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("ref64.")}
+    B, N, D, seed = (int(v) for v in d["meta"])
+    return inp, ref, ref64, dict(B=B, N=N, D=D, seed=seed)
+
+
+def load_state_dict(D):
+    d = np.load(os.path.join(GOLDEN, f"state_dict_D{D}.npz"))
+    return {k: torch.from_numpy(d[k]) for k in d.files}
+
+
+def scale_rel_err(a, b):
+    """SURVEY.md 8(d) tolerance definition: max|a-b| / max|b|."""
+    a, b = a.double(), b.double()
+    denom = b.abs().max().clamp(min=1e-30)
+    return float((a - b).abs().max() / denom)
+
+
+CASES = ["B1N5", "B3N5", "B2N20", "B2N2", "sparse"]
+GRAD_CASES = ["B3N5", "B2N20", "sparse"]
