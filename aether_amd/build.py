@@ -1,0 +1,45 @@
+"""Build libaether_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "aether_hip.hip")
+LIB = os.path.join(HERE, "libaether_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+         "-Wno-unused-result"]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; the HIP library cannot be built")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [SRC, os.path.join(os.path.dirname(HERE), "include", "aether_hip.h")]
+    deps += [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+
+
+def build_library(force=False, verbose=True, extra_flags=()):
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path(), *FLAGS, *extra_flags, SRC, "-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,115 @@
+/*
+ * aether_hip.h -- C ABI of libaether_hip.so: the MI355X (gfx950) implementation of
+ * the Aether state2state step.
+ *
+ * The reference has no FFI / plugin registry: the seam of this path is the Python
+ * nn.Module surface.  The entry points below are what the
+ * build's own nn.Module (aether_amd/nn/state2state/aether.py) binds through ctypes;
+ * each one names the reference interface it replaces.  Plain pointers and sizes only:
+ * every pointer is a DEVICE pointer (HIP) unless it says "host"; `stream` is a
+ * hipStream_t passed as void*.  No call allocates, frees or synchronises except
+ * aether_graph_build (which synchronises `stream` once to report bad indices).
+ * All functions return 0 on success, a negative AETHER_E* code on error;
+ * aether_last_error() returns a host string for the calling thread's last error.
+ */
+#ifndef AETHER_HIP_H
+#define AETHER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AETHER_OK 0
+#define AETHER_EINVAL (-1)   /* bad argument (dims, null pointer, size)       */
+#define AETHER_EINDEX (-2)   /* edge index outside [0, n_nodes)               */
+#define AETHER_EHIP (-3)     /* a HIP runtime call or kernel launch failed    */
+#define AETHER_ESPACE (-4)   /* workspace too small                           */
+
+#define AETHER_HIDDEN 64     /* hidden width the kernels are built for (experiments/lorentz/main.py:42-43) */
+
+/*
+ * Parameter pointers, one per tensor of the reference state_dict
+ * (nn/state2state/aether.py:143-160, nn/state2state/locs/locs.py:142-225; key list
+ * in SURVEY.md 8b).  nn.Linear layout: weight[out][in] row-major, bias[out].
+ * The same struct, pointing at gradient buffers, receives the parameter gradients.
+ */
+typedef struct AetherParams {
+    /* field_net.* -- aether.py:108-121 */
+    float* field_w0; float* field_b0;       /* [32][2D+16], [32] */
+    float* field_w2; float* field_b2;       /* [32][32],    [32] */
+    float* field_w4; float* field_b4;       /* [D][32],     [D]  */
+    float* field_emb;                       /* [3][16]           */
+    /* gnn.layer_1.* -- locs.py:170-178 (only_edge_attr=True) */
+    float* l1_msg_w0; float* l1_msg_b0;     /* [64][7D+O+2], [64] */
+    float* l1_msg_w2; float* l1_msg_b2;     /* [64][64],     [64] */
+    float* l1_res_w;  float* l1_res_b;      /* [64][3D],     [64] */
+    float* l1_upd_w0; float* l1_upd_b0;     /* [128][64],    [128] */
+    float* l1_upd_w2; float* l1_upd_b2;     /* [64][128],    [64] */
+    /* gnn.layer_{2,3,4}.* -- locs.py:179-181 */
+    float* ln_msg_w0[3]; float* ln_msg_b0[3];   /* [64][192], [64] */
+    float* ln_msg_w2[3]; float* ln_msg_b2[3];   /* [64][64],  [64] */
+    float* ln_upd_w0[3]; float* ln_upd_b0[3];   /* [128][64], [128] */
+    float* ln_upd_w2[3]; float* ln_upd_b2[3];   /* [64][128], [64] */
+    /* gnn.out_mlp.{0,3,6} -- locs.py:160-168 */
+    float* out_w0; float* out_b0;           /* [64][64], [64] */
+    float* out_w3; float* out_b3;           /* [64][64], [64] */
+    float* out_w6; float* out_b6;           /* [D][64],  [D]  */
+} AetherParams;
+
+/* Library / build identification (host string, static storage). */
+const char* aether_version(void);
+const char* aether_last_error(void);
+
+/*
+ * Graph preparation: receiver-sorted (CSR) view of an edge index.
+ * Replaces what torch_scatter.scatter does implicitly on every call
+ * (nn/state2state/locs/locs.py:236-238) with a one-time stable sort by receiver, so
+ * that the per-layer mean is a deterministic segmented sum in edge order.
+ *   send, recv : int64[E]   edges[0], edges[1] of Aether.forward (aether.py:169)
+ *   graph      : device buffer of aether_graph_bytes(E, n_nodes) bytes, filled here
+ * Synchronises `stream` once; returns AETHER_EINDEX if any index is out of range.
+ */
+size_t aether_graph_bytes(int64_t n_edges, int64_t n_nodes);
+int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges,
+                       int64_t n_nodes, void* graph, size_t graph_bytes, void* stream);
+/* Debug / test access: copies the sorted-position -> original-edge-id map (int32[E]). */
+int aether_graph_perm(const void* graph, int64_t n_edges, int64_t n_nodes, int32_t* perm_out,
+                      void* stream);
+
+/* Bytes of scratch the forward (and, with keep_for_backward, the backward) needs. */
+size_t aether_workspace_bytes(int64_t n_nodes, int64_t n_edges, int num_dims,
+                              int keep_for_backward);
+
+/*
+ * Forward step: replaces Aether.forward (nn/state2state/aether.py:169-186):
+ * field query -> local frames -> edge features -> 4 x (edge MLP, mean by receiver,
+ * node update) -> out MLP -> rotate back -> x + pred.
+ *   x, vel          : float[n_nodes][D]      positions, velocities
+ *   charges         : float[n_nodes]         in {-1, 0, +1}  (aether.py:122-124)
+ *   edge_attr_orig  : float[E][2]            [q_i q_j, |x_i - x_j|], ORIGINAL edge order
+ *   graph           : from aether_graph_build for this (send, recv)
+ *   out             : float[n_nodes][D]
+ * `h` of the reference signature is unused by the reference and has no counterpart.
+ * Stream-ordered, re-entrant per (workspace, out) pair.
+ */
+int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
+                   const float* x, const float* vel, const float* charges,
+                   const float* edge_attr_orig, const void* graph, void* workspace,
+                   size_t workspace_bytes, float* out, void* stream);
+
+/*
+ * Test hook: copy one named intermediate of the last aether_forward on `workspace`
+ * into `dst` (device).  Names: "field"[n][D] "rel_feat"[n][3D] "R"[n][D*D] "x1".."x4"[n][64]
+ * "e1".."e4"[E][64] (receiver-sorted order; map back with aether_graph_perm).
+ * Returns the number of floats written, or a negative error.
+ */
+int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int64_t n_edges,
+                           const void* workspace, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AETHER_HIP_H */

@@ -1,0 +1,97 @@
+"""CPU-side checks: edge index (bit-exact), state_dict surface, C-ABI symbols."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO, load_state_dict
+from aether_amd import _lib
+from aether_amd.edges import fully_connected_edges, get_edges, prepare_edge_attr
+from aether_amd.nn.state2state.aether import Aether
+
+
+@pytest.mark.parametrize("B,N", [(1, 5), (3, 5), (128, 20), (2, 2), (1, 3)])
+def test_edge_index_bit_exact(B, N):
+    """dataset4newton.py:84-94 -- int64 equality against tensors captured from the reference."""
+    d = np.load(os.path.join(GOLDEN, "edges.npz"))
+    send, recv = get_edges(B, N)
+    assert send.dtype == torch.int64 and recv.dtype == torch.int64
+    assert np.array_equal(send.numpy(), d[f"send_B{B}_N{N}"])
+    assert np.array_equal(recv.numpy(), d[f"recv_B{B}_N{N}"])
+
+
+def test_edge_order_is_where_not_eye():
+    """Same order as torch.where(~torch.eye(N)) (nn/utils/augmented_global_to_local.py:31-32)."""
+    for n in (2, 4, 7):
+        s, r = torch.where(~torch.eye(n, dtype=torch.bool))
+        rows, cols = fully_connected_edges(n)
+        assert rows == s.tolist() and cols == r.tolist()
+        a, b = get_edges(1, n)
+        assert torch.equal(a, s) and torch.equal(b, r)
+
+
+def test_prepare_edge_attr():
+    x = torch.tensor([[0.0, 0.0], [3.0, 4.0], [0.0, 1.0]])
+    edges = get_edges(1, 3)
+    q = torch.tensor([[1.0], [-1.0], [1.0]])
+    ea = prepare_edge_attr(x, edges, q[edges[0]] * q[edges[1]])
+    assert ea.shape == (6, 2)
+    assert torch.allclose(ea[0], torch.tensor([-1.0, 5.0]))
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_state_dict_surface_and_default_init(D):
+    """Keys, shapes, order and (under the runner's seed 1) values equal the reference's."""
+    torch.manual_seed(1)
+    m = Aether(2 * D, 64, 0.0, D, device="cpu")
+    ref = load_state_dict(D)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert len(sd) == 47
+    for k in ref:
+        assert sd[k].shape == ref[k].shape, k
+        assert torch.equal(sd[k], ref[k]), k
+    assert int(m.params) == (131892 if D == 2 else 132822)
+    m2 = Aether(2 * D, 64, 0.0, D, device="cpu")
+    m2.load_state_dict(ref, strict=True)
+
+
+def test_ctor_rejects_unsupported():
+    with pytest.raises(ValueError):
+        Aether(4, 32, 0.0, 2, device="cpu")
+    with pytest.raises(ValueError):
+        Aether(4, 64, 0.1, 2, device="cpu")
+
+
+def test_cpu_tensor_fails_loudly():
+    m = Aether(4, 64, 0.0, 2, device="cpu")
+    e = get_edges(1, 3)
+    with pytest.raises(_lib.AetherHipError):
+        m(torch.zeros(3, 1), torch.zeros(3, 2), e, torch.ones(3, 2), torch.zeros(6, 2), torch.ones(3, 1))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports what include/aether_hip.h declares."""
+    hdr = open(os.path.join(REPO, "include", "aether_hip.h")).read()
+    declared = set(re.findall(r"\b(aether_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.aether_version()
+    # size queries are host-only arithmetic
+    assert lib.aether_workspace_bytes(2560, 48640, 2, 0) > 48640 * 64 * 4 * 4
+    assert lib.aether_workspace_bytes(10, 10, 4, 0) == 0
+
+
+def test_params_struct_layout_matches_header():
+    hdr = open(os.path.join(REPO, "include", "aether_hip.h")).read()
+    body = hdr[hdr.index("typedef struct AetherParams"):hdr.index("} AetherParams;")]
+    names = re.findall(r"float\*\s+([a-z0-9_]+)(?:\[3\])?;", body)
+    assert names == [n for n, _ in _lib.PARAM_FIELDS]
+    n_ptr = sum(3 if "{}" in k else 1 for _, k in _lib.PARAM_FIELDS)
+    assert ctypes.sizeof(_lib.AetherParams) == 8 * n_ptr == 8 * 47
