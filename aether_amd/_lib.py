@@ -63,6 +63,10 @@ SIGNATURES = {
                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "aether_debug_fetch": (C.c_int64, [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "aether_profile_enable": (C.c_int, [C.c_int]),
+    "aether_profile_kernels": (C.c_int, []),
+    "aether_profile_kernel_name": (C.c_char_p, [C.c_int]),
+    "aether_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
 }
 
 _lib = None

@@ -57,6 +57,34 @@ int fail(int code, const char* msg) {
         }                                                                         \
     } while (0)
 
+// ------------------------------------------------------------------ per-kernel HIP-event timing
+// Optional (aether_profile_enable): brackets every launch with a pair of events on the
+// launch stream so bench.py can report the dominant kernel's average duration.
+enum KernelId { K_NODE_PREP = 0, K_EDGE_L1, K_NODE_UPDATE, K_EDGE_LN, K_NODE_LAST, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_node_prep", "k_edge_layer1", "k_node_update",
+                                           "k_edge_layer", "k_node_update_last"};
+struct ProfSlot { hipEvent_t a, b; int id; };
+constexpr int PROF_SLOTS = 8192;
+ProfSlot g_prof[PROF_SLOTS];
+int g_prof_created = 0, g_prof_used = 0;
+bool g_prof_on = false;
+
+struct ProfScope {
+    hipStream_t st; int slot = -1;
+    ProfScope(int id, hipStream_t s) : st(s) {
+        if (!g_prof_on || g_prof_used >= PROF_SLOTS) return;
+        if (g_prof_used >= g_prof_created) {
+            if (hipEventCreate(&g_prof[g_prof_created].a) != hipSuccess ||
+                hipEventCreate(&g_prof[g_prof_created].b) != hipSuccess) return;
+            ++g_prof_created;
+        }
+        slot = g_prof_used++;
+        g_prof[slot].id = id;
+        (void)hipEventRecord(g_prof[slot].a, st);
+    }
+    ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st); }
+};
+
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -571,37 +599,48 @@ int forward_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, c
     const int32_t *perm = gp(G.perm), *send_s = gp(G.send_s), *recv_s = gp(G.recv_s), *rowptr = gp(G.rowptr);
     float* nodeinfo = wp(W.nodeinfo);
 
-    k_node_prep<D><<<dim3((unsigned)((Nn + 255) / 256)), dim3(256), 0, st>>>(P, x, vel, charges, nodeinfo,
-                                                                          wp(W.x[0]), Nn);
+    {
+        ProfScope ps(K_NODE_PREP, st);
+        k_node_prep<D><<<dim3((unsigned)((Nn + 255) / 256)), dim3(256), 0, st>>>(P, x, vel, charges,
+                                                                              nodeinfo, wp(W.x[0]), Nn);
+    }
     const int64_t n_chunks = (E + 255) / 256;
     const int64_t n_tiles = (E + 15) / 16;
     const unsigned node_grid = (unsigned)((Nn + 15) / 16);
     if (E > 0) {
         const size_t lds1 = (size_t)(H * LDF + H * LDW + 2 * H + 256 * LDF) * 4;
         unsigned g1 = (unsigned)(n_chunks < 2048 ? n_chunks : 2048);
+        ProfScope ps(K_EDGE_L1, st);
         k_edge_layer1<D><<<dim3(g1), dim3(256), lds1, st>>>(P, nodeinfo, ea, perm, send_s, recv_s,
                                                            wp(W.e[0]), nullptr, E);
     }
-    k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
+    {
+        ProfScope ps(K_NODE_UPDATE, st);
+        k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
         P, 1, wp(W.x[0]), wp(W.e[0]), rowptr, wp(W.x[1]), wp(W.ps[0]), wp(W.pr[0]), nodeinfo, x, out, Nn);
+    }
     for (int l = 2; l <= 4; ++l) {
         if (E > 0) {
             const size_t lds = (size_t)(2 * H * LDW + H) * 4;
             int64_t wgs = (n_tiles + 3) / 4;
             unsigned g = (unsigned)(wgs < 1024 ? wgs : 1024);
+            ProfScope ps(K_EDGE_LN, st);
             k_edge_layer<<<dim3(g), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2],
                                                          P.ln_msg_b2[l - 2], wp(W.ps[l - 2]),
                                                          wp(W.pr[l - 2]), wp(W.e[l - 2]), send_s, recv_s,
                                                          wp(W.e[l - 1]), E);
         }
-        if (l < 4)
+        if (l < 4) {
+            ProfScope ps(K_NODE_UPDATE, st);
             k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.e[l - 1]), rowptr, wp(W.x[l]), wp(W.ps[l - 1]), wp(W.pr[l - 1]),
                 nodeinfo, x, out, Nn);
-        else
+        } else {
+            ProfScope ps(K_NODE_LAST, st);
             k_node_update<D, true><<<dim3(node_grid), dim3(64), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.e[l - 1]), rowptr, wp(W.x[l]), nullptr, nullptr, nodeinfo, x,
                 out, Nn);
+        }
     }
     HIP_OK(hipGetLastError());
     return AETHER_OK;
@@ -614,6 +653,32 @@ extern "C" {
 
 const char* aether_version(void) { return "aether_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 const char* aether_last_error(void) { return g_err; }
+
+int aether_profile_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return AETHER_OK;
+}
+
+int aether_profile_kernels(void) { return K_COUNT; }
+
+const char* aether_profile_kernel_name(int id) {
+    return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : "";
+}
+
+int aether_profile_read(double* total_ms, int64_t* launches, int n) {
+    if (!total_ms || !launches || n < K_COUNT) return fail(AETHER_EINVAL, "profile_read: need K_COUNT slots");
+    for (int k = 0; k < n; ++k) { total_ms[k] = 0.0; launches[k] = 0; }
+    for (int s = 0; s < g_prof_used; ++s) {
+        HIP_OK(hipEventSynchronize(g_prof[s].b));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, g_prof[s].a, g_prof[s].b));
+        total_ms[g_prof[s].id] += ms;
+        launches[g_prof[s].id] += 1;
+    }
+    g_prof_used = 0;
+    return AETHER_OK;
+}
 
 size_t aether_graph_bytes(int64_t n_edges, int64_t n_nodes) {
     if (n_edges < 0 || n_nodes <= 0) return 0;

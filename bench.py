@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the Aether state2state hot path on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (under torch.distributed.run
+for N > 1, one rank per GPU) prints ONE JSON line on rank 0.
+
+* workload  : BASELINE.json configs[1] -- electrostatic 2-D, N=20 fully connected,
+              batch=128 graphs per GPU (2,560 nodes, 48,640 edges), synthetic inputs
+              (aether_amd/synthetic.py), seed-1 random-init weights.
+* step      : one forward pass of the hot path (Aether.forward) over one resident batch.
+* metric    : edge-messages/s = 4 * E * n_gpus / t_step   (one edge-message =
+              one GNNLayer.message_fn evaluation on one edge; a forward does 4E of them).
+* scaling   : weak -- every rank processes its own 128 graphs; the forward has no exchange
+              step, so there is no data-path collective (graphs are independent).
+* roofline  : dominant kernel k_edge_layer (layers 2-4): ALGORITHMIC flops per launch
+              (reference formulation: E * 2*(192*64 + 64*64) = E * 32,768) / its average launch
+              duration, measured with HIP events on the launch stream in a separate
+              instrumented pass of the same K steps; peak = 157.3 TFLOP/s dense fp32 MFMA.
+* cpu_baseline : the oracle (oracle/aether_oracle.py, PyTorch CPU restatement pinned to the
+              reference) on the same batch on this host's cores, bounded to ~15 s.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOAD = dict(name="electrostatic-2d-N20-B128", B=128, N=20, D=2)
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense
+FLOP_PER_EDGE_LAYER_N = 2 * (192 * 64 + 64 * 64)      # locs.py:206-212 on [x_s|x_r|e] (192 -> 64 -> 64)
+FLOP_PER_EDGE_STEP = {2: 108672, 3: 109824}
+FLOP_PER_NODE_STEP = {2: 151936, 3: 152640}
+
+
+def _dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def _cpu_baseline(sd, inp, budget_s=15.0):
+    """Oracle forward on the host cores; bounded sample of the same workload."""
+    from oracle import aether_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    args = (sd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+    with torch.no_grad():
+        for _ in range(2):
+            O.aether_forward(*args)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            O.aether_forward(*args)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 400:
+                break
+    E = inp["edges"][0].numel()
+    return {
+        "value": 4.0 * E * n / el, "unit": "edge-messages/s", "cores": cores, "kind": "port",
+        "ms_per_step": 1e3 * el / n,
+        "sample": f"{n} forward steps of the same B=128 N=20 D=2 batch in {el:.1f} s, "
+                  f"torch CPU fp32, {cores} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dims", type=int, default=WORKLOAD["D"], help="2 (headline) or 3 (cfg3)")
+    ap.add_argument("--batch", type=int, default=WORKLOAD["B"])
+    ap.add_argument("--nodes", type=int, default=WORKLOAD["N"])
+    args = ap.parse_args()
+
+    rank, world, local = _dist_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    from aether_amd import _lib
+    from aether_amd.nn.state2state.aether import Aether
+    from aether_amd.synthetic import make_batch
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, N, D = args.batch, args.nodes, args.dims
+    torch.manual_seed(1)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = Aether(2 * D, 64, 0.0, D, device=dev)
+    host = make_batch(B, N, D, seed=rank)              # every rank its own graphs (weak scaling)
+    inp = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in host.items()}
+    inp["edges"] = [e.to(dev) for e in host["edges"]]
+    E = inp["edges"][0].numel()
+    Nn = B * N
+    call = lambda: model(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+
+    with torch.no_grad():
+        out = call()                                   # builds the graph view + workspace
+        torch.cuda.synchronize()
+        use_graph = not args.no_graph
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    call()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = call()
+            step = g.replay
+        else:
+            step = call
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+
+        # ---- instrumented pass: per-kernel HIP events on the launch stream (eager) --------
+        roof = None
+        kernels = {}
+        if rank == 0:
+            lib = _lib.load()
+            nk = lib.aether_profile_kernels()
+            lib.aether_profile_enable(1)
+            ksteps = min(args.steps, 8192 // 9)
+            for _ in range(ksteps):
+                call()
+            torch.cuda.synchronize()
+            ms = (C.c_double * nk)()
+            cnt = (C.c_int64 * nk)()
+            _lib.check(lib.aether_profile_read(ms, cnt, nk), "aether_profile_read")
+            lib.aether_profile_enable(0)
+            for k in range(nk):
+                if cnt[k]:
+                    kernels[lib.aether_profile_kernel_name(k).decode()] = {
+                        "launches_per_step": cnt[k] / ksteps, "avg_us": 1e3 * ms[k] / cnt[k]}
+            dom = kernels.get("k_edge_layer")
+            if dom:
+                flops = float(E) * FLOP_PER_EDGE_LAYER_N
+                achieved = flops / (dom["avg_us"] * 1e-6) / 1e12
+                traffic = None
+                tpath = os.path.join(REPO, "profiles", "traffic.json")
+                if os.path.exists(tpath):
+                    try:
+                        tj = json.load(open(tpath))
+                        if tj.get("workload") == WORKLOAD["name"] and (B, N, D) == (128, 20, 2):
+                            traffic = tj.get("k_edge_layer_hbm_bytes_per_launch")
+                    except Exception:
+                        traffic = None
+                roof = {"bound": "mfma", "kernel": "k_edge_layer", "achieved": achieved,
+                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        "avg_launch_us": dom["avg_us"], "algorithmic_flop_per_launch": flops,
+                        "executed_flop_per_launch": float(E) * 2 * (64 * 64 * 2)}
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        value = 4.0 * E * world / (dt / args.steps)
+        step_flops = E * FLOP_PER_EDGE_STEP[D] + Nn * FLOP_PER_NODE_STEP[D]
+        line = {
+            "metric": "edge-messages/sec (forward, electrostatic N=20 batch=128 per GPU)",
+            "value": value, "unit": "edge-messages/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD["name"] if (B, N, D) == (128, 20, 2) else f"D{D}-N{N}-B{B}",
+                       "num_dims": D, "nodes_per_graph": N, "graphs_per_gpu": B, "edges_per_gpu": E,
+                       "hidden": 64, "launch": "hipgraph" if use_graph else "eager",
+                       "parallelism": f"graphs sharded over {world} rank(s), no forward collective"},
+            "edges_per_s": E * world / (dt / args.steps),
+            "step_algorithmic_tflops": step_flops * world / (dt / args.steps) / 1e12,
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            line["cpu_baseline"] = _cpu_baseline(sd, host)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

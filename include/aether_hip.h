@@ -102,12 +102,24 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
 
 /*
  * Test hook: copy one named intermediate of the last aether_forward on `workspace`
- * into `dst` (device).  Names: "field"[n][D] "rel_feat"[n][3D] "R"[n][D*D] "x1".."x4"[n][64]
+ * into `dst` (device).  Names: "field"[n][D] "canon"[n][2D] (= rel_feat[:, D:]) "R"[n][D*D] "x0".."x4"[n][64]
  * "e1".."e4"[E][64] (receiver-sorted order; map back with aether_graph_perm).
  * Returns the number of floats written, or a negative error.
  */
 int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int64_t n_edges,
                            const void* workspace, float* dst, void* stream);
+
+/*
+ * Per-kernel timing for bench.py's roofline line: when enabled, every launch made by
+ * aether_forward is bracketed by a pair of HIP events on the launch stream.
+ * aether_profile_read synchronises those events, adds up elapsed milliseconds and launch
+ * counts per kernel id (0 .. aether_profile_kernels()-1) and clears the record.
+ * Not thread-safe; measurement only (the event records perturb back-to-back launches).
+ */
+int aether_profile_enable(int on);
+int aether_profile_kernels(void);
+const char* aether_profile_kernel_name(int id);
+int aether_profile_read(double* total_ms, int64_t* launches, int n);
 
 #ifdef __cplusplus
 }
