@@ -49,18 +49,28 @@ def params_struct(tensors: dict) -> AetherParams:
     return p
 
 
+class AetherGraphInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("n_groups", C.c_int32),
+                ("max_group_nodes", C.c_int32), ("max_group_edges", C.c_int32), ("reserved", C.c_int32)]
+
+
+FLAG_KEEP_INTERMEDIATES = 1
+FLAG_FORCE_STREAMED = 2
+FLAG_FORCE_FUSED = 4
+
 # name -> (restype, argtypes); every symbol include/aether_hip.h declares
 SIGNATURES = {
     "aether_version": (C.c_char_p, []),
     "aether_last_error": (C.c_char_p, []),
     "aether_graph_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "aether_graph_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
-                                     C.c_size_t, C.c_void_p]),
+                                     C.c_size_t, C.POINTER(AetherGraphInfo), C.c_void_p]),
     "aether_graph_perm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "aether_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "aether_forward": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int64, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+                                 C.POINTER(AetherGraphInfo), C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.c_int, C.c_void_p]),
     "aether_debug_fetch": (C.c_int64, [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "aether_profile_enable": (C.c_int, [C.c_int]),

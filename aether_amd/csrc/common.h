@@ -1,0 +1,164 @@
+// common.h -- device helpers shared by the streamed and the fused kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/aether_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H = AETHER_HIDDEN;     // 64
+constexpr int LDW = H + 4;           // padded LDS row (floats) for K = 64 weights / activations
+constexpr int FPAD = 32;             // layer-1 feature count padded to two 16-wide k blocks
+constexpr int LDF = FPAD + 4;        // padded LDS row for K = 32
+constexpr float PI_F = 3.14159274101257324f;       // float(np.pi)
+constexpr float TWO_PI_F = 6.28318548202514648f;   // float(2*np.pi)
+constexpr float EPS_F = 1e-7f;                     // nn/utils/geometry.py:62
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float silu(float x) {      // torch.nn.SiLU: x * sigmoid(x)
+    return x / (1.0f + expf(-x));
+}
+__device__ __forceinline__ f32x4 silu4(f32x4 v) {
+    f32x4 o;
+    o[0] = silu(v[0]); o[1] = silu(v[1]); o[2] = silu(v[2]); o[3] = silu(v[3]);
+    return o;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// acc[mb] += W[16mb + i][k] * act[item][k], k = 16a + 4q + b, W rows at stride ldw floats.
+// W may be LDS or global; both are read as one 16-byte fragment per (mb, a).
+template <int MB, int KB>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ w, int ldw,
+                                          const f32x4 (&bop)[KB], f32x4 (&acc)[MB], int i, int q) {
+#pragma unroll
+    for (int a = 0; a < KB; ++a) {
+        f32x4 wv[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) wv[mb] = ld4(w + (16 * mb + i) * ldw + 16 * a + 4 * q);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(wv[mb][b], bop[a][b], acc[mb]);
+        }
+    }
+}
+
+// Cooperative copy of W[rows][cols] (global, row stride src_ld) into LDS [rows][ldw], zero padded.
+__device__ __forceinline__ void stage_weight(float* lds, const float* __restrict__ w, int rows,
+                                             int cols, int src_ld, int ldw) {
+    for (int idx = threadIdx.x; idx < rows * ldw; idx += blockDim.x) {
+        int r = idx / ldw, c = idx - r * ldw;
+        lds[idx] = (c < cols) ? w[(size_t)r * src_ld + c] : 0.0f;
+    }
+}
+
+template <int D> struct NodeInfo {
+    // [p(D) v(D) f(D) R(D*D row-major) cv(D) cf(D)], padded to a multiple of 4 floats
+    static constexpr int P = 0, V = D, F = 2 * D, R = 3 * D, CV = 3 * D + D * D, CF = CV + D;
+    static constexpr int STRIDE = (D == 2) ? 16 : 24;
+};
+
+
+// Frame R from velocity (geometry.py:7-73): theta in [0, 2pi), phi = acos(clamp(vz/(|v|+eps)));
+// canonical velocity / force cv = R^T v, cf = R^T f (aether.py:33-50).
+template <int D>
+__device__ __forceinline__ void node_frame(const float (&v)[D], const float (&f)[D], float (&R)[D][D],
+                                           float (&cv)[D], float (&cf)[D]) {
+    float theta = atan2f(v[1], v[0]);
+    if (theta < 0.0f) theta += TWO_PI_F;
+    float c = cosf(theta), s = sinf(theta);
+    if constexpr (D == 2) {
+        R[0][0] = c; R[0][1] = -s; R[1][0] = s; R[1][1] = c;
+    } else {
+        float rho = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        float cz = v[2] / (rho + EPS_F);
+        cz = fminf(fmaxf(cz, -1.0f), 1.0f);
+        float phi = acosf(cz);
+        float cp = cosf(phi), sp = sinf(phi);
+        R[0][0] = cp * c; R[0][1] = -s;  R[0][2] = sp * c;
+        R[1][0] = cp * s; R[1][1] = c;   R[1][2] = sp * s;
+        R[2][0] = -sp;    R[2][1] = 0.f; R[2][2] = cp;
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {                             // R^T v, R^T f
+        float sv = 0.f, sf = 0.f;
+#pragma unroll
+        for (int b = 0; b < D; ++b) { sv += R[b][a] * v[b]; sf += R[b][a] * f[b]; }
+        cv[a] = sv; cf[a] = sf;
+    }
+}
+
+// Local-frame edge features for edge j -> i (aether.py:52-100, geometry.py:76-101), followed by
+// [rel_feat[recv] | edge_attr_orig] (aether.py:99,177); `nj` / `nir` are NodeInfo records.
+template <int D>
+__device__ __forceinline__ void edge_features(const float* __restrict__ nj,
+                                              const float* __restrict__ nir,
+                                              const float* __restrict__ ea, float* __restrict__ o) {
+    using NI = NodeInfo<D>;
+    constexpr int O = D * (D - 1) / 2;
+    float rel[D], rrel[D], rv[D], rf[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) rel[d] = nj[NI::P + d] - nir[NI::P + d];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            float rba = nir[NI::R + b * D + a];               // (R_i^T)[a][b]
+            s0 += rba * rel[b];
+            s1 += rba * nj[NI::V + b];
+            s2 += rba * nj[NI::F + b];
+        }
+        rrel[a] = s0; rv[a] = s1; rf[a] = s2;
+    }
+    auto M = [&](int a, int c) {                              // (R_i^T R_j)[a][c]
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < D; ++b) s += nir[NI::R + b * D + a] * nj[NI::R + b * D + c];
+        return s;
+    };
+    int k = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[k++] = rrel[d];
+    if constexpr (D == 2) {
+        o[k++] = atan2f(M(1, 0), M(0, 0)) / PI_F;
+    } else {
+        o[k++] = atan2f(M(1, 0), M(0, 0)) / PI_F;
+        o[k++] = asinf(-M(2, 0)) / PI_F;                      // no clamp (geometry.py:93)
+        o[k++] = atan2f(M(2, 1), M(2, 2)) / PI_F;
+    }
+    float d2 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { d2 += rel[d] * rel[d]; r2 += rrel[d] * rrel[d]; }
+    o[k++] = sqrtf(d2);                                       // |x_j - x_i| (aether.py:71)
+    o[k++] = atan2f(rrel[1], rrel[0]);                        // symmetric theta, not normalised
+    if constexpr (D == 3) {
+        float cz = rrel[2] / (sqrtf(r2) + EPS_F);
+        o[k++] = acosf(fminf(fmaxf(cz, -1.0f), 1.0f));
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[k++] = rv[d];
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[k++] = rf[d];
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[k++] = 0.0f;                // rel_feat[recv] = [0 | cv | cf]
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[k++] = nir[NI::CV + d];
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[k++] = nir[NI::CF + d];
+    o[k++] = ea[0];
+    o[k++] = ea[1];
+    static_assert(7 * D + O + 2 <= FPAD, "feature pad");
+#pragma unroll
+    for (; k < FPAD; ++k) o[k] = 0.0f;
+}
+
+
+}  // namespace

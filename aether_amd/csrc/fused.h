@@ -1,0 +1,419 @@
+// fused.h -- the whole Aether step for one *group* of small graphs in ONE launch.
+//
+// A group is a contiguous node range [nb, ne) whose in-edges all have senders inside the range
+// (one or several whole graphs; built by aether_graph_build), with at most FUSED_MAX_NODES nodes
+// and 128*ROUNDS edges.  One 512-thread workgroup (8 waves, 2 per SIMD) owns the group from the
+// field query to the output; nothing but the inputs, the weights and the D output floats per
+// node touches HBM:
+//   * every edge message tile (16 edges x 64) stays in the owning wave's registers across the four
+//     layers (it is the next layer's MFMA B operand as it stands);
+//   * node state (x, n, P_s, P_r) and the per-layer edge weights live in LDS (padded rows);
+//   * the mean over in-edges is done per round of 8 tiles through a double-buffered LDS staging
+//     area: a thread owns one (node, 4 columns) pair and adds that node's rows in edge order, so the
+//     result is deterministic (no atomics);
+//   * node-level GEMMs are split along their output rows over the 8 waves; their weights come from
+//     L2 in MFMA fragment shape (each is used once per group and layer).
+// References: see common.h / streamed.h; the arithmetic per stage is identical to the streamed path.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int FUSED_THREADS = 512;
+constexpr int FUSED_WAVES = 8;
+constexpr int FUSED_MAX_NODES = 32;          // two 16-node MFMA tiles
+constexpr int FUSED_ROUND_EDGES = 16 * FUSED_WAVES;   // 128 edges per round
+constexpr int FUSED_MAX_ROUNDS = 3;          // 384 edges (N=20 fully connected: 380)
+constexpr int LDU = 2 * H + 4;               // padded LDS row for the 128-wide update hidden
+
+struct FusedLds {                            // offsets in floats
+    static constexpr int WA = 0;                                   // [64][LDW]  W_e  (layer 1: W1, ld LDF)
+    static constexpr int WB = WA + H * LDW;                        // [64][LDW]  W2
+    static constexpr int BIAS = WB + H * LDW;                      // [128]      b1 | b2
+    static constexpr int XBUF = BIAS + 2 * H;                      // [32][LDW]  x_{l-1} / x_l
+    static constexpr int NBUF = XBUF + FUSED_MAX_NODES * LDW;      // [32][LDW]  n = x + mean
+    static constexpr int PS = NBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
+    static constexpr int PR = PS + FUSED_MAX_NODES * LDW;          // [32][LDW]  W_r x + b1
+    static constexpr int NINFO = PR + FUSED_MAX_NODES * LDW;       // [32][24]   NodeInfo records
+    static constexpr int STAGE = NINFO + FUSED_MAX_NODES * 24;     // 2 x [128][LDW] message staging
+    static constexpr int TOTAL = STAGE + 2 * FUSED_ROUND_EDGES * LDW;
+    // regions that alias STAGE while it is idle:
+    static constexpr int FIELD_Z = STAGE;                          // [32][24]  p | v | emb
+    static constexpr int FIELD_H1 = FIELD_Z + FUSED_MAX_NODES * 24;    // [32][32]
+    static constexpr int FIELD_H2 = FIELD_H1 + FUSED_MAX_NODES * 32;   // [32][32]
+    static constexpr int FIELD_F = FIELD_H2 + FUSED_MAX_NODES * 32;    // [32][4]
+    static constexpr int FEAT = STAGE;                             // [8 waves][48][LDF]
+    static constexpr int UBUF = STAGE;                             // [32][LDU]
+    static constexpr int OBUF1 = STAGE;                            // [32][LDW]
+    static constexpr int OBUF2 = STAGE + FUSED_MAX_NODES * LDW;    // [32][LDW]
+};
+static_assert(FusedLds::FEAT + FUSED_WAVES * 16 * FUSED_MAX_ROUNDS * LDF <= FusedLds::TOTAL, "feat scratch");
+static_assert(FusedLds::TOTAL * 4 <= 160 * 1024, "LDS budget");
+
+// Optional global copies of the intermediates (same layout as the streamed path's workspace), so
+// that the parity tests and (later) the backward can read them.
+struct FusedDebug {
+    float* nodeinfo; float* x[5]; float* e[4];
+};
+
+template <int D, int ROUNDS, bool KEEP>
+__global__ void __launch_bounds__(FUSED_THREADS)
+k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
+        const float* __restrict__ charges, const float* __restrict__ edge_attr_orig,
+        const int32_t* __restrict__ perm, const int32_t* __restrict__ send_s,
+        const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
+        const int32_t* __restrict__ group_nb, FusedDebug dbg, float* __restrict__ out) {
+    using NI = NodeInfo<D>;
+    using L = FusedLds;
+    constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+    constexpr int FIN = 2 * D + 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wA = smem + L::WA;
+    float* wB = smem + L::WB;
+    float* bias = smem + L::BIAS;
+    float* xbuf = smem + L::XBUF;
+    float* nbuf = smem + L::NBUF;
+    float* psb = smem + L::PS;
+    float* prb = smem + L::PR;
+    float* ninfo = smem + L::NINFO;
+    float* stage = smem + L::STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int nb = group_nb[blockIdx.x], ne = group_nb[blockIdx.x + 1];
+    const int n = ne - nb;
+    const int eb = rowptr[nb], ee = rowptr[ne];
+    const int m = ee - eb;
+    const int n_tiles = (m + 15) >> 4;
+
+    // ---------------------------------------------------------------- P0: stage layer-1 weights
+    stage_weight(wA, P.l1_msg_w0, H, F1, F1, LDF);
+    stage_weight(wB, P.l1_msg_w2, H, H, H, LDW);
+    if (tid < H) { bias[tid] = P.l1_msg_b0[tid]; bias[H + tid] = P.l1_msg_b2[tid]; }
+
+    // ---------------------------------------------------------------- P1: field net (aether.py:108-134)
+    {
+        float* z = smem + L::FIELD_Z;
+        float* h1 = smem + L::FIELD_H1;
+        float* h2 = smem + L::FIELD_H2;
+        float* ff = smem + L::FIELD_F;
+        for (int idx = tid; idx < n * FIN; idx += FUSED_THREADS) {
+            int node = idx / FIN, k = idx - node * FIN;
+            float val;
+            if (k < D) val = x[(int64_t)(nb + node) * D + k];
+            else if (k < 2 * D) val = vel[(int64_t)(nb + node) * D + (k - D)];
+            else {
+                long ci = (long)(charges[nb + node] + 1.0f);
+                ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
+                val = P.field_emb[ci * 16 + (k - 2 * D)];
+            }
+            z[node * 24 + k] = val;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n * 32; idx += FUSED_THREADS) {
+            int node = idx >> 5, o = idx & 31;
+            float s = P.field_b0[o];
+#pragma unroll
+            for (int k = 0; k < FIN; ++k) s += P.field_w0[o * FIN + k] * z[node * 24 + k];
+            h1[node * 32 + o] = silu(s);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n * 32; idx += FUSED_THREADS) {
+            int node = idx >> 5, o = idx & 31;
+            float s = P.field_b2[o];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += P.field_w2[o * 32 + k] * h1[node * 32 + k];
+            h2[node * 32 + o] = silu(s);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n * D; idx += FUSED_THREADS) {
+            int node = idx / D, d = idx - node * D;
+            float s = P.field_b4[d];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += P.field_w4[d * 32 + k] * h2[node * 32 + k];
+            ff[node * 4 + d] = s;
+        }
+        __syncthreads();
+        // frames + rel_feat (geometry.py:7-73, aether.py:33-50): one thread per node
+        if (tid < n) {
+            float v[D], f[D], R[D][D], cv[D], cf[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { v[d] = z[tid * 24 + D + d]; f[d] = ff[tid * 4 + d]; }
+            node_frame<D>(v, f, R, cv, cf);
+            float* ni = ninfo + tid * 24;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                ni[NI::P + d] = z[tid * 24 + d]; ni[NI::V + d] = v[d]; ni[NI::F + d] = f[d];
+                ni[NI::CV + d] = cv[d]; ni[NI::CF + d] = cf[d];
+#pragma unroll
+                for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
+            }
+            if constexpr (KEEP) {
+                float* g = dbg.nodeinfo + (int64_t)(nb + tid) * NI::STRIDE;
+#pragma unroll
+                for (int t = 0; t < NI::STRIDE; ++t) g[t] = t < NI::CF + D ? ni[t] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // x0 = layer_1.res(rel_feat) (locs.py:214-218); rows of unused node slots are zero
+        for (int idx = tid; idx < FUSED_MAX_NODES * H; idx += FUSED_THREADS) {
+            int node = idx >> 6, o = idx & 63;
+            float acc = 0.0f;
+            if (node < n) {
+                acc = P.l1_res_b[o];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    acc += P.l1_res_w[o * 3 * D + D + d] * ninfo[node * 24 + NI::CV + d];
+                    acc += P.l1_res_w[o * 3 * D + 2 * D + d] * ninfo[node * 24 + NI::CF + d];
+                }
+                if constexpr (KEEP) dbg.x[0][(int64_t)(nb + node) * H + o] = acc;
+            }
+            xbuf[node * LDW + o] = acc;
+        }
+        __syncthreads();       // field scratch (aliases STAGE) is dead from here on
+    }
+
+    // ---------------------------------------------------------------- P2: edge features -> B operands
+    // Wave w owns tiles {w, w+8, w+16}; lane j < 16*ROUNDS builds the features of one of their edges
+    // into a per-wave scratch, then every lane reads its B fragments back.
+    int sl[ROUNDS], rl[ROUNDS];
+    f32x4 e[ROUNDS][4];                      // message tiles, MFMA accumulator layout
+    {
+        float* scratch = smem + L::FEAT + wave * (16 * FUSED_MAX_ROUNDS * LDF);
+        if (lane < 16 * ROUNDS) {
+            const int r = lane >> 4, ii = lane & 15;
+            const int local = 16 * (FUSED_WAVES * r + wave) + ii;
+            float o[FPAD];
+            if (local < m) {
+                const int k = eb + local;
+                const float* nj = ninfo + (send_s[k] - nb) * 24;
+                const float* nr = ninfo + (recv_s[k] - nb) * 24;
+                float njl[NI::STRIDE], nrl[NI::STRIDE];
+#pragma unroll
+                for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
+                const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                float eal[2] = {ea[0], ea[1]};
+                edge_features<D>(njl, nrl, eal, o);
+            } else {
+#pragma unroll
+                for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < FPAD; t += 4)
+                st4(scratch + lane * LDF + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            e[r][0] = ld4(scratch + (16 * r + i) * LDF + 4 * q);        // features as bop[0..1]
+            e[r][1] = ld4(scratch + (16 * r + i) * LDF + 16 + 4 * q);
+            e[r][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int local = 16 * (FUSED_WAVES * r + wave) + i;
+            const int k = eb + (local < m ? local : 0);
+            sl[r] = m > 0 ? send_s[k] - nb : 0;
+            rl[r] = m > 0 ? recv_s[k] - nb : 0;
+        }
+        __syncthreads();       // feature scratch (aliases STAGE) is dead from here on
+    }
+
+    // aggregation ownership: thread -> (node slot, 4 columns)
+    const int aslot = tid >> 4, ac4 = (tid & 15) * 4;
+    int abeg = 0, aend = 0;
+    if (aslot < n) { abeg = rowptr[nb + aslot] - eb; aend = rowptr[nb + aslot + 1] - eb; }
+    const float adeg = (float)(aend - abeg > 1 ? aend - abeg : 1);
+
+#pragma unroll 1
+    for (int layer = 1; layer <= 4; ++layer) {
+        // ------------------------------------------------------------ edge rounds (locs.py:227-238)
+        f32x4 nsum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int tile = FUSED_WAVES * r + wave;
+            float* st = stage + (r & 1) * (FUSED_ROUND_EDGES * LDW);
+            if (tile < n_tiles) {                                  // wave-uniform
+                f32x4 acc[4], acc2[4], h1[4];
+                if (layer == 1) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[mb] = ld4(bias + 16 * mb + 4 * q);
+                    f32x4 bop[2] = {e[r][0], e[r][1]};
+                    gemm_tile<4, 2>(wA, LDF, bop, acc, i, q);
+                } else {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+                        acc[mb] = ld4(psb + sl[r] * LDW + 16 * mb + 4 * q) +
+                                  ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
+                    gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    h1[mb] = silu4(acc[mb]);
+                    acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
+                }
+                gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    e[r][mb] = silu4(acc2[mb]);
+                    st4(st + (16 * wave + i) * LDW + 16 * mb + 4 * q, e[r][mb]);
+                }
+                if constexpr (KEEP) {
+                    const int local = 16 * tile + i;
+                    if (local < m) {
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb)
+                            st4(dbg.e[layer - 1] + (int64_t)(eb + local) * H + 16 * mb + 4 * q, e[r][mb]);
+                    }
+                }
+            }
+            __syncthreads();
+            // segmented sum of this round's rows, in edge order (deterministic)
+            {
+                const int lo = abeg > FUSED_ROUND_EDGES * r ? abeg : FUSED_ROUND_EDGES * r;
+                const int hi = aend < FUSED_ROUND_EDGES * (r + 1) ? aend : FUSED_ROUND_EDGES * (r + 1);
+                for (int k = lo; k < hi; ++k) nsum += ld4(st + (k - FUSED_ROUND_EDGES * r) * LDW + ac4);
+            }
+        }
+        // ------------------------------------------------------------ node phase (locs.py:240-241)
+        const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
+        const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
+        const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
+        const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
+        // step 1: n = x_prev + sum / max(deg, 1)
+        st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + nsum / adeg);
+        __syncthreads();       // nbuf complete; every wave is past its last read of wA / wB / STAGE
+        // next layer's edge weights (W_e = W1[:, 128:192], W2) go to LDS while the node GEMMs run
+        if (layer < 4) {
+            stage_weight(wA, P.ln_msg_w0[layer - 1] + 2 * H, H, H, 3 * H, LDW);
+            stage_weight(wB, P.ln_msg_w2[layer - 1], H, H, H, LDW);
+            if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
+        }
+        // step 2: u = SiLU(W3 n + b3): wave w computes rows 16w..16w+15 for both node tiles
+        {
+            float* ubuf = smem + L::UBUF;
+            f32x4 wv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wv[a] = ld4(w3 + (16 * wave + i) * H + 16 * a + 4 * q);
+            const f32x4 bv = ld4(b3 + 16 * wave + 4 * q);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                if (16 * tn < n) {
+                    f32x4 acc = bv;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const f32x4 b4v = ld4(nbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc = mfma16(wv[a][b], b4v[b], acc);
+                    }
+                    st4(ubuf + (16 * tn + i) * LDU + 16 * wave + 4 * q, silu4(acc));
+                }
+            }
+        }
+        __syncthreads();
+        // step 3: x = n + W4 u + b4: wave w computes rows 16(w&3).. of node tile w>>2
+        {
+            const float* ubuf = smem + L::UBUF;
+            const int mb = wave & 3, tn = wave >> 2;
+            if (16 * tn < n) {
+                f32x4 acc = ld4(b4 + 16 * mb + 4 * q);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const f32x4 wv = ld4(w4 + (16 * mb + i) * (2 * H) + 16 * a + 4 * q);
+                    const f32x4 uv = ld4(ubuf + (16 * tn + i) * LDU + 16 * a + 4 * q);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc = mfma16(wv[b], uv[b], acc);
+                }
+                acc += ld4(nbuf + (16 * tn + i) * LDW + 16 * mb + 4 * q);
+                st4(xbuf + (16 * tn + i) * LDW + 16 * mb + 4 * q, acc);
+                if constexpr (KEEP) {
+                    if (16 * tn + i < n)
+                        st4(dbg.x[layer] + (int64_t)(nb + 16 * tn + i) * H + 16 * mb + 4 * q, acc);
+                }
+            }
+        }
+        __syncthreads();
+        // step 4: next layer's node terms P_s = W_s x, P_r = W_r x + b1 (locs.py:233 split)
+        if (layer < 4) {
+            const float* w1n = P.ln_msg_w0[layer - 1];
+            const float* b1n = P.ln_msg_b0[layer - 1];
+            const int mb = wave & 3, tn = wave >> 2;
+            if (16 * tn < n) {
+                f32x4 accs = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 accr = ld4(b1n + 16 * mb + 4 * q);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 ws = ld4(w1n + (16 * mb + i) * (3 * H) + 16 * a + 4 * q);
+                    const f32x4 wr = ld4(w1n + (16 * mb + i) * (3 * H) + H + 16 * a + 4 * q);
+                    const f32x4 xv = ld4(xbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        accs = mfma16(ws[b], xv[b], accs);
+                        accr = mfma16(wr[b], xv[b], accr);
+                    }
+                }
+                st4(psb + (16 * tn + i) * LDW + 16 * mb + 4 * q, accs);
+                st4(prb + (16 * tn + i) * LDW + 16 * mb + 4 * q, accr);
+            }
+            __syncthreads();   // P_s / P_r and the staged weights are visible to the next rounds
+        }
+    }
+
+    // ---------------------------------------------------------------- out MLP + globalise + residual
+    // locs.py:160-168,193; local_to_global.py:12-13; aether.py:185
+    {
+        float* o1 = smem + L::OBUF1;
+        float* o2 = smem + L::OBUF2;
+        const int mb = wave & 3, tn = wave >> 2;
+        if (16 * tn < n) {
+            f32x4 acc = ld4(P.out_b0 + 16 * mb + 4 * q);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 wv = ld4(P.out_w0 + (16 * mb + i) * H + 16 * a + 4 * q);
+                const f32x4 xv = ld4(xbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc = mfma16(wv[b], xv[b], acc);
+            }
+            st4(o1 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
+        }
+        __syncthreads();
+        if (16 * tn < n) {
+            f32x4 acc = ld4(P.out_b3 + 16 * mb + 4 * q);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 wv = ld4(P.out_w3 + (16 * mb + i) * H + 16 * a + 4 * q);
+                const f32x4 xv = ld4(o1 + (16 * tn + i) * LDW + 16 * a + 4 * q);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc = mfma16(wv[b], xv[b], acc);
+            }
+            st4(o2 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
+        }
+        __syncthreads();
+        if (wave < 2 && 16 * wave < n) {
+            const int tn2 = wave;
+            const int row = i < D ? i : D - 1;       // rows >= D of the 16-row block are discarded
+            f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 wv = ld4(P.out_w6 + row * H + 16 * a + 4 * q);
+                const f32x4 xv = ld4(o2 + (16 * tn2 + i) * LDW + 16 * a + 4 * q);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) y = mfma16(wv[b], xv[b], y);
+            }
+            const int node = 16 * tn2 + i;
+            if (q == 0 && node < n) {
+                float yl[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) yl[d] = y[d] + P.out_b6[d];
+                const float* ni = ninfo + node * 24;
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * yl[b];
+                    out[(int64_t)(nb + node) * D + a] = ni[NI::P + a] + s;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace

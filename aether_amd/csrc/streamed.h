@@ -1,0 +1,313 @@
+// streamed.h -- layer-by-layer kernels: the general path (any graph size); every [E,64] message
+// tensor streams through HBM/L2 once per layer in receiver-sorted order.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ K0: per-node prep
+// field net (aether.py:108-134), frame R from velocity (geometry.py:7-73),
+// rel_feat = [0 | R^T v | R^T f] (aether.py:33-50), and x0 = layer_1.res(rel_feat)
+// (locs.py:214-218,240).  One thread per node; the weights are wave-uniform (scalar loads).
+template <int D>
+__global__ void __launch_bounds__(256)
+k_node_prep(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
+            const float* __restrict__ charges, float* __restrict__ nodeinfo,
+            float* __restrict__ x0, int64_t n_nodes) {
+    using NI = NodeInfo<D>;
+    constexpr int FIN = 2 * D + 16;
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    float z[FIN];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { z[d] = x[n * D + d]; z[D + d] = vel[n * D + d]; }
+    long ci = (long)(charges[n] + 1.0f);                      // aether.py:122-124 (truncation)
+    ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) z[2 * D + k] = P.field_emb[ci * 16 + k];
+    float h1[32], h2[32];
+#pragma unroll 4
+    for (int o = 0; o < 32; ++o) {
+        float s = P.field_b0[o];
+#pragma unroll
+        for (int k = 0; k < FIN; ++k) s += P.field_w0[o * FIN + k] * z[k];
+        h1[o] = silu(s);
+    }
+#pragma unroll 4
+    for (int o = 0; o < 32; ++o) {
+        float s = P.field_b2[o];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += P.field_w2[o * 32 + k] * h1[k];
+        h2[o] = silu(s);
+    }
+    float f[D], v[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float s = P.field_b4[d];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += P.field_w4[d * 32 + k] * h2[k];
+        f[d] = s;
+        v[d] = z[D + d];
+    }
+    float R[D][D], cv[D], cf[D];
+    node_frame<D>(v, f, R, cv, cf);
+    float* ni = nodeinfo + n * NI::STRIDE;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        ni[NI::P + d] = z[d]; ni[NI::V + d] = v[d]; ni[NI::F + d] = f[d];
+        ni[NI::CV + d] = cv[d]; ni[NI::CF + d] = cf[d];
+#pragma unroll
+        for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
+    }
+    // x0 = W_res [0 | cv | cf] + b_res
+    float* xo = x0 + n * H;
+#pragma unroll 4
+    for (int o = 0; o < H; ++o) {
+        float acc = P.l1_res_b[o];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            acc += P.l1_res_w[o * 3 * D + D + d] * cv[d];
+            acc += P.l1_res_w[o * 3 * D + 2 * D + d] * cf[d];
+        }
+        xo[o] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ K1: layer-1 edge kernel
+// Phase A (one thread per edge): local-frame edge features, aether.py:52-100 +
+// geometry.py:76-101, followed by [rel_feat[recv] | edge_attr_orig] (aether.py:99,177).
+// Phase B (one wave per 16-edge tile): e1 = SiLU(W2 SiLU(W1 a + b1) + b2), locs.py:206-212.
+template <int D>
+__global__ void __launch_bounds__(256)
+k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
+              const float* __restrict__ edge_attr_orig, const int32_t* __restrict__ perm,
+              const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
+              float* __restrict__ e_out, float* __restrict__ feat_dbg, int64_t n_edges) {
+    using NI = NodeInfo<D>;
+    constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w1 = smem;                       // [64][LDF]
+    float* w2 = w1 + H * LDF;               // [64][LDW]
+    float* bias = w2 + H * LDW;             // [128]: b1 | b2
+    float* feat = bias + 2 * H;             // [256][LDF]
+    stage_weight(w1, P.l1_msg_w0, H, F1, F1, LDF);
+    stage_weight(w2, P.l1_msg_w2, H, H, H, LDW);
+    if (threadIdx.x < H) {
+        bias[threadIdx.x] = P.l1_msg_b0[threadIdx.x];
+        bias[H + threadIdx.x] = P.l1_msg_b2[threadIdx.x];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t n_chunks = (n_edges + 255) / 256;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        __syncthreads();                    // weights staged / previous chunk's feat consumed
+        {
+            int64_t k = chunk * 256 + threadIdx.x;
+            float o[FPAD];
+            if (k < n_edges) {
+                const float* nj = nodeinfo + (int64_t)send_s[k] * NI::STRIDE;
+                const float* nr = nodeinfo + (int64_t)recv_s[k] * NI::STRIDE;
+                float njl[NI::STRIDE], nrl[NI::STRIDE];
+#pragma unroll
+                for (int t = 0; t < NI::STRIDE; t += 4) {
+                    f32x4 a = ld4(nj + t), b = ld4(nr + t);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { njl[t + u] = a[u]; nrl[t + u] = b[u]; }
+                }
+                const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                float eal[2] = {ea[0], ea[1]};
+                edge_features<D>(njl, nrl, eal, o);
+                if (feat_dbg) {
+#pragma unroll
+                    for (int t = 0; t < FPAD; ++t) feat_dbg[k * FPAD + t] = o[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
+            }
+            float* fr = feat + threadIdx.x * LDF;
+#pragma unroll
+            for (int t = 0; t < FPAD; t += 4) st4(fr + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            const int local = wave * 64 + t * 16 + i;
+            const int64_t k = chunk * 256 + local;
+            if (chunk * 256 + wave * 64 + t * 16 >= n_edges) break;     // wave-uniform
+            f32x4 bop[2];
+            bop[0] = ld4(feat + local * LDF + 4 * q);
+            bop[1] = ld4(feat + local * LDF + 16 + 4 * q);
+            f32x4 acc[4], acc2[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                acc[mb] = ld4(bias + 16 * mb + 4 * q);
+                acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
+            }
+            gemm_tile<4, 2>(w1, LDF, bop, acc, i, q);
+            f32x4 h1[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
+            gemm_tile<4, 4>(w2, LDW, h1, acc2, i, q);
+            if (k < n_edges) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, silu4(acc2[mb]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K3: layers 2-4 edge kernel
+// e_l = SiLU(W2 SiLU(W_s x_s + W_r x_r + b1 + W_e e_{l-1}) + b2), locs.py:227-235 with the
+// node terms P_s = W_s x, P_r = W_r x + b1 gathered as the accumulator's initial value.
+__global__ void __launch_bounds__(256)
+k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
+             const float* __restrict__ b_msg2, const float* __restrict__ Ps,
+             const float* __restrict__ Pr, const float* __restrict__ e_prev,
+             const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
+             float* __restrict__ e_out, int64_t n_edges) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* we = smem;                       // [64][LDW]  = W1[:, 128:192]
+    float* w2 = we + H * LDW;               // [64][LDW]
+    float* bias = w2 + H * LDW;             // [64] b2
+    stage_weight(we, w_msg0 + 2 * H, H, H, 3 * H, LDW);
+    stage_weight(w2, w_msg2, H, H, H, LDW);
+    if (threadIdx.x < H) bias[threadIdx.x] = b_msg2[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t n_tiles = (n_edges + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    f32x4 b2v[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) b2v[mb] = ld4(bias + 16 * mb + 4 * q);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        const int64_t k = tile * 16 + i;
+        const int64_t kc = k < n_edges ? k : n_edges - 1;
+        const int64_t s = send_s[kc], r = recv_s[kc];
+        f32x4 acc[4], bop[4], acc2[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            acc[mb] = ld4(Ps + s * H + 16 * mb + 4 * q) + ld4(Pr + r * H + 16 * mb + 4 * q);
+            bop[mb] = ld4(e_prev + kc * H + 16 * mb + 4 * q);
+            acc2[mb] = b2v[mb];
+        }
+        gemm_tile<4, 4>(we, LDW, bop, acc, i, q);
+        f32x4 h1[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
+        gemm_tile<4, 4>(w2, LDW, h1, acc2, i, q);
+        if (k < n_edges) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, silu4(acc2[mb]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K2: node update kernel
+// n = x_prev + mean_{j->i} e (locs.py:236-240); x = n + W4 SiLU(W3 n + b3) + b4 (:241);
+// then either the next layer's node terms P_s, P_r, or (LAST) the out MLP (locs.py:160-168),
+// globalise (local_to_global.py:12-13) and the residual x + pred (aether.py:185).
+// One wave per 16-node tile; weights are read from L2 in fragment shape (used once per wave).
+template <int D, bool LAST>
+__global__ void __launch_bounds__(64)
+k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_prev,
+              const float* __restrict__ e, const int32_t* __restrict__ rowptr,
+              float* __restrict__ x_out, float* __restrict__ Ps, float* __restrict__ Pr,
+              const float* __restrict__ nodeinfo, const float* __restrict__ pos,
+              float* __restrict__ out, int64_t n_nodes) {
+    using NI = NodeInfo<D>;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t node = (int64_t)blockIdx.x * 16 + i;
+    const int64_t nc = node < n_nodes ? node : n_nodes - 1;
+    const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
+    const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
+    const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
+    const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
+    // segmented sum over the node's contiguous run of receiver-sorted edges, in edge order
+    const int beg = rowptr[nc], end = rowptr[nc + 1];
+    f32x4 n[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) n[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = beg; k < end; ++k) {
+        const float* er = e + (int64_t)k * H + 4 * q;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) n[mb] += ld4(er + 16 * mb);
+    }
+    const float deg = (float)(end - beg > 1 ? end - beg : 1);    // count clamped to >= 1
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) n[mb] = ld4(x_prev + nc * H + 16 * mb + 4 * q) + n[mb] / deg;
+    f32x4 u[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) u[mb] = ld4(b3 + 16 * mb + 4 * q);
+    gemm_tile<8, 4>(w3, H, n, u, i, q);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) u[mb] = silu4(u[mb]);
+    f32x4 xn[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) xn[mb] = ld4(b4 + 16 * mb + 4 * q);
+    gemm_tile<4, 8>(w4, 2 * H, u, xn, i, q);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) xn[mb] += n[mb];
+    if (node < n_nodes) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) st4(x_out + node * H + 16 * mb + 4 * q, xn[mb]);
+    }
+    if constexpr (!LAST) {
+        const float* w1n = P.ln_msg_w0[layer - 1];            // next layer's W1 [64][192]
+        const float* b1n = P.ln_msg_b0[layer - 1];
+        f32x4 ps[4], pr[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            ps[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pr[mb] = ld4(b1n + 16 * mb + 4 * q);
+        }
+        gemm_tile<4, 4>(w1n, 3 * H, xn, ps, i, q);
+        gemm_tile<4, 4>(w1n + H, 3 * H, xn, pr, i, q);
+        if (node < n_nodes) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                st4(Ps + node * H + 16 * mb + 4 * q, ps[mb]);
+                st4(Pr + node * H + 16 * mb + 4 * q, pr[mb]);
+            }
+        }
+    } else {
+        f32x4 o1[4], o2[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) o1[mb] = ld4(P.out_b0 + 16 * mb + 4 * q);
+        gemm_tile<4, 4>(P.out_w0, H, xn, o1, i, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { o1[mb] = silu4(o1[mb]); o2[mb] = ld4(P.out_b3 + 16 * mb + 4 * q); }
+        gemm_tile<4, 4>(P.out_w3, H, o1, o2, i, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) o2[mb] = silu4(o2[mb]);
+        // last Linear has D (2|3) output rows: rows >= D of the 16-row block read row D-1
+        // (in bounds) and are discarded.
+        const int row = i < D ? i : D - 1;
+        f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f32x4 wv = ld4(P.out_w6 + row * H + 16 * a + 4 * q);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) y = mfma16(wv[b], o2[a][b], y);
+        }
+        // rows 0..D-1 of y sit in lanes q == 0, registers 0..D-1, for node (lane & 15)
+        if (q == 0 && node < n_nodes) {
+            float yl[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) yl[d] = y[d] + P.out_b6[d];
+            const float* ni = nodeinfo + node * NI::STRIDE;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                float s = 0.f;
+#pragma unroll
+                for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * yl[b];   // R y
+                out[node * D + a] = pos[node * D + a] + s;
+            }
+        }
+    }
+}
+
+
+}  // namespace

@@ -45,19 +45,22 @@ class GraphCache:
         E = send.numel()
         nbytes = lib.aether_graph_bytes(E, n_nodes)
         buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=send.device)
+        info = _lib.AetherGraphInfo()
         stream = torch.cuda.current_stream(send.device).cuda_stream
         _lib.check(lib.aether_graph_build(send.data_ptr(), recv.data_ptr(), E, n_nodes,
-                                          buf.data_ptr(), buf.numel(), stream), "aether_graph_build")
+                                          buf.data_ptr(), buf.numel(), C.byref(info), stream),
+                   "aether_graph_build")
         # keep the index tensors alive so the key (their addresses) stays unique
-        self._d[key] = (buf, send, recv)
+        self._d[key] = ((buf, info), send, recv)
         while len(self._d) > self.max_entries:
             self._d.popitem(last=False)
-        return buf
+        return buf, info
 
 
 class _AetherStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, vel, edge_attr, charges, graph, n_edges, *params):
+        graph, ginfo = graph
         lib = _lib.load()
         D = module.num_dims
         n_nodes = x.shape[0]
@@ -67,8 +70,8 @@ class _AetherStep(torch.autograd.Function):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         st = lib.aether_forward(C.byref(module._param_struct()), D, n_nodes, n_edges,
                                 x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
-                                edge_attr.data_ptr(), graph.data_ptr(), ws.data_ptr(), ws.numel(),
-                                out.data_ptr(), stream)
+                                edge_attr.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                ws.numel(), out.data_ptr(), module.flags, stream)
         _lib.check(st, "aether_forward")
         return out
 
@@ -144,6 +147,7 @@ class Aether(nn.Module):
         self.num_dims = num_dims
         self.field_net = _FieldNetwork(num_dims, 32, 16)
         self._graphs = GraphCache()
+        self.flags = 0                    # _lib.FLAG_* bits passed to aether_forward
         self._ws = None
         self._pstruct = None
         self.to(device)
@@ -215,7 +219,7 @@ class Aether(nn.Module):
 
     def graph_perm(self, edges, n_nodes):
         lib = _lib.load()
-        g = self.prepare_graph(edges, n_nodes)
+        g, _ = self.prepare_graph(edges, n_nodes)
         E = edges[0].numel()
         perm = torch.empty(E, dtype=torch.int32, device=edges[0].device)
         _lib.check(lib.aether_graph_perm(g.data_ptr(), E, n_nodes, perm.data_ptr(),

@@ -59,6 +59,20 @@ typedef struct AetherParams {
     float* out_w6; float* out_b6;           /* [D][64],  [D]  */
 } AetherParams;
 
+/* Host-side summary of a built graph; filled by aether_graph_build, passed back to aether_forward. */
+typedef struct AetherGraphInfo {
+    int64_t n_nodes, n_edges;
+    int32_t n_groups;          /* > 0: the graph splits into this many fused-kernel groups        */
+    int32_t max_group_nodes;   /* largest group (<= 32 nodes, <= 384 edges), else n_groups == 0    */
+    int32_t max_group_edges;
+    int32_t reserved;
+} AetherGraphInfo;
+
+/* aether_forward flags */
+#define AETHER_FLAG_KEEP_INTERMEDIATES 1  /* also write nodeinfo, x0..x4, e1..e4 to the workspace */
+#define AETHER_FLAG_FORCE_STREAMED 2      /* use the layer-by-layer kernels even for small graphs */
+#define AETHER_FLAG_FORCE_FUSED 4         /* fail instead of falling back to the streamed kernels */
+
 /* Library / build identification (host string, static storage). */
 const char* aether_version(void);
 const char* aether_last_error(void);
@@ -70,11 +84,15 @@ const char* aether_last_error(void);
  * that the per-layer mean is a deterministic segmented sum in edge order.
  *   send, recv : int64[E]   edges[0], edges[1] of Aether.forward (aether.py:169)
  *   graph      : device buffer of aether_graph_bytes(E, n_nodes) bytes, filled here
- * Synchronises `stream` once; returns AETHER_EINDEX if any index is out of range.
+ * It also finds the contiguous node ranges that no edge leaves (whole graphs of a batch) and
+ * packs them into groups for the single-launch fused kernel (small graphs only; `info`).
+ * Synchronises `stream` (it reports bad indices and sizes the groups on the host); uses
+ * temporary host memory.  Returns AETHER_EINDEX if any index is out of range.
  */
 size_t aether_graph_bytes(int64_t n_edges, int64_t n_nodes);
 int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges,
-                       int64_t n_nodes, void* graph, size_t graph_bytes, void* stream);
+                       int64_t n_nodes, void* graph, size_t graph_bytes, AetherGraphInfo* info,
+                       void* stream);
 /* Debug / test access: copies the sorted-position -> original-edge-id map (int32[E]). */
 int aether_graph_perm(const void* graph, int64_t n_edges, int64_t n_nodes, int32_t* perm_out,
                       void* stream);
@@ -93,15 +111,17 @@ size_t aether_workspace_bytes(int64_t n_nodes, int64_t n_edges, int num_dims,
  *   graph           : from aether_graph_build for this (send, recv)
  *   out             : float[n_nodes][D]
  * `h` of the reference signature is unused by the reference and has no counterpart.
- * Stream-ordered, re-entrant per (workspace, out) pair.
+ * Small graphs (info->n_groups > 0) run as ONE kernel launch (csrc/fused.h); anything else runs
+ * layer by layer (csrc/streamed.h).  Stream-ordered, re-entrant per (workspace, out) pair.
  */
 int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
                    const float* x, const float* vel, const float* charges,
-                   const float* edge_attr_orig, const void* graph, void* workspace,
-                   size_t workspace_bytes, float* out, void* stream);
+                   const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
+                   void* workspace, size_t workspace_bytes, float* out, int flags, void* stream);
 
 /*
  * Test hook: copy one named intermediate of the last aether_forward on `workspace`
+ * (the fused path writes them only under AETHER_FLAG_KEEP_INTERMEDIATES)
  * into `dst` (device).  Names: "field"[n][D] "canon"[n][2D] (= rel_feat[:, D:]) "R"[n][D*D] "x0".."x4"[n][64]
  * "e1".."e4"[E][64] (receiver-sorted order; map back with aether_graph_perm).
  * Returns the number of floats written, or a negative error.

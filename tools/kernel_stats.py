@@ -1,7 +1,18 @@
 #!/usr/bin/env python3
 """Print per-kernel register / LDS / instruction-mix stats from a hipcc -save-temps .s file."""
-import re, sys
-txt = open(sys.argv[1]).read()
+import os, re, subprocess, sys, tempfile
+if len(sys.argv) > 1 and sys.argv[1].endswith(".s"):
+    txt = open(sys.argv[1]).read()
+else:   # compile the library's device code with -save-temps into a scratch dir
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(repo, "aether_amd", "csrc", "aether_hip.hip")
+    tmp = tempfile.mkdtemp(prefix="aether_isa_")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only",
+                    "-save-temps", src, "-o", "dev.o"], cwd=tmp, check=True,
+                   stderr=subprocess.DEVNULL)
+    sfile = [f for f in os.listdir(tmp) if f.endswith(".s")][0]
+    txt = open(os.path.join(tmp, sfile)).read()
+    print("# ISA in", os.path.join(tmp, sfile))
 # metadata
 meta = {}
 for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:
