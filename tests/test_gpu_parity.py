@@ -160,11 +160,11 @@ def test_large_graph_takes_the_streamed_path():
 def test_fused_and_streamed_agree_and_groups_pack():
     D = 3
     mf, ms = _model(D, "fused"), _model(D, "streamed")
-    inp = make_batch(300, 4, D, seed=41)             # 1,200 nodes -> packed, several graphs per group
+    inp = make_batch(2000, 4, D, seed=41)            # 8,000 nodes -> 8 graphs packed per group
     of, edges = _run(mf, inp)
     os_, _ = _run(ms, inp)
-    info = mf.prepare_graph(edges, 1200)[1]
-    assert 0 < info.n_groups < 300 and info.max_group_nodes <= 32 and info.max_group_nodes % 4 == 0
+    info = mf.prepare_graph(edges, 8000)[1]
+    assert info.n_groups == 250 and info.max_group_nodes == 32 and info.max_group_edges == 96
     assert scale_rel_err(of.cpu(), os_.cpu()) <= 2e-6
 
 
