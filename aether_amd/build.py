@@ -29,15 +29,21 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
-def build_library(force=False, verbose=True, extra_flags=()):
-    if not force and not is_stale():
+def build_library(force=False, verbose=True, extra_flags=(), out=LIB):
+    if not force and not is_stale() and out == LIB:
         return LIB
-    cmd = [hipcc_path(), *FLAGS, *extra_flags, SRC, "-o", LIB + ".tmp"]
+    cmd = [hipcc_path(), *FLAGS, *extra_flags, SRC, "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_diagnostic():
+    """Separate library with in-kernel phase stamps (tools/fused_phases.py); never the product."""
+    return build_library(force=True, extra_flags=("-DAETHER_FUSED_STAMPS",),
+                         out=os.path.join(HERE, "libaether_hip_diag.so"))
 
 
 if __name__ == "__main__":

@@ -148,7 +148,7 @@ struct GraphLayout {
 };
 
 struct WsLayout {
-    size_t nodeinfo, x[5], ps[3], pr[3], e[4], feat, total;
+    size_t nodeinfo, x[5], ps[3], pr[3], e[4], feat, stamps, total;
     WsLayout(int64_t Nn, int64_t E, int D, bool debug_feat) {
         size_t off = 0;
         auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
@@ -158,6 +158,7 @@ struct WsLayout {
         for (auto& v : pr) v = take((size_t)Nn * H);
         for (auto& v : e) v = take((size_t)E * H);
         feat = debug_feat ? take((size_t)E * FPAD) : 0;
+        stamps = take((size_t)4096 * FUSED_STAMPS);
         total = off;
     }
 };
@@ -195,6 +196,7 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     dbg.nodeinfo = wp(W.nodeinfo);
     for (int k = 0; k < 5; ++k) dbg.x[k] = wp(W.x[k]);
     for (int k = 0; k < 4; ++k) dbg.e[k] = wp(W.e[k]);
+    dbg.stamps = wp(W.stamps);
     const int rounds = info.max_group_edges <= 128 ? 1 : (info.max_group_edges <= 256 ? 2 : 3);
     int rc;
 #define AETHER_FUSED_CASE(R)                                                                          \
@@ -465,6 +467,8 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
     if (!strcmp(name, "field")) return copy2d(ni, n_nodes, NIS, 2 * D, D);
     if (!strcmp(name, "R")) return copy2d(ni, n_nodes, NIS, 3 * D, D * D);
     if (!strcmp(name, "canon")) return copy2d(ni, n_nodes, NIS, 3 * D + D * D, 2 * D);
+    if (!strcmp(name, "stamps"))
+        return copy2d((const float*)(ws + W.stamps), n_nodes, FUSED_STAMPS, 0, FUSED_STAMPS);
     if (name[0] == 'x' && name[1] >= '0' && name[1] <= '4' && !name[2])
         return copy2d((const float*)(ws + W.x[name[1] - '0']), n_nodes, H, 0, H);
     if (name[0] == 'e' && name[1] >= '1' && name[1] <= '4' && !name[2])

@@ -54,7 +54,21 @@ static_assert(FusedLds::TOTAL * 4 <= 160 * 1024, "LDS budget");
 // that the parity tests and (later) the backward can read them.
 struct FusedDebug {
     float* nodeinfo; float* x[5]; float* e[4];
+    float* stamps;          // [groups][FUSED_STAMPS] microseconds since kernel entry (diagnostic build)
 };
+constexpr int FUSED_STAMPS = 64;
+
+// In-kernel phase stamps: only in the diagnostic build (-DAETHER_FUSED_STAMPS); thread 0 of each
+// workgroup records the 100 MHz wall clock at phase boundaries into a buffer nothing else reads.
+#ifdef AETHER_FUSED_STAMPS
+#define FUSED_STAMP(id)                                                                          \
+    do {                                                                                         \
+        if (tid == 0 && blockIdx.x < 4096)                                                       \
+            dbg.stamps[blockIdx.x * FUSED_STAMPS + (id)] = (float)(wall_clock64() - t_entry) * 0.01f; \
+    } while (0)
+#else
+#define FUSED_STAMP(id)
+#endif
 
 template <int D, int ROUNDS, bool KEEP>
 __global__ void __launch_bounds__(FUSED_THREADS)
@@ -85,11 +99,16 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     const int eb = rowptr[nb], ee = rowptr[ne];
     const int m = ee - eb;
     const int n_tiles = (m + 15) >> 4;
+#ifdef AETHER_FUSED_STAMPS
+    const unsigned long long t_entry = wall_clock64();
+#endif
+    FUSED_STAMP(0);
 
     // ---------------------------------------------------------------- P0: stage layer-1 weights
     stage_weight(wA, P.l1_msg_w0, H, F1, F1, LDF);
     stage_weight(wB, P.l1_msg_w2, H, H, H, LDW);
     if (tid < H) { bias[tid] = P.l1_msg_b0[tid]; bias[H + tid] = P.l1_msg_b2[tid]; }
+    FUSED_STAMP(1);
 
     // ---------------------------------------------------------------- P1: field net (aether.py:108-134)
     {
@@ -172,6 +191,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();       // field scratch (aliases STAGE) is dead from here on
     }
+    FUSED_STAMP(2);
 
     // ---------------------------------------------------------------- P2: edge features -> B operands
     // Wave w owns tiles {w, w+8, w+16}; lane j < 16*ROUNDS builds the features of one of their edges
@@ -216,6 +236,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();       // feature scratch (aliases STAGE) is dead from here on
     }
+    FUSED_STAMP(3);
 
     // aggregation ownership: thread -> (node slot, 4 columns)
     const int aslot = tid >> 4, ac4 = (tid & 15) * 4;
@@ -272,6 +293,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 const int hi = aend < FUSED_ROUND_EDGES * (r + 1) ? aend : FUSED_ROUND_EDGES * (r + 1);
                 for (int k = lo; k < hi; ++k) nsum += ld4(st + (k - FUSED_ROUND_EDGES * r) * LDW + ac4);
             }
+            FUSED_STAMP(4 + 8 * (layer - 1) + r);
         }
         // ------------------------------------------------------------ node phase (locs.py:240-241)
         const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
@@ -281,6 +303,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // step 1: n = x_prev + sum / max(deg, 1)
         st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + nsum / adeg);
         __syncthreads();       // nbuf complete; every wave is past its last read of wA / wB / STAGE
+        FUSED_STAMP(4 + 8 * (layer - 1) + 3);
         // next layer's edge weights (W_e = W1[:, 128:192], W2) go to LDS while the node GEMMs run
         if (layer < 4) {
             stage_weight(wA, P.ln_msg_w0[layer - 1] + 2 * H, H, H, 3 * H, LDW);
@@ -309,6 +332,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
         }
         __syncthreads();
+        FUSED_STAMP(4 + 8 * (layer - 1) + 4);
         // step 3: x = n + W4 u + b4: wave w computes rows 16(w&3).. of node tile w>>2
         {
             const float* ubuf = smem + L::UBUF;
@@ -331,6 +355,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
         }
         __syncthreads();
+        FUSED_STAMP(4 + 8 * (layer - 1) + 5);
         // step 4: next layer's node terms P_s = W_s x, P_r = W_r x + b1 (locs.py:233 split)
         if (layer < 4) {
             const float* w1n = P.ln_msg_w0[layer - 1];
@@ -354,6 +379,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 st4(prb + (16 * tn + i) * LDW + 16 * mb + 4 * q, accr);
             }
             __syncthreads();   // P_s / P_r and the staged weights are visible to the next rounds
+            FUSED_STAMP(4 + 8 * (layer - 1) + 6);
         }
     }
 
@@ -414,6 +440,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
         }
     }
+    FUSED_STAMP(40);
 }
 
 }  // namespace

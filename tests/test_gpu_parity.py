@@ -164,7 +164,8 @@ def test_fused_and_streamed_agree_and_groups_pack():
     of, edges = _run(mf, inp)
     os_, _ = _run(ms, inp)
     info = mf.prepare_graph(edges, 8000)[1]
-    assert info.n_groups == 250 and info.max_group_nodes == 32 and info.max_group_edges == 96
+    assert 250 <= info.n_groups < 400 and info.max_group_nodes <= 32 and info.max_group_nodes % 4 == 0
+    assert info.max_group_edges == 3 * info.max_group_nodes
     assert scale_rel_err(of.cpu(), os_.cpu()) <= 2e-6
 
 

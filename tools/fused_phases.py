@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does k_fused spend its time?  Builds the stamped library variant, runs the
+headline workload and prints the median (over workgroups) time between phase stamps.
+Run on the GPU box:  python tools/fused_phases.py [--dims 2] [--batch 128] [--nodes 20]"""
+import argparse, contextlib, io, os, sys
+import numpy as np
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from aether_amd import build as B, _lib
+ap = argparse.ArgumentParser()
+ap.add_argument("--dims", type=int, default=2); ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--nodes", type=int, default=20)
+a = ap.parse_args()
+_lib.LIB_PATH = B.build_diagnostic()
+from aether_amd.nn.state2state.aether import Aether
+from aether_amd.synthetic import make_batch
+torch.manual_seed(1)
+with contextlib.redirect_stdout(io.StringIO()):
+    m = Aether(2 * a.dims, 64, 0.0, a.dims, device="cuda")
+inp = make_batch(a.batch, a.nodes, a.dims, seed=0, device="cuda")
+Nn, E = inp["x"].shape[0], inp["edges"][0].numel()
+with torch.no_grad():
+    for _ in range(20):
+        m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+torch.cuda.synchronize()
+G = m.prepare_graph(inp["edges"], Nn)[1].n_groups
+st = m.debug_fetch("stamps", min(G, 4096), E, 64).cpu().numpy()
+med = np.median(st, axis=0)
+names = {0: "entry", 1: "w1 staged (issued)", 2: "field+frames+x0", 3: "edge features", 40: "out mlp + store"}
+for l in range(4):
+    b = 4 + 8 * l
+    for r in range(3):
+        names[b + r] = f"L{l+1} round {r} (+aggregate)"
+    names[b + 3] = f"L{l+1} n = x + mean; barrier"
+    names[b + 4] = f"L{l+1} u = silu(W3 n)"
+    names[b + 5] = f"L{l+1} x = n + W4 u"
+    names[b + 6] = f"L{l+1} P_s, P_r"
+prev = 0.0
+print(f"groups={G}  (median over workgroups, microseconds)")
+for k in sorted(names):
+    if med[k] == 0 and k != 0:
+        continue
+    print(f"  {names[k]:32s} t={med[k]:8.2f}  d={med[k]-prev:7.2f}")
+    prev = med[k]
+print(f"  kernel span (max over WGs of last stamp): {st[:, 40].max():.2f} us; min start->end {st[:,40].min():.2f}")
