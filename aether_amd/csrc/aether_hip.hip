@@ -468,7 +468,7 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
     if (!strcmp(name, "R")) return copy2d(ni, n_nodes, NIS, 3 * D, D * D);
     if (!strcmp(name, "canon")) return copy2d(ni, n_nodes, NIS, 3 * D + D * D, 2 * D);
     if (!strcmp(name, "stamps"))
-        return copy2d((const float*)(ws + W.stamps), n_nodes, FUSED_STAMPS, 0, FUSED_STAMPS);
+        return copy2d((const float*)(ws + W.stamps), 4096, FUSED_STAMPS, 0, FUSED_STAMPS);
     if (name[0] == 'x' && name[1] >= '0' && name[1] <= '4' && !name[2])
         return copy2d((const float*)(ws + W.x[name[1] - '0']), n_nodes, H, 0, H);
     if (name[0] == 'e' && name[1] >= '1' && name[1] <= '4' && !name[2])

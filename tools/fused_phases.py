@@ -25,7 +25,12 @@ with torch.no_grad():
         m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
 torch.cuda.synchronize()
 G = m.prepare_graph(inp["edges"], Nn)[1].n_groups
-st = m.debug_fetch("stamps", min(G, 4096), E, 64).cpu().numpy()
+dst = torch.zeros(4096, 64, device="cuda")
+lib = _lib.load()
+_lib.check(lib.aether_debug_fetch(b"stamps", a.dims, Nn, E, m._ws.data_ptr(), dst.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream), "fetch stamps")
+torch.cuda.synchronize()
+st = dst.cpu().numpy()[:min(G, 4096)]
 med = np.median(st, axis=0)
 names = {0: "entry", 1: "w1 staged (issued)", 2: "field+frames+x0", 3: "edge features", 40: "out mlp + store"}
 for l in range(4):
