@@ -21,8 +21,13 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float silu(float x) {      // torch.nn.SiLU: x * sigmoid(x)
-    return x / (1.0f + expf(-x));
+// torch.nn.SiLU: x * sigmoid(x) = x / (1 + exp(-x)).  v_exp_f32 / v_rcp_f32 are 1-ulp hardware
+// ops; the only extra error is the rounding of x*log2(e) (<= |x| * 9e-8 relative in exp(-x)),
+// which is below fp32 resolution of the result for the pre-activation range seen here.  Measured
+// against the fp64 reference in tests/test_gpu_parity.py (same 1e-5 scale-relative bar).
+__device__ __forceinline__ float silu(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ f32x4 silu4(f32x4 v) {
     f32x4 o;
@@ -56,6 +61,25 @@ __device__ __forceinline__ void stage_weight(float* lds, const float* __restrict
     for (int idx = threadIdx.x; idx < rows * ldw; idx += blockDim.x) {
         int r = idx / ldw, c = idx - r * ldw;
         lds[idx] = (c < cols) ? w[(size_t)r * src_ld + c] : 0.0f;
+    }
+}
+
+// Vectorised copy of a [64][64] weight slice (row stride src_ld floats, 16-byte aligned rows) into
+// LDS [64][LDW]: all global loads are issued before the first LDS store.
+template <int THREADS>
+__device__ __forceinline__ void stage_weight64(float* lds, const float* __restrict__ w, int src_ld) {
+    constexpr int PER = (H * H / 4) / THREADS;
+    static_assert(PER * THREADS * 4 == H * H, "thread count must divide 1024");
+    f32x4 v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = threadIdx.x + THREADS * j, r = idx >> 4, c = (idx & 15) * 4;
+        v[j] = ld4(w + (size_t)r * src_ld + c);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = threadIdx.x + THREADS * j, r = idx >> 4, c = (idx & 15) * 4;
+        st4(lds + r * LDW + c, v[j]);
     }
 }
 

@@ -106,7 +106,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 
     // ---------------------------------------------------------------- P0: stage layer-1 weights
     stage_weight(wA, P.l1_msg_w0, H, F1, F1, LDF);
-    stage_weight(wB, P.l1_msg_w2, H, H, H, LDW);
+    stage_weight64<FUSED_THREADS>(wB, P.l1_msg_w2, H);
     if (tid < H) { bias[tid] = P.l1_msg_b0[tid]; bias[H + tid] = P.l1_msg_b2[tid]; }
     FUSED_STAMP(1);
 
@@ -291,7 +291,14 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             {
                 const int lo = abeg > FUSED_ROUND_EDGES * r ? abeg : FUSED_ROUND_EDGES * r;
                 const int hi = aend < FUSED_ROUND_EDGES * (r + 1) ? aend : FUSED_ROUND_EDGES * (r + 1);
-                for (int k = lo; k < hi; ++k) nsum += ld4(st + (k - FUSED_ROUND_EDGES * r) * LDW + ac4);
+                const float* row = st + (lo - FUSED_ROUND_EDGES * r) * LDW + ac4;
+                int k = lo;
+                for (; k + 4 <= hi; k += 4, row += 4 * LDW) {       // 4 loads in flight, same add order
+                    const f32x4 a0 = ld4(row), a1 = ld4(row + LDW), a2 = ld4(row + 2 * LDW),
+                                a3 = ld4(row + 3 * LDW);
+                    nsum += a0; nsum += a1; nsum += a2; nsum += a3;
+                }
+                for (; k < hi; ++k, row += LDW) nsum += ld4(row);
             }
             FUSED_STAMP(4 + 8 * (layer - 1) + r);
         }
@@ -300,22 +307,28 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
         const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
         const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
-        // step 1: n = x_prev + sum / max(deg, 1)
-        st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + nsum / adeg);
-        __syncthreads();       // nbuf complete; every wave is past its last read of wA / wB / STAGE
-        FUSED_STAMP(4 + 8 * (layer - 1) + 3);
-        // next layer's edge weights (W_e = W1[:, 128:192], W2) go to LDS while the node GEMMs run
+        // Every wave is past the last round's barrier, hence past its last read of wA / wB: the next
+        // layer's edge weights (W_e = W1[:, 128:192], W2) go to LDS now; their global loads and the
+        // W3 / W4 fragments of the node GEMMs are issued before the barrier below so that their L2
+        // latency overlaps it.
+        f32x4 w3v[4], w4v[8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * wave + i) * H + 16 * a + 4 * q);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * (wave & 3) + i) * (2 * H) + 16 * a + 4 * q);
         if (layer < 4) {
-            stage_weight(wA, P.ln_msg_w0[layer - 1] + 2 * H, H, H, 3 * H, LDW);
-            stage_weight(wB, P.ln_msg_w2[layer - 1], H, H, H, LDW);
+            stage_weight64<FUSED_THREADS>(wA, P.ln_msg_w0[layer - 1] + 2 * H, 3 * H);
+            stage_weight64<FUSED_THREADS>(wB, P.ln_msg_w2[layer - 1], H);
             if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
         }
+        // step 1: n = x_prev + sum / max(deg, 1)
+        st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + nsum / adeg);
+        __syncthreads();       // nbuf complete; STAGE is idle
+        FUSED_STAMP(4 + 8 * (layer - 1) + 3);
         // step 2: u = SiLU(W3 n + b3): wave w computes rows 16w..16w+15 for both node tiles
         {
             float* ubuf = smem + L::UBUF;
-            f32x4 wv[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) wv[a] = ld4(w3 + (16 * wave + i) * H + 16 * a + 4 * q);
+            const f32x4 (&wv)[4] = w3v;
             const f32x4 bv = ld4(b3 + 16 * wave + 4 * q);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
@@ -341,7 +354,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 f32x4 acc = ld4(b4 + 16 * mb + 4 * q);
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
-                    const f32x4 wv = ld4(w4 + (16 * mb + i) * (2 * H) + 16 * a + 4 * q);
+                    const f32x4 wv = w4v[a];
                     const f32x4 uv = ld4(ubuf + (16 * tn + i) * LDU + 16 * a + 4 * q);
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc = mfma16(wv[b], uv[b], acc);

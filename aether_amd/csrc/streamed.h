@@ -91,7 +91,7 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
     float* bias = w2 + H * LDW;             // [128]: b1 | b2
     float* feat = bias + 2 * H;             // [256][LDF]
     stage_weight(w1, P.l1_msg_w0, H, F1, F1, LDF);
-    stage_weight(w2, P.l1_msg_w2, H, H, H, LDW);
+    stage_weight64<256>(w2, P.l1_msg_w2, H);
     if (threadIdx.x < H) {
         bias[threadIdx.x] = P.l1_msg_b0[threadIdx.x];
         bias[H + threadIdx.x] = P.l1_msg_b2[threadIdx.x];
@@ -170,8 +170,8 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
     float* we = smem;                       // [64][LDW]  = W1[:, 128:192]
     float* w2 = we + H * LDW;               // [64][LDW]
     float* bias = w2 + H * LDW;             // [64] b2
-    stage_weight(we, w_msg0 + 2 * H, H, H, 3 * H, LDW);
-    stage_weight(w2, w_msg2, H, H, H, LDW);
+    stage_weight64<256>(we, w_msg0 + 2 * H, 3 * H);
+    stage_weight64<256>(w2, w_msg2, H);
     if (threadIdx.x < H) bias[threadIdx.x] = b_msg2[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
