@@ -8,9 +8,10 @@
 //   * every edge message tile (16 edges x 64) stays in the owning wave's registers across the four
 //     layers (it is the next layer's MFMA B operand as it stands);
 //   * node state (x, n, P_s, P_r) and the per-layer edge weights live in LDS (padded rows);
-//   * the mean over in-edges is done per round of 8 tiles through a double-buffered LDS staging
-//     area: a thread owns one (node, 4 columns) pair and adds that node's rows in edge order, so the
-//     result is deterministic (no atomics);
+//   * the mean over in-edges needs no workgroup barrier inside a layer: each wave parks its tile in
+//     16 private LDS rows, adds the rows of every receiver segment in edge order and publishes one
+//     partial row per (receiver, tile); the node phase adds a node's partial rows in tile order.
+//     Fixed order everywhere: deterministic, no atomics;
 //   * node-level GEMMs are split along their output rows over the 8 waves; their weights come from
 //     L2 in MFMA fragment shape (each is used once per group and layer).
 // References: see common.h / streamed.h; the arithmetic per stage is identical to the streamed path.
@@ -31,13 +32,15 @@ struct FusedLds {                            // offsets in floats
     static constexpr int WB = WA + H * LDW;                        // [64][LDW]  W2
     static constexpr int BIAS = WB + H * LDW;                      // [128]      b1 | b2
     static constexpr int XBUF = BIAS + 2 * H;                      // [32][LDW]  x_{l-1} / x_l
-    static constexpr int NBUF = XBUF + FUSED_MAX_NODES * LDW;      // [32][LDW]  n = x + mean
-    static constexpr int PS = NBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
+    static constexpr int PS = XBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
     static constexpr int PR = PS + FUSED_MAX_NODES * LDW;          // [32][LDW]  W_r x + b1
     static constexpr int NINFO = PR + FUSED_MAX_NODES * LDW;       // [32][24]   NodeInfo records
-    static constexpr int STAGE = NINFO + FUSED_MAX_NODES * 24;     // 2 x [128][LDW] message staging
-    static constexpr int TOTAL = STAGE + 2 * FUSED_ROUND_EDGES * LDW;
-    // regions that alias STAGE while it is idle:
+    static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [56][LDW]  per-(receiver, tile) sums
+    static constexpr int PART_ROWS = FUSED_MAX_NODES + 8 * FUSED_MAX_ROUNDS;
+    static constexpr int STAGE = PART + PART_ROWS * LDW;           // scratch, aliased by:
+    static constexpr int WSTAGE = STAGE;                           // [8 waves][16][LDW] tile staging
+    static constexpr int TOTAL = STAGE + FUSED_WAVES * 16 * FUSED_MAX_ROUNDS * LDF;
+    // regions that alias STAGE while the wave staging is idle:
     static constexpr int FIELD_Z = STAGE;                          // [32][24]  p | v | emb
     static constexpr int FIELD_H1 = FIELD_Z + FUSED_MAX_NODES * 24;    // [32][32]
     static constexpr int FIELD_H2 = FIELD_H1 + FUSED_MAX_NODES * 32;   // [32][32]
@@ -48,6 +51,9 @@ struct FusedLds {                            // offsets in floats
     static constexpr int OBUF2 = STAGE + FUSED_MAX_NODES * LDW;    // [32][LDW]
 };
 static_assert(FusedLds::FEAT + FUSED_WAVES * 16 * FUSED_MAX_ROUNDS * LDF <= FusedLds::TOTAL, "feat scratch");
+static_assert(FusedLds::WSTAGE + FUSED_WAVES * 16 * LDW <= FusedLds::TOTAL, "wave staging");
+static_assert(FusedLds::UBUF + FUSED_MAX_NODES * LDU <= FusedLds::TOTAL, "ubuf");
+static_assert(FusedLds::OBUF2 + FUSED_MAX_NODES * LDW <= FusedLds::TOTAL, "obuf");
 static_assert(FusedLds::TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 // Optional global copies of the intermediates (same layout as the streamed path's workspace), so
@@ -86,11 +92,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     float* wB = smem + L::WB;
     float* bias = smem + L::BIAS;
     float* xbuf = smem + L::XBUF;
-    float* nbuf = smem + L::NBUF;
     float* psb = smem + L::PS;
     float* prb = smem + L::PR;
     float* ninfo = smem + L::NINFO;
-    float* stage = smem + L::STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -238,20 +242,39 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     }
     FUSED_STAMP(3);
 
-    // aggregation ownership: thread -> (node slot, 4 columns)
-    const int aslot = tid >> 4, ac4 = (tid & 15) * 4;
-    int abeg = 0, aend = 0;
-    if (aslot < n) { abeg = rowptr[nb + aslot] - eb; aend = rowptr[nb + aslot + 1] - eb; }
-    const float adeg = (float)(aend - abeg > 1 ? aend - abeg : 1);
+    // node-sum ownership for the node phase: lane (node i, q) of node tile tn needs, for hidden
+    // columns 16a+4q.., x[node] + (sum over the node's in-edges) / deg.  The in-edge sum arrives as
+    // per-(receiver, tile) partial rows `part[node + tile]` written by the edge waves.
+    int nt0[2], nt1[2];                      // first / last+1 tile of the node's run, per node tile
+    float ninv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int slot = 16 * tn + i;
+        int beg = 0, end = 0;
+        if (slot < n) { beg = rowptr[nb + slot] - eb; end = rowptr[nb + slot + 1] - eb; }
+        nt0[tn] = beg >> 4;
+        nt1[tn] = end > beg ? ((end - 1) >> 4) + 1 : beg >> 4;
+        ninv[tn] = (float)(end - beg > 1 ? end - beg : 1);
+    }
+    float* wst = smem + L::WSTAGE + wave * (16 * LDW);
+    float* part = smem + L::PART;
+    // n[node][cols 4c..4c+3] = x + sum / deg, summed in tile (= edge) order: deterministic
+    auto node_n = [&](int tn, int col) -> f32x4 {
+        const int slot = 16 * tn + i;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = nt0[tn]; t < nt1[tn]; ++t) sum += ld4(part + (slot + t) * LDW + col);
+        return ld4(xbuf + slot * LDW + col) + sum / ninv[tn];
+    };
 
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
-        // ------------------------------------------------------------ edge rounds (locs.py:227-238)
-        f32x4 nsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ------------------------------------------------------------ edge tiles (locs.py:227-238)
+        // No workgroup barrier in here: a wave computes its tile, parks it in its private LDS
+        // staging rows, reduces it per receiver segment (rows in edge order) and publishes one
+        // partial row per (receiver, tile).
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int tile = FUSED_WAVES * r + wave;
-            float* st = stage + (r & 1) * (FUSED_ROUND_EDGES * LDW);
             if (tile < n_tiles) {                                  // wave-uniform
                 f32x4 acc[4], acc2[4], h1[4];
                 if (layer == 1) {
@@ -272,63 +295,87 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
                 }
                 gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
+                const int local = 16 * tile + i;
+                const int rcv = local < m ? rl[r] : -1;            // padding rows form a dead segment
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     e[r][mb] = silu4(acc2[mb]);
-                    st4(st + (16 * wave + i) * LDW + 16 * mb + 4 * q, e[r][mb]);
+                    st4(wst + i * LDW + 16 * mb + 4 * q, e[r][mb]);
                 }
+                if (q == 0) wst[i * LDW + H] = __int_as_float(rcv);  // receiver id in the pad column
                 if constexpr (KEEP) {
-                    const int local = 16 * tile + i;
                     if (local < m) {
 #pragma unroll
                         for (int mb = 0; mb < 4; ++mb)
                             st4(dbg.e[layer - 1] + (int64_t)(eb + local) * H + 16 * mb + 4 * q, e[r][mb]);
                     }
                 }
-            }
-            __syncthreads();
-            // segmented sum of this round's rows, in edge order (deterministic)
-            {
-                const int lo = abeg > FUSED_ROUND_EDGES * r ? abeg : FUSED_ROUND_EDGES * r;
-                const int hi = aend < FUSED_ROUND_EDGES * (r + 1) ? aend : FUSED_ROUND_EDGES * (r + 1);
-                const float* row = st + (lo - FUSED_ROUND_EDGES * r) * LDW + ac4;
-                int k = lo;
-                for (; k + 4 <= hi; k += 4, row += 4 * LDW) {       // 4 loads in flight, same add order
-                    const f32x4 a0 = ld4(row), a1 = ld4(row + LDW), a2 = ld4(row + 2 * LDW),
-                                a3 = ld4(row + 3 * LDW);
-                    nsum += a0; nsum += a1; nsum += a2; nsum += a3;
+                // segment starts among the 16 rows (receiver-sorted): bit j set <=> row j starts one
+                const int prev = __shfl_up(rcv, 1, 16);
+                const unsigned smask =
+                    (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;     // wave-uniform
+                const int nseg = __popc(smask) + 1;
+                __builtin_amdgcn_wave_barrier();
+                for (int base = 0; base < nseg; base += 4) {       // lane group q takes segment base+q
+                    const int g = base + q;
+                    if (g < nseg) {
+                        int s0 = 0;
+                        unsigned mm = smask;
+                        for (int t = 0; t < g; ++t) { s0 = __ffs(mm) - 1; mm &= mm - 1; }
+                        const int s1 = mm ? __ffs(mm) - 1 : 16;
+                        const int node = __float_as_int(wst[s0 * LDW + H]);
+                        if (node >= 0) {
+                            const float* row = wst + s0 * LDW + 4 * i;
+                            f32x4 sum = ld4(row);
+                            int j = s0 + 1;
+                            row += LDW;
+                            for (; j + 4 <= s1; j += 4, row += 4 * LDW) {   // 4 loads in flight, edge order
+                                const f32x4 a0 = ld4(row), a1 = ld4(row + LDW), a2 = ld4(row + 2 * LDW),
+                                            a3 = ld4(row + 3 * LDW);
+                                sum += a0; sum += a1; sum += a2; sum += a3;
+                            }
+                            for (; j < s1; ++j, row += LDW) sum += ld4(row);
+                            st4(part + (node + tile) * LDW + 4 * i, sum);
+                        }
+                    }
                 }
-                for (; k < hi; ++k, row += LDW) nsum += ld4(row);
+                __builtin_amdgcn_wave_barrier();
             }
-            FUSED_STAMP(4 + 8 * (layer - 1) + r);
         }
+        FUSED_STAMP(4 + 8 * (layer - 1) + 2);
         // ------------------------------------------------------------ node phase (locs.py:240-241)
         const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
         const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
         const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
         const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
-        // Every wave is past the last round's barrier, hence past its last read of wA / wB: the next
-        // layer's edge weights (W_e = W1[:, 128:192], W2) go to LDS now; their global loads and the
-        // W3 / W4 fragments of the node GEMMs are issued before the barrier below so that their L2
-        // latency overlaps it.
-        f32x4 w3v[4], w4v[8];
+        const int mb3 = wave & 3, tn3 = wave >> 2;      // (row block, node tile) of steps 3 and 4
+        // Issue every L2 load of the node phase now, so that their latency hides behind the barrier
+        // and the earlier steps: W3 / W4 / next-layer W_s, W_r fragments and the next layer's edge
+        // weights (W_e = W1[:, 128:192], W2) that go to LDS once every wave has left the edge tiles.
+        f32x4 w3v[4], w4v[8], wsv[4], wrv[4], stA[2], stB[2];
 #pragma unroll
         for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * wave + i) * H + 16 * a + 4 * q);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * (wave & 3) + i) * (2 * H) + 16 * a + 4 * q);
+        for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * a + 4 * q);
         if (layer < 4) {
-            stage_weight64<FUSED_THREADS>(wA, P.ln_msg_w0[layer - 1] + 2 * H, 3 * H);
-            stage_weight64<FUSED_THREADS>(wB, P.ln_msg_w2[layer - 1], H);
-            if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
+            const float* w1n = P.ln_msg_w0[layer - 1];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
+                wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + FUSED_THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+                stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
+                stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
+            }
         }
-        // step 1: n = x_prev + sum / max(deg, 1)
-        st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + nsum / adeg);
-        __syncthreads();       // nbuf complete; STAGE is idle
+        __syncthreads();       // all partial rows are published; wA / wB / wave staging are idle
         FUSED_STAMP(4 + 8 * (layer - 1) + 3);
-        // step 2: u = SiLU(W3 n + b3): wave w computes rows 16w..16w+15 for both node tiles
+        // step 2: u = SiLU(W3 n + b3), n = x_prev + mean: wave w computes rows 16w..16w+15 of u
         {
             float* ubuf = smem + L::UBUF;
-            const f32x4 (&wv)[4] = w3v;
             const f32x4 bv = ld4(b3 + 16 * wave + 4 * q);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
@@ -336,34 +383,44 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     f32x4 acc = bv;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const f32x4 b4v = ld4(nbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
+                        const f32x4 nv = node_n(tn, 16 * a + 4 * q);
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) acc = mfma16(wv[a][b], b4v[b], acc);
+                        for (int b = 0; b < 4; ++b) acc = mfma16(w3v[a][b], nv[b], acc);
                     }
                     st4(ubuf + (16 * tn + i) * LDU + 16 * wave + 4 * q, silu4(acc));
                 }
             }
         }
-        __syncthreads();
+        // residual term of step 3, read before the partial rows / x are overwritten
+        f32x4 nres = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (16 * tn3 < n) nres = node_n(tn3, 16 * mb3 + 4 * q);
+        if (layer < 4) {       // next layer's edge weights -> LDS (loads were issued above)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + FUSED_THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+                st4(wA + rr * LDW + cc, stA[j]);
+                st4(wB + rr * LDW + cc, stB[j]);
+            }
+            if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
+        }
+        __syncthreads();       // u complete; every wave has read x_prev and the partial rows
         FUSED_STAMP(4 + 8 * (layer - 1) + 4);
         // step 3: x = n + W4 u + b4: wave w computes rows 16(w&3).. of node tile w>>2
         {
             const float* ubuf = smem + L::UBUF;
-            const int mb = wave & 3, tn = wave >> 2;
-            if (16 * tn < n) {
-                f32x4 acc = ld4(b4 + 16 * mb + 4 * q);
+            if (16 * tn3 < n) {
+                f32x4 acc = ld4(b4 + 16 * mb3 + 4 * q);
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
-                    const f32x4 wv = w4v[a];
-                    const f32x4 uv = ld4(ubuf + (16 * tn + i) * LDU + 16 * a + 4 * q);
+                    const f32x4 uv = ld4(ubuf + (16 * tn3 + i) * LDU + 16 * a + 4 * q);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc = mfma16(wv[b], uv[b], acc);
+                    for (int b = 0; b < 4; ++b) acc = mfma16(w4v[a][b], uv[b], acc);
                 }
-                acc += ld4(nbuf + (16 * tn + i) * LDW + 16 * mb + 4 * q);
-                st4(xbuf + (16 * tn + i) * LDW + 16 * mb + 4 * q, acc);
+                acc += nres;
+                st4(xbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, acc);
                 if constexpr (KEEP) {
-                    if (16 * tn + i < n)
-                        st4(dbg.x[layer] + (int64_t)(nb + 16 * tn + i) * H + 16 * mb + 4 * q, acc);
+                    if (16 * tn3 + i < n)
+                        st4(dbg.x[layer] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, acc);
                 }
             }
         }
@@ -371,27 +428,23 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         FUSED_STAMP(4 + 8 * (layer - 1) + 5);
         // step 4: next layer's node terms P_s = W_s x, P_r = W_r x + b1 (locs.py:233 split)
         if (layer < 4) {
-            const float* w1n = P.ln_msg_w0[layer - 1];
             const float* b1n = P.ln_msg_b0[layer - 1];
-            const int mb = wave & 3, tn = wave >> 2;
-            if (16 * tn < n) {
+            if (16 * tn3 < n) {
                 f32x4 accs = f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 accr = ld4(b1n + 16 * mb + 4 * q);
+                f32x4 accr = ld4(b1n + 16 * mb3 + 4 * q);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const f32x4 ws = ld4(w1n + (16 * mb + i) * (3 * H) + 16 * a + 4 * q);
-                    const f32x4 wr = ld4(w1n + (16 * mb + i) * (3 * H) + H + 16 * a + 4 * q);
-                    const f32x4 xv = ld4(xbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
+                    const f32x4 xv = ld4(xbuf + (16 * tn3 + i) * LDW + 16 * a + 4 * q);
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        accs = mfma16(ws[b], xv[b], accs);
-                        accr = mfma16(wr[b], xv[b], accr);
+                        accs = mfma16(wsv[a][b], xv[b], accs);
+                        accr = mfma16(wrv[a][b], xv[b], accr);
                     }
                 }
-                st4(psb + (16 * tn + i) * LDW + 16 * mb + 4 * q, accs);
-                st4(prb + (16 * tn + i) * LDW + 16 * mb + 4 * q, accr);
+                st4(psb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accs);
+                st4(prb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accr);
             }
-            __syncthreads();   // P_s / P_r and the staged weights are visible to the next rounds
+            __syncthreads();   // P_s / P_r and the staged weights are visible to the next edge tiles
             FUSED_STAMP(4 + 8 * (layer - 1) + 6);
         }
     }

@@ -35,9 +35,8 @@ med = np.median(st, axis=0)
 names = {0: "entry", 1: "w1 staged (issued)", 2: "field+frames+x0", 3: "edge features", 40: "out mlp + store"}
 for l in range(4):
     b = 4 + 8 * l
-    for r in range(3):
-        names[b + r] = f"L{l+1} round {r} (+aggregate)"
-    names[b + 3] = f"L{l+1} n = x + mean; barrier"
+    names[b + 2] = f"L{l+1} edge tiles (wave 0 done)"
+    names[b + 3] = f"L{l+1} barrier (all tiles done)"
     names[b + 4] = f"L{l+1} u = silu(W3 n)"
     names[b + 5] = f"L{l+1} x = n + W4 u"
     names[b + 6] = f"L{l+1} P_s, P_r"
