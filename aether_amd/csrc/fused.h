@@ -32,7 +32,8 @@ struct FusedLds {                            // offsets in floats
     static constexpr int WB = WA + H * LDW;                        // [64][LDW]  W2
     static constexpr int BIAS = WB + H * LDW;                      // [128]      b1 | b2
     static constexpr int XBUF = BIAS + 2 * H;                      // [32][LDW]  x_{l-1} / x_l
-    static constexpr int PS = XBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
+    static constexpr int NBUF = XBUF + FUSED_MAX_NODES * LDW;      // [32][LDW]  n = x + mean
+    static constexpr int PS = NBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
     static constexpr int PR = PS + FUSED_MAX_NODES * LDW;          // [32][LDW]  W_r x + b1
     static constexpr int NINFO = PR + FUSED_MAX_NODES * LDW;       // [32][24]   NodeInfo records
     static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [56][LDW]  per-(receiver, tile) sums
@@ -242,29 +243,20 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     }
     FUSED_STAMP(3);
 
-    // node-sum ownership for the node phase: lane (node i, q) of node tile tn needs, for hidden
-    // columns 16a+4q.., x[node] + (sum over the node's in-edges) / deg.  The in-edge sum arrives as
-    // per-(receiver, tile) partial rows `part[node + tile]` written by the edge waves.
-    int nt0[2], nt1[2];                      // first / last+1 tile of the node's run, per node tile
-    float ninv[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int slot = 16 * tn + i;
-        int beg = 0, end = 0;
-        if (slot < n) { beg = rowptr[nb + slot] - eb; end = rowptr[nb + slot + 1] - eb; }
-        nt0[tn] = beg >> 4;
-        nt1[tn] = end > beg ? ((end - 1) >> 4) + 1 : beg >> 4;
-        ninv[tn] = (float)(end - beg > 1 ? end - beg : 1);
+    // node-sum ownership (step 1 of the node phase): thread -> (node slot, 4 columns).  The in-edge
+    // sum of a node arrives as per-(receiver, tile) partial rows `part[node + tile]`.
+    const int aslot = tid >> 4, ac4 = (tid & 15) * 4;
+    int at0 = 0, at1 = 0;
+    float adeg = 1.0f;
+    if (aslot < n) {
+        const int beg = rowptr[nb + aslot] - eb, end = rowptr[nb + aslot + 1] - eb;
+        at0 = beg >> 4;
+        at1 = end > beg ? ((end - 1) >> 4) + 1 : at0;
+        adeg = (float)(end - beg > 1 ? end - beg : 1);
     }
     float* wst = smem + L::WSTAGE + wave * (16 * LDW);
     float* part = smem + L::PART;
-    // n[node][cols 4c..4c+3] = x + sum / deg, summed in tile (= edge) order: deterministic
-    auto node_n = [&](int tn, int col) -> f32x4 {
-        const int slot = 16 * tn + i;
-        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t = nt0[tn]; t < nt1[tn]; ++t) sum += ld4(part + (slot + t) * LDW + col);
-        return ld4(xbuf + slot * LDW + col) + sum / ninv[tn];
-    };
+    float* nbuf = smem + L::NBUF;
 
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
@@ -310,32 +302,40 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                             st4(dbg.e[layer - 1] + (int64_t)(eb + local) * H + 16 * mb + 4 * q, e[r][mb]);
                     }
                 }
-                // segment starts among the 16 rows (receiver-sorted): bit j set <=> row j starts one
+                // Per-receiver sums of the tile as a 16x16x64 product on the matrix core:
+                // out[seg][h] = sum_edge S[seg][edge] * E[edge][h], S = 0/1 segment membership.
+                // Rows are receiver-sorted, so segment ids are 0.. in row order; bit j of smask set
+                // <=> row j starts a new segment.  k runs in edge order: deterministic.
                 const int prev = __shfl_up(rcv, 1, 16);
                 const unsigned smask =
                     (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;     // wave-uniform
-                const int nseg = __popc(smask) + 1;
                 __builtin_amdgcn_wave_barrier();
-                for (int base = 0; base < nseg; base += 4) {       // lane group q takes segment base+q
-                    const int g = base + q;
-                    if (g < nseg) {
-                        int s0 = 0;
+                f32x4 red[4];
+#pragma unroll
+                for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int edge = 4 * s4 + q;                                    // this lane's k
+                    const int seg_of_edge = __popc(smask & ((2u << edge) - 1u));
+                    const float sel = seg_of_edge == i ? 1.0f : 0.0f;              // A[seg = i][k]
+#pragma unroll
+                    for (int nbk = 0; nbk < 4; ++nbk)
+                        red[nbk] = mfma16(sel, wst[edge * LDW + 16 * nbk + i], red[nbk]);
+                }
+                // lane (h = 16 nbk + i, q) register r holds segment 4q + r; its receiver sits in the
+                // pad column of the segment's first row
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int seg = 4 * q + r4;
+                    if (seg <= __popc(smask)) {
+                        // first row of segment `seg`: position of its start bit (segment 0 starts at row 0)
                         unsigned mm = smask;
-                        for (int t = 0; t < g; ++t) { s0 = __ffs(mm) - 1; mm &= mm - 1; }
-                        const int s1 = mm ? __ffs(mm) - 1 : 16;
+                        int s0 = 0;
+                        for (int t = 0; t < seg; ++t) { s0 = __ffs(mm) - 1; mm &= mm - 1; }
                         const int node = __float_as_int(wst[s0 * LDW + H]);
                         if (node >= 0) {
-                            const float* row = wst + s0 * LDW + 4 * i;
-                            f32x4 sum = ld4(row);
-                            int j = s0 + 1;
-                            row += LDW;
-                            for (; j + 4 <= s1; j += 4, row += 4 * LDW) {   // 4 loads in flight, edge order
-                                const f32x4 a0 = ld4(row), a1 = ld4(row + LDW), a2 = ld4(row + 2 * LDW),
-                                            a3 = ld4(row + 3 * LDW);
-                                sum += a0; sum += a1; sum += a2; sum += a3;
-                            }
-                            for (; j < s1; ++j, row += LDW) sum += ld4(row);
-                            st4(part + (node + tile) * LDW + 4 * i, sum);
+                            float* dst = part + (node + tile) * LDW + i;
+                            dst[0] = red[0][r4]; dst[16] = red[1][r4]; dst[32] = red[2][r4]; dst[48] = red[3][r4];
                         }
                     }
                 }
@@ -373,6 +373,23 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();       // all partial rows are published; wA / wB / wave staging are idle
         FUSED_STAMP(4 + 8 * (layer - 1) + 3);
+        // step 1: n = x_prev + (sum of the node's partial rows, in tile order) / max(deg, 1)
+        {
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = at0; t < at1; ++t) sum += ld4(part + (aslot + t) * LDW + ac4);
+            st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + sum / adeg);
+        }
+        if (layer < 4) {       // next layer's edge weights -> LDS (loads were issued above)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + FUSED_THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+                st4(wA + rr * LDW + cc, stA[j]);
+                st4(wB + rr * LDW + cc, stB[j]);
+            }
+            if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
+        }
+        __syncthreads();       // n complete
+        FUSED_STAMP(4 + 8 * (layer - 1) + 7);
         // step 2: u = SiLU(W3 n + b3), n = x_prev + mean: wave w computes rows 16w..16w+15 of u
         {
             float* ubuf = smem + L::UBUF;
@@ -383,7 +400,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     f32x4 acc = bv;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const f32x4 nv = node_n(tn, 16 * a + 4 * q);
+                        const f32x4 nv = ld4(nbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
 #pragma unroll
                         for (int b = 0; b < 4; ++b) acc = mfma16(w3v[a][b], nv[b], acc);
                     }
@@ -391,19 +408,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
         }
-        // residual term of step 3, read before the partial rows / x are overwritten
-        f32x4 nres = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (16 * tn3 < n) nres = node_n(tn3, 16 * mb3 + 4 * q);
-        if (layer < 4) {       // next layer's edge weights -> LDS (loads were issued above)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = tid + FUSED_THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
-                st4(wA + rr * LDW + cc, stA[j]);
-                st4(wB + rr * LDW + cc, stB[j]);
-            }
-            if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
-        }
-        __syncthreads();       // u complete; every wave has read x_prev and the partial rows
+        __syncthreads();       // u complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 4);
         // step 3: x = n + W4 u + b4: wave w computes rows 16(w&3).. of node tile w>>2
         {
@@ -416,7 +421,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc = mfma16(w4v[a][b], uv[b], acc);
                 }
-                acc += nres;
+                acc += ld4(nbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q);
                 st4(xbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, acc);
                 if constexpr (KEEP) {
                     if (16 * tn3 + i < n)

@@ -37,12 +37,14 @@ for l in range(4):
     b = 4 + 8 * l
     names[b + 2] = f"L{l+1} edge tiles (wave 0 done)"
     names[b + 3] = f"L{l+1} barrier (all tiles done)"
+    names[b + 7] = f"L{l+1} n = x + mean"
     names[b + 4] = f"L{l+1} u = silu(W3 n)"
     names[b + 5] = f"L{l+1} x = n + W4 u"
     names[b + 6] = f"L{l+1} P_s, P_r"
 prev = 0.0
 print(f"groups={G}  (median over workgroups, microseconds)")
-for k in sorted(names):
+order = [0, 1, 2, 3] + [4 + 8 * l + o for l in range(4) for o in (2, 3, 7, 4, 5, 6)] + [40]
+for k in order:
     if med[k] == 0 and k != 0:
         continue
     print(f"  {names[k]:32s} t={med[k]:8.2f}  d={med[k]-prev:7.2f}")
