@@ -63,7 +63,7 @@ struct FusedDebug {
     float* nodeinfo; float* x[5]; float* e[4];
     float* stamps;          // [groups][FUSED_STAMPS] microseconds since kernel entry (diagnostic build)
 };
-constexpr int FUSED_STAMPS = 64;
+constexpr int FUSED_STAMPS = 512;
 
 // In-kernel phase stamps: only in the diagnostic build (-DAETHER_FUSED_STAMPS); thread 0 of each
 // workgroup records the 100 MHz wall clock at phase boundaries into a buffer nothing else reads.
@@ -73,8 +73,16 @@ constexpr int FUSED_STAMPS = 64;
         if (tid == 0 && blockIdx.x < 4096)                                                       \
             dbg.stamps[blockIdx.x * FUSED_STAMPS + (id)] = (float)(wall_clock64() - t_entry) * 0.01f; \
     } while (0)
+// per-wave sub-tile stamps in shader-clock cycles (s_memtime): slot 64 + wave*48 + round*8 + k
+#define FUSED_WSTAMP(layer_, r_, k_)                                                              \
+    do {                                                                                         \
+        if ((layer_) == 2 && lane == 0 && blockIdx.x < 4096)                                     \
+            dbg.stamps[blockIdx.x * FUSED_STAMPS + 64 + wave * 48 + (r_) * 8 + (k_)] =            \
+                (float)(__builtin_amdgcn_s_memtime() - c_entry);                                 \
+    } while (0)
 #else
 #define FUSED_STAMP(id)
+#define FUSED_WSTAMP(layer_, r_, k_)
 #endif
 
 template <int D, int ROUNDS, bool KEEP>
@@ -106,6 +114,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     const int n_tiles = (m + 15) >> 4;
 #ifdef AETHER_FUSED_STAMPS
     const unsigned long long t_entry = wall_clock64();
+    const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
 #endif
     FUSED_STAMP(0);
 
@@ -268,6 +277,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         for (int r = 0; r < ROUNDS; ++r) {
             const int tile = FUSED_WAVES * r + wave;
             if (tile < n_tiles) {                                  // wave-uniform
+                FUSED_WSTAMP(layer, r, 0);
                 f32x4 acc[4], acc2[4], h1[4];
                 if (layer == 1) {
 #pragma unroll
@@ -281,12 +291,15 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                                   ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
                     gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
                 }
+                FUSED_WSTAMP(layer, r, 1);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     h1[mb] = silu4(acc[mb]);
                     acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
                 }
+                FUSED_WSTAMP(layer, r, 2);
                 gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
+                FUSED_WSTAMP(layer, r, 3);
                 const int local = 16 * tile + i;
                 const int rcv = local < m ? rl[r] : -1;            // padding rows form a dead segment
 #pragma unroll
@@ -302,6 +315,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                             st4(dbg.e[layer - 1] + (int64_t)(eb + local) * H + 16 * mb + 4 * q, e[r][mb]);
                     }
                 }
+                FUSED_WSTAMP(layer, r, 4);
                 // Per-receiver sums of the tile as a 16x16x64 product on the matrix core:
                 // out[seg][h] = sum_edge S[seg][edge] * E[edge][h], S = 0/1 segment membership.
                 // Rows are receiver-sorted, so segment ids are 0.. in row order; bit j of smask set
@@ -340,6 +354,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                FUSED_WSTAMP(layer, r, 5);
             }
         }
         FUSED_STAMP(4 + 8 * (layer - 1) + 2);
@@ -512,6 +527,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
     }
     FUSED_STAMP(40);
+#ifdef AETHER_FUSED_STAMPS
+    if (tid == 0 && blockIdx.x < 4096)      // total cycles, for the clock estimate
+        dbg.stamps[blockIdx.x * FUSED_STAMPS + 41] = (float)(__builtin_amdgcn_s_memtime() - c_entry);
+#endif
 }
 
 }  // namespace

@@ -25,7 +25,7 @@ with torch.no_grad():
         m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
 torch.cuda.synchronize()
 G = m.prepare_graph(inp["edges"], Nn)[1].n_groups
-dst = torch.zeros(4096, 64, device="cuda")
+dst = torch.zeros(4096, 512, device="cuda")
 lib = _lib.load()
 _lib.check(lib.aether_debug_fetch(b"stamps", a.dims, Nn, E, m._ws.data_ptr(), dst.data_ptr(),
                                   torch.cuda.current_stream().cuda_stream), "fetch stamps")
@@ -49,4 +49,14 @@ for k in order:
         continue
     print(f"  {names[k]:32s} t={med[k]:8.2f}  d={med[k]-prev:7.2f}")
     prev = med[k]
+clk = np.median(st[:, 41] / st[:, 40])
+print(f"  shader clock during the kernel: {clk:.0f} MHz (s_memtime cycles / wall us)")
+print("  layer-2 per-wave tile timeline, cycles since kernel entry (median over workgroups):")
+print("   wave round   start   gemm1   silu1   gemm2  silu2+stage  reduce   | total")
+for w in range(8):
+    for r in range(3):
+        v = med[64 + w * 48 + r * 8: 64 + w * 48 + r * 8 + 6]
+        if v[5] == 0: continue
+        d = np.diff(v)
+        print(f"   {w:4d} {r:5d} {v[0]:8.0f} " + " ".join(f"{x:7.0f}" for x in d) + f"    | {v[5]-v[0]:6.0f}")
 print(f"  kernel span (max over WGs of last stamp): {st[:, 40].max():.2f} us; min start->end {st[:,40].min():.2f}")
