@@ -165,13 +165,15 @@ struct WsLayout {
 
 inline int bits_for(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
-template <int D, int ROUNDS, bool KEEP>
+int g_fused_waves = 8;        // aether_set_option("fused_waves", 8 | 16)
+
+template <int D, int NW, int ROUNDS>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
                  const float* ea, const int32_t* perm, const int32_t* send_s, const int32_t* recv_s,
                  const int32_t* rowptr, const int32_t* groups, int n_groups, const FusedDebug& dbg,
-                 float* out, hipStream_t st) {
-    auto kern = k_fused<D, ROUNDS, KEEP>;
-    constexpr size_t lds = (size_t)FusedLds::TOTAL * 4;
+                 int keep, float* out, hipStream_t st) {
+    auto kern = k_fused<D, NW, ROUNDS>;
+    constexpr size_t lds = (size_t)FusedLds<NW>::TOTAL * 4;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -179,8 +181,8 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
         attr_set = true;
     }
     ProfScope ps(K_FUSED, st);
-    kern<<<dim3((unsigned)n_groups), dim3(FUSED_THREADS), lds, st>>>(P, x, vel, charges, ea, perm, send_s,
-                                                                   recv_s, rowptr, groups, dbg, out);
+    kern<<<dim3((unsigned)n_groups), dim3(NW * 64), lds, st>>>(P, x, vel, charges, ea, perm, send_s, recv_s,
+                                                              rowptr, groups, dbg, keep, out);
     return AETHER_OK;
 }
 
@@ -197,16 +199,20 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     for (int k = 0; k < 5; ++k) dbg.x[k] = wp(W.x[k]);
     for (int k = 0; k < 4; ++k) dbg.e[k] = wp(W.e[k]);
     dbg.stamps = wp(W.stamps);
-    const int rounds = info.max_group_edges <= 128 ? 1 : (info.max_group_edges <= 256 ? 2 : 3);
+    const int tiles = (info.max_group_edges + 15) / 16;
+    const int nw = g_fused_waves;
+    const int rounds = (tiles + nw - 1) / nw;
     int rc;
-#define AETHER_FUSED_CASE(R)                                                                          \
-    rc = keep ? fused_launch<D, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s), gp(G.recv_s), \
-                                         gp(G.rowptr), gp(G.groups), info.n_groups, dbg, out, st)     \
-              : fused_launch<D, R, false>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s), gp(G.recv_s), \
-                                          gp(G.rowptr), gp(G.groups), info.n_groups, dbg, out, st)
-    if (rounds == 1) { AETHER_FUSED_CASE(1); }
-    else if (rounds == 2) { AETHER_FUSED_CASE(2); }
-    else { AETHER_FUSED_CASE(3); }
+#define AETHER_FUSED_CASE(NWV, R)                                                                     \
+    rc = fused_launch<D, NWV, R>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s), gp(G.recv_s),      \
+                                 gp(G.rowptr), gp(G.groups), info.n_groups, dbg, keep ? 1 : 0, out, st)
+    if (nw == 16) {
+        if (rounds <= 1) { AETHER_FUSED_CASE(16, 1); } else { AETHER_FUSED_CASE(16, 2); }
+    } else {
+        if (rounds <= 1) { AETHER_FUSED_CASE(8, 1); }
+        else if (rounds == 2) { AETHER_FUSED_CASE(8, 2); }
+        else { AETHER_FUSED_CASE(8, 3); }
+    }
 #undef AETHER_FUSED_CASE
     if (rc != AETHER_OK) return rc;
     HIP_OK(hipGetLastError());
@@ -278,6 +284,16 @@ extern "C" {
 
 const char* aether_version(void) { return "aether_hip 0.2 (gfx950, fp32 MFMA 16x16x4, fused + streamed)"; }
 const char* aether_last_error(void) { return g_err; }
+
+int aether_set_option(const char* name, int value) {
+    if (!name) return fail(AETHER_EINVAL, "set_option: null name");
+    if (!strcmp(name, "fused_waves")) {
+        if (value != 8 && value != 16) return fail(AETHER_EINVAL, "set_option: fused_waves must be 8 or 16");
+        g_fused_waves = value;
+        return AETHER_OK;
+    }
+    return fail(AETHER_EINVAL, "set_option: unknown option");
+}
 
 int aether_profile_enable(int on) {
     g_prof_on = on != 0;
@@ -359,7 +375,7 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
     HIP_OK(hipMemcpyAsync(h_rowptr.data(), rowptr, (size_t)(n_nodes + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     // components = maximal ranges with no crossing edge at their boundaries
-    const int cap_n = FUSED_MAX_NODES, cap_e = FUSED_ROUND_EDGES * FUSED_MAX_ROUNDS;
+    const int cap_n = FUSED_MAX_NODES, cap_e = FUSED_MAX_EDGES;
     bool ok = true;
     int64_t max_cn = 0, max_ce = 0;
     for (int64_t c0 = 0; c0 < n_nodes && ok;) {

@@ -2,32 +2,31 @@
 //
 // A group is a contiguous node range [nb, ne) whose in-edges all have senders inside the range
 // (one or several whole graphs; built by aether_graph_build), with at most FUSED_MAX_NODES nodes
-// and 128*ROUNDS edges.  One 512-thread workgroup (8 waves, 2 per SIMD) owns the group from the
-// field query to the output; nothing but the inputs, the weights and the D output floats per
-// node touches HBM:
+// and FUSED_MAX_EDGES edges.  One workgroup of NW waves owns the group from the field query to the
+// output; nothing but the inputs, the weights and the D output floats per node touches HBM:
 //   * every edge message tile (16 edges x 64) stays in the owning wave's registers across the four
 //     layers (it is the next layer's MFMA B operand as it stands);
 //   * node state (x, n, P_s, P_r) and the per-layer edge weights live in LDS (padded rows);
-//   * the mean over in-edges needs no workgroup barrier inside a layer: each wave parks its tile in
-//     16 private LDS rows, adds the rows of every receiver segment in edge order and publishes one
-//     partial row per (receiver, tile); the node phase adds a node's partial rows in tile order.
-//     Fixed order everywhere: deterministic, no atomics;
-//   * node-level GEMMs are split along their output rows over the 8 waves; their weights come from
-//     L2 in MFMA fragment shape (each is used once per group and layer).
+//   * the mean over in-edges needs no workgroup barrier inside a layer and no LDS staging: a tile's
+//     rows sit on the 16 lanes of a DPP row, so the sum over each receiver segment is a masked 4-step
+//     DPP butterfly per register; one partial row per (receiver, tile) goes to LDS and the node
+//     phase adds a node's partial rows in tile order.  Fixed order everywhere: deterministic, no
+//     atomics;
+//   * node-level GEMMs are split along their output rows over the waves; their weights come from L2
+//     in MFMA fragment shape (each is used once per group and layer), all issued before the barrier
+//     that ends the edge phase.
 // References: see common.h / streamed.h; the arithmetic per stage is identical to the streamed path.
 #pragma once
 #include "common.h"
 
 namespace {
 
-constexpr int FUSED_THREADS = 512;
-constexpr int FUSED_WAVES = 8;
 constexpr int FUSED_MAX_NODES = 32;          // two 16-node MFMA tiles
-constexpr int FUSED_ROUND_EDGES = 16 * FUSED_WAVES;   // 128 edges per round
-constexpr int FUSED_MAX_ROUNDS = 3;          // 384 edges (N=20 fully connected: 380)
+constexpr int FUSED_MAX_EDGES = 384;         // 24 tiles (N=20 fully connected: 380 edges)
+constexpr int FUSED_MAX_TILES = FUSED_MAX_EDGES / 16;
 constexpr int LDU = 2 * H + 4;               // padded LDS row for the 128-wide update hidden
 
-struct FusedLds {                            // offsets in floats
+template <int NW> struct FusedLds {          // offsets in floats
     static constexpr int WA = 0;                                   // [64][LDW]  W_e  (layer 1: W1, ld LDF)
     static constexpr int WB = WA + H * LDW;                        // [64][LDW]  W2
     static constexpr int BIAS = WB + H * LDW;                      // [128]      b1 | b2
@@ -36,48 +35,47 @@ struct FusedLds {                            // offsets in floats
     static constexpr int PS = NBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
     static constexpr int PR = PS + FUSED_MAX_NODES * LDW;          // [32][LDW]  W_r x + b1
     static constexpr int NINFO = PR + FUSED_MAX_NODES * LDW;       // [32][24]   NodeInfo records
+    static constexpr int PART_ROWS = FUSED_MAX_NODES + FUSED_MAX_TILES;
     static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [56][LDW]  per-(receiver, tile) sums
-    static constexpr int PART_ROWS = FUSED_MAX_NODES + 8 * FUSED_MAX_ROUNDS;
-    static constexpr int STAGE = PART + PART_ROWS * LDW;           // scratch, aliased by:
-    static constexpr int WSTAGE = STAGE;                           // [8 waves][16][LDW] tile staging
-    static constexpr int TOTAL = STAGE + FUSED_WAVES * 16 * FUSED_MAX_ROUNDS * LDF;
-    // regions that alias STAGE while the wave staging is idle:
-    static constexpr int FIELD_Z = STAGE;                          // [32][24]  p | v | emb
+    static constexpr int SCRATCH = PART + PART_ROWS * LDW;         // aliased by the regions below
+    static constexpr int SCRATCH_SIZE = NW * 16 * LDF;
+    static constexpr int TOTAL = SCRATCH + SCRATCH_SIZE;
+    static constexpr int FIELD_Z = SCRATCH;                            // [32][24]  p | v | emb
     static constexpr int FIELD_H1 = FIELD_Z + FUSED_MAX_NODES * 24;    // [32][32]
     static constexpr int FIELD_H2 = FIELD_H1 + FUSED_MAX_NODES * 32;   // [32][32]
     static constexpr int FIELD_F = FIELD_H2 + FUSED_MAX_NODES * 32;    // [32][4]
-    static constexpr int FEAT = STAGE;                             // [8 waves][48][LDF]
-    static constexpr int UBUF = STAGE;                             // [32][LDU]
-    static constexpr int OBUF1 = STAGE;                            // [32][LDW]
-    static constexpr int OBUF2 = STAGE + FUSED_MAX_NODES * LDW;    // [32][LDW]
+    static constexpr int FEAT = SCRATCH;                               // [NW waves][16][LDF]
+    static constexpr int UBUF = SCRATCH;                               // [32][LDU]
+    static constexpr int OBUF1 = SCRATCH;                              // [32][LDW]
+    static constexpr int OBUF2 = SCRATCH + FUSED_MAX_NODES * LDW;      // [32][LDW]
+    static_assert(FIELD_F + FUSED_MAX_NODES * 4 <= TOTAL, "field scratch");
+    static_assert(UBUF + FUSED_MAX_NODES * LDU <= TOTAL, "ubuf");
+    static_assert(OBUF2 + FUSED_MAX_NODES * LDW <= TOTAL, "obuf");
+    static_assert(TOTAL * 4 <= 160 * 1024, "LDS budget");
 };
-static_assert(FusedLds::FEAT + FUSED_WAVES * 16 * FUSED_MAX_ROUNDS * LDF <= FusedLds::TOTAL, "feat scratch");
-static_assert(FusedLds::WSTAGE + FUSED_WAVES * 16 * LDW <= FusedLds::TOTAL, "wave staging");
-static_assert(FusedLds::UBUF + FUSED_MAX_NODES * LDU <= FusedLds::TOTAL, "ubuf");
-static_assert(FusedLds::OBUF2 + FUSED_MAX_NODES * LDW <= FusedLds::TOTAL, "obuf");
-static_assert(FusedLds::TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 // Optional global copies of the intermediates (same layout as the streamed path's workspace), so
 // that the parity tests and (later) the backward can read them.
 struct FusedDebug {
     float* nodeinfo; float* x[5]; float* e[4];
-    float* stamps;          // [groups][FUSED_STAMPS] microseconds since kernel entry (diagnostic build)
+    float* stamps;          // [groups][FUSED_STAMPS] diagnostic build only
 };
 constexpr int FUSED_STAMPS = 512;
 
-// In-kernel phase stamps: only in the diagnostic build (-DAETHER_FUSED_STAMPS); thread 0 of each
-// workgroup records the 100 MHz wall clock at phase boundaries into a buffer nothing else reads.
+// In-kernel phase stamps: only in the diagnostic build (-DAETHER_FUSED_STAMPS).  Thread 0 of each
+// workgroup records the 100 MHz wall clock (microseconds since entry) at phase boundaries; lane 0 of
+// each wave records shader-clock cycles around the pieces of its layer-2 tiles.  The stamps go to a
+// buffer nothing else reads.
 #ifdef AETHER_FUSED_STAMPS
 #define FUSED_STAMP(id)                                                                          \
     do {                                                                                         \
         if (tid == 0 && blockIdx.x < 4096)                                                       \
             dbg.stamps[blockIdx.x * FUSED_STAMPS + (id)] = (float)(wall_clock64() - t_entry) * 0.01f; \
     } while (0)
-// per-wave sub-tile stamps in shader-clock cycles (s_memtime): slot 64 + wave*48 + round*8 + k
 #define FUSED_WSTAMP(layer_, r_, k_)                                                              \
     do {                                                                                         \
-        if ((layer_) == 2 && lane == 0 && blockIdx.x < 4096)                                     \
-            dbg.stamps[blockIdx.x * FUSED_STAMPS + 64 + wave * 48 + (r_) * 8 + (k_)] =            \
+        if ((layer_) == 2 && lane == 0 && blockIdx.x < 4096 && wave < 16)                        \
+            dbg.stamps[blockIdx.x * FUSED_STAMPS + 64 + wave * 24 + (r_) * 8 + (k_)] =            \
                 (float)(__builtin_amdgcn_s_memtime() - c_entry);                                 \
     } while (0)
 #else
@@ -85,25 +83,41 @@ constexpr int FUSED_STAMPS = 512;
 #define FUSED_WSTAMP(layer_, r_, k_)
 #endif
 
-template <int D, int ROUNDS, bool KEEP>
-__global__ void __launch_bounds__(FUSED_THREADS)
+// Sum of v over the 16 lanes of a DPP row (lane & 15 = tile row), result in every lane.
+template <int CTRL> __device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_allreduce16(float v) {
+    v += dpp_perm<0xB1>(v);      // quad_perm [1,0,3,2]  : lane ^ 1
+    v += dpp_perm<0x4E>(v);      // quad_perm [2,3,0,1]  : lane ^ 2
+    v += dpp_perm<0x141>(v);     // row_half_mirror      : the other quad of the 8-lane half
+    v += dpp_perm<0x140>(v);     // row_mirror           : the other half of the row
+    return v;
+}
+
+template <int D, int NW, int ROUNDS>
+__global__ void __launch_bounds__(NW * 64)
 k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
         const float* __restrict__ charges, const float* __restrict__ edge_attr_orig,
         const int32_t* __restrict__ perm, const int32_t* __restrict__ send_s,
         const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
-        const int32_t* __restrict__ group_nb, FusedDebug dbg, float* __restrict__ out) {
+        const int32_t* __restrict__ group_nb, FusedDebug dbg, int keep, float* __restrict__ out) {
     using NI = NodeInfo<D>;
-    using L = FusedLds;
+    using L = FusedLds<NW>;
+    constexpr int THREADS = NW * 64;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
     constexpr int FIN = 2 * D + 16;
+    static_assert(NW == 8 || NW == 16, "node-phase decomposition is written for 8 or 16 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wA = smem + L::WA;
     float* wB = smem + L::WB;
     float* bias = smem + L::BIAS;
     float* xbuf = smem + L::XBUF;
+    float* nbuf = smem + L::NBUF;
     float* psb = smem + L::PS;
     float* prb = smem + L::PR;
     float* ninfo = smem + L::NINFO;
+    float* part = smem + L::PART;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -120,7 +134,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 
     // ---------------------------------------------------------------- P0: stage layer-1 weights
     stage_weight(wA, P.l1_msg_w0, H, F1, F1, LDF);
-    stage_weight64<FUSED_THREADS>(wB, P.l1_msg_w2, H);
+    stage_weight64<THREADS>(wB, P.l1_msg_w2, H);
     if (tid < H) { bias[tid] = P.l1_msg_b0[tid]; bias[H + tid] = P.l1_msg_b2[tid]; }
     FUSED_STAMP(1);
 
@@ -130,7 +144,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         float* h1 = smem + L::FIELD_H1;
         float* h2 = smem + L::FIELD_H2;
         float* ff = smem + L::FIELD_F;
-        for (int idx = tid; idx < n * FIN; idx += FUSED_THREADS) {
+        for (int idx = tid; idx < n * FIN; idx += THREADS) {
             int node = idx / FIN, k = idx - node * FIN;
             float val;
             if (k < D) val = x[(int64_t)(nb + node) * D + k];
@@ -143,7 +157,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             z[node * 24 + k] = val;
         }
         __syncthreads();
-        for (int idx = tid; idx < n * 32; idx += FUSED_THREADS) {
+        for (int idx = tid; idx < n * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
             float s = P.field_b0[o];
 #pragma unroll
@@ -151,7 +165,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             h1[node * 32 + o] = silu(s);
         }
         __syncthreads();
-        for (int idx = tid; idx < n * 32; idx += FUSED_THREADS) {
+        for (int idx = tid; idx < n * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
             float s = P.field_b2[o];
 #pragma unroll
@@ -159,7 +173,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             h2[node * 32 + o] = silu(s);
         }
         __syncthreads();
-        for (int idx = tid; idx < n * D; idx += FUSED_THREADS) {
+        for (int idx = tid; idx < n * D; idx += THREADS) {
             int node = idx / D, d = idx - node * D;
             float s = P.field_b4[d];
 #pragma unroll
@@ -181,7 +195,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                 for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
             }
-            if constexpr (KEEP) {
+            if (keep) {
                 float* g = dbg.nodeinfo + (int64_t)(nb + tid) * NI::STRIDE;
 #pragma unroll
                 for (int t = 0; t < NI::STRIDE; ++t) g[t] = t < NI::CF + D ? ni[t] : 0.0f;
@@ -189,7 +203,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();
         // x0 = layer_1.res(rel_feat) (locs.py:214-218); rows of unused node slots are zero
-        for (int idx = tid; idx < FUSED_MAX_NODES * H; idx += FUSED_THREADS) {
+        for (int idx = tid; idx < FUSED_MAX_NODES * H; idx += THREADS) {
             int node = idx >> 6, o = idx & 63;
             float acc = 0.0f;
             if (node < n) {
@@ -199,62 +213,73 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     acc += P.l1_res_w[o * 3 * D + D + d] * ninfo[node * 24 + NI::CV + d];
                     acc += P.l1_res_w[o * 3 * D + 2 * D + d] * ninfo[node * 24 + NI::CF + d];
                 }
-                if constexpr (KEEP) dbg.x[0][(int64_t)(nb + node) * H + o] = acc;
+                if (keep) dbg.x[0][(int64_t)(nb + node) * H + o] = acc;
             }
             xbuf[node * LDW + o] = acc;
         }
-        __syncthreads();       // field scratch (aliases STAGE) is dead from here on
+        __syncthreads();       // field scratch (aliases SCRATCH) is dead from here on
     }
     FUSED_STAMP(2);
 
     // ---------------------------------------------------------------- P2: edge features -> B operands
-    // Wave w owns tiles {w, w+8, w+16}; lane j < 16*ROUNDS builds the features of one of their edges
-    // into a per-wave scratch, then every lane reads its B fragments back.
-    int sl[ROUNDS], rl[ROUNDS];
+    // Wave w owns tiles {w, w+NW, ..}.  Per tile, 16 lanes each build the features of one edge into
+    // the wave's scratch rows; then every lane reads its B fragments back.  Per-tile constants of
+    // the graph structure (sender / receiver slot, receiver-segment index) are computed once here.
+    int sl[ROUNDS], rl[ROUNDS], segi[ROUNDS], nseg[ROUNDS];
     f32x4 e[ROUNDS][4];                      // message tiles, MFMA accumulator layout
     {
-        float* scratch = smem + L::FEAT + wave * (16 * FUSED_MAX_ROUNDS * LDF);
-        if (lane < 16 * ROUNDS) {
-            const int r = lane >> 4, ii = lane & 15;
-            const int local = 16 * (FUSED_WAVES * r + wave) + ii;
-            float o[FPAD];
-            if (local < m) {
-                const int k = eb + local;
-                const float* nj = ninfo + (send_s[k] - nb) * 24;
-                const float* nr = ninfo + (recv_s[k] - nb) * 24;
-                float njl[NI::STRIDE], nrl[NI::STRIDE];
-#pragma unroll
-                for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
-                const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
-                float eal[2] = {ea[0], ea[1]};
-                edge_features<D>(njl, nrl, eal, o);
-            } else {
-#pragma unroll
-                for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
-            }
-#pragma unroll
-            for (int t = 0; t < FPAD; t += 4)
-                st4(scratch + lane * LDF + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
-        }
-        __builtin_amdgcn_wave_barrier();
+        float* scratch = smem + L::FEAT + wave * (16 * LDF);
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            e[r][0] = ld4(scratch + (16 * r + i) * LDF + 4 * q);        // features as bop[0..1]
-            e[r][1] = ld4(scratch + (16 * r + i) * LDF + 16 + 4 * q);
-            e[r][2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int local = 16 * (FUSED_WAVES * r + wave) + i;
-            const int k = eb + (local < m ? local : 0);
+            const int tile = NW * r + wave;
+            const int local = 16 * tile + i;
+            const bool valid = local < m;
+            const int k = eb + (valid ? local : 0);
             sl[r] = m > 0 ? send_s[k] - nb : 0;
             rl[r] = m > 0 ? recv_s[k] - nb : 0;
+            if (tile < n_tiles && lane < 16) {
+                float o[FPAD];
+                if (valid) {
+                    const float* nj = ninfo + sl[r] * 24;
+                    const float* nr = ninfo + rl[r] * 24;
+                    float njl[NI::STRIDE], nrl[NI::STRIDE];
+#pragma unroll
+                    for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
+                    const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                    float eal[2] = {ea[0], ea[1]};
+                    edge_features<D>(njl, nrl, eal, o);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
+                }
+#pragma unroll
+                for (int t = 0; t < FPAD; t += 4)
+                    st4(scratch + lane * LDF + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+            }
+            __builtin_amdgcn_wave_barrier();
+            e[r][0] = ld4(scratch + i * LDF + 4 * q);              // features as bop[0..1]
+            e[r][1] = ld4(scratch + i * LDF + 16 + 4 * q);
+            e[r][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_wave_barrier();
+            // receiver segments of the tile (rows are receiver-sorted): segment index per row,
+            // padding rows get an index no segment loop reaches
+            const int rcv = valid ? rl[r] : -1;
+            const int prev = __shfl_up(rcv, 1, 16);
+            const unsigned smask = (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;
+            const int sidx = __popc(smask & ((2u << i) - 1u));
+            segi[r] = valid ? sidx : 99;
+            const unsigned vmask = (unsigned)__ballot(q == 0 && valid) & 0xFFFFu;
+            // number of segments that contain valid rows (valid rows come first)
+            nseg[r] = vmask ? __popc(smask & vmask) + 1 : 0;
         }
-        __syncthreads();       // feature scratch (aliases STAGE) is dead from here on
+        __syncthreads();       // feature scratch (aliases SCRATCH) is dead from here on
     }
     FUSED_STAMP(3);
 
     // node-sum ownership (step 1 of the node phase): thread -> (node slot, 4 columns).  The in-edge
     // sum of a node arrives as per-(receiver, tile) partial rows `part[node + tile]`.
-    const int aslot = tid >> 4, ac4 = (tid & 15) * 4;
+    const int aslot = (tid >> 4) & (FUSED_MAX_NODES - 1), ac4 = (tid & 15) * 4;
     int at0 = 0, at1 = 0;
     float adeg = 1.0f;
     if (aslot < n) {
@@ -263,19 +288,14 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         at1 = end > beg ? ((end - 1) >> 4) + 1 : at0;
         adeg = (float)(end - beg > 1 ? end - beg : 1);
     }
-    float* wst = smem + L::WSTAGE + wave * (16 * LDW);
-    float* part = smem + L::PART;
-    float* nbuf = smem + L::NBUF;
 
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
         // ------------------------------------------------------------ edge tiles (locs.py:227-238)
-        // No workgroup barrier in here: a wave computes its tile, parks it in its private LDS
-        // staging rows, reduces it per receiver segment (rows in edge order) and publishes one
-        // partial row per (receiver, tile).
+        // No workgroup barrier in here.
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int tile = FUSED_WAVES * r + wave;
+            const int tile = NW * r + wave;
             if (tile < n_tiles) {                                  // wave-uniform
                 FUSED_WSTAMP(layer, r, 0);
                 f32x4 acc[4], acc2[4], h1[4];
@@ -300,15 +320,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 FUSED_WSTAMP(layer, r, 2);
                 gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
                 FUSED_WSTAMP(layer, r, 3);
-                const int local = 16 * tile + i;
-                const int rcv = local < m ? rl[r] : -1;            // padding rows form a dead segment
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    e[r][mb] = silu4(acc2[mb]);
-                    st4(wst + i * LDW + 16 * mb + 4 * q, e[r][mb]);
-                }
-                if (q == 0) wst[i * LDW + H] = __int_as_float(rcv);  // receiver id in the pad column
-                if constexpr (KEEP) {
+                for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
+                if (keep) {
+                    const int local = 16 * tile + i;
                     if (local < m) {
 #pragma unroll
                         for (int mb = 0; mb < 4; ++mb)
@@ -316,44 +331,22 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     }
                 }
                 FUSED_WSTAMP(layer, r, 4);
-                // Per-receiver sums of the tile as a 16x16x64 product on the matrix core:
-                // out[seg][h] = sum_edge S[seg][edge] * E[edge][h], S = 0/1 segment membership.
-                // Rows are receiver-sorted, so segment ids are 0.. in row order; bit j of smask set
-                // <=> row j starts a new segment.  k runs in edge order: deterministic.
-                const int prev = __shfl_up(rcv, 1, 16);
-                const unsigned smask =
-                    (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;     // wave-uniform
-                __builtin_amdgcn_wave_barrier();
-                f32x4 red[4];
+                // per-receiver sums of the tile: masked DPP butterfly over the 16 rows, one partial
+                // row per (receiver, tile); lanes 0..3 of each DPP row store 16 bytes each
+                const int ns = __builtin_amdgcn_readfirstlane(nseg[r]);
+                for (int sg = 0; sg < ns; ++sg) {
+                    const bool mine = segi[r] == sg;
+                    const int first = __ffsll((unsigned long long)__ballot(mine)) - 1;
+                    const int node = __builtin_amdgcn_readlane(rl[r], first);
+                    f32x4 red[4];
 #pragma unroll
-                for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int edge = 4 * s4 + q;                                    // this lane's k
-                    const int seg_of_edge = __popc(smask & ((2u << edge) - 1u));
-                    const float sel = seg_of_edge == i ? 1.0f : 0.0f;              // A[seg = i][k]
-#pragma unroll
-                    for (int nbk = 0; nbk < 4; ++nbk)
-                        red[nbk] = mfma16(sel, wst[edge * LDW + 16 * nbk + i], red[nbk]);
-                }
-                // lane (h = 16 nbk + i, q) register r holds segment 4q + r; its receiver sits in the
-                // pad column of the segment's first row
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int seg = 4 * q + r4;
-                    if (seg <= __popc(smask)) {
-                        // first row of segment `seg`: position of its start bit (segment 0 starts at row 0)
-                        unsigned mm = smask;
-                        int s0 = 0;
-                        for (int t = 0; t < seg; ++t) { s0 = __ffs(mm) - 1; mm &= mm - 1; }
-                        const int node = __float_as_int(wst[s0 * LDW + H]);
-                        if (node >= 0) {
-                            float* dst = part + (node + tile) * LDW + i;
-                            dst[0] = red[0][r4]; dst[16] = red[1][r4]; dst[32] = red[2][r4]; dst[48] = red[3][r4];
-                        }
+                        for (int c = 0; c < 4; ++c) red[mb][c] = row_allreduce16(mine ? e[r][mb][c] : 0.0f);
                     }
+                    const f32x4 pick = i == 0 ? red[0] : (i == 1 ? red[1] : (i == 2 ? red[2] : red[3]));
+                    if (i < 4) st4(part + (node + tile) * LDW + 16 * i + 4 * q, pick);
                 }
-                __builtin_amdgcn_wave_barrier();
                 FUSED_WSTAMP(layer, r, 5);
             }
         }
@@ -363,41 +356,48 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
         const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
         const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
-        const int mb3 = wave & 3, tn3 = wave >> 2;      // (row block, node tile) of steps 3 and 4
+        // work split: step 2 has 16 (row block, node tile) units, step 3 has 8, step 4 has 16
+        const int mb2 = wave & 7;                         // step 2: rows 16*mb2.. of the 128
+        const int mb3 = wave & 3, tn3 = (wave >> 2) & 1;  // steps 3, 4: rows 16*mb3.. of node tile tn3
+        const bool act3 = wave < 8;                       // step 3 / out MLP: 8 units
+        const int sel4 = NW == 16 ? wave >> 3 : 0;        // step 4 (NW=16): 0 -> P_s, 1 -> P_r
         // Issue every L2 load of the node phase now, so that their latency hides behind the barrier
         // and the earlier steps: W3 / W4 / next-layer W_s, W_r fragments and the next layer's edge
         // weights (W_e = W1[:, 128:192], W2) that go to LDS once every wave has left the edge tiles.
-        f32x4 w3v[4], w4v[8], wsv[4], wrv[4], stA[2], stB[2];
+        constexpr int STG = (H * H / 4) / THREADS;        // float4 per thread per staged matrix
+        f32x4 w3v[4], w4v[8], wsv[4], wrv[4], stA[STG], stB[STG];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * wave + i) * H + 16 * a + 4 * q);
+        for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * mb2 + i) * H + 16 * a + 4 * q);
+        if (act3) {
 #pragma unroll
-        for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * a + 4 * q);
+            for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * a + 4 * q);
+        }
         if (layer < 4) {
             const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
-                wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+                if (NW == 8 || sel4 == 0) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
+                if (NW == 8 || sel4 == 1) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = tid + FUSED_THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+            for (int j = 0; j < STG; ++j) {
+                const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
                 stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
                 stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
             }
         }
-        __syncthreads();       // all partial rows are published; wA / wB / wave staging are idle
+        __syncthreads();       // all partial rows are published; wA / wB are idle
         FUSED_STAMP(4 + 8 * (layer - 1) + 3);
         // step 1: n = x_prev + (sum of the node's partial rows, in tile order) / max(deg, 1)
-        {
+        if (tid < FUSED_MAX_NODES * 16) {
             f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int t = at0; t < at1; ++t) sum += ld4(part + (aslot + t) * LDW + ac4);
             st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + sum / adeg);
         }
         if (layer < 4) {       // next layer's edge weights -> LDS (loads were issued above)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = tid + FUSED_THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+            for (int j = 0; j < STG; ++j) {
+                const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
                 st4(wA + rr * LDW + cc, stA[j]);
                 st4(wB + rr * LDW + cc, stB[j]);
             }
@@ -405,12 +405,13 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();       // n complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 7);
-        // step 2: u = SiLU(W3 n + b3), n = x_prev + mean: wave w computes rows 16w..16w+15 of u
+        // step 2: u = SiLU(W3 n + b3): rows 16*mb2.. of u for node tile(s)
         {
             float* ubuf = smem + L::UBUF;
-            const f32x4 bv = ld4(b3 + 16 * wave + 4 * q);
+            const f32x4 bv = ld4(b3 + 16 * mb2 + 4 * q);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
+            for (int t2 = 0; t2 < (NW == 8 ? 2 : 1); ++t2) {
+                const int tn = NW == 8 ? t2 : wave >> 3;
                 if (16 * tn < n) {
                     f32x4 acc = bv;
 #pragma unroll
@@ -419,30 +420,26 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                         for (int b = 0; b < 4; ++b) acc = mfma16(w3v[a][b], nv[b], acc);
                     }
-                    st4(ubuf + (16 * tn + i) * LDU + 16 * wave + 4 * q, silu4(acc));
+                    st4(ubuf + (16 * tn + i) * LDU + 16 * mb2 + 4 * q, silu4(acc));
                 }
             }
         }
         __syncthreads();       // u complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 4);
-        // step 3: x = n + W4 u + b4: wave w computes rows 16(w&3).. of node tile w>>2
-        {
+        // step 3: x = n + W4 u + b4: rows 16*mb3.. of node tile tn3
+        if (act3 && 16 * tn3 < n) {
             const float* ubuf = smem + L::UBUF;
-            if (16 * tn3 < n) {
-                f32x4 acc = ld4(b4 + 16 * mb3 + 4 * q);
+            f32x4 acc = ld4(b4 + 16 * mb3 + 4 * q);
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    const f32x4 uv = ld4(ubuf + (16 * tn3 + i) * LDU + 16 * a + 4 * q);
+            for (int a = 0; a < 8; ++a) {
+                const f32x4 uv = ld4(ubuf + (16 * tn3 + i) * LDU + 16 * a + 4 * q);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc = mfma16(w4v[a][b], uv[b], acc);
-                }
-                acc += ld4(nbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q);
-                st4(xbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, acc);
-                if constexpr (KEEP) {
-                    if (16 * tn3 + i < n)
-                        st4(dbg.x[layer] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, acc);
-                }
+                for (int b = 0; b < 4; ++b) acc = mfma16(w4v[a][b], uv[b], acc);
             }
+            acc += ld4(nbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q);
+            st4(xbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, acc);
+            if (keep && 16 * tn3 + i < n)
+                st4(dbg.x[layer] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, acc);
         }
         __syncthreads();
         FUSED_STAMP(4 + 8 * (layer - 1) + 5);
@@ -450,19 +447,25 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         if (layer < 4) {
             const float* b1n = P.ln_msg_b0[layer - 1];
             if (16 * tn3 < n) {
-                f32x4 accs = f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 accr = ld4(b1n + 16 * mb3 + 4 * q);
+                f32x4 xv[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const f32x4 xv = ld4(xbuf + (16 * tn3 + i) * LDW + 16 * a + 4 * q);
+                for (int a = 0; a < 4; ++a) xv[a] = ld4(xbuf + (16 * tn3 + i) * LDW + 16 * a + 4 * q);
+                if (NW == 8 || sel4 == 0) {
+                    f32x4 accs = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        accs = mfma16(wsv[a][b], xv[b], accs);
-                        accr = mfma16(wrv[a][b], xv[b], accr);
-                    }
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) accs = mfma16(wsv[a][b], xv[a][b], accs);
+                    st4(psb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accs);
                 }
-                st4(psb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accs);
-                st4(prb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accr);
+                if (NW == 8 || sel4 == 1) {
+                    f32x4 accr = ld4(b1n + 16 * mb3 + 4 * q);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) accr = mfma16(wrv[a][b], xv[a][b], accr);
+                    st4(prb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accr);
+                }
             }
             __syncthreads();   // P_s / P_r and the staged weights are visible to the next edge tiles
             FUSED_STAMP(4 + 8 * (layer - 1) + 6);
@@ -474,8 +477,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     {
         float* o1 = smem + L::OBUF1;
         float* o2 = smem + L::OBUF2;
-        const int mb = wave & 3, tn = wave >> 2;
-        if (16 * tn < n) {
+        const int mb = wave & 3, tn = (wave >> 2) & 1;
+        const bool act = wave < 8 && 16 * tn < n;
+        if (act) {
             f32x4 acc = ld4(P.out_b0 + 16 * mb + 4 * q);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -487,7 +491,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             st4(o1 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
         }
         __syncthreads();
-        if (16 * tn < n) {
+        if (act) {
             f32x4 acc = ld4(P.out_b3 + 16 * mb + 4 * q);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {

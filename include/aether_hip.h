@@ -130,6 +130,12 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
                            const void* workspace, float* dst, void* stream);
 
 /*
+ * Tuning knobs (process-wide; not thread-safe).  "fused_waves": 8 or 16 waves per workgroup of
+ * the fused kernel.
+ */
+int aether_set_option(const char* name, int value);
+
+/*
  * Per-kernel timing for bench.py's roofline line: when enabled, every launch made by
  * aether_forward is bracketed by a pair of HIP events on the launch stream.
  * aether_profile_read synchronises those events, adds up elapsed milliseconds and launch
