@@ -7,11 +7,12 @@
 //   * every edge message tile (16 edges x 64) stays in the owning wave's registers across the four
 //     layers (it is the next layer's MFMA B operand as it stands);
 //   * node state (x, n, P_s, P_r) and the per-layer edge weights live in LDS (padded rows);
-//   * the mean over in-edges needs no workgroup barrier inside a layer and no LDS staging: a tile's
-//     rows sit on the 16 lanes of a DPP row, so the sum over each receiver segment is a masked 4-step
-//     DPP butterfly per register; one partial row per (receiver, tile) goes to LDS and the node
-//     phase adds a node's partial rows in tile order.  Fixed order everywhere: deterministic, no
-//     atomics;
+//   * the mean over in-edges needs no workgroup barrier inside a layer: the wave parks its tile in
+//     16 private LDS rows and multiplies it, transposed, by the tile's 0/1 receiver-segment matrix
+//     on the matrix core (16 extra MFMAs, built once per tile from the graph structure); one
+//     partial row per (receiver, tile) goes to LDS and the node phase adds a node's partial rows in
+//     tile order.  Fixed order everywhere: deterministic, no atomics.  (A masked DPP butterfly was
+//     measured 2-4x slower here: the kernel is VALU-issue-bound, not MFMA-bound.)
 //   * node-level GEMMs are split along their output rows over the waves; their weights come from L2
 //     in MFMA fragment shape (each is used once per group and layer), all issued before the barrier
 //     that ends the edge phase.
@@ -38,13 +39,16 @@ template <int NW> struct FusedLds {          // offsets in floats
     static constexpr int PART_ROWS = FUSED_MAX_NODES + FUSED_MAX_TILES;
     static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [56][LDW]  per-(receiver, tile) sums
     static constexpr int SCRATCH = PART + PART_ROWS * LDW;         // aliased by the regions below
-    static constexpr int SCRATCH_SIZE = NW * 16 * LDF;
+    static constexpr int FEAT_ROWS = 16 * ((FUSED_MAX_TILES + NW - 1) / NW);   // per wave
+    static constexpr int SCRATCH_SIZE =
+        NW * FEAT_ROWS * LDF > NW * 16 * LDW ? NW * FEAT_ROWS * LDF : NW * 16 * LDW;
     static constexpr int TOTAL = SCRATCH + SCRATCH_SIZE;
     static constexpr int FIELD_Z = SCRATCH;                            // [32][24]  p | v | emb
     static constexpr int FIELD_H1 = FIELD_Z + FUSED_MAX_NODES * 24;    // [32][32]
     static constexpr int FIELD_H2 = FIELD_H1 + FUSED_MAX_NODES * 32;   // [32][32]
     static constexpr int FIELD_F = FIELD_H2 + FUSED_MAX_NODES * 32;    // [32][4]
-    static constexpr int FEAT = SCRATCH;                               // [NW waves][16][LDF]
+    static constexpr int FEAT = SCRATCH;                               // [NW waves][FEAT_ROWS][LDF]
+    static constexpr int WSTAGE = SCRATCH;                             // [NW waves][16][LDW] tile staging
     static constexpr int UBUF = SCRATCH;                               // [32][LDU]
     static constexpr int OBUF1 = SCRATCH;                              // [32][LDW]
     static constexpr int OBUF2 = SCRATCH + FUSED_MAX_NODES * LDW;      // [32][LDW]
@@ -82,18 +86,6 @@ constexpr int FUSED_STAMPS = 512;
 #define FUSED_STAMP(id)
 #define FUSED_WSTAMP(layer_, r_, k_)
 #endif
-
-// Sum of v over the 16 lanes of a DPP row (lane & 15 = tile row), result in every lane.
-template <int CTRL> __device__ __forceinline__ float dpp_perm(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row_allreduce16(float v) {
-    v += dpp_perm<0xB1>(v);      // quad_perm [1,0,3,2]  : lane ^ 1
-    v += dpp_perm<0x4E>(v);      // quad_perm [2,3,0,1]  : lane ^ 2
-    v += dpp_perm<0x141>(v);     // row_half_mirror      : the other quad of the 8-lane half
-    v += dpp_perm<0x140>(v);     // row_mirror           : the other half of the row
-    return v;
-}
 
 template <int D, int NW, int ROUNDS>
 __global__ void __launch_bounds__(NW * 64)
@@ -225,53 +217,78 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     // Wave w owns tiles {w, w+NW, ..}.  Per tile, 16 lanes each build the features of one edge into
     // the wave's scratch rows; then every lane reads its B fragments back.  Per-tile constants of
     // the graph structure (sender / receiver slot, receiver-segment index) are computed once here.
-    int sl[ROUNDS], rl[ROUNDS], segi[ROUNDS], nseg[ROUNDS];
+    int sl[ROUNDS], rl[ROUNDS];
+    unsigned selbits[ROUNDS];                // bit s4: S[seg = i][edge = 4*s4 + q] of the tile
+    unsigned destpack[ROUNDS];               // byte r4: partial row of segment 4q + r4, 0xFF = none
     f32x4 e[ROUNDS][4];                      // message tiles, MFMA accumulator layout
     {
-        float* scratch = smem + L::FEAT + wave * (16 * LDF);
+        float* scratch = smem + L::FEAT + wave * (L::FEAT_ROWS * LDF);
+        if (lane < 16 * ROUNDS) {
+            const int r = lane >> 4, ii = lane & 15;
+            const int local = 16 * (NW * r + wave) + ii;
+            float o[FPAD];
+            if (local < m) {
+                const int k = eb + local;
+                const float* nj = ninfo + (send_s[k] - nb) * 24;
+                const float* nr = ninfo + (recv_s[k] - nb) * 24;
+                float njl[NI::STRIDE], nrl[NI::STRIDE];
+#pragma unroll
+                for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
+                const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                float eal[2] = {ea[0], ea[1]};
+                edge_features<D>(njl, nrl, eal, o);
+            } else {
+#pragma unroll
+                for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < FPAD; t += 4)
+                st4(scratch + lane * LDF + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
+            e[r][0] = ld4(scratch + (16 * r + i) * LDF + 4 * q);   // features as bop[0..1]
+            e[r][1] = ld4(scratch + (16 * r + i) * LDF + 16 + 4 * q);
+            e[r][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile = NW * r + wave;
             const int local = 16 * tile + i;
             const bool valid = local < m;
             const int k = eb + (valid ? local : 0);
             sl[r] = m > 0 ? send_s[k] - nb : 0;
             rl[r] = m > 0 ? recv_s[k] - nb : 0;
-            if (tile < n_tiles && lane < 16) {
-                float o[FPAD];
-                if (valid) {
-                    const float* nj = ninfo + sl[r] * 24;
-                    const float* nr = ninfo + rl[r] * 24;
-                    float njl[NI::STRIDE], nrl[NI::STRIDE];
-#pragma unroll
-                    for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
-                    const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
-                    float eal[2] = {ea[0], ea[1]};
-                    edge_features<D>(njl, nrl, eal, o);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
-                }
-#pragma unroll
-                for (int t = 0; t < FPAD; t += 4)
-                    st4(scratch + lane * LDF + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
-            }
-            __builtin_amdgcn_wave_barrier();
-            e[r][0] = ld4(scratch + i * LDF + 4 * q);              // features as bop[0..1]
-            e[r][1] = ld4(scratch + i * LDF + 16 + 4 * q);
-            e[r][2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_wave_barrier();
-            // receiver segments of the tile (rows are receiver-sorted): segment index per row,
-            // padding rows get an index no segment loop reaches
+            // Receiver segments of the tile (rows are receiver-sorted).  smask bit j: row j starts a
+            // new segment; segment ids count up in row order; padding rows belong to no segment.
             const int rcv = valid ? rl[r] : -1;
             const int prev = __shfl_up(rcv, 1, 16);
             const unsigned smask = (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;
-            const int sidx = __popc(smask & ((2u << i) - 1u));
-            segi[r] = valid ? sidx : 99;
             const unsigned vmask = (unsigned)__ballot(q == 0 && valid) & 0xFFFFu;
-            // number of segments that contain valid rows (valid rows come first)
-            nseg[r] = vmask ? __popc(smask & vmask) + 1 : 0;
+            unsigned sb = 0, dp = 0;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int edge = 4 * s4 + q;
+                const int seg_of_edge = __popc(smask & ((2u << edge) - 1u));
+                if (((vmask >> edge) & 1u) && seg_of_edge == i) sb |= 1u << s4;
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int seg = 4 * q + r4;
+                // first row of segment `seg`: row 0 for segment 0, else the seg-th set bit of smask
+                unsigned mm = smask;
+                int s0 = 0;
+                bool exists = true;
+                for (int t = 0; t < seg; ++t) {
+                    if (mm == 0) { exists = false; break; }
+                    s0 = __ffs(mm) - 1;
+                    mm &= mm - 1;
+                }
+                const int node = __shfl(rl[r], (lane & 48) + s0);          // receiver slot of row s0
+                const unsigned row = (exists && ((vmask >> s0) & 1u)) ? (unsigned)(node + tile) : 0xFFu;
+                dp |= row << (8 * r4);
+            }
+            selbits[r] = sb;
+            destpack[r] = dp;
         }
         __syncthreads();       // feature scratch (aliases SCRATCH) is dead from here on
     }
@@ -331,21 +348,34 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     }
                 }
                 FUSED_WSTAMP(layer, r, 4);
-                // per-receiver sums of the tile: masked DPP butterfly over the 16 rows, one partial
-                // row per (receiver, tile); lanes 0..3 of each DPP row store 16 bytes each
-                const int ns = __builtin_amdgcn_readfirstlane(nseg[r]);
-                for (int sg = 0; sg < ns; ++sg) {
-                    const bool mine = segi[r] == sg;
-                    const int first = __ffsll((unsigned long long)__ballot(mine)) - 1;
-                    const int node = __builtin_amdgcn_readlane(rl[r], first);
+                // Per-receiver sums of the tile on the matrix core: park the tile in the wave's 16
+                // private LDS rows, read it back transposed and multiply by the 0/1 segment matrix,
+                // out[seg][h] = sum_edge S[seg][edge] * E[edge][h]  (k runs in edge order).
+                {
+                    float* wst = smem + L::WSTAGE + wave * (16 * LDW);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) st4(wst + i * LDW + 16 * mb + 4 * q, e[r][mb]);
+                    __builtin_amdgcn_wave_barrier();
                     f32x4 red[4];
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
+                    for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) red[mb][c] = row_allreduce16(mine ? e[r][mb][c] : 0.0f);
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const float sel = (selbits[r] >> s4) & 1u ? 1.0f : 0.0f;
+                        const float* erow = wst + (4 * s4 + q) * LDW + i;
+#pragma unroll
+                        for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = mfma16(sel, erow[16 * nbk], red[nbk]);
                     }
-                    const f32x4 pick = i == 0 ? red[0] : (i == 1 ? red[1] : (i == 2 ? red[2] : red[3]));
-                    if (i < 4) st4(part + (node + tile) * LDW + 16 * i + 4 * q, pick);
+                    // lane (h = 16 nbk + i, q) register r4 holds segment 4q + r4
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const unsigned row = (destpack[r] >> (8 * r4)) & 0xFFu;
+                        if (row != 0xFFu) {
+                            float* dst = part + row * LDW + i;
+                            dst[0] = red[0][r4]; dst[16] = red[1][r4]; dst[32] = red[2][r4]; dst[48] = red[3][r4];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 FUSED_WSTAMP(layer, r, 5);
             }
