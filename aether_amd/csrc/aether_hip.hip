@@ -165,7 +165,8 @@ struct WsLayout {
 
 inline int bits_for(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
-int g_fused_waves = 8;        // aether_set_option("fused_waves", 8 | 16)
+int g_fused_waves = 8;
+int g_edge_minw = 2;          // aether_set_option("edge_min_waves", 2 | 3 | 4): occupancy target of k_edge_layer        // aether_set_option("fused_waves", 8 | 16)
 
 template <int D, int NW, int ROUNDS>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
@@ -256,10 +257,14 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
             int64_t wgs = (n_tiles + 3) / 4;
             unsigned g = (unsigned)(wgs < 1024 ? wgs : 1024);
             ProfScope ps(K_EDGE_LN, st);
-            k_edge_layer<<<dim3(g), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2],
-                                                         P.ln_msg_b2[l - 2], wp(W.ps[l - 2]),
-                                                         wp(W.pr[l - 2]), wp(W.e[l - 2]), send_s, recv_s,
-                                                         wp(W.e[l - 1]), E);
+            auto launch = [&](auto kern) {
+                kern<<<dim3(g), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2],
+                                                     P.ln_msg_b2[l - 2], wp(W.ps[l - 2]), wp(W.pr[l - 2]),
+                                                     wp(W.e[l - 2]), send_s, recv_s, wp(W.e[l - 1]), E);
+            };
+            if (g_edge_minw == 4) launch(k_edge_layer<4>);
+            else if (g_edge_minw == 3) launch(k_edge_layer<3>);
+            else launch(k_edge_layer<2>);
         }
         if (l < 4) {
             ProfScope ps(K_NODE_UPDATE, st);
@@ -290,6 +295,11 @@ int aether_set_option(const char* name, int value) {
     if (!strcmp(name, "fused_waves")) {
         if (value != 8 && value != 16) return fail(AETHER_EINVAL, "set_option: fused_waves must be 8 or 16");
         g_fused_waves = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "edge_min_waves")) {
+        if (value < 2 || value > 4) return fail(AETHER_EINVAL, "set_option: edge_min_waves must be 2..4");
+        g_edge_minw = value;
         return AETHER_OK;
     }
     return fail(AETHER_EINVAL, "set_option: unknown option");

@@ -160,7 +160,11 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
 // ------------------------------------------------------------------ K3: layers 2-4 edge kernel
 // e_l = SiLU(W2 SiLU(W_s x_s + W_r x_r + b1 + W_e e_{l-1}) + b2), locs.py:227-235 with the
 // node terms P_s = W_s x, P_r = W_r x + b1 gathered as the accumulator's initial value.
-__global__ void __launch_bounds__(256)
+// Weights: staged once per workgroup in LDS, then each wave keeps its MFMA A fragments of W_e and
+// W2 in registers (128 VGPRs) for all its tiles.  Inputs of the next tile (indices two tiles ahead,
+// gathered rows one tile ahead) are in flight while the current tile's 128 MFMAs issue.
+template <int MINW>
+__global__ void __launch_bounds__(256, MINW)
 k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
              const float* __restrict__ b_msg2, const float* __restrict__ Ps,
              const float* __restrict__ Pr, const float* __restrict__ e_prev,
@@ -178,25 +182,64 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
     const int i = lane & 15, q = lane >> 4;
     const int64_t n_tiles = (n_edges + 15) / 16;
     const int64_t stride = (int64_t)gridDim.x * 4;
-    f32x4 b2v[4];
+    f32x4 wef[4][4], w2f[4][4], b2v[4];     // [a][mb] fragments
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) b2v[mb] = ld4(bias + 16 * mb + 4 * q);
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
-        const int64_t k = tile * 16 + i;
-        const int64_t kc = k < n_edges ? k : n_edges - 1;
-        const int64_t s = send_s[kc], r = recv_s[kc];
-        f32x4 acc[4], bop[4], acc2[4];
+    for (int a = 0; a < 4; ++a) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            acc[mb] = ld4(Ps + s * H + 16 * mb + 4 * q) + ld4(Pr + r * H + 16 * mb + 4 * q);
-            bop[mb] = ld4(e_prev + kc * H + 16 * mb + 4 * q);
-            acc2[mb] = b2v[mb];
+            wef[a][mb] = ld4(we + (16 * mb + i) * LDW + 16 * a + 4 * q);
+            w2f[a][mb] = ld4(w2 + (16 * mb + i) * LDW + 16 * a + 4 * q);
         }
-        gemm_tile<4, 4>(we, LDW, bop, acc, i, q);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) b2v[mb] = ld4(bias + 16 * mb + 4 * q);
+
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;
+    auto clampk = [&](int64_t t) { int64_t k = t * 16 + i; return k < n_edges ? k : n_edges - 1; };
+    // software pipeline: (s1, r1) = indices of tile+stride; (ps, pr, ev) = rows of the current tile
+    int64_t kc = clampk(tile);
+    int32_t s0 = send_s[kc], r0 = recv_s[kc];
+    f32x4 psv[4], prv[4], ev[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        psv[mb] = ld4(Ps + (int64_t)s0 * H + 16 * mb + 4 * q);
+        prv[mb] = ld4(Pr + (int64_t)r0 * H + 16 * mb + 4 * q);
+        ev[mb] = ld4(e_prev + kc * H + 16 * mb + 4 * q);
+    }
+    int64_t kn = clampk(tile + stride < n_tiles ? tile + stride : tile);
+    int32_t s1 = send_s[kn], r1 = recv_s[kn];
+    for (; tile < n_tiles; tile += stride) {
+        f32x4 acc[4], bop[4], acc2[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { acc[mb] = psv[mb] + prv[mb]; bop[mb] = ev[mb]; acc2[mb] = b2v[mb]; }
+        // issue the next tile's row gathers and the indices of the tile after it
+        const int64_t k = tile * 16 + i;
+        const int64_t kn2 = clampk(tile + 2 * stride < n_tiles ? tile + 2 * stride : tile);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            psv[mb] = ld4(Ps + (int64_t)s1 * H + 16 * mb + 4 * q);
+            prv[mb] = ld4(Pr + (int64_t)r1 * H + 16 * mb + 4 * q);
+            ev[mb] = ld4(e_prev + kn * H + 16 * mb + 4 * q);
+        }
+        kn = kn2;
+        s1 = send_s[kn2];
+        r1 = recv_s[kn2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma16(wef[a][mb][b], bop[a][b], acc[mb]);
         f32x4 h1[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
-        gemm_tile<4, 4>(w2, LDW, h1, acc2, i, q);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc2[mb] = mfma16(w2f[a][mb][b], h1[a][b], acc2[mb]);
         if (k < n_edges) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, silu4(acc2[mb]));
