@@ -166,7 +166,7 @@ struct WsLayout {
 inline int bits_for(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
 int g_fused_waves = 8;
-int g_edge_minw = 2;          // aether_set_option("edge_min_waves", 2 | 3 | 4): occupancy target of k_edge_layer        // aether_set_option("fused_waves", 8 | 16)
+int g_edge_variant = 0;       // aether_set_option("edge_variant", n): scheduling experiments of k_edge_layer        // aether_set_option("fused_waves", 8 | 16)
 
 template <int D, int NW, int ROUNDS>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
@@ -262,9 +262,9 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
                                                      P.ln_msg_b2[l - 2], wp(W.ps[l - 2]), wp(W.pr[l - 2]),
                                                      wp(W.e[l - 2]), send_s, recv_s, wp(W.e[l - 1]), E);
             };
-            if (g_edge_minw == 4) launch(k_edge_layer<4>);
-            else if (g_edge_minw == 3) launch(k_edge_layer<3>);
-            else launch(k_edge_layer<2>);
+            if (g_edge_variant == 1) launch(k_edge_layer<2, 1>);
+            else if (g_edge_variant == 2) launch(k_edge_layer<2, 2>);
+            else launch(k_edge_layer<2, 0>);
         }
         if (l < 4) {
             ProfScope ps(K_NODE_UPDATE, st);
@@ -297,9 +297,9 @@ int aether_set_option(const char* name, int value) {
         g_fused_waves = value;
         return AETHER_OK;
     }
-    if (!strcmp(name, "edge_min_waves")) {
-        if (value < 2 || value > 4) return fail(AETHER_EINVAL, "set_option: edge_min_waves must be 2..4");
-        g_edge_minw = value;
+    if (!strcmp(name, "edge_variant")) {
+        if (value < 0 || value > 2) return fail(AETHER_EINVAL, "set_option: edge_variant must be 0..2");
+        g_edge_variant = value;
         return AETHER_OK;
     }
     return fail(AETHER_EINVAL, "set_option: unknown option");

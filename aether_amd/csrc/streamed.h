@@ -163,7 +163,7 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
 // Weights: staged once per workgroup in LDS, then each wave keeps its MFMA A fragments of W_e and
 // W2 in registers (128 VGPRs) for all its tiles.  Inputs of the next tile (indices two tiles ahead,
 // gathered rows one tile ahead) are in flight while the current tile's 128 MFMAs issue.
-template <int MINW>
+template <int MINW, int VAR>
 __global__ void __launch_bounds__(256, MINW)
 k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
              const float* __restrict__ b_msg2, const float* __restrict__ Ps,
@@ -225,21 +225,29 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
         kn = kn2;
         s1 = send_s[kn2];
         r1 = recv_s[kn2];
+        if (VAR == 1) __builtin_amdgcn_sched_barrier(0);
+        if (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma16(wef[a][mb][b], bop[a][b], acc[mb]);
+        if (VAR == 1) __builtin_amdgcn_sched_barrier(0);
+        if (VAR == 2) __builtin_amdgcn_s_setprio(0);
         f32x4 h1[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
+        if (VAR == 1) __builtin_amdgcn_sched_barrier(0);
+        if (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc2[mb] = mfma16(w2f[a][mb][b], h1[a][b], acc2[mb]);
+        if (VAR == 1) __builtin_amdgcn_sched_barrier(0);
+        if (VAR == 2) __builtin_amdgcn_s_setprio(0);
         if (k < n_edges) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, silu4(acc2[mb]));
