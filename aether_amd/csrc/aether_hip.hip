@@ -262,9 +262,8 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
                                                      P.ln_msg_b2[l - 2], wp(W.ps[l - 2]), wp(W.pr[l - 2]),
                                                      wp(W.e[l - 2]), send_s, recv_s, wp(W.e[l - 1]), E);
             };
-            if (g_edge_variant == 1) launch(k_edge_layer<2, 1>);
-            else if (g_edge_variant == 2) launch(k_edge_layer<2, 2>);
-            else launch(k_edge_layer<2, 0>);
+            if (g_edge_variant == 1) launch(k_edge_layer<false>);
+            else launch(k_edge_layer<true>);
         }
         if (l < 4) {
             ProfScope ps(K_NODE_UPDATE, st);
