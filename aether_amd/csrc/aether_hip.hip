@@ -166,7 +166,8 @@ struct WsLayout {
 inline int bits_for(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
 int g_fused_waves = 8;
-int g_edge_variant = 0;       // aether_set_option("edge_variant", n): scheduling experiments of k_edge_layer        // aether_set_option("fused_waves", 8 | 16)
+int g_edge_variant = 1;       // aether_set_option("edge_variant", 0|1): 0 = weights in registers, 2 waves/SIMD;
+                              // 1 = weights re-read from LDS, 3 waves/SIMD, deferred stores (faster: 411 vs 457 us @2.5M edges)        // aether_set_option("fused_waves", 8 | 16)
 
 template <int D, int NW, int ROUNDS>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
