@@ -30,6 +30,7 @@
 #include "common.h"
 #include "streamed.h"
 #include "fused.h"
+#include "backward.h"
 
 #include <vector>
 
@@ -91,6 +92,23 @@ __global__ void k_graph_keys(const int64_t* __restrict__ send, const int64_t* __
     vals[k] = (int32_t)k;
 }
 
+__global__ void k_iota(int32_t* __restrict__ v, int64_t n) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) v[k] = (int32_t)k;
+}
+
+// rowptr of a sorted key array (covers empty rows)
+__global__ void k_rowptr(const int32_t* __restrict__ keys_sorted, int64_t n, int64_t n_rows,
+                         int32_t* __restrict__ rowptr) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int32_t r = keys_sorted[k];
+    int32_t rp = k == 0 ? -1 : keys_sorted[k - 1];
+    for (int32_t j = rp + 1; j <= r; ++j) rowptr[j] = (int32_t)k;
+    if (k == n - 1)
+        for (int64_t j = r + 1; j <= n_rows; ++j) rowptr[j] = (int32_t)n;
+}
+
 // Component detection: an edge (s, r) "crosses" every boundary n with min < n <= max.
 // diff is a difference array; its inclusive prefix sum is the number of crossing edges.
 __global__ void k_graph_cross(const int64_t* __restrict__ send, const int64_t* __restrict__ recv,
@@ -122,7 +140,8 @@ __global__ void k_graph_finish(const int64_t* __restrict__ send, const int32_t* 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GraphLayout {
-    size_t perm, send_s, recv_s, rowptr, groups, keys, vals, diff, cross, flag, cub, total, cub_bytes;
+    size_t perm, send_s, recv_s, rowptr, groups, sperm, srowptr, keys, vals, diff, cross, flag, cub, total,
+        cub_bytes;
     GraphLayout(int64_t E, int64_t Nn, bool with_sort_scratch = true) {
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -130,6 +149,8 @@ struct GraphLayout {
         perm = take(e4); send_s = take(e4); recv_s = take(e4);
         rowptr = take((size_t)(Nn + 1) * 4);
         groups = take((size_t)(Nn + 1) * 4);
+        sperm = take(e4);                       // receiver-sorted positions grouped by sender (stable)
+        srowptr = take((size_t)(Nn + 1) * 4);
         keys = take(e4); vals = take(e4);
         diff = take((size_t)(Nn + 2) * 4); cross = take((size_t)(Nn + 2) * 4);
         flag = take(256);
@@ -147,19 +168,38 @@ struct GraphLayout {
     }
 };
 
+constexpr int OUTER_MAX_CHUNKS = 64;
+
 struct WsLayout {
-    size_t nodeinfo, x[5], ps[3], pr[3], e[4], feat, stamps, total;
-    WsLayout(int64_t Nn, int64_t E, int D, bool debug_feat) {
+    // forward (always)
+    size_t nodeinfo, x[5], ps[3], pr[3], e[4], stamps, fwd_total;
+    // saved by the forward under KEEP_INTERMEDIATES for the backward
+    size_t n[4], feat;
+    // backward temporaries
+    size_t DX, DN, U, DPU, O1, O2, DPO1, DPO2, DY, DE, G, H1, DP2, DA, DPS, DPR, RELF, Z, H1f, H2f, DPH1,
+        DPH2, DF, DZE, ONEHOT, partial;
+    size_t total;
+    WsLayout(int64_t Nn, int64_t E, int D, bool training) {
         size_t off = 0;
         auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-        nodeinfo = take((size_t)Nn * (D == 2 ? 16 : 24));
-        for (auto& v : x) v = take((size_t)Nn * H);
-        for (auto& v : ps) v = take((size_t)Nn * H);
-        for (auto& v : pr) v = take((size_t)Nn * H);
-        for (auto& v : e) v = take((size_t)E * H);
-        feat = debug_feat ? take((size_t)E * FPAD) : 0;
+        const size_t nn = (size_t)Nn, ee = (size_t)E;
+        nodeinfo = take(nn * (D == 2 ? 16 : 24));
+        for (auto& v : x) v = take(nn * H);
+        for (auto& v : ps) v = take(nn * H);
+        for (auto& v : pr) v = take(nn * H);
+        for (auto& v : e) v = take(ee * H);
         stamps = take((size_t)4096 * FUSED_STAMPS);
-        total = off;
+        fwd_total = off;
+        for (auto& v : n) v = take(nn * H);
+        feat = take(ee * FPAD);
+        DX = take(nn * H); DN = take(nn * H); U = take(nn * 2 * H); DPU = take(nn * 2 * H);
+        O1 = take(nn * H); O2 = take(nn * H); DPO1 = take(nn * H); DPO2 = take(nn * H); DY = take(nn * 16);
+        DE = take(ee * H); G = take(ee * H); H1 = take(ee * H); DP2 = take(ee * H); DA = take(ee * FPAD);
+        DPS = take(nn * H); DPR = take(nn * H); RELF = take(nn * 16);
+        Z = take(nn * 32); H1f = take(nn * 32); H2f = take(nn * 32); DPH1 = take(nn * 32); DPH2 = take(nn * 32);
+        DF = take(nn * 16); DZE = take(nn * 16); ONEHOT = take(nn * 16);
+        partial = take((size_t)OUTER_MAX_TASKS * OUTER_MAX_CHUNKS * 64 * 272);
+        total = training ? off : fwd_total;
     }
 };
 
@@ -193,13 +233,16 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
                const float* vel, const float* charges, const float* ea, const char* graph, char* ws,
                float* out, bool keep, hipStream_t st) {
     GraphLayout G(E, Nn, false);
-    WsLayout W(Nn, E, D, false);
+    WsLayout W(Nn, E, D, keep);
     auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
     auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     FusedDebug dbg;
     dbg.nodeinfo = wp(W.nodeinfo);
     for (int k = 0; k < 5; ++k) dbg.x[k] = wp(W.x[k]);
     for (int k = 0; k < 4; ++k) dbg.e[k] = wp(W.e[k]);
+    for (int k = 0; k < 4; ++k) dbg.n[k] = wp(W.n[k]);
+    for (int k = 0; k < 3; ++k) { dbg.ps[k] = wp(W.ps[k]); dbg.pr[k] = wp(W.pr[k]); }
+    dbg.feat = wp(W.feat);
     dbg.stamps = wp(W.stamps);
     const int tiles = (info.max_group_edges + 15) / 16;
     const int nw = g_fused_waves;
@@ -224,9 +267,9 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
 template <int D>
 int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, const float* vel,
                   const float* charges, const float* ea, const char* graph, char* ws, float* out,
-                  hipStream_t st) {
+                  bool keep, hipStream_t st) {
     GraphLayout G(E, Nn, false);
-    WsLayout W(Nn, E, D, false);
+    WsLayout W(Nn, E, D, keep);
     auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
     auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int32_t *perm = gp(G.perm), *send_s = gp(G.send_s), *recv_s = gp(G.recv_s), *rowptr = gp(G.rowptr);
@@ -245,12 +288,13 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
         unsigned g1 = (unsigned)(n_chunks < 2048 ? n_chunks : 2048);
         ProfScope ps(K_EDGE_L1, st);
         k_edge_layer1<D><<<dim3(g1), dim3(256), lds1, st>>>(P, nodeinfo, ea, perm, send_s, recv_s,
-                                                           wp(W.e[0]), nullptr, E);
+                                                           wp(W.e[0]), keep ? wp(W.feat) : nullptr, E);
     }
     {
         ProfScope ps(K_NODE_UPDATE, st);
         k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
-        P, 1, wp(W.x[0]), wp(W.e[0]), rowptr, wp(W.x[1]), wp(W.ps[0]), wp(W.pr[0]), nodeinfo, x, out, Nn);
+        P, 1, wp(W.x[0]), wp(W.e[0]), rowptr, wp(W.x[1]), wp(W.ps[0]), wp(W.pr[0]), nodeinfo, x, out,
+        keep ? wp(W.n[0]) : nullptr, Nn);
     }
     for (int l = 2; l <= 4; ++l) {
         if (E > 0) {
@@ -270,12 +314,157 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
             ProfScope ps(K_NODE_UPDATE, st);
             k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.e[l - 1]), rowptr, wp(W.x[l]), wp(W.ps[l - 1]), wp(W.pr[l - 1]),
-                nodeinfo, x, out, Nn);
+                nodeinfo, x, out, keep ? wp(W.n[l - 1]) : nullptr, Nn);
         } else {
             ProfScope ps(K_NODE_LAST, st);
             k_node_update<D, true><<<dim3(node_grid), dim3(64), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.e[l - 1]), rowptr, wp(W.x[l]), nullptr, nullptr, nodeinfo, x,
-                out, Nn);
+                out, keep ? wp(W.n[l - 1]) : nullptr, Nn);
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+// ------------------------------------------------------------------ backward orchestration
+struct OuterList {
+    OuterBatch b;
+    OuterList() { b.n_tasks = 0; b.chunks = 1; }
+    void add(const float* A, int lda, int M, const float* B, int ldb, int N, int64_t rows, float* C, int ldc,
+             float* bias) {
+        OuterTask& t = b.t[b.n_tasks++];
+        t.A = A; t.B = B; t.C = C; t.bias = bias; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.M = M; t.N = N;
+        t.rows = rows;
+    }
+};
+
+int run_outer(OuterList& L, float* partial, hipStream_t st) {
+    if (L.b.n_tasks == 0) return AETHER_OK;
+    int64_t max_tiles = 1;
+    int max_blocks = 1;
+    for (int k = 0; k < L.b.n_tasks; ++k) {
+        int64_t tiles = (L.b.t[k].rows + 15) / 16;
+        if (tiles > max_tiles) max_tiles = tiles;
+        int blocks = ((L.b.t[k].M + 15) / 16) * ((L.b.t[k].N + 15) / 16);
+        if (blocks > max_blocks) max_blocks = blocks;
+    }
+    int64_t chunks = (max_tiles + 31) / 32;             // >= 8 tiles per wave and chunk
+    if (chunks < 1) chunks = 1;
+    if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
+    L.b.chunks = (int)chunks;
+    k_outer<<<dim3((unsigned)max_blocks, (unsigned)chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
+    k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
+    return AETHER_OK;
+}
+
+template <int D>
+int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int64_t E, const float* x,
+                  const float* vel, const float* charges, const char* graph, char* ws, const float* g_out,
+                  hipStream_t st) {
+    constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+    constexpr int FIN = 2 * D + 16;
+    GraphLayout G(E, Nn, false);
+    WsLayout W(Nn, E, D, true);
+    auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
+    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int32_t *send_s = gp(G.send_s), *recv_s = gp(G.recv_s), *rowptr = gp(G.rowptr);
+    const int32_t *sperm = gp(G.sperm), *srowptr = gp(G.srowptr);
+    float* partial = wp(W.partial);
+    const int64_t ntile = (Nn + 15) / 16, etile = (E + 15) / 16;
+    const unsigned ngrid = (unsigned)((ntile + 3) / 4 < 512 ? (ntile + 3) / 4 : 512);
+    const unsigned egrid = (unsigned)((etile + 3) / 4 < 1024 ? (etile + 3) / 4 : 1024);
+    auto optin = [&](const void* k, size_t lds) -> int {
+        HIP_OK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        return AETHER_OK;
+    };
+    // ---- out MLP
+    {
+        const size_t lds = (size_t)(4 * H * LDW + H * 20) * 4;
+        if (optin(reinterpret_cast<const void*>(kb_out<D>), lds)) return AETHER_EHIP;
+        kb_out<D><<<dim3(ngrid), dim3(256), lds, st>>>(P, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DX), wp(W.O1),
+                                                      wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn);
+        OuterList L;
+        L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
+        L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
+        L.add(wp(W.DY), 16, D, wp(W.O2), H, H, Nn, Gr.out_w6, H, Gr.out_b6);
+        run_outer(L, partial, st);
+    }
+    for (int l = 4; l >= 1; --l) {
+        const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
+        const float* b3 = l == 1 ? P.l1_upd_b0 : P.ln_upd_b0[l - 2];
+        const float* w4 = l == 1 ? P.l1_upd_w2 : P.ln_upd_w2[l - 2];
+        float* gw3 = l == 1 ? Gr.l1_upd_w0 : Gr.ln_upd_w0[l - 2];
+        float* gb3 = l == 1 ? Gr.l1_upd_b0 : Gr.ln_upd_b0[l - 2];
+        float* gw4 = l == 1 ? Gr.l1_upd_w2 : Gr.ln_upd_w2[l - 2];
+        float* gb4 = l == 1 ? Gr.l1_upd_b2 : Gr.ln_upd_b2[l - 2];
+        const float* w2 = l == 1 ? P.l1_msg_w2 : P.ln_msg_w2[l - 2];
+        const float* b2 = l == 1 ? P.l1_msg_b2 : P.ln_msg_b2[l - 2];
+        float* gw2 = l == 1 ? Gr.l1_msg_w2 : Gr.ln_msg_w2[l - 2];
+        float* gb2 = l == 1 ? Gr.l1_msg_b2 : Gr.ln_msg_b2[l - 2];
+        // ---- node update: dx_l -> dn_l
+        {
+            const size_t lds = (size_t)(2 * 2 * H * LDW + H * (2 * H + 4)) * 4;
+            if (optin(reinterpret_cast<const void*>(kb_node), lds)) return AETHER_EHIP;
+            kb_node<<<dim3(ngrid), dim3(256), lds, st>>>(w3, b3, w4, wp(W.n[l - 1]), wp(W.DX), wp(W.DN), wp(W.U),
+                                                        wp(W.DPU), Nn);
+            OuterList L;
+            L.add(wp(W.DX), H, H, wp(W.U), 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
+            L.add(wp(W.DPU), 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
+            run_outer(L, partial, st);
+        }
+        // ---- edge MLP
+        if (E > 0) {
+            const size_t lds = (size_t)(4 * H * LDW) * 4;
+            if (l == 1) {
+                if (optin(reinterpret_cast<const void*>(kb_edge<true>), lds)) return AETHER_EHIP;
+                kb_edge<true><<<dim3(egrid), dim3(256), lds, st>>>(
+                    P.l1_msg_w0, F1, P.l1_msg_b0, w2, b2, nullptr, nullptr, nullptr, wp(W.feat), send_s, recv_s,
+                    rowptr, wp(W.DN), wp(W.DE), 1, wp(W.G), wp(W.H1), wp(W.DP2), wp(W.DA), E);
+            } else {
+                if (optin(reinterpret_cast<const void*>(kb_edge<false>), lds)) return AETHER_EHIP;
+                kb_edge<false><<<dim3(egrid), dim3(256), lds, st>>>(
+                    P.ln_msg_w0[l - 2], 0, nullptr, w2, b2, wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]),
+                    nullptr, send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), l < 4 ? 1 : 0, wp(W.G), wp(W.H1),
+                    wp(W.DP2), nullptr, E);
+            }
+            OuterList L;
+            L.add(wp(W.DP2), H, H, wp(W.H1), H, H, E, gw2, H, gb2);
+            if (l == 1) L.add(wp(W.G), H, H, wp(W.feat), FPAD, F1, E, Gr.l1_msg_w0, F1, Gr.l1_msg_b0);
+            else L.add(wp(W.G), H, H, wp(W.e[l - 2]), H, H, E, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
+            run_outer(L, partial, st);
+        } else {
+            HIP_OK(hipMemsetAsync(gw2, 0, (size_t)H * H * 4, st));
+            HIP_OK(hipMemsetAsync(gb2, 0, (size_t)H * 4, st));
+            if (l == 1) {
+                HIP_OK(hipMemsetAsync(Gr.l1_msg_w0, 0, (size_t)H * F1 * 4, st));
+                HIP_OK(hipMemsetAsync(Gr.l1_msg_b0, 0, (size_t)H * 4, st));
+            }
+        }
+        if (l >= 2) {
+            // ---- gather G onto nodes: dx_{l-1}
+            const size_t lds = (size_t)(2 * H * LDW) * 4;
+            if (optin(reinterpret_cast<const void*>(kb_gather), lds)) return AETHER_EHIP;
+            if (E == 0) HIP_OK(hipMemsetAsync(wp(W.G), 0, 4, st));
+            kb_gather<<<dim3(ngrid), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], wp(W.G), rowptr, srowptr, sperm,
+                                                          wp(W.DN), wp(W.DX), wp(W.DPS), wp(W.DPR), Nn);
+            OuterList L;
+            L.add(wp(W.DPS), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
+            L.add(wp(W.DPR), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
+            if (E == 0) L.add(wp(W.DPS), H, H, wp(W.DPS), H, H, 0, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
+            run_outer(L, partial, st);
+        } else {
+            // ---- res + field net
+            kb_field<D><<<dim3((unsigned)((Nn + 255) / 256)), dim3(256), 0, st>>>(
+                P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
+                wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
+                wp(W.ONEHOT), Nn);
+            OuterList L;
+            L.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
+            L.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
+            L.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
+            L.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
+            L.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
+            run_outer(L, partial, st);
         }
     }
     HIP_OK(hipGetLastError());
@@ -354,6 +543,7 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
     HIP_OK(hipMemsetAsync(flag, 0, 4, st));
     if (n_edges == 0) {
         HIP_OK(hipMemsetAsync(rowptr, 0, (size_t)(n_nodes + 1) * 4, st));
+        HIP_OK(hipMemsetAsync(g + G.srowptr, 0, (size_t)(n_nodes + 1) * 4, st));
         HIP_OK(hipStreamSynchronize(st));
         return AETHER_OK;
     }
@@ -367,6 +557,15 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
                                               (int)n_edges, 0, bits_for(n_nodes), st));
     k_graph_finish<<<dim3(blocks), dim3(256), 0, st>>>(send, recv_s, perm, n_edges, n_nodes,
                                                       (int32_t*)(g + G.send_s), rowptr);
+    // sender lists for the backward: stable sort of the receiver-sorted positions by sender
+    {
+        int32_t* send_s = (int32_t*)(g + G.send_s);
+        k_iota<<<dim3(blocks), dim3(256), 0, st>>>(vals, n_edges);
+        size_t cb = G.cub_bytes;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(g + G.cub, cb, send_s, keys, vals, (int32_t*)(g + G.sperm),
+                                                  (int)n_edges, 0, bits_for(n_nodes), st));
+        k_rowptr<<<dim3(blocks), dim3(256), 0, st>>>(keys, n_edges, n_nodes, (int32_t*)(g + G.srowptr));
+    }
     HIP_OK(hipGetLastError());
     int32_t bad = 0;
     HIP_OK(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, st));
@@ -438,9 +637,8 @@ int aether_graph_perm(const void* graph, int64_t n_edges, int64_t n_nodes, int32
 }
 
 size_t aether_workspace_bytes(int64_t n_nodes, int64_t n_edges, int num_dims, int keep_for_backward) {
-    (void)keep_for_backward;
     if (n_nodes <= 0 || n_edges < 0 || (num_dims != 2 && num_dims != 3)) return 0;
-    return WsLayout(n_nodes, n_edges, num_dims, false).total;
+    return WsLayout(n_nodes, n_edges, num_dims, keep_for_backward != 0).total;
 }
 
 int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
@@ -454,7 +652,8 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
     if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "forward: num_dims must be 2 or 3");
     if (n_nodes <= 0 || n_edges < 0) return fail(AETHER_EINVAL, "forward: bad sizes");
     if (n_edges > 0 && !edge_attr_orig) return fail(AETHER_EINVAL, "forward: null edge_attr");
-    if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 0))
+    if (workspace_bytes <
+        aether_workspace_bytes(n_nodes, n_edges, num_dims, (flags & AETHER_FLAG_KEEP_INTERMEDIATES) ? 1 : 0))
         return fail(AETHER_ESPACE, "forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const bool fused = info->n_groups > 0 && n_edges > 0 && !(flags & AETHER_FLAG_FORCE_STREAMED);
@@ -470,9 +669,28 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
     }
     if (num_dims == 2)
         return streamed_impl<2>(*params, n_nodes, n_edges, x, vel, charges, edge_attr_orig,
-                                (const char*)graph, (char*)workspace, out, st);
+                                (const char*)graph, (char*)workspace, out, keep, st);
     return streamed_impl<3>(*params, n_nodes, n_edges, x, vel, charges, edge_attr_orig,
-                            (const char*)graph, (char*)workspace, out, st);
+                            (const char*)graph, (char*)workspace, out, keep, st);
+}
+
+int aether_backward(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,
+                    int64_t n_edges, const float* x, const float* vel, const float* charges,
+                    const void* graph, const AetherGraphInfo* info, void* workspace, size_t workspace_bytes,
+                    const float* grad_out, void* stream) {
+    if (!params || !grads || !x || !vel || !charges || !graph || !info || !workspace || !grad_out)
+        return fail(AETHER_EINVAL, "backward: null pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "backward: num_dims must be 2 or 3");
+    if (n_nodes <= 0 || n_edges < 0 || info->n_nodes != n_nodes || info->n_edges != n_edges)
+        return fail(AETHER_EINVAL, "backward: bad sizes");
+    if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 1))
+        return fail(AETHER_ESPACE, "backward: workspace too small (forward must run with KEEP_INTERMEDIATES)");
+    hipStream_t st = (hipStream_t)stream;
+    if (num_dims == 2)
+        return backward_impl<2>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
+                                (char*)workspace, grad_out, st);
+    return backward_impl<3>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
+                            (char*)workspace, grad_out, st);
 }
 
 int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int64_t n_edges,

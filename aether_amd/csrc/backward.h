@@ -1,0 +1,512 @@
+// backward.h -- gradients of the Aether step w.r.t. its parameters (positions, velocities, charges
+// and edge attributes are data: the reference detaches them, experiments/lorentz/main.py:243-247).
+//
+// Structure (first version; correctness before speed):
+//   * data-gradient kernels mirror the forward kernels tile for tile -- the same accumulator-layout
+//     chains, with the weights staged TRANSPOSED in LDS so that W^T g is again
+//     `gemm_tile(A = W^T, B = g)`; pre-activations are recomputed from the saved x / n / e tensors;
+//   * every weight / bias gradient is a sum over rows (nodes or edges) of an outer product
+//     A[row] (x) B[row]: ONE generic MFMA kernel (k_outer) computes all of them from the [rows, .]
+//     tensors the data-gradient kernels leave in the workspace, in fixed order (per-chunk partials +
+//     ordered reduce): deterministic, no atomics;
+//   * sums over a node's out-edges (gradients flowing back along the sender index) use a second,
+//     sender-sorted edge list built with the graph.
+// Reference: the oracle's autograd (oracle/aether_oracle.py) is the gradient oracle; see
+// tests/test_gpu_backward.py.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// d silu(z) / dz = s * (1 + z * (1 - s)), s = sigmoid(z)
+__device__ __forceinline__ float dsilu(float z) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f));
+    return s * (1.0f + z * (1.0f - s));
+}
+__device__ __forceinline__ f32x4 dsilu4(f32x4 v) {
+    f32x4 o;
+    o[0] = dsilu(v[0]); o[1] = dsilu(v[1]); o[2] = dsilu(v[2]); o[3] = dsilu(v[3]);
+    return o;
+}
+
+// LDS copy of W^T: dst[c][r] = W[r][col0 + c] for r < rows, c < cols; dst rows padded to ldt, zero
+// filled up to rows_pad x cols_pad.
+__device__ __forceinline__ void stage_weight_T(float* lds, const float* __restrict__ w, int rows,
+                                               int cols, int src_ld, int col0, int ldt, int cols_pad) {
+    for (int idx = threadIdx.x; idx < cols_pad * ldt; idx += blockDim.x) {
+        const int c = idx / ldt, r = idx - c * ldt;
+        lds[idx] = (c < cols && r < rows) ? w[(size_t)r * src_ld + col0 + c] : 0.0f;
+    }
+}
+
+// load / store a 16-item x 64 tile in accumulator layout from a row-major [rows][ld] tensor
+__device__ __forceinline__ void load_tile64(f32x4 (&t)[4], const float* __restrict__ p, int64_t row,
+                                            int ld, int q) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) t[mb] = ld4(p + row * ld + 16 * mb + 4 * q);
+}
+__device__ __forceinline__ void store_tile64(float* __restrict__ p, int64_t row, int ld, int q,
+                                             const f32x4 (&t)[4]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) st4(p + row * ld + 16 * mb + 4 * q, t[mb]);
+}
+
+// ------------------------------------------------------------------ generic outer-product kernel
+// C[m][n] (ldc) = sum_row A[row][m] * B[row][n], m < M, n < N; optional bias[m] = sum_row A[row][m].
+struct OuterTask {
+    const float* A; const float* B; float* C; float* bias;
+    int lda, ldb, ldc, M, N;        // M, N = valid output extents (blocks of 16 cover them)
+    int64_t rows;
+};
+constexpr int OUTER_MAX_TASKS = 8;
+struct OuterBatch { OuterTask t[OUTER_MAX_TASKS]; int n_tasks; int chunks; };
+
+// grid = (max blocks over tasks, chunks, n_tasks); partial[(task, chunk, block)][256 + 16]
+__global__ void __launch_bounds__(256)
+k_outer(OuterBatch batch, float* __restrict__ partial) {
+    const OuterTask T = batch.t[blockIdx.z];
+    const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
+    if ((int)blockIdx.x >= MBn * NBn) return;
+    const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t tiles = (T.rows + 15) >> 4;
+    const int64_t per = (tiles + batch.chunks - 1) / batch.chunks;
+    const int64_t t0 = per * blockIdx.y, t1 = t0 + per < tiles ? t0 + per : tiles;
+    const bool am = 16 * mb + i < T.M, bn = 16 * nb + i < T.N;
+    const bool want_bias = T.bias != nullptr && nb == 0;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t t = t0 + wave; t < t1; t += 4) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t row = 16 * t + 4 * s + q;
+            const bool ok = row < T.rows;
+            av[s] = (ok && am) ? T.A[row * T.lda + 16 * mb + i] : 0.0f;
+            bv[s] = (ok && bn) ? T.B[row * T.ldb + 16 * nb + i] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(av[s], bv[s], acc);
+        if (want_bias) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bacc = mfma16(av[s], 1.0f, bacc);
+        }
+    }
+    // ordered cross-wave sum through LDS, then one partial block per (task, chunk, block)
+    __shared__ float red[4][64][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[wave][lane][r] = acc[r]; red[wave][lane][4 + r] = bacc[r]; }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = partial + (((size_t)blockIdx.z * batch.chunks + blockIdx.y) * 64 + blockIdx.x) * 272;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = ((red[0][lane][r] + red[1][lane][r]) + red[2][lane][r]) + red[3][lane][r];
+            dst[(4 * q + r) * 16 + i] = v;                            // block row 4q+r, col i
+        }
+        if (want_bias && i == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[256 + 4 * q + r] = ((red[0][lane][4 + r] + red[1][lane][4 + r]) + red[2][lane][4 + r]) +
+                                       red[3][lane][4 + r];
+        }
+    }
+}
+
+// grid = (64 blocks max, n_tasks): sums the chunk partials in chunk order and writes C / bias
+__global__ void __launch_bounds__(256)
+k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
+    const OuterTask T = batch.t[blockIdx.y];
+    const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
+    if ((int)blockIdx.x >= MBn * NBn) return;
+    const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    float s = 0.0f, sb = 0.0f;
+    for (int ch = 0; ch < batch.chunks; ++ch) {
+        const float* src = partial + (((size_t)blockIdx.y * batch.chunks + ch) * 64 + blockIdx.x) * 272;
+        s += src[r * 16 + c];
+        if (c == 0) sb += src[256 + r];
+    }
+    const int m = 16 * mb + r, n = 16 * nb + c;
+    if (m < T.M && n < T.N) T.C[(size_t)m * T.ldc + n] = s;
+    if (T.bias != nullptr && nb == 0 && c == 0 && m < T.M) T.bias[m] = sb;
+}
+
+// ------------------------------------------------------------------ out MLP backward
+// forward (locs.py:160-168, local_to_global.py:12-13, aether.py:185):
+//   o1 = silu(Wo0 x4 + b), o2 = silu(Wo3 o1 + b), y = Wo6 o2 + b, out = p + R y
+// in: g = dL/dout.  out: dx4 and the row tensors of the weight gradients.
+template <int D>
+__global__ void __launch_bounds__(256)
+kb_out(AetherParams P, const float* __restrict__ x4, const float* __restrict__ nodeinfo,
+       const float* __restrict__ g_out, float* __restrict__ DX, float* __restrict__ O1,
+       float* __restrict__ O2, float* __restrict__ DPO1, float* __restrict__ DPO2,
+       float* __restrict__ DY, int64_t n_nodes) {
+    using NI = NodeInfo<D>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w0 = smem;                  // Wo0   [64][LDW]
+    float* w3 = w0 + H * LDW;          // Wo3
+    float* w0t = w3 + H * LDW;         // Wo0^T
+    float* w3t = w0t + H * LDW;        // Wo3^T
+    float* w6t = w3t + H * LDW;        // Wo6^T [64][20]: row m = hidden, col k = output dim (zero padded)
+    stage_weight64<256>(w0, P.out_w0, H);
+    stage_weight64<256>(w3, P.out_w3, H);
+    stage_weight_T(w0t, P.out_w0, H, H, H, 0, LDW, H);
+    stage_weight_T(w3t, P.out_w3, H, H, H, 0, LDW, H);
+    stage_weight_T(w6t, P.out_w6, D, H, H, 0, 20, H);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t tiles = (n_nodes + 15) >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t node = 16 * t + i;
+        const bool ok = node < n_nodes;
+        const int64_t nc = ok ? node : n_nodes - 1;
+        f32x4 xt[4], p1[4], p2[4], o1[4], o2[4];
+        load_tile64(xt, x4, nc, H, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(P.out_b0 + 16 * mb + 4 * q);
+        gemm_tile<4, 4>(w0, LDW, xt, p1, i, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { o1[mb] = silu4(p1[mb]); p2[mb] = ld4(P.out_b3 + 16 * mb + 4 * q); }
+        gemm_tile<4, 4>(w3, LDW, o1, p2, i, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) o2[mb] = silu4(p2[mb]);
+        // dy = R^T g (rows 0..D-1 of a 16-row block: lanes q == 0, registers 0..D-1)
+        f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q == 0 && ok) {
+            const float* ni = nodeinfo + node * NI::STRIDE;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                float s = 0.f;
+#pragma unroll
+                for (int b = 0; b < D; ++b) s += ni[NI::R + b * D + a] * g_out[node * D + b];
+                dy[a] = s;
+            }
+        }
+        // do2 = Wo6^T dy  (K = 16, only k < D non-zero)
+        f32x4 d2[4], d1[4], dx[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 wv = ld4(w6t + (16 * mb + i) * 20 + 4 * q);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d2[mb] = mfma16(wv[b], dy[b], d2[mb]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { d2[mb] = d2[mb] * dsilu4(p2[mb]); d1[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        gemm_tile<4, 4>(w3t, LDW, d2, d1, i, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { d1[mb] = d1[mb] * dsilu4(p1[mb]); dx[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        gemm_tile<4, 4>(w0t, LDW, d1, dx, i, q);
+        if (ok) {
+            store_tile64(DX, node, H, q, dx);
+            store_tile64(O1, node, H, q, o1);
+            store_tile64(O2, node, H, q, o2);
+            store_tile64(DPO1, node, H, q, d1);
+            store_tile64(DPO2, node, H, q, d2);
+            st4(DY + node * 16 + 4 * q, dy);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ node update backward
+// forward (locs.py:240-241): u = silu(W3 n + b3), x = n + W4 u + b4.   in: dx.  out: dn, u, dpre_u.
+__global__ void __launch_bounds__(256)
+kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const float* __restrict__ w4g,
+        const float* __restrict__ nbuf, const float* __restrict__ DX, float* __restrict__ DN,
+        float* __restrict__ U, float* __restrict__ DPU, int64_t n_nodes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w3 = smem;                         // W3    [128][LDW]
+    float* w4t = w3 + 2 * H * LDW;            // W4^T  [128][LDW]   (row = u index, col = x index)
+    float* w3t = w4t + 2 * H * LDW;           // W3^T  [64][2H+4]   (row = n index, col = u index)
+    for (int idx = threadIdx.x; idx < 2 * H * (H / 4); idx += 256) {
+        const int r = idx >> 4, c = (idx & 15) * 4;
+        st4(w3 + r * LDW + c, ld4(w3g + (size_t)r * H + c));
+    }
+    stage_weight_T(w4t, w4g, H, 2 * H, 2 * H, 0, LDW, 2 * H);
+    stage_weight_T(w3t, w3g, 2 * H, H, H, 0, 2 * H + 4, H);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t tiles = (n_nodes + 15) >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t node = 16 * t + i;
+        const bool ok = node < n_nodes;
+        const int64_t nc = ok ? node : n_nodes - 1;
+        f32x4 nt[4], dx[4], pu[8], du[8], dn[4];
+        load_tile64(nt, nbuf, nc, H, q);
+        load_tile64(dx, DX, nc, H, q);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) { pu[mb] = ld4(b3g + 16 * mb + 4 * q); du[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        gemm_tile<8, 4>(w3, LDW, nt, pu, i, q);
+        gemm_tile<8, 4>(w4t, LDW, dx, du, i, q);
+        f32x4 u[8];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) { u[mb] = silu4(pu[mb]); du[mb] = du[mb] * dsilu4(pu[mb]); }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) dn[mb] = dx[mb];
+        gemm_tile<4, 8>(w3t, 2 * H + 4, du, dn, i, q);
+        if (ok) {
+            store_tile64(DN, node, H, q, dn);
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                st4(U + node * 2 * H + 16 * mb + 4 * q, u[mb]);
+                st4(DPU + node * 2 * H + 16 * mb + 4 * q, du[mb]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ edge MLP backward
+// forward (locs.py:227-238): pre1 = [layer 1: W1 a + b1 | else: P_s[s] + P_r[r] + W_e e_prev],
+//   h = silu(pre1), pre2 = W2 h + b2, e = silu(pre2), aggr_i = mean_{k: recv = i} e_k.
+// de_k = DN[recv_k] / deg[recv_k] (+ DE[k], the gradient through the next layer's W_e)
+// out: G = dL/dpre1, H1 = h, DP2 = dL/dpre2, and  FIRST: DA = W1^T G   else: DE[k] <- W_e^T G.
+template <bool FIRST>
+__global__ void __launch_bounds__(256)
+kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192]*/, int f1,
+        const float* __restrict__ b_in, const float* __restrict__ w2g, const float* __restrict__ b2g,
+        const float* __restrict__ Ps, const float* __restrict__ Pr, const float* __restrict__ e_prev,
+        const float* __restrict__ feat, const int32_t* __restrict__ send_s,
+        const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
+        const float* __restrict__ DN, float* __restrict__ DE, int have_de, float* __restrict__ G,
+        float* __restrict__ H1, float* __restrict__ DP2, float* __restrict__ DA, int64_t n_edges) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wi = smem;                  // W_in   [64][LDW]   (FIRST: K = 32 used)
+    float* w2 = wi + H * LDW;          // W2
+    float* w2t = w2 + H * LDW;         // W2^T
+    float* wit = w2t + H * LDW;        // W_in^T [64 | 32][LDW]
+    if (FIRST) {
+        stage_weight(wi, w_in, H, f1, f1, LDW);
+        stage_weight_T(wit, w_in, H, f1, f1, 0, LDW, FPAD);
+    } else {
+        stage_weight64<256>(wi, w_in + 2 * H, 3 * H);
+        stage_weight_T(wit, w_in, H, H, 3 * H, 2 * H, LDW, H);
+    }
+    stage_weight64<256>(w2, w2g, H);
+    stage_weight_T(w2t, w2g, H, H, H, 0, LDW, H);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t tiles = (n_edges + 15) >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t k = 16 * t + i;
+        const bool ok = k < n_edges;
+        const int64_t kc = ok ? k : n_edges - 1;
+        const int64_t s = send_s[kc], r = recv_s[kc];
+        f32x4 p1[4], p2[4], h[4];
+        if (FIRST) {
+            f32x4 bop[2];
+            bop[0] = ld4(feat + kc * FPAD + 4 * q);
+            bop[1] = ld4(feat + kc * FPAD + 16 + 4 * q);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(b_in + 16 * mb + 4 * q);
+            gemm_tile<4, 2>(wi, LDW, bop, p1, i, q);
+        } else {
+            f32x4 bop[4];
+            load_tile64(bop, e_prev, kc, H, q);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                p1[mb] = ld4(Ps + s * H + 16 * mb + 4 * q) + ld4(Pr + r * H + 16 * mb + 4 * q);
+            gemm_tile<4, 4>(wi, LDW, bop, p1, i, q);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { h[mb] = silu4(p1[mb]); p2[mb] = ld4(b2g + 16 * mb + 4 * q); }
+        gemm_tile<4, 4>(w2, LDW, h, p2, i, q);
+        // de = dn[recv] / deg (+ gradient through the next layer's edge input)
+        const int deg = rowptr[r + 1] - rowptr[r];
+        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        f32x4 d2[4], dh[4], g[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            f32x4 de = ld4(DN + r * H + 16 * mb + 4 * q) * inv;
+            if (have_de) de += ld4(DE + kc * H + 16 * mb + 4 * q);
+            d2[mb] = de * dsilu4(p2[mb]);
+            dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        gemm_tile<4, 4>(w2t, LDW, d2, dh, i, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu4(p1[mb]);
+        if (FIRST) {
+            f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            gemm_tile<2, 4>(wit, LDW, g, da, i, q);
+            if (ok) { st4(DA + k * FPAD + 4 * q, da[0]); st4(DA + k * FPAD + 16 + 4 * q, da[1]); }
+        } else {
+            f32x4 dep[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_tile<4, 4>(wit, LDW, g, dep, i, q);
+            if (ok) store_tile64(DE, k, H, q, dep);
+        }
+        if (ok) {
+            store_tile64(G, k, H, q, g);
+            store_tile64(H1, k, H, q, h);
+            store_tile64(DP2, k, H, q, d2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ gather of G onto nodes
+// dP_r[i] = sum_{k: recv = i} G_k (contiguous run), dP_s[j] = sum_{k: send = j} G_k (sender list);
+// dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed).
+__global__ void __launch_bounds__(256)
+kb_gather(const float* __restrict__ w1g /*msg_w0 [64][192]*/, const float* __restrict__ G,
+          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ srowptr,
+          const int32_t* __restrict__ sperm, const float* __restrict__ DN, float* __restrict__ DX,
+          float* __restrict__ DPS, float* __restrict__ DPR, int64_t n_nodes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wst = smem;                 // W_s^T [64][LDW]
+    float* wrt = wst + H * LDW;        // W_r^T
+    stage_weight_T(wst, w1g, H, H, 3 * H, 0, LDW, H);
+    stage_weight_T(wrt, w1g, H, H, 3 * H, H, LDW, H);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t tiles = (n_nodes + 15) >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t node = 16 * t + i;
+        const bool ok = node < n_nodes;
+        const int64_t nc = ok ? node : n_nodes - 1;
+        f32x4 dps[4], dpr[4], dx[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { dps[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; dpr[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int k = rowptr[nc]; k < rowptr[nc + 1]; ++k) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) dpr[mb] += ld4(G + (int64_t)k * H + 16 * mb + 4 * q);
+        }
+        for (int k = srowptr[nc]; k < srowptr[nc + 1]; ++k) {
+            const int64_t row = sperm[k];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) dps[mb] += ld4(G + row * H + 16 * mb + 4 * q);
+        }
+        load_tile64(dx, DN, nc, H, q);
+        gemm_tile<4, 4>(wst, LDW, dps, dx, i, q);
+        gemm_tile<4, 4>(wrt, LDW, dpr, dx, i, q);
+        if (ok) {
+            store_tile64(DX, node, H, q, dx);
+            store_tile64(DPS, node, H, q, dps);
+            store_tile64(DPR, node, H, q, dpr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ field net backward
+// One thread per node.  Gradient of the loss w.r.t. the field f of node j arrives through
+//   * the R_i^T f_j columns of its out-edges' features (DA columns RF, rotated back with R_recv),
+//   * the rel_feat[recv] columns R_j^T f_j of its in-edges' features (DA columns CF),
+//   * layer_1.res(rel_feat) (aether.py:39-48, locs.py:214-218): W_res^T dn_1, columns 2D..3D.
+// Then through the 3-layer field MLP (aether.py:113-119).  Leaves the row tensors for k_outer.
+template <int D>
+__global__ void __launch_bounds__(256)
+kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
+         const float* __restrict__ charges, const float* __restrict__ nodeinfo,
+         const float* __restrict__ DA, const float* __restrict__ DN1,
+         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ recv_s,
+         const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm,
+         float* __restrict__ RELF, float* __restrict__ Z, float* __restrict__ H1f,
+         float* __restrict__ H2f, float* __restrict__ DPH1, float* __restrict__ DPH2,
+         float* __restrict__ DF, float* __restrict__ DZE, float* __restrict__ ONEHOT, int64_t n_nodes) {
+    using NI = NodeInfo<D>;
+    constexpr int FIN = 2 * D + 16;
+    constexpr int O = D * (D - 1) / 2;
+    constexpr int C_RF = 3 * D + O;           // feature columns of R_i^T f_j
+    constexpr int C_CF = 6 * D + O;           // feature columns of rel_feat[recv]'s R_i^T f_i part
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    const float* ni = nodeinfo + n * NI::STRIDE;
+    // gradient w.r.t. cf_n = R_n^T f_n
+    float dcf[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) dcf[d] = 0.f;
+    for (int k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) dcf[d] += DA[(int64_t)k * FPAD + C_CF + d];
+    }
+#pragma unroll 4
+    for (int o = 0; o < H; ++o) {
+        const float g = DN1[n * H + o];
+#pragma unroll
+        for (int d = 0; d < D; ++d) dcf[d] += P.l1_res_w[o * 3 * D + 2 * D + d] * g;
+    }
+    float df[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {                              // f = R cf  ->  df = R dcf
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * dcf[b];
+        df[a] = s;
+    }
+    for (int kk = srowptr[n]; kk < srowptr[n + 1]; ++kk) {     // out-edges: rf = R_recv^T f_n
+        const int64_t k = sperm[kk];
+        const float* nr = nodeinfo + (int64_t)recv_s[k] * NI::STRIDE;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+            for (int b = 0; b < D; ++b) df[a] += nr[NI::R + a * D + b] * DA[k * FPAD + C_RF + b];
+        }
+    }
+    // rel_feat row for dW_res (columns 0..3D-1 of a 16-wide row)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float v = 0.f;
+        if (c >= D && c < 2 * D) v = ni[NI::CV + c - D];
+        if (c >= 2 * D && c < 3 * D) v = ni[NI::CF + c - 2 * D];
+        RELF[n * 16 + c] = v;
+    }
+    // recompute the field MLP
+    float z[FIN];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { z[d] = x[n * D + d]; z[D + d] = vel[n * D + d]; }
+    long ci = (long)(charges[n] + 1.0f);
+    ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) z[2 * D + k] = P.field_emb[ci * 16 + k];
+    float p1[32], p2[32], h1[32], h2[32];
+#pragma unroll 4
+    for (int o = 0; o < 32; ++o) {
+        float s = P.field_b0[o];
+#pragma unroll
+        for (int k = 0; k < FIN; ++k) s += P.field_w0[o * FIN + k] * z[k];
+        p1[o] = s; h1[o] = silu(s);
+    }
+#pragma unroll 4
+    for (int o = 0; o < 32; ++o) {
+        float s = P.field_b2[o];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += P.field_w2[o * 32 + k] * h1[k];
+        p2[o] = s; h2[o] = silu(s);
+    }
+    float d2[32], d1[32];
+#pragma unroll 4
+    for (int k = 0; k < 32; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s += P.field_w4[d * 32 + k] * df[d];
+        d2[k] = s * dsilu(p2[k]);
+    }
+#pragma unroll 4
+    for (int k = 0; k < 32; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) s += P.field_w2[o * 32 + k] * d2[o];
+        d1[k] = s * dsilu(p1[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        Z[n * 32 + k] = k < FIN ? z[k] : 0.f;
+        H1f[n * 32 + k] = h1[k]; H2f[n * 32 + k] = h2[k];
+        DPH1[n * 32 + k] = d1[k]; DPH2[n * 32 + k] = d2[k];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        DF[n * 16 + c] = c < D ? df[c] : 0.f;
+        ONEHOT[n * 16 + c] = c == (int)ci ? 1.f : 0.f;
+        float s = 0.f;                                          // d z[2D + c] (embedding columns)
+#pragma unroll 8
+        for (int o = 0; o < 32; ++o) s += P.field_w0[o * FIN + 2 * D + c] * d1[o];
+        DZE[n * 16 + c] = s;
+    }
+}
+
+}  // namespace

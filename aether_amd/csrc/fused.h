@@ -62,6 +62,7 @@ template <int NW> struct FusedLds {          // offsets in floats
 // that the parity tests and (later) the backward can read them.
 struct FusedDebug {
     float* nodeinfo; float* x[5]; float* e[4];
+    float* n[4]; float* ps[3]; float* pr[3]; float* feat;     // saved for the backward
     float* stamps;          // [groups][FUSED_STAMPS] diagnostic build only
 };
 constexpr int FUSED_STAMPS = 512;
@@ -237,6 +238,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
                 float eal[2] = {ea[0], ea[1]};
                 edge_features<D>(njl, nrl, eal, o);
+                if (keep) {
+#pragma unroll
+                    for (int t = 0; t < FPAD; t += 4)
+                        st4(dbg.feat + (int64_t)k * FPAD + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+                }
             } else {
 #pragma unroll
                 for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
@@ -422,7 +428,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         if (tid < FUSED_MAX_NODES * 16) {
             f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int t = at0; t < at1; ++t) sum += ld4(part + (aslot + t) * LDW + ac4);
-            st4(nbuf + aslot * LDW + ac4, ld4(xbuf + aslot * LDW + ac4) + sum / adeg);
+            const f32x4 nv = ld4(xbuf + aslot * LDW + ac4) + sum / adeg;
+            st4(nbuf + aslot * LDW + ac4, nv);
+            if (keep && aslot < n) st4(dbg.n[layer - 1] + (int64_t)(nb + aslot) * H + ac4, nv);
         }
         if (layer < 4) {       // next layer's edge weights -> LDS (loads were issued above)
 #pragma unroll
@@ -487,6 +495,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                         for (int b = 0; b < 4; ++b) accs = mfma16(wsv[a][b], xv[a][b], accs);
                     st4(psb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accs);
+                    if (keep && 16 * tn3 + i < n)
+                        st4(dbg.ps[layer - 1] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, accs);
                 }
                 if (NW == 8 || sel4 == 1) {
                     f32x4 accr = ld4(b1n + 16 * mb3 + 4 * q);
@@ -495,6 +505,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                         for (int b = 0; b < 4; ++b) accr = mfma16(wrv[a][b], xv[a][b], accr);
                     st4(prb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accr);
+                    if (keep && 16 * tn3 + i < n)
+                        st4(dbg.pr[layer - 1] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, accr);
                 }
             }
             __syncthreads();   // P_s / P_r and the staged weights are visible to the next edge tiles

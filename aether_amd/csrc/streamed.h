@@ -296,7 +296,7 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
               const float* __restrict__ e, const int32_t* __restrict__ rowptr,
               float* __restrict__ x_out, float* __restrict__ Ps, float* __restrict__ Pr,
               const float* __restrict__ nodeinfo, const float* __restrict__ pos,
-              float* __restrict__ out, int64_t n_nodes) {
+              float* __restrict__ out, float* __restrict__ nsave, int64_t n_nodes) {
     using NI = NodeInfo<D>;
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
@@ -319,6 +319,10 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
     const float deg = (float)(end - beg > 1 ? end - beg : 1);    // count clamped to >= 1
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) n[mb] = ld4(x_prev + nc * H + 16 * mb + 4 * q) + n[mb] / deg;
+    if (nsave != nullptr && node < n_nodes) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) st4(nsave + node * H + 16 * mb + 4 * q, n[mb]);
+    }
     f32x4 u[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) u[mb] = ld4(b3 + 16 * mb + 4 * q);

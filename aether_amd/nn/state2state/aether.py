@@ -58,26 +58,58 @@ class GraphCache:
 
 
 class _AetherStep(torch.autograd.Function):
+    """aether_forward / aether_backward behind torch.autograd (parameters only get gradients:
+    the runner detaches positions and edge attributes, experiments/lorentz/main.py:243-247)."""
+
+    N_FIXED = 7          # module, x, vel, edge_attr, charges, graph, n_edges precede the parameters
+
     @staticmethod
     def forward(ctx, module, x, vel, edge_attr, charges, graph, n_edges, *params):
-        graph, ginfo = graph
         lib = _lib.load()
+        graph, ginfo = graph
         D = module.num_dims
         n_nodes = x.shape[0]
-        ws_bytes = lib.aether_workspace_bytes(n_nodes, n_edges, D, 0)
-        ws = module._workspace(ws_bytes, x.device)
+        train = any(ctx.needs_input_grad[_AetherStep.N_FIXED:])
+        flags = module.flags | (_lib.FLAG_KEEP_INTERMEDIATES if train else 0)
+        keep = bool(flags & _lib.FLAG_KEEP_INTERMEDIATES)
+        ws_bytes = lib.aether_workspace_bytes(n_nodes, n_edges, D, 1 if keep else 0)
+        if train:        # the backward reads this forward's intermediates: one workspace per call
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        else:
+            ws = module._workspace(ws_bytes, x.device)
         out = torch.empty_like(x)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         st = lib.aether_forward(C.byref(module._param_struct()), D, n_nodes, n_edges,
                                 x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
                                 edge_attr.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
-                                ws.numel(), out.data_ptr(), module.flags, stream)
+                                ws.numel(), out.data_ptr(), flags, stream)
         _lib.check(st, "aether_forward")
+        if train:
+            ctx.module = module
+            ctx.saved = (x, vel, charges, graph, ginfo, ws, n_edges)
+        module._last_ws = ws
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError("aether_backward: HIP backward kernels are not built yet")
+        lib = _lib.load()
+        module = ctx.module
+        x, vel, charges, graph, ginfo, ws, n_edges = ctx.saved
+        D = module.num_dims
+        flat, gstruct, views = module._grad_buffers()
+        g = grad_out.to(torch.float32).contiguous()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        st = lib.aether_backward(C.byref(module._param_struct()), C.byref(gstruct), D, x.shape[0], n_edges,
+                                 x.data_ptr(), vel.data_ptr(), charges.data_ptr(), graph.data_ptr(),
+                                 C.byref(ginfo), ws.data_ptr(), ws.numel(), g.data_ptr(), stream)
+        _lib.check(st, "aether_backward")
+        if module.dp_group is not None:            # one fused all-reduce of the flat buffer (RCCL)
+            import torch.distributed as dist
+            dist.all_reduce(flat, group=module.dp_group)
+            flat.div_(dist.get_world_size(module.dp_group))
+        need = ctx.needs_input_grad[_AetherStep.N_FIXED:]
+        grads = tuple(v.clone() if n else None for v, n in zip(views, need))
+        return (None,) * _AetherStep.N_FIXED + grads
 
 
 class _FieldNetwork(nn.Module):
@@ -148,6 +180,9 @@ class Aether(nn.Module):
         self.field_net = _FieldNetwork(num_dims, 32, 16)
         self._graphs = GraphCache()
         self.flags = 0                    # _lib.FLAG_* bits passed to aether_forward
+        self.dp_group = None              # set by aether_amd.parallel.attach_data_parallel
+        self._last_ws = None
+        self._gbuf = None
         self._ws = None
         self._pstruct = None
         self.to(device)
@@ -173,6 +208,23 @@ class Aether(nn.Module):
         if self._pstruct is None or self._pstruct[0] != key:
             self._pstruct = (key, _lib.params_struct(sd))
         return self._pstruct[1]
+
+    def _grad_buffers(self):
+        """Flat fp32 gradient buffer + an AetherParams struct and per-parameter views into it."""
+        named = list(self.named_parameters())
+        total = sum(p.numel() for _, p in named)
+        dev = named[0][1].device
+        if self._gbuf is None or self._gbuf[0].device != dev or self._gbuf[0].numel() != total:
+            # every tensor starts on a 16-byte boundary (the kernels use 16-byte accesses)
+            offs, off = [], 0
+            for _, p in named:
+                offs.append(off)
+                off += (p.numel() + 3) // 4 * 4
+            flat = torch.zeros(off, dtype=torch.float32, device=dev)
+            views = [flat[o:o + p.numel()].view_as(p) for o, (_, p) in zip(offs, named)]
+            gstruct = _lib.params_struct({n: v for (n, _), v in zip(named, views)})
+            self._gbuf = (flat, gstruct, views)
+        return self._gbuf
 
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
@@ -211,7 +263,7 @@ class Aether(nn.Module):
         rows = n_edges if name.startswith("e") else n_nodes
         dst = torch.empty(rows, cols, dtype=torch.float32, device=dev)
         n = lib.aether_debug_fetch(name.encode(), self.num_dims, n_nodes, n_edges,
-                                   self._ws.data_ptr(), dst.data_ptr(),
+                                   self._last_ws.data_ptr(), dst.data_ptr(),
                                    torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(n, "aether_debug_fetch")
         assert n == rows * cols, (n, rows, cols)

@@ -120,6 +120,22 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
                    void* workspace, size_t workspace_bytes, float* out, int flags, void* stream);
 
 /*
+ * Backward step: gradients of a scalar loss w.r.t. every parameter, given grad_out = dL/d(out).
+ * Replaces torch.autograd through Aether.forward (the runner's loss.backward(),
+ * experiments/lorentz/main.py:289-291).  Inputs (x, vel, charges, edge attributes) are data and
+ * receive no gradient, as in the runner (main.py:243-247 detaches them).
+ *   The forward on the same `workspace` must have run with AETHER_FLAG_KEEP_INTERMEDIATES and a
+ *   workspace of aether_workspace_bytes(..., keep_for_backward = 1) bytes.
+ *   grads : AetherParams whose pointers address the gradient buffers (same shapes as params);
+ *           every element is overwritten (not accumulated).
+ * Deterministic (ordered partial sums, no atomics).  Stream-ordered.
+ */
+int aether_backward(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,
+                    int64_t n_edges, const float* x, const float* vel, const float* charges,
+                    const void* graph, const AetherGraphInfo* info, void* workspace, size_t workspace_bytes,
+                    const float* grad_out, void* stream);
+
+/*
  * Test hook: copy one named intermediate of the last aether_forward on `workspace`
  * (the fused path writes them only under AETHER_FLAG_KEEP_INTERMEDIATES)
  * into `dst` (device).  Names: "field"[n][D] "canon"[n][2D] (= rel_feat[:, D:]) "R"[n][D*D] "x0".."x4"[n][64]

@@ -1,0 +1,83 @@
+"""Parameter gradients of the HIP backward vs the reference's (golden) and the oracle's autograd."""
+import pytest
+import torch
+
+from conftest import GRAD_CASES, load_case, load_state_dict, scale_rel_err
+from aether_amd import _lib
+from aether_amd.nn.state2state.aether import Aether
+from aether_amd.synthetic import make_batch
+from oracle import aether_oracle as O
+
+pytestmark = pytest.mark.gpu
+GTOL = 5e-5     # gradients: sums over thousands of edges in a different (fixed) order than autograd
+
+
+def _model(D, path):
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    m.load_state_dict(load_state_dict(D))
+    m.flags = _lib.FLAG_FORCE_FUSED if path == "fused" else _lib.FLAG_FORCE_STREAMED
+    return m
+
+
+def _loss_backward(m, inp):
+    dev = "cuda"
+    m.zero_grad(set_to_none=True)
+    out = m(inp["h"].to(dev), inp["x"].to(dev), [e.to(dev) for e in inp["edges"]], inp["vel"].to(dev),
+            inp["edge_attr"].to(dev), inp["charges"].to(dev))
+    loss = torch.nn.functional.mse_loss(out, inp["target"].to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("path", ["fused", "streamed"])
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("case", GRAD_CASES)
+def test_parameter_gradients_match_reference(D, case, path):
+    inp, ref, ref64, meta = load_case(f"case_D{D}_{case}.npz")
+    m = _model(D, path)
+    loss, grads = _loss_backward(m, inp)
+    assert abs(loss - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+    worst = 0.0
+    for k, g in grads.items():
+        assert torch.isfinite(g).all(), k
+        err = scale_rel_err(g, ref["grad." + k])
+        worst = max(worst, err)
+        assert err <= GTOL, (k, err)
+    if ref64:       # the reference's own fp64 gradients, where stored
+        for k, g in grads.items():
+            if "grad." + k in ref64:
+                assert scale_rel_err(g, ref64["grad." + k]) <= GTOL, k
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_gradients_vs_oracle_autograd_fresh_inputs(D):
+    sd = load_state_dict(D)
+    for (B, N, seed, path) in [(5, 7, 51, "fused"), (3, 40, 52, "streamed"), (130, 20, 53, "fused")]:
+        inp = make_batch(B, N, D, seed=seed)
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out = O.aether_forward(sdg, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+        torch.nn.functional.mse_loss(out, inp["target"]).backward()
+        m = _model(D, path)
+        if path == "streamed" and N == 40:
+            m.flags = 0                      # too big for a fused group: default dispatch must cope
+        _, grads = _loss_backward(m, inp)
+        for k, g in grads.items():
+            assert scale_rel_err(g, sdg[k].grad) <= GTOL, (B, N, k)
+
+
+def test_backward_is_deterministic_and_optimizer_step_runs():
+    D = 2
+    m = _model(D, "fused")
+    inp = make_batch(16, 20, D, seed=61)
+    _, g1 = _loss_backward(m, inp)
+    _, g2 = _loss_backward(m, inp)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-4, weight_decay=1e-12)   # main.py:86,164
+    l0, _ = _loss_backward(m, inp)
+    for _ in range(20):
+        _loss_backward(m, inp)
+        opt.step()
+    l1, _ = _loss_backward(m, inp)
+    assert l1 < l0
