@@ -55,9 +55,11 @@ int fail(int code, const char* msg) {
 // ------------------------------------------------------------------ per-kernel HIP-event timing
 // Optional (aether_profile_enable): brackets every launch with a pair of events on the
 // launch stream so bench.py can report the dominant kernel's average duration.
-enum KernelId { K_NODE_PREP = 0, K_EDGE_L1, K_NODE_UPDATE, K_EDGE_LN, K_NODE_LAST, K_FUSED, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_node_prep", "k_edge_layer1", "k_node_update",
-                                           "k_edge_layer", "k_node_update_last", "k_fused"};
+enum KernelId { K_NODE_PREP = 0, K_EDGE_L1, K_NODE_UPDATE, K_EDGE_LN, K_NODE_LAST, K_FUSED, KB_OUT, KB_NODE,
+                KB_EDGE, KB_GATHER, KB_FIELD, KB_OUTER, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_node_prep", "k_edge_layer1", "k_node_update", "k_edge_layer",
+                                           "k_node_update_last", "k_fused", "kb_out", "kb_node", "kb_edge",
+                                           "kb_gather", "kb_field", "k_outer+reduce"};
 struct ProfSlot { hipEvent_t a, b; int id; };
 constexpr int PROF_SLOTS = 8192;
 ProfSlot g_prof[PROF_SLOTS];
@@ -352,6 +354,7 @@ int run_outer(OuterList& L, float* partial, hipStream_t st) {
     if (chunks < 1) chunks = 1;
     if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
     L.b.chunks = (int)chunks;
+    ProfScope ps(KB_OUTER, st);
     k_outer<<<dim3((unsigned)max_blocks, (unsigned)chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
     k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
     return AETHER_OK;
@@ -373,16 +376,20 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     const int64_t ntile = (Nn + 15) / 16, etile = (E + 15) / 16;
     const unsigned ngrid = (unsigned)((ntile + 3) / 4 < 512 ? (ntile + 3) / 4 : 512);
     const unsigned egrid = (unsigned)((etile + 3) / 4 < 1024 ? (etile + 3) / 4 : 1024);
-    auto optin = [&](const void* k, size_t lds) -> int {
+    auto optin = [&](const void* k, size_t lds) -> int {     // once per kernel and process
+        static std::vector<const void*> done;
+        for (const void* d : done) if (d == k) return AETHER_OK;
         HIP_OK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done.push_back(k);
         return AETHER_OK;
     };
     // ---- out MLP
     {
         const size_t lds = (size_t)(4 * H * LDW + H * 20) * 4;
         if (optin(reinterpret_cast<const void*>(kb_out<D>), lds)) return AETHER_EHIP;
+        { ProfScope ps(KB_OUT, st);
         kb_out<D><<<dim3(ngrid), dim3(256), lds, st>>>(P, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DX), wp(W.O1),
-                                                      wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn);
+                                                      wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
         OuterList L;
         L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
         L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
@@ -405,8 +412,9 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         {
             const size_t lds = (size_t)(2 * 2 * H * LDW + H * (2 * H + 4)) * 4;
             if (optin(reinterpret_cast<const void*>(kb_node), lds)) return AETHER_EHIP;
+            { ProfScope ps(KB_NODE, st);
             kb_node<<<dim3(ngrid), dim3(256), lds, st>>>(w3, b3, w4, wp(W.n[l - 1]), wp(W.DX), wp(W.DN), wp(W.U),
-                                                        wp(W.DPU), Nn);
+                                                        wp(W.DPU), Nn); }
             OuterList L;
             L.add(wp(W.DX), H, H, wp(W.U), 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
             L.add(wp(W.DPU), 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
@@ -415,6 +423,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         // ---- edge MLP
         if (E > 0) {
             const size_t lds = (size_t)(4 * H * LDW) * 4;
+            ProfScope* pse = new ProfScope(KB_EDGE, st);
             if (l == 1) {
                 if (optin(reinterpret_cast<const void*>(kb_edge<true>), lds)) return AETHER_EHIP;
                 kb_edge<true><<<dim3(egrid), dim3(256), lds, st>>>(
@@ -427,6 +436,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
                     nullptr, send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), l < 4 ? 1 : 0, wp(W.G), wp(W.H1),
                     wp(W.DP2), nullptr, E);
             }
+            delete pse;
             OuterList L;
             L.add(wp(W.DP2), H, H, wp(W.H1), H, H, E, gw2, H, gb2);
             if (l == 1) L.add(wp(W.G), H, H, wp(W.feat), FPAD, F1, E, Gr.l1_msg_w0, F1, Gr.l1_msg_b0);
@@ -445,8 +455,9 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
             const size_t lds = (size_t)(2 * H * LDW) * 4;
             if (optin(reinterpret_cast<const void*>(kb_gather), lds)) return AETHER_EHIP;
             if (E == 0) HIP_OK(hipMemsetAsync(wp(W.G), 0, 4, st));
+            { ProfScope ps(KB_GATHER, st);
             kb_gather<<<dim3(ngrid), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], wp(W.G), rowptr, srowptr, sperm,
-                                                          wp(W.DN), wp(W.DX), wp(W.DPS), wp(W.DPR), Nn);
+                                                          wp(W.DN), wp(W.DX), wp(W.DPS), wp(W.DPR), Nn); }
             OuterList L;
             L.add(wp(W.DPS), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
             L.add(wp(W.DPR), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
@@ -454,10 +465,11 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
             run_outer(L, partial, st);
         } else {
             // ---- res + field net
+            { ProfScope ps(KB_FIELD, st);
             kb_field<D><<<dim3((unsigned)((Nn + 255) / 256)), dim3(256), 0, st>>>(
                 P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
                 wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
-                wp(W.ONEHOT), Nn);
+                wp(W.ONEHOT), Nn); }
             OuterList L;
             L.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
             L.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);

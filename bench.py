@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step (fwd+bwd+opt) figure")
     ap.add_argument("--streamed", action="store_true", help="force the layer-by-layer kernels")
     ap.add_argument("--fused-waves", type=int, default=0, help="8 or 16 (tuning; 0 = library default)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to aether_set_option")
@@ -209,6 +210,59 @@ def main():
                         "avg_launch_us": dom["avg_us"], "algorithmic_flop_per_launch": flops,
                         "executed_flop_per_launch": executed}
 
+    # ---- training step: forward + HIP backward + gradient all-reduce (N > 1) + AdamW ----------------
+    train = None
+    if not args.no_train:
+        if world > 1:
+            from aether_amd.parallel import attach_data_parallel
+            attach_data_parallel(model)
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12)     # main.py:86,164
+        tgt = inp["target"]
+
+        def tstep():
+            opt.zero_grad(set_to_none=True)
+            o = call()
+            loss = torch.nn.functional.mse_loss(o, tgt)
+            loss.backward()
+            opt.step()
+        tsteps = max(10, args.steps // 4)
+        for _ in range(5):
+            tstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(tsteps):
+            tstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tdt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([tdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = float(t.item())
+        train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps,
+                 "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
+                 "includes": "forward + HIP backward + " + ("RCCL grad all-reduce + " if world > 1 else "")
+                             + "torch AdamW, eager launches"}
+        if rank == 0:       # per-kernel breakdown of one training step
+            lib = _lib.load()
+            nk = lib.aether_profile_kernels()
+            lib.aether_profile_enable(1)
+            ks = 10
+            for _ in range(ks):
+                tstep()
+            torch.cuda.synchronize()
+            ms = (C.c_double * nk)()
+            cnt = (C.c_int64 * nk)()
+            _lib.check(lib.aether_profile_read(ms, cnt, nk), "aether_profile_read")
+            lib.aether_profile_enable(0)
+            train["kernels_us_per_step"] = {lib.aether_profile_kernel_name(k).decode(): 1e3 * ms[k] / ks
+                                            for k in range(nk) if cnt[k]}
+
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
         value = 4.0 * E * world / (dt / args.steps)
@@ -224,7 +278,7 @@ def main():
                        "parallelism": f"graphs sharded over {world} rank(s), no forward collective"},
             "edges_per_s": E * world / (dt / args.steps),
             "step_algorithmic_tflops": step_flops * world / (dt / args.steps) / 1e12,
-            "roofline": roof, "kernels": kernels,
+            "roofline": roof, "kernels": kernels, "train": train,
         }
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
