@@ -253,13 +253,9 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = fused_launch<D, NWV, R>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s), gp(G.recv_s),      \
                                  gp(G.rowptr), gp(G.groups), info.n_groups, dbg, keep ? 1 : 0, out, st)
-    if (nw == 16) {
-        if (rounds <= 1) { AETHER_FUSED_CASE(16, 1); } else { AETHER_FUSED_CASE(16, 2); }
-    } else {
-        if (rounds <= 1) { AETHER_FUSED_CASE(8, 1); }
-        else if (rounds == 2) { AETHER_FUSED_CASE(8, 2); }
-        else { AETHER_FUSED_CASE(8, 3); }
-    }
+    if (rounds <= 1) { AETHER_FUSED_CASE(8, 1); }
+    else if (rounds == 2) { AETHER_FUSED_CASE(8, 2); }
+    else { AETHER_FUSED_CASE(8, 3); }
 #undef AETHER_FUSED_CASE
     if (rc != AETHER_OK) return rc;
     HIP_OK(hipGetLastError());
@@ -385,7 +381,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     };
     // ---- out MLP
     {
-        const size_t lds = (size_t)(4 * H * LDW + H * 20) * 4;
+        const size_t lds = (size_t)(4 * H * LDW + H * 24) * 4;
         if (optin(reinterpret_cast<const void*>(kb_out<D>), lds)) return AETHER_EHIP;
         { ProfScope ps(KB_OUT, st);
         kb_out<D><<<dim3(ngrid), dim3(256), lds, st>>>(P, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DX), wp(W.O1),
@@ -410,7 +406,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         float* gb2 = l == 1 ? Gr.l1_msg_b2 : Gr.ln_msg_b2[l - 2];
         // ---- node update: dx_l -> dn_l
         {
-            const size_t lds = (size_t)(2 * 2 * H * LDW + H * (2 * H + 4)) * 4;
+            const size_t lds = (size_t)(2 * 2 * H * LDW + H * (2 * H + 8)) * 4;
             if (optin(reinterpret_cast<const void*>(kb_node), lds)) return AETHER_EHIP;
             { ProfScope ps(KB_NODE, st);
             kb_node<<<dim3(ngrid), dim3(256), lds, st>>>(w3, b3, w4, wp(W.n[l - 1]), wp(W.DX), wp(W.DN), wp(W.U),
@@ -494,7 +490,9 @@ const char* aether_last_error(void) { return g_err; }
 int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");
     if (!strcmp(name, "fused_waves")) {
-        if (value != 8 && value != 16) return fail(AETHER_EINVAL, "set_option: fused_waves must be 8 or 16");
+        // 16 waves (4 per SIMD) was measured slower: 128-VGPR cap -> spills, and its LDS scratch no
+        // longer fits next to the conflict-free row strides
+        if (value != 8) return fail(AETHER_EINVAL, "set_option: fused_waves must be 8");
         g_fused_waves = value;
         return AETHER_OK;
     }

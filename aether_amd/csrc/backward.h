@@ -148,12 +148,12 @@ kb_out(AetherParams P, const float* __restrict__ x4, const float* __restrict__ n
     float* w3 = w0 + H * LDW;          // Wo3
     float* w0t = w3 + H * LDW;         // Wo0^T
     float* w3t = w0t + H * LDW;        // Wo3^T
-    float* w6t = w3t + H * LDW;        // Wo6^T [64][20]: row m = hidden, col k = output dim (zero padded)
+    float* w6t = w3t + H * LDW;        // Wo6^T [64][24]: row m = hidden, col k = output dim (zero padded)
     stage_weight64<256>(w0, P.out_w0, H);
     stage_weight64<256>(w3, P.out_w3, H);
     stage_weight_T(w0t, P.out_w0, H, H, H, 0, LDW, H);
     stage_weight_T(w3t, P.out_w3, H, H, H, 0, LDW, H);
-    stage_weight_T(w6t, P.out_w6, D, H, H, 0, 20, H);
+    stage_weight_T(w6t, P.out_w6, D, H, H, 0, 24, H);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -189,7 +189,7 @@ kb_out(AetherParams P, const float* __restrict__ x4, const float* __restrict__ n
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 wv = ld4(w6t + (16 * mb + i) * 20 + 4 * q);
+            const f32x4 wv = ld4(w6t + (16 * mb + i) * 24 + 4 * q);
 #pragma unroll
             for (int b = 0; b < 4; ++b) d2[mb] = mfma16(wv[b], dy[b], d2[mb]);
         }
@@ -219,13 +219,13 @@ kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const floa
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* w3 = smem;                         // W3    [128][LDW]
     float* w4t = w3 + 2 * H * LDW;            // W4^T  [128][LDW]   (row = u index, col = x index)
-    float* w3t = w4t + 2 * H * LDW;           // W3^T  [64][2H+4]   (row = n index, col = u index)
+    float* w3t = w4t + 2 * H * LDW;           // W3^T  [64][2H+8]   (row = n index, col = u index)
     for (int idx = threadIdx.x; idx < 2 * H * (H / 4); idx += 256) {
         const int r = idx >> 4, c = (idx & 15) * 4;
         st4(w3 + r * LDW + c, ld4(w3g + (size_t)r * H + c));
     }
     stage_weight_T(w4t, w4g, H, 2 * H, 2 * H, 0, LDW, 2 * H);
-    stage_weight_T(w3t, w3g, 2 * H, H, H, 0, 2 * H + 4, H);
+    stage_weight_T(w3t, w3g, 2 * H, H, H, 0, 2 * H + 8, H);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -246,7 +246,7 @@ kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const floa
         for (int mb = 0; mb < 8; ++mb) { u[mb] = silu4(pu[mb]); du[mb] = du[mb] * dsilu4(pu[mb]); }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) dn[mb] = dx[mb];
-        gemm_tile<4, 8>(w3t, 2 * H + 4, du, dn, i, q);
+        gemm_tile<4, 8>(w3t, 2 * H + 8, du, dn, i, q);
         if (ok) {
             store_tile64(DN, node, H, q, dn);
 #pragma unroll

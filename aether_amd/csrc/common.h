@@ -9,9 +9,15 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int H = AETHER_HIDDEN;     // 64
-constexpr int LDW = H + 4;           // padded LDS row (floats) for K = 64 weights / activations
+// LDS row strides (floats).  A fragment read is one ds_read_b128 per lane at
+// row*(stride) + 16a + 4q, row = lane & 15, q = lane >> 4; its 16-lane groups mix rows of two q
+// values, so the 16-byte slot index (stride/4 * row + q) mod 16 must be distinct inside a group:
+// stride = 64 + 8 (slot = 2*row + q: even / odd) is conflict-free, 64 + 4 is 2-way in every group
+// (measured: 39 % of LDS cycles were conflict cycles with + 4).
+constexpr int LDW = H + 8;           // K = 64 weights / activations
 constexpr int FPAD = 32;             // layer-1 feature count padded to two 16-wide k blocks
-constexpr int LDF = FPAD + 4;        // padded LDS row for K = 32
+constexpr int LDF = FPAD + 8;        // K = 32 (slot = 10*row + q)
+constexpr int LDST = H + 4;          // wave-private tile staging: conflict-free 16-byte row writes
 constexpr float PI_F = 3.14159274101257324f;       // float(np.pi)
 constexpr float TWO_PI_F = 6.28318548202514648f;   // float(2*np.pi)
 constexpr float EPS_F = 1e-7f;                     // nn/utils/geometry.py:62

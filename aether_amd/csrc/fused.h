@@ -25,7 +25,7 @@ namespace {
 constexpr int FUSED_MAX_NODES = 32;          // two 16-node MFMA tiles
 constexpr int FUSED_MAX_EDGES = 384;         // 24 tiles (N=20 fully connected: 380 edges)
 constexpr int FUSED_MAX_TILES = FUSED_MAX_EDGES / 16;
-constexpr int LDU = 2 * H + 4;               // padded LDS row for the 128-wide update hidden
+constexpr int LDU = 2 * H + 8;               // padded LDS row for the 128-wide update hidden
 
 template <int NW> struct FusedLds {          // offsets in floats
     static constexpr int WA = 0;                                   // [64][LDW]  W_e  (layer 1: W1, ld LDF)
@@ -358,9 +358,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 // private LDS rows, read it back transposed and multiply by the 0/1 segment matrix,
                 // out[seg][h] = sum_edge S[seg][edge] * E[edge][h]  (k runs in edge order).
                 {
-                    float* wst = smem + L::WSTAGE + wave * (16 * LDW);
+                    float* wst = smem + L::WSTAGE + wave * (16 * LDST);
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) st4(wst + i * LDW + 16 * mb + 4 * q, e[r][mb]);
+                    for (int mb = 0; mb < 4; ++mb) st4(wst + i * LDST + 16 * mb + 4 * q, e[r][mb]);
                     __builtin_amdgcn_wave_barrier();
                     f32x4 red[4];
 #pragma unroll
@@ -368,7 +368,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const float sel = (selbits[r] >> s4) & 1u ? 1.0f : 0.0f;
-                        const float* erow = wst + (4 * s4 + q) * LDW + i;
+                        const float* erow = wst + (4 * s4 + q) * LDST + i;
 #pragma unroll
                         for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = mfma16(sel, erow[16 * nbk], red[nbk]);
                     }
