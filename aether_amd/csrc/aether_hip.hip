@@ -211,12 +211,12 @@ int g_fused_waves = 8;
 int g_edge_variant = 1;       // aether_set_option("edge_variant", 0|1): 0 = weights in registers, 2 waves/SIMD;
                               // 1 = weights re-read from LDS, 3 waves/SIMD, deferred stores (faster: 411 vs 457 us @2.5M edges)        // aether_set_option("fused_waves", 8 | 16)
 
-template <int D, int NW, int ROUNDS>
+template <int D, int NW, int ROUNDS, bool KEEP>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
                  const float* ea, const int32_t* perm, const int32_t* send_s, const int32_t* recv_s,
                  const int32_t* rowptr, const int32_t* groups, int n_groups, const FusedDebug& dbg,
-                 int keep, float* out, hipStream_t st) {
-    auto kern = k_fused<D, NW, ROUNDS>;
+                 float* out, hipStream_t st) {
+    auto kern = k_fused<D, NW, ROUNDS, KEEP>;
     constexpr size_t lds = (size_t)FusedLds<NW>::TOTAL * 4;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {
@@ -226,7 +226,7 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
     }
     ProfScope ps(K_FUSED, st);
     kern<<<dim3((unsigned)n_groups), dim3(NW * 64), lds, st>>>(P, x, vel, charges, ea, perm, send_s, recv_s,
-                                                              rowptr, groups, dbg, keep, out);
+                                                              rowptr, groups, dbg, out);
     return AETHER_OK;
 }
 
@@ -251,8 +251,12 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     const int rounds = (tiles + nw - 1) / nw;
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
-    rc = fused_launch<D, NWV, R>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s), gp(G.recv_s),      \
-                                 gp(G.rowptr), gp(G.groups), info.n_groups, dbg, keep ? 1 : 0, out, st)
+    rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
+                                              gp(G.recv_s), gp(G.rowptr), gp(G.groups), info.n_groups,\
+                                              dbg, out, st)                                           \
+              : fused_launch<D, NWV, R, false>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),      \
+                                               gp(G.recv_s), gp(G.rowptr), gp(G.groups), info.n_groups,\
+                                               dbg, out, st)
     if (rounds <= 1) { AETHER_FUSED_CASE(8, 1); }
     else if (rounds == 2) { AETHER_FUSED_CASE(8, 2); }
     else { AETHER_FUSED_CASE(8, 3); }

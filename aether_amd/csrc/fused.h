@@ -88,13 +88,14 @@ constexpr int FUSED_STAMPS = 512;
 #define FUSED_WSTAMP(layer_, r_, k_)
 #endif
 
-template <int D, int NW, int ROUNDS>
+template <int D, int NW, int ROUNDS, bool KEEP>
 __global__ void __launch_bounds__(NW * 64)
 k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
         const float* __restrict__ charges, const float* __restrict__ edge_attr_orig,
         const int32_t* __restrict__ perm, const int32_t* __restrict__ send_s,
         const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
-        const int32_t* __restrict__ group_nb, FusedDebug dbg, int keep, float* __restrict__ out) {
+        const int32_t* __restrict__ group_nb, FusedDebug dbg, float* __restrict__ out) {
+    constexpr bool keep = KEEP;      // inference build carries none of the save-for-backward stores
     using NI = NodeInfo<D>;
     using L = FusedLds<NW>;
     constexpr int THREADS = NW * 64;
@@ -411,11 +412,6 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         if (layer < 4) {
             const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (NW == 8 || sel4 == 0) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
-                if (NW == 8 || sel4 == 1) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
-            }
-#pragma unroll
             for (int j = 0; j < STG; ++j) {
                 const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
                 stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
@@ -464,6 +460,14 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();       // u complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 4);
+        if (layer < 4) {       // step 4's fragments: issued now, they land while step 3 computes
+            const float* w1n = P.ln_msg_w0[layer - 1];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (NW == 8 || sel4 == 0) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
+                if (NW == 8 || sel4 == 1) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+            }
+        }
         // step 3: x = n + W4 u + b4: rows 16*mb3.. of node tile tn3
         if (act3 && 16 * tn3 < n) {
             const float* ubuf = smem + L::UBUF;
