@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 G = m.prepare_graph(inp["edges"], Nn)[1].n_groups
 dst = torch.zeros(4096, 512, device="cuda")
 lib = _lib.load()
-_lib.check(lib.aether_debug_fetch(b"stamps", a.dims, Nn, E, m._ws.data_ptr(), dst.data_ptr(),
+_lib.check(lib.aether_debug_fetch(b"stamps", a.dims, Nn, E, m._last_ws.data_ptr(), dst.data_ptr(),
                                   torch.cuda.current_stream().cuda_stream), "fetch stamps")
 torch.cuda.synchronize()
 st = dst.cpu().numpy()[:min(G, 4096)]
