@@ -313,6 +313,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         adeg = (float)(end - beg > 1 ? end - beg : 1);
     }
 
+#ifdef AETHER_FUSED_PRIO
+    if (__builtin_amdgcn_readfirstlane(tid) >= AETHER_FUSED_PRIO) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
         // ------------------------------------------------------------ edge tiles (locs.py:227-238)
@@ -412,6 +415,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         if (layer < 4) {
             const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (NW == 8 || sel4 == 0) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
+                if (NW == 8 || sel4 == 1) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+            }
+#pragma unroll
             for (int j = 0; j < STG; ++j) {
                 const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
                 stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
@@ -460,14 +468,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();       // u complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 4);
-        if (layer < 4) {       // step 4's fragments: issued now, they land while step 3 computes
-            const float* w1n = P.ln_msg_w0[layer - 1];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (NW == 8 || sel4 == 0) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
-                if (NW == 8 || sel4 == 1) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
-            }
-        }
+
         // step 3: x = n + W4 u + b4: rows 16*mb3.. of node tile tn3
         if (act3 && 16 * tn3 < n) {
             const float* ubuf = smem + L::UBUF;
