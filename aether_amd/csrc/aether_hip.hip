@@ -141,16 +141,27 @@ __global__ void k_graph_finish(const int64_t* __restrict__ send, const int32_t* 
 // ------------------------------------------------------------------ host-side layouts
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int64_t FUSED_TABLE_MAX_EDGES = 4 << 20;
+int g_fused_split = 1;        // aether_set_option("fused_split", 0|1): two workgroups per group when CUs are idle
+
 struct GraphLayout {
-    size_t perm, send_s, recv_s, rowptr, groups, sperm, srowptr, keys, vals, diff, cross, flag, cub, total,
-        cub_bytes;
+    size_t perm, send_s, recv_s, rowptr, wgdesc, tdesc, tsel, tdst, sperm, srowptr, keys, vals, diff, cross, flag,
+        cub, total, cub_bytes;
+    int64_t max_wgs, max_tiles;
     GraphLayout(int64_t E, int64_t Nn, bool with_sort_scratch = true) {
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
         size_t e4 = (size_t)(E > 0 ? E : 1) * 4;
         perm = take(e4); send_s = take(e4); recv_s = take(e4);
         rowptr = take((size_t)(Nn + 1) * 4);
-        groups = take((size_t)(Nn + 1) * 4);
+        // fused-path tables; skipped for graphs far beyond what the fused kernel serves
+        const bool tables = E <= FUSED_TABLE_MAX_EDGES;
+        max_wgs = tables ? 2 * Nn : 0;
+        max_tiles = tables ? (E + 15) / 16 + 2 * Nn : 0;
+        wgdesc = take((size_t)max_wgs * sizeof(FusedWG) + 4);
+        tdesc = take((size_t)max_tiles * sizeof(FusedTile) + 4);
+        tsel = take((size_t)max_tiles * 64 * 4 + 4);
+        tdst = take((size_t)max_tiles * 64 * 4 + 4);
         sperm = take(e4);                       // receiver-sorted positions grouped by sender (stable)
         srowptr = take((size_t)(Nn + 1) * 4);
         keys = take(e4); vals = take(e4);
@@ -172,9 +183,10 @@ struct GraphLayout {
 
 constexpr int OUTER_MAX_CHUNKS = 64;
 
+
 struct WsLayout {
     // forward (always)
-    size_t nodeinfo, x[5], ps[3], pr[3], e[4], stamps, fwd_total;
+    size_t nodeinfo, x[5], ps[3], pr[3], e[4], stamps, flags, fwd_total;
     // saved by the forward under KEEP_INTERMEDIATES for the backward
     size_t n[4], feat;
     // backward temporaries
@@ -191,6 +203,7 @@ struct WsLayout {
         for (auto& v : pr) v = take(nn * H);
         for (auto& v : e) v = take(ee * H);
         stamps = take((size_t)4096 * FUSED_STAMPS);
+        flags = take(2 * nn + 64);              // split-mode hand-off flags, one int per workgroup
         fwd_total = off;
         for (auto& v : n) v = take(nn * H);
         feat = take(ee * FPAD);
@@ -214,8 +227,8 @@ int g_edge_variant = 1;       // aether_set_option("edge_variant", 0|1): 0 = wei
 template <int D, int NW, int ROUNDS, bool KEEP>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
                  const float* ea, const int32_t* perm, const int32_t* send_s, const int32_t* recv_s,
-                 const int32_t* rowptr, const int32_t* groups, int n_groups, const FusedDebug& dbg,
-                 float* out, hipStream_t st) {
+                 const int32_t* rowptr, const FusedWG* wgdesc, const uint32_t* tsel, const uint32_t* tdst,
+                 int n_groups, const FusedDebug& dbg, float* out, hipStream_t st) {
     auto kern = k_fused<D, NW, ROUNDS, KEEP>;
     constexpr size_t lds = (size_t)FusedLds<NW>::TOTAL * 4;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
@@ -226,7 +239,7 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
     }
     ProfScope ps(K_FUSED, st);
     kern<<<dim3((unsigned)n_groups), dim3(NW * 64), lds, st>>>(P, x, vel, charges, ea, perm, send_s, recv_s,
-                                                              rowptr, groups, dbg, out);
+                                                              rowptr, wgdesc, tsel, tdst, dbg, out);
     return AETHER_OK;
 }
 
@@ -246,17 +259,23 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     for (int k = 0; k < 3; ++k) { dbg.ps[k] = wp(W.ps[k]); dbg.pr[k] = wp(W.pr[k]); }
     dbg.feat = wp(W.feat);
     dbg.stamps = wp(W.stamps);
+    dbg.flags = reinterpret_cast<int*>(ws + W.flags);
+    const FusedWG* wgd = reinterpret_cast<const FusedWG*>(graph + G.wgdesc);
+    const uint32_t* tsel = reinterpret_cast<const uint32_t*>(graph + G.tsel);
+    const uint32_t* tdst = reinterpret_cast<const uint32_t*>(graph + G.tdst);
+    if (info.reserved & 1)      // split mode: every polled word is zero before the launch
+        HIP_OK(hipMemsetAsync(dbg.flags, 0, (size_t)info.n_groups * 4, st));
     const int tiles = (info.max_group_edges + 15) / 16;
     const int nw = g_fused_waves;
     const int rounds = (tiles + nw - 1) / nw;
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
-                                              gp(G.recv_s), gp(G.rowptr), gp(G.groups), info.n_groups,\
-                                              dbg, out, st)                                           \
+                                              gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,            \
+                                              info.n_groups, dbg, out, st)                            \
               : fused_launch<D, NWV, R, false>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),      \
-                                               gp(G.recv_s), gp(G.rowptr), gp(G.groups), info.n_groups,\
-                                               dbg, out, st)
+                                               gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,           \
+                                               info.n_groups, dbg, out, st)
     if (rounds <= 1) { AETHER_FUSED_CASE(8, 1); }
     else if (rounds == 2) { AETHER_FUSED_CASE(8, 2); }
     else { AETHER_FUSED_CASE(8, 3); }
@@ -500,6 +519,10 @@ int aether_set_option(const char* name, int value) {
         g_fused_waves = value;
         return AETHER_OK;
     }
+    if (!strcmp(name, "fused_split")) {      // takes effect at the next aether_graph_build
+        g_fused_split = value != 0;
+        return AETHER_OK;
+    }
     if (!strcmp(name, "edge_variant")) {
         if (value < 0 || value > 2) return fail(AETHER_EINVAL, "set_option: edge_variant must be 0..2");
         g_edge_variant = value;
@@ -632,11 +655,57 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
             c0 = c1;
         }
         grp.push_back((int32_t)n_nodes);
-        HIP_OK(hipMemcpyAsync(g + G.groups, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, st));
-        HIP_OK(hipStreamSynchronize(st));
-        info->n_groups = (int32_t)grp.size() - 1;
-        info->max_group_nodes = (int32_t)mgn;
-        info->max_group_edges = (int32_t)mge;
+        const int n_grp = (int)grp.size() - 1;
+        if (G.max_wgs >= 2 * (int64_t)n_grp) {
+            // Workgroup descriptors.  With fewer groups than half the CUs, each group is split over two
+            // workgroups by receiver range (balanced by in-edge count); see FusedWG.
+            int cus = 256;
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            bool split = g_fused_split && 2 * n_grp <= cus;
+            for (int k = 0; k < n_grp && split; ++k) if (grp[k + 1] - grp[k] < 2) split = false;
+            std::vector<FusedWG> wgs;
+            std::vector<FusedTile> tiles;
+            mgn = 0; mge = 0;
+            auto add_wg = [&](int vb, int ve, int nb, int ne, int partner) {
+                FusedWG w = {vb, ve, nb, ne, (int)tiles.size(), partner, 0, 0};
+                const int eb = h_rowptr[nb], m = h_rowptr[ne] - eb;
+                for (int t = 0; t < (m + 15) / 16; ++t) tiles.push_back(FusedTile{eb, m, nb, t});
+                if (ne - nb > mgn) mgn = ne - nb;
+                if (m > mge) mge = m;
+                wgs.push_back(w);
+            };
+            for (int k = 0; k < n_grp; ++k) {
+                const int a = grp[k], b = grp[k + 1];
+                if (!split) { add_wg(a, b, a, b, -1); continue; }
+                const int64_t tot = h_rowptr[b] - h_rowptr[a];
+                int nm = a + 1;
+                int64_t best = -1;
+                for (int c = a + 1; c < b; ++c) {
+                    int64_t left = h_rowptr[c] - h_rowptr[a], d = left * 2 > tot ? left * 2 - tot : tot - left * 2;
+                    if (best < 0 || d < best) { best = d; nm = c; }
+                }
+                const int idx = (int)wgs.size();
+                add_wg(a, b, a, nm, idx + 1);
+                add_wg(a, b, nm, b, idx);
+            }
+            if ((int64_t)tiles.size() <= G.max_tiles) {
+                HIP_OK(hipMemcpyAsync(g + G.wgdesc, wgs.data(), wgs.size() * sizeof(FusedWG), hipMemcpyHostToDevice, st));
+                if (!tiles.empty()) {
+                    HIP_OK(hipMemcpyAsync(g + G.tdesc, tiles.data(), tiles.size() * sizeof(FusedTile),
+                                          hipMemcpyHostToDevice, st));
+                    k_graph_tiles<<<dim3((unsigned)tiles.size()), dim3(64), 0, st>>>(
+                        (const FusedTile*)(g + G.tdesc), recv_s, (uint32_t*)(g + G.tsel), (uint32_t*)(g + G.tdst));
+                }
+                HIP_OK(hipStreamSynchronize(st));       // host vectors must outlive the copies
+                info->n_groups = (int32_t)wgs.size();
+                info->max_group_nodes = (int32_t)mgn;
+                info->max_group_edges = (int32_t)mge;
+                info->reserved = split ? 1 : 0;
+            }
+        }
     }
     return AETHER_OK;
 }

@@ -63,6 +63,7 @@ template <int NW> struct FusedLds {          // offsets in floats
 struct FusedDebug {
     float* nodeinfo; float* x[5]; float* e[4];
     float* n[4]; float* ps[3]; float* pr[3]; float* feat;     // saved for the backward
+    int* flags;             // [workgroups] split mode: layer whose P_s rows this workgroup has published
     float* stamps;          // [groups][FUSED_STAMPS] diagnostic build only
 };
 constexpr int FUSED_STAMPS = 512;
@@ -88,13 +89,63 @@ constexpr int FUSED_STAMPS = 512;
 #define FUSED_WSTAMP(layer_, r_, k_)
 #endif
 
+// One workgroup's share of a group: it sees nodes [vb, ve) (whole graphs: every sender of its edges)
+// and owns nodes [nb, ne) -- their in-edges, their node updates, their outputs.  Unsplit: own = visible.
+// Split (two workgroups per group, when there are fewer groups than half the CUs): the partner owns
+// the rest and the two exchange their P_s rows once per layer through global memory.
+struct FusedWG { int vb, ve, nb, ne, tile0, partner, pad0, pad1; };
+struct FusedTile { int eb, m, nb, t; };      // first sorted edge of the owner, its edge count, owner's nb, tile index
+
+// Per-tile structure of the receiver-sorted edge list, built once with the graph: for every lane of
+// the tile's wave the 0/1 column of the segment matrix it feeds to the matrix core (tsel) and the
+// partial rows its four result registers go to (tdst, one byte each, 0xFF = none).
+__global__ void __launch_bounds__(64)
+k_graph_tiles(const FusedTile* __restrict__ tdesc, const int32_t* __restrict__ recv_s,
+              uint32_t* __restrict__ tsel, uint32_t* __restrict__ tdst) {
+    const FusedTile T = tdesc[blockIdx.x];
+    const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+    const int local = 16 * T.t + i;
+    const bool valid = local < T.m;
+    const int rcv = valid ? recv_s[T.eb + local] - T.nb : -1;
+    // rows are receiver-sorted.  smask bit j: row j starts a new segment; segment ids count up in
+    // row order; padding rows belong to no segment.
+    const int prev = __shfl_up(rcv, 1, 16);
+    const unsigned smask = (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;
+    const unsigned vmask = (unsigned)__ballot(q == 0 && valid) & 0xFFFFu;
+    unsigned sb = 0, dp = 0;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int edge = 4 * s4 + q;
+        const int seg_of_edge = __popc(smask & ((2u << edge) - 1u));
+        if (((vmask >> edge) & 1u) && seg_of_edge == i) sb |= 1u << s4;
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int seg = 4 * q + r4;
+        unsigned mm = smask;                 // first row of segment `seg`: its start bit (segment 0: row 0)
+        int s0 = 0;
+        bool exists = true;
+        for (int t = 0; t < seg; ++t) {
+            if (mm == 0) { exists = false; break; }
+            s0 = __ffs(mm) - 1;
+            mm &= mm - 1;
+        }
+        const int node = __shfl(rcv, (lane & 48) + s0);           // owner-local receiver of row s0
+        const unsigned row = (exists && ((vmask >> s0) & 1u)) ? (unsigned)(node + T.t) : 0xFFu;
+        dp |= row << (8 * r4);
+    }
+    tsel[(size_t)blockIdx.x * 64 + lane] = sb;
+    tdst[(size_t)blockIdx.x * 64 + lane] = dp;
+}
+
 template <int D, int NW, int ROUNDS, bool KEEP>
 __global__ void __launch_bounds__(NW * 64)
 k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
         const float* __restrict__ charges, const float* __restrict__ edge_attr_orig,
         const int32_t* __restrict__ perm, const int32_t* __restrict__ send_s,
         const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
-        const int32_t* __restrict__ group_nb, FusedDebug dbg, float* __restrict__ out) {
+        const FusedWG* __restrict__ wgdesc, const uint32_t* __restrict__ tsel,
+        const uint32_t* __restrict__ tdst, FusedDebug dbg, float* __restrict__ out) {
     constexpr bool keep = KEEP;      // inference build carries none of the save-for-backward stores
     using NI = NodeInfo<D>;
     using L = FusedLds<NW>;
@@ -115,8 +166,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int nb = group_nb[blockIdx.x], ne = group_nb[blockIdx.x + 1];
-    const int n = ne - nb;
+    const FusedWG wg = wgdesc[blockIdx.x];
+    const int vb = wg.vb, nv = wg.ve - wg.vb;            // visible nodes (slots of ninfo / psb)
+    const int nb = wg.nb, ne = wg.ne;                    // own nodes (slots of xbuf / nbuf / prb / part)
+    const int n = ne - nb, off = nb - vb;
     const int eb = rowptr[nb], ee = rowptr[ne];
     const int m = ee - eb;
     const int n_tiles = (m + 15) >> 4;
@@ -138,20 +191,20 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         float* h1 = smem + L::FIELD_H1;
         float* h2 = smem + L::FIELD_H2;
         float* ff = smem + L::FIELD_F;
-        for (int idx = tid; idx < n * FIN; idx += THREADS) {
+        for (int idx = tid; idx < nv * FIN; idx += THREADS) {
             int node = idx / FIN, k = idx - node * FIN;
             float val;
-            if (k < D) val = x[(int64_t)(nb + node) * D + k];
-            else if (k < 2 * D) val = vel[(int64_t)(nb + node) * D + (k - D)];
+            if (k < D) val = x[(int64_t)(vb + node) * D + k];
+            else if (k < 2 * D) val = vel[(int64_t)(vb + node) * D + (k - D)];
             else {
-                long ci = (long)(charges[nb + node] + 1.0f);
+                long ci = (long)(charges[vb + node] + 1.0f);
                 ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
                 val = P.field_emb[ci * 16 + (k - 2 * D)];
             }
             z[node * 24 + k] = val;
         }
         __syncthreads();
-        for (int idx = tid; idx < n * 32; idx += THREADS) {
+        for (int idx = tid; idx < nv * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
             float s = P.field_b0[o];
 #pragma unroll
@@ -159,7 +212,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             h1[node * 32 + o] = silu(s);
         }
         __syncthreads();
-        for (int idx = tid; idx < n * 32; idx += THREADS) {
+        for (int idx = tid; idx < nv * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
             float s = P.field_b2[o];
 #pragma unroll
@@ -167,7 +220,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             h2[node * 32 + o] = silu(s);
         }
         __syncthreads();
-        for (int idx = tid; idx < n * D; idx += THREADS) {
+        for (int idx = tid; idx < nv * D; idx += THREADS) {
             int node = idx / D, d = idx - node * D;
             float s = P.field_b4[d];
 #pragma unroll
@@ -176,7 +229,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();
         // frames + rel_feat (geometry.py:7-73, aether.py:33-50): one thread per node
-        if (tid < n) {
+        if (tid < nv) {
             float v[D], f[D], R[D][D], cv[D], cf[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) { v[d] = z[tid * 24 + D + d]; f[d] = ff[tid * 4 + d]; }
@@ -189,8 +242,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                 for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
             }
-            if (keep) {
-                float* g = dbg.nodeinfo + (int64_t)(nb + tid) * NI::STRIDE;
+            if (keep && tid >= off && tid < off + n) {
+                float* g = dbg.nodeinfo + (int64_t)(vb + tid) * NI::STRIDE;
 #pragma unroll
                 for (int t = 0; t < NI::STRIDE; ++t) g[t] = t < NI::CF + D ? ni[t] : 0.0f;
             }
@@ -204,8 +257,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 acc = P.l1_res_b[o];
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    acc += P.l1_res_w[o * 3 * D + D + d] * ninfo[node * 24 + NI::CV + d];
-                    acc += P.l1_res_w[o * 3 * D + 2 * D + d] * ninfo[node * 24 + NI::CF + d];
+                    acc += P.l1_res_w[o * 3 * D + D + d] * ninfo[(off + node) * 24 + NI::CV + d];
+                    acc += P.l1_res_w[o * 3 * D + 2 * D + d] * ninfo[(off + node) * 24 + NI::CF + d];
                 }
                 if (keep) dbg.x[0][(int64_t)(nb + node) * H + o] = acc;
             }
@@ -219,7 +272,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     // Wave w owns tiles {w, w+NW, ..}.  Per tile, 16 lanes each build the features of one edge into
     // the wave's scratch rows; then every lane reads its B fragments back.  Per-tile constants of
     // the graph structure (sender / receiver slot, receiver-segment index) are computed once here.
-    int sl[ROUNDS], rl[ROUNDS];
+    int sl[ROUNDS], rl[ROUNDS];              // sender slot (visible numbering), receiver slot (own numbering)
     unsigned selbits[ROUNDS];                // bit s4: S[seg = i][edge = 4*s4 + q] of the tile
     unsigned destpack[ROUNDS];               // byte r4: partial row of segment 4q + r4, 0xFF = none
     f32x4 e[ROUNDS][4];                      // message tiles, MFMA accumulator layout
@@ -231,8 +284,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             float o[FPAD];
             if (local < m) {
                 const int k = eb + local;
-                const float* nj = ninfo + (send_s[k] - nb) * 24;
-                const float* nr = ninfo + (recv_s[k] - nb) * 24;
+                const float* nj = ninfo + (send_s[k] - vb) * 24;
+                const float* nr = ninfo + (recv_s[k] - vb) * 24;
                 float njl[NI::STRIDE], nrl[NI::STRIDE];
 #pragma unroll
                 for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
@@ -261,41 +314,12 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile = NW * r + wave;
             const int local = 16 * tile + i;
-            const bool valid = local < m;
-            const int k = eb + (valid ? local : 0);
-            sl[r] = m > 0 ? send_s[k] - nb : 0;
+            const int k = eb + (local < m ? local : 0);
+            sl[r] = m > 0 ? send_s[k] - vb : 0;
             rl[r] = m > 0 ? recv_s[k] - nb : 0;
-            // Receiver segments of the tile (rows are receiver-sorted).  smask bit j: row j starts a
-            // new segment; segment ids count up in row order; padding rows belong to no segment.
-            const int rcv = valid ? rl[r] : -1;
-            const int prev = __shfl_up(rcv, 1, 16);
-            const unsigned smask = (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;
-            const unsigned vmask = (unsigned)__ballot(q == 0 && valid) & 0xFFFFu;
-            unsigned sb = 0, dp = 0;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int edge = 4 * s4 + q;
-                const int seg_of_edge = __popc(smask & ((2u << edge) - 1u));
-                if (((vmask >> edge) & 1u) && seg_of_edge == i) sb |= 1u << s4;
-            }
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int seg = 4 * q + r4;
-                // first row of segment `seg`: row 0 for segment 0, else the seg-th set bit of smask
-                unsigned mm = smask;
-                int s0 = 0;
-                bool exists = true;
-                for (int t = 0; t < seg; ++t) {
-                    if (mm == 0) { exists = false; break; }
-                    s0 = __ffs(mm) - 1;
-                    mm &= mm - 1;
-                }
-                const int node = __shfl(rl[r], (lane & 48) + s0);          // receiver slot of row s0
-                const unsigned row = (exists && ((vmask >> s0) & 1u)) ? (unsigned)(node + tile) : 0xFFu;
-                dp |= row << (8 * r4);
-            }
-            selbits[r] = sb;
-            destpack[r] = dp;
+            const bool have = tile < n_tiles;
+            selbits[r] = have ? tsel[(size_t)(wg.tile0 + tile) * 64 + lane] : 0u;
+            destpack[r] = have ? tdst[(size_t)(wg.tile0 + tile) * 64 + lane] : 0xFFFFFFFFu;
         }
         __syncthreads();       // feature scratch (aliases SCRATCH) is dead from here on
     }
@@ -499,9 +523,19 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) accs = mfma16(wsv[a][b], xv[a][b], accs);
-                    st4(psb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accs);
-                    if (keep && 16 * tn3 + i < n)
-                        st4(dbg.ps[layer - 1] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, accs);
+                    if (16 * tn3 + i < n) {      // sender rows live in the visible numbering
+                        st4(psb + (off + 16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accs);
+                        float* gps = dbg.ps[layer - 1] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q;
+                        if (wg.partner >= 0) {       // write-through (sc1) payload: no release fence needed
+                            typedef unsigned long long u64;
+                            const u64 lo = ((u64)__float_as_uint(accs[1]) << 32) | __float_as_uint(accs[0]);
+                            const u64 hi = ((u64)__float_as_uint(accs[3]) << 32) | __float_as_uint(accs[2]);
+                            __hip_atomic_store((u64*)gps, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store((u64*)gps + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else if (keep) {
+                            st4(gps, accs);
+                        }
+                    }
                 }
                 if (NW == 8 || sel4 == 1) {
                     f32x4 accr = ld4(b1n + 16 * mb3 + 4 * q);
@@ -514,10 +548,44 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                         st4(dbg.pr[layer - 1] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, accr);
                 }
             }
+            if (wg.partner >= 0) {
+                // Hand the own P_s rows to the partner workgroup and fetch its rows
+                // (cdna_hip_programming.md Guideline 16, form R1 with write-through payload): every
+                // byte of the payload is stored sc1 (8-byte agent-scope stores above) and every storing
+                // wave drains its stores before the barrier; one lane then raises the flag and polls the
+                // partner's (bounded); after the second barrier every wave reads the partner's rows with
+                // sc1 (L1-bypassing) 8-byte loads -- the only loads of those bytes in this launch.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_store(dbg.flags + blockIdx.x, layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(dbg.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < layer) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 24)) break;           // partner not resident: give up, never hang
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                __syncthreads();
+                // partner rows = visible slots outside [off, off + n)
+                const int np = nv - n;
+                for (int idx = tid; idx < np * 32; idx += THREADS) {
+                    typedef unsigned long long u64;
+                    int slot = idx >> 5;
+                    if (slot >= off) slot += n;
+                    const int c = (idx & 31) * 2;
+                    const u64 v = __hip_atomic_load((const u64*)(dbg.ps[layer - 1] + (int64_t)(vb + slot) * H + c),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    psb[slot * LDW + c] = __uint_as_float((unsigned)v);
+                    psb[slot * LDW + c + 1] = __uint_as_float((unsigned)(v >> 32));
+                }
+            }
             __syncthreads();   // P_s / P_r and the staged weights are visible to the next edge tiles
             FUSED_STAMP(4 + 8 * (layer - 1) + 6);
         }
     }
+    if (wg.partner >= 0 && tid == 0)       // the partner's last flag value has been consumed: re-arm it
+        __hip_atomic_store(dbg.flags + wg.partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---------------------------------------------------------------- out MLP + globalise + residual
     // locs.py:160-168,193; local_to_global.py:12-13; aether.py:185
@@ -566,7 +634,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 float yl[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) yl[d] = y[d] + P.out_b6[d];
-                const float* ni = ninfo + node * 24;
+                const float* ni = ninfo + (off + node) * 24;
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
                     float s = 0.f;

@@ -62,10 +62,10 @@ typedef struct AetherParams {
 /* Host-side summary of a built graph; filled by aether_graph_build, passed back to aether_forward. */
 typedef struct AetherGraphInfo {
     int64_t n_nodes, n_edges;
-    int32_t n_groups;          /* > 0: the graph splits into this many fused-kernel groups        */
-    int32_t max_group_nodes;   /* largest group (<= 32 nodes, <= 384 edges), else n_groups == 0    */
+    int32_t n_groups;          /* > 0: workgroups of the fused kernel (0: streamed path only)      */
+    int32_t max_group_nodes;   /* most nodes / in-edges one workgroup owns (<= 32 / <= 384)         */
     int32_t max_group_edges;
-    int32_t reserved;
+    int32_t reserved;          /* bit 0: groups are split over two cooperating workgroups           */
 } AetherGraphInfo;
 
 /* aether_forward flags */
@@ -146,8 +146,9 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
                            const void* workspace, float* dst, void* stream);
 
 /*
- * Tuning knobs (process-wide; not thread-safe).  "fused_waves": 8 or 16 waves per workgroup of
- * the fused kernel.
+ * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
+ * there are fewer groups than half the CUs; read by aether_graph_build), "edge_variant" 0|1
+ * (streamed edge kernel: weights in registers | re-read from LDS with 3 waves per SIMD).
  */
 int aether_set_option(const char* name, int value);
 
