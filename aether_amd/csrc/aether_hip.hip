@@ -230,7 +230,7 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
                  const int32_t* rowptr, const FusedWG* wgdesc, const uint32_t* tsel, const uint32_t* tdst,
                  int n_groups, const FusedDebug& dbg, float* out, hipStream_t st) {
     auto kern = k_fused<D, NW, ROUNDS, KEEP>;
-    constexpr size_t lds = (size_t)FusedLds<NW>::TOTAL * 4;
+    constexpr size_t lds = (size_t)FusedLds<NW, ROUNDS>::TOTAL * 4;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -267,7 +267,6 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
         HIP_OK(hipMemsetAsync(dbg.flags, 0, (size_t)info.n_groups * 4, st));
     const int tiles = (info.max_group_edges + 15) / 16;
     const int nw = g_fused_waves;
-    const int rounds = (tiles + nw - 1) / nw;
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
@@ -276,8 +275,9 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
               : fused_launch<D, NWV, R, false>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),      \
                                                gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,           \
                                                info.n_groups, dbg, out, st)
-    if (rounds <= 1) { AETHER_FUSED_CASE(8, 1); }
-    else if (rounds == 2) { AETHER_FUSED_CASE(8, 2); }
+    if (nw == 16 && tiles <= 16) { AETHER_FUSED_CASE(16, 1); }
+    else if (tiles <= 8) { AETHER_FUSED_CASE(8, 1); }
+    else if (tiles <= 16) { AETHER_FUSED_CASE(8, 2); }
     else { AETHER_FUSED_CASE(8, 3); }
 #undef AETHER_FUSED_CASE
     if (rc != AETHER_OK) return rc;
@@ -513,9 +513,8 @@ const char* aether_last_error(void) { return g_err; }
 int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");
     if (!strcmp(name, "fused_waves")) {
-        // 16 waves (4 per SIMD) was measured slower: 128-VGPR cap -> spills, and its LDS scratch no
-        // longer fits next to the conflict-free row strides
-        if (value != 8) return fail(AETHER_EINVAL, "set_option: fused_waves must be 8");
+        // 16 waves (4 per SIMD, one tile per wave) is used only when a workgroup owns <= 16 tiles
+        if (value != 8 && value != 16) return fail(AETHER_EINVAL, "set_option: fused_waves must be 8 or 16");
         g_fused_waves = value;
         return AETHER_OK;
     }

@@ -27,7 +27,7 @@ constexpr int FUSED_MAX_EDGES = 384;         // 24 tiles (N=20 fully connected: 
 constexpr int FUSED_MAX_TILES = FUSED_MAX_EDGES / 16;
 constexpr int LDU = 2 * H + 8;               // padded LDS row for the 128-wide update hidden
 
-template <int NW> struct FusedLds {          // offsets in floats
+template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static constexpr int WA = 0;                                   // [64][LDW]  W_e  (layer 1: W1, ld LDF)
     static constexpr int WB = WA + H * LDW;                        // [64][LDW]  W2
     static constexpr int BIAS = WB + H * LDW;                      // [128]      b1 | b2
@@ -39,16 +39,16 @@ template <int NW> struct FusedLds {          // offsets in floats
     static constexpr int PART_ROWS = FUSED_MAX_NODES + FUSED_MAX_TILES;
     static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [56][LDW]  per-(receiver, tile) sums
     static constexpr int SCRATCH = PART + PART_ROWS * LDW;         // aliased by the regions below
-    static constexpr int FEAT_ROWS = 16 * ((FUSED_MAX_TILES + NW - 1) / NW);   // per wave
+    static constexpr int FEAT_ROWS = 16 * ROUNDS;                              // per wave
     static constexpr int SCRATCH_SIZE =
-        NW * FEAT_ROWS * LDF > NW * 16 * LDW ? NW * FEAT_ROWS * LDF : NW * 16 * LDW;
+        NW * FEAT_ROWS * LDF > NW * 16 * LDST ? NW * FEAT_ROWS * LDF : NW * 16 * LDST;
     static constexpr int TOTAL = SCRATCH + SCRATCH_SIZE;
     static constexpr int FIELD_Z = SCRATCH;                            // [32][24]  p | v | emb
     static constexpr int FIELD_H1 = FIELD_Z + FUSED_MAX_NODES * 24;    // [32][32]
     static constexpr int FIELD_H2 = FIELD_H1 + FUSED_MAX_NODES * 32;   // [32][32]
     static constexpr int FIELD_F = FIELD_H2 + FUSED_MAX_NODES * 32;    // [32][4]
     static constexpr int FEAT = SCRATCH;                               // [NW waves][FEAT_ROWS][LDF]
-    static constexpr int WSTAGE = SCRATCH;                             // [NW waves][16][LDW] tile staging
+    static constexpr int WSTAGE = SCRATCH;                             // [NW waves][16][LDST] tile staging
     static constexpr int UBUF = SCRATCH;                               // [32][LDU]
     static constexpr int OBUF1 = SCRATCH;                              // [32][LDW]
     static constexpr int OBUF2 = SCRATCH + FUSED_MAX_NODES * LDW;      // [32][LDW]
@@ -148,7 +148,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         const uint32_t* __restrict__ tdst, FusedDebug dbg, float* __restrict__ out) {
     constexpr bool keep = KEEP;      // inference build carries none of the save-for-backward stores
     using NI = NodeInfo<D>;
-    using L = FusedLds<NW>;
+    using L = FusedLds<NW, ROUNDS>;
     constexpr int THREADS = NW * 64;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
     constexpr int FIN = 2 * D + 16;
