@@ -343,75 +343,89 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
         // ------------------------------------------------------------ edge tiles (locs.py:227-238)
-        // No workgroup barrier in here.
+        // No workgroup barrier in here.  A wave with K tiles runs them through one branch-free block
+        // (front = first Linear + SiLU, back = second Linear + SiLU + per-receiver sums) so that the
+        // compiler can overlap one tile's VALU / LDS tail with the next tile's MFMAs.
+        auto front = [&](int r, f32x4 (&h1)[4]) {
+            f32x4 acc[4];
+            if (layer == 1) {
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
+                for (int mb = 0; mb < 4; ++mb) acc[mb] = ld4(bias + 16 * mb + 4 * q);
+                f32x4 bop[2] = {e[r][0], e[r][1]};
+                gemm_tile<4, 2>(wA, LDF, bop, acc, i, q);
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb] = ld4(psb + sl[r] * LDW + 16 * mb + 4 * q) + ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
+                gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
+        };
+        auto back = [&](int r, const f32x4 (&h1)[4]) {
             const int tile = NW * r + wave;
-            if (tile < n_tiles) {                                  // wave-uniform
-                FUSED_WSTAMP(layer, r, 0);
-                f32x4 acc[4], acc2[4], h1[4];
-                if (layer == 1) {
+            f32x4 acc2[4];
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb] = ld4(bias + 16 * mb + 4 * q);
-                    f32x4 bop[2] = {e[r][0], e[r][1]};
-                    gemm_tile<4, 2>(wA, LDF, bop, acc, i, q);
-                } else {
+            for (int mb = 0; mb < 4; ++mb) acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
+            gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
+            if (keep) {
+                const int local = 16 * tile + i;
+                if (local < m) {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
-                        acc[mb] = ld4(psb + sl[r] * LDW + 16 * mb + 4 * q) +
-                                  ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
-                    gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
+                        st4(dbg.e[layer - 1] + (int64_t)(eb + local) * H + 16 * mb + 4 * q, e[r][mb]);
                 }
-                FUSED_WSTAMP(layer, r, 1);
+            }
+            // Per-receiver sums of the tile on the matrix core: park the tile in 16 LDS rows (one set
+            // per round, private to the wave), read it back transposed and multiply by the 0/1 segment
+            // matrix, out[seg][h] = sum_edge S[seg][edge] * E[edge][h]  (k runs in edge order).
+            float* wst = smem + L::WSTAGE + wave * (16 * LDST);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    h1[mb] = silu4(acc[mb]);
-                    acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
+            for (int mb = 0; mb < 4; ++mb) st4(wst + i * LDST + 16 * mb + 4 * q, e[r][mb]);
+            __builtin_amdgcn_wave_barrier();
+            f32x4 red[4];
+#pragma unroll
+            for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float sel = (selbits[r] >> s4) & 1u ? 1.0f : 0.0f;
+                const float* erow = wst + (4 * s4 + q) * LDST + i;
+#pragma unroll
+                for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = mfma16(sel, erow[16 * nbk], red[nbk]);
+            }
+            // lane (h = 16 nbk + i, q) register r4 holds segment 4q + r4
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const unsigned row = (destpack[r] >> (8 * r4)) & 0xFFu;
+                if (row != 0xFFu) {
+                    float* dst = part + row * LDW + i;
+                    dst[0] = red[0][r4]; dst[16] = red[1][r4]; dst[32] = red[2][r4]; dst[48] = red[3][r4];
                 }
-                FUSED_WSTAMP(layer, r, 2);
-                gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
-                FUSED_WSTAMP(layer, r, 3);
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        {
+            const int nvalid = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;    // wave-uniform
+            if (ROUNDS == 2 && nvalid == 2) {
+                f32x4 ha[4], hb[4];
+                front(0, ha);
+                front(1, hb);
+                back(0, ha);
+                back(1, hb);
+            } else {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
-                if (keep) {
-                    const int local = 16 * tile + i;
-                    if (local < m) {
-#pragma unroll
-                        for (int mb = 0; mb < 4; ++mb)
-                            st4(dbg.e[layer - 1] + (int64_t)(eb + local) * H + 16 * mb + 4 * q, e[r][mb]);
+                for (int r = 0; r < ROUNDS; ++r) {
+                    if (r < nvalid) {
+                        FUSED_WSTAMP(layer, r, 0);
+                        f32x4 h1[4];
+                        front(r, h1);
+                        FUSED_WSTAMP(layer, r, 2);
+                        back(r, h1);
+                        FUSED_WSTAMP(layer, r, 5);
                     }
                 }
-                FUSED_WSTAMP(layer, r, 4);
-                // Per-receiver sums of the tile on the matrix core: park the tile in the wave's 16
-                // private LDS rows, read it back transposed and multiply by the 0/1 segment matrix,
-                // out[seg][h] = sum_edge S[seg][edge] * E[edge][h]  (k runs in edge order).
-                {
-                    float* wst = smem + L::WSTAGE + wave * (16 * LDST);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) st4(wst + i * LDST + 16 * mb + 4 * q, e[r][mb]);
-                    __builtin_amdgcn_wave_barrier();
-                    f32x4 red[4];
-#pragma unroll
-                    for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const float sel = (selbits[r] >> s4) & 1u ? 1.0f : 0.0f;
-                        const float* erow = wst + (4 * s4 + q) * LDST + i;
-#pragma unroll
-                        for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = mfma16(sel, erow[16 * nbk], red[nbk]);
-                    }
-                    // lane (h = 16 nbk + i, q) register r4 holds segment 4q + r4
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const unsigned row = (destpack[r] >> (8 * r4)) & 0xFFu;
-                        if (row != 0xFFu) {
-                            float* dst = part + row * LDW + i;
-                            dst[0] = red[0][r4]; dst[16] = red[1][r4]; dst[32] = red[2][r4]; dst[48] = red[3][r4];
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                FUSED_WSTAMP(layer, r, 5);
             }
         }
         FUSED_STAMP(4 + 8 * (layer - 1) + 2);
