@@ -56,10 +56,10 @@ int fail(int code, const char* msg) {
 // Optional (aether_profile_enable): brackets every launch with a pair of events on the
 // launch stream so bench.py can report the dominant kernel's average duration.
 enum KernelId { K_NODE_PREP = 0, K_EDGE_L1, K_NODE_UPDATE, K_EDGE_LN, K_NODE_LAST, K_FUSED, KB_OUT, KB_NODE,
-                KB_EDGE, KB_GATHER, KB_FIELD, KB_OUTER, K_COUNT };
+                KB_EDGE, KB_GATHER, KB_FIELD, KB_OUTER, K_SEGMEAN, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_node_prep", "k_edge_layer1", "k_node_update", "k_edge_layer",
                                            "k_node_update_last", "k_fused", "kb_out", "kb_node", "kb_edge",
-                                           "kb_gather", "kb_field", "k_outer+reduce"};
+                                           "kb_gather", "kb_field", "k_outer+reduce", "k_segment_mean"};
 struct ProfSlot { hipEvent_t a, b; int id; };
 constexpr int PROF_SLOTS = 8192;
 ProfSlot g_prof[PROF_SLOTS];
@@ -186,7 +186,7 @@ constexpr int OUTER_MAX_CHUNKS = 64;
 
 struct WsLayout {
     // forward (always)
-    size_t nodeinfo, x[5], ps[3], pr[3], e[4], stamps, flags, fwd_total;
+    size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, stamps, flags, fwd_total;
     // saved by the forward under KEEP_INTERMEDIATES for the backward
     size_t n[4], feat;
     // backward temporaries
@@ -202,6 +202,7 @@ struct WsLayout {
         for (auto& v : ps) v = take(nn * H);
         for (auto& v : pr) v = take(nn * H);
         for (auto& v : e) v = take(ee * H);
+        aggr = take(nn * H);
         stamps = take((size_t)4096 * FUSED_STAMPS);
         flags = take(2 * nn + 64);              // split-mode hand-off flags, one int per workgroup
         fwd_total = off;
@@ -311,10 +312,15 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
         k_edge_layer1<D><<<dim3(g1), dim3(256), lds1, st>>>(P, nodeinfo, ea, perm, send_s, recv_s,
                                                            wp(W.e[0]), keep ? wp(W.feat) : nullptr, E);
     }
+    auto seg_mean = [&](int l) {
+        ProfScope ps(K_SEGMEAN, st);
+        k_segment_mean<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(wp(W.e[l - 1]), rowptr, wp(W.aggr), Nn);
+    };
+    seg_mean(1);
     {
         ProfScope ps(K_NODE_UPDATE, st);
         k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
-        P, 1, wp(W.x[0]), wp(W.e[0]), rowptr, wp(W.x[1]), wp(W.ps[0]), wp(W.pr[0]), nodeinfo, x, out,
+        P, 1, wp(W.x[0]), wp(W.aggr), wp(W.x[1]), wp(W.ps[0]), wp(W.pr[0]), nodeinfo, x, out,
         keep ? wp(W.n[0]) : nullptr, Nn);
     }
     for (int l = 2; l <= 4; ++l) {
@@ -331,15 +337,16 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
             if (g_edge_variant == 1) launch(k_edge_layer<false>);
             else launch(k_edge_layer<true>);
         }
+        seg_mean(l);
         if (l < 4) {
             ProfScope ps(K_NODE_UPDATE, st);
             k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
-                P, l, wp(W.x[l - 1]), wp(W.e[l - 1]), rowptr, wp(W.x[l]), wp(W.ps[l - 1]), wp(W.pr[l - 1]),
+                P, l, wp(W.x[l - 1]), wp(W.aggr), wp(W.x[l]), wp(W.ps[l - 1]), wp(W.pr[l - 1]),
                 nodeinfo, x, out, keep ? wp(W.n[l - 1]) : nullptr, Nn);
         } else {
             ProfScope ps(K_NODE_LAST, st);
             k_node_update<D, true><<<dim3(node_grid), dim3(64), 0, st>>>(
-                P, l, wp(W.x[l - 1]), wp(W.e[l - 1]), rowptr, wp(W.x[l]), nullptr, nullptr, nodeinfo, x,
+                P, l, wp(W.x[l - 1]), wp(W.aggr), wp(W.x[l]), nullptr, nullptr, nodeinfo, x,
                 out, keep ? wp(W.n[l - 1]) : nullptr, Nn);
         }
     }

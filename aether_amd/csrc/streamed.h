@@ -285,15 +285,39 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
     }
 }
 
+// ------------------------------------------------------------------ segmented mean by receiver
+// torch_scatter.scatter(e, recv, reduce="mean") (locs.py:236-238) on the receiver-sorted messages:
+// one wave per node, lane = column, rows added in edge order (deterministic); 8 row loads in flight.
+__global__ void __launch_bounds__(256)
+k_segment_mean(const float* __restrict__ e, const int32_t* __restrict__ rowptr,
+               float* __restrict__ aggr, int64_t n_nodes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n_nodes) return;
+    const int beg = rowptr[node], end = rowptr[node + 1];
+    const float* p = e + (int64_t)beg * H + lane;
+    float s = 0.f;
+    int k = beg;
+    for (; k + 8 <= end; k += 8, p += 8 * H) {
+        const float a0 = p[0], a1 = p[H], a2 = p[2 * H], a3 = p[3 * H], a4 = p[4 * H], a5 = p[5 * H],
+                    a6 = p[6 * H], a7 = p[7 * H];
+        s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
+    }
+    for (; k < end; ++k, p += H) s += p[0];
+    const float deg = (float)(end - beg > 1 ? end - beg : 1);    // count clamped to >= 1
+    aggr[node * H + lane] = s / deg;
+}
+
 // ------------------------------------------------------------------ K2: node update kernel
 // n = x_prev + mean_{j->i} e (locs.py:236-240); x = n + W4 SiLU(W3 n + b3) + b4 (:241);
 // then either the next layer's node terms P_s, P_r, or (LAST) the out MLP (locs.py:160-168),
 // globalise (local_to_global.py:12-13) and the residual x + pred (aether.py:185).
 // One wave per 16-node tile; weights are read from L2 in fragment shape (used once per wave).
+// The mean over in-edges comes from k_segment_mean.
 template <int D, bool LAST>
 __global__ void __launch_bounds__(64)
 k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_prev,
-              const float* __restrict__ e, const int32_t* __restrict__ rowptr,
+              const float* __restrict__ aggr,
               float* __restrict__ x_out, float* __restrict__ Ps, float* __restrict__ Pr,
               const float* __restrict__ nodeinfo, const float* __restrict__ pos,
               float* __restrict__ out, float* __restrict__ nsave, int64_t n_nodes) {
@@ -306,19 +330,11 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
     const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
     const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
     const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
-    // segmented sum over the node's contiguous run of receiver-sorted edges, in edge order
-    const int beg = rowptr[nc], end = rowptr[nc + 1];
+    // n = x_prev + mean over in-edges (k_segment_mean)
     f32x4 n[4];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) n[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = beg; k < end; ++k) {
-        const float* er = e + (int64_t)k * H + 4 * q;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) n[mb] += ld4(er + 16 * mb);
-    }
-    const float deg = (float)(end - beg > 1 ? end - beg : 1);    // count clamped to >= 1
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) n[mb] = ld4(x_prev + nc * H + 16 * mb + 4 * q) + n[mb] / deg;
+    for (int mb = 0; mb < 4; ++mb)
+        n[mb] = ld4(x_prev + nc * H + 16 * mb + 4 * q) + ld4(aggr + nc * H + 16 * mb + 4 * q);
     if (nsave != nullptr && node < n_nodes) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) st4(nsave + node * H + 16 * mb + 4 * q, n[mb]);
