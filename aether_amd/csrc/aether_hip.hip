@@ -190,7 +190,7 @@ struct WsLayout {
     // saved by the forward under KEEP_INTERMEDIATES for the backward
     size_t n[4], feat;
     // backward temporaries
-    size_t DX, DN, U, DPU, O1, O2, DPO1, DPO2, DY, DE, G, H1, DP2, DA, DPS, DPR, RELF, Z, H1f, H2f, DPH1,
+    size_t DX, DX2, wt, DN, U, DPU, O1, O2, DPO1, DPO2, DY, DE, G, H1, DP2, DA, DPS, DPR, RELF, Z, H1f, H2f, DPH1,
         DPH2, DF, DZE, ONEHOT, partial;
     size_t total;
     WsLayout(int64_t Nn, int64_t E, int D, bool training) {
@@ -208,7 +208,7 @@ struct WsLayout {
         fwd_total = off;
         for (auto& v : n) v = take(nn * H);
         feat = take(ee * FPAD);
-        DX = take(nn * H); DN = take(nn * H); U = take(nn * 2 * H); DPU = take(nn * 2 * H);
+        DX = take(nn * H); DX2 = take(nn * H); wt = take((size_t)160 * 1024); DN = take(nn * H); U = take(nn * 2 * H); DPU = take(nn * 2 * H);
         O1 = take(nn * H); O2 = take(nn * H); DPO1 = take(nn * H); DPO2 = take(nn * H); DY = take(nn * 16);
         DE = take(ee * H); G = take(ee * H); H1 = take(ee * H); DP2 = take(ee * H); DA = take(ee * FPAD);
         DPS = take(nn * H); DPR = take(nn * H); RELF = take(nn * 16);
@@ -400,7 +400,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     const int32_t *sperm = gp(G.sperm), *srowptr = gp(G.srowptr);
     float* partial = wp(W.partial);
     const int64_t ntile = (Nn + 15) / 16, etile = (E + 15) / 16;
-    const unsigned ngrid = (unsigned)((ntile + 3) / 4 < 512 ? (ntile + 3) / 4 : 512);
+    const unsigned ngrid = (unsigned)ntile;
     const unsigned egrid = (unsigned)((etile + 3) / 4 < 1024 ? (etile + 3) / 4 : 1024);
     auto optin = [&](const void* k, size_t lds) -> int {     // once per kernel and process
         static std::vector<const void*> done;
@@ -409,23 +409,50 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         done.push_back(k);
         return AETHER_OK;
     };
+    // ---- transposed weight copies (one launch)
+    BwdWT WT;
+    {
+        float* base = wp(W.wt);
+        size_t off = 0;
+        TransposeBatch TB;
+        TB.n_tasks = 0;
+        auto add = [&](const float* src, int rows, int cols, int src_ld, int col0, int ldd, int cols_pad) {
+            float* dst = base + off;
+            TB.t[TB.n_tasks++] = TransposeTask{src, dst, rows, cols, src_ld, col0, ldd, cols_pad};
+            off += (size_t)cols_pad * ldd;
+            return (const float*)dst;
+        };
+        WT.out_w0t = add(P.out_w0, H, H, H, 0, H, H);
+        WT.out_w3t = add(P.out_w3, H, H, H, 0, H, H);
+        WT.out_w6t = add(P.out_w6, D, H, H, 0, 16, H);
+        for (int l = 1; l <= 4; ++l) {
+            const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
+            const float* w4 = l == 1 ? P.l1_upd_w2 : P.ln_upd_w2[l - 2];
+            const float* w2 = l == 1 ? P.l1_msg_w2 : P.ln_msg_w2[l - 2];
+            WT.upd_w2t[l - 1] = add(w4, H, 2 * H, 2 * H, 0, H, 2 * H);          // [128][64]
+            WT.upd_w0t[l - 1] = add(w3, 2 * H, H, H, 0, 2 * H, H);              // [64][128]
+            WT.msg_w2t[l - 1] = add(w2, H, H, H, 0, H, H);
+            if (l == 1) WT.msg_w0t[0] = add(P.l1_msg_w0, H, F1, F1, 0, H, FPAD); // [32][64]
+            else WT.msg_w0t[l - 1] = add(P.ln_msg_w0[l - 2], H, 3 * H, 3 * H, 0, H, 3 * H);   // [192][64]
+        }
+        k_transpose<<<dim3(8, (unsigned)TB.n_tasks), dim3(256), 0, st>>>(TB);
+    }
     // ---- out MLP
     {
-        const size_t lds = (size_t)(4 * H * LDW + H * 24) * 4;
-        if (optin(reinterpret_cast<const void*>(kb_out<D>), lds)) return AETHER_EHIP;
         { ProfScope ps(KB_OUT, st);
-        kb_out<D><<<dim3(ngrid), dim3(256), lds, st>>>(P, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DX), wp(W.O1),
-                                                      wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
+        kb_out<D><<<dim3(ngrid), dim3(64), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DX), wp(W.O1),
+                                                   wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
         OuterList L;
         L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
         L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
         L.add(wp(W.DY), 16, D, wp(W.O2), H, H, Nn, Gr.out_w6, H, Gr.out_b6);
         run_outer(L, partial, st);
     }
+    float* dx_cur = wp(W.DX);       // dL/dx_l; kb_gather writes dL/dx_{l-1} into the other buffer
+    float* dx_nxt = wp(W.DX2);
     for (int l = 4; l >= 1; --l) {
         const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
         const float* b3 = l == 1 ? P.l1_upd_b0 : P.ln_upd_b0[l - 2];
-        const float* w4 = l == 1 ? P.l1_upd_w2 : P.ln_upd_w2[l - 2];
         float* gw3 = l == 1 ? Gr.l1_upd_w0 : Gr.ln_upd_w0[l - 2];
         float* gb3 = l == 1 ? Gr.l1_upd_b0 : Gr.ln_upd_b0[l - 2];
         float* gw4 = l == 1 ? Gr.l1_upd_w2 : Gr.ln_upd_w2[l - 2];
@@ -434,18 +461,13 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         const float* b2 = l == 1 ? P.l1_msg_b2 : P.ln_msg_b2[l - 2];
         float* gw2 = l == 1 ? Gr.l1_msg_w2 : Gr.ln_msg_w2[l - 2];
         float* gb2 = l == 1 ? Gr.l1_msg_b2 : Gr.ln_msg_b2[l - 2];
+        OuterList L;                 // all weight gradients of this layer: one k_outer launch
         // ---- node update: dx_l -> dn_l
-        {
-            const size_t lds = (size_t)(2 * 2 * H * LDW + H * (2 * H + 8)) * 4;
-            if (optin(reinterpret_cast<const void*>(kb_node), lds)) return AETHER_EHIP;
-            { ProfScope ps(KB_NODE, st);
-            kb_node<<<dim3(ngrid), dim3(256), lds, st>>>(w3, b3, w4, wp(W.n[l - 1]), wp(W.DX), wp(W.DN), wp(W.U),
-                                                        wp(W.DPU), Nn); }
-            OuterList L;
-            L.add(wp(W.DX), H, H, wp(W.U), 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
-            L.add(wp(W.DPU), 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
-            run_outer(L, partial, st);
-        }
+        { ProfScope ps(KB_NODE, st);
+        kb_node<<<dim3(ngrid), dim3(64), 0, st>>>(w3, b3, WT.upd_w2t[l - 1], WT.upd_w0t[l - 1], wp(W.n[l - 1]),
+                                                 dx_cur, wp(W.DN), wp(W.U), wp(W.DPU), Nn); }
+        L.add(dx_cur, H, H, wp(W.U), 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
+        L.add(wp(W.DPU), 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
         // ---- edge MLP
         if (E > 0) {
             const size_t lds = (size_t)(4 * H * LDW) * 4;
@@ -453,56 +475,57 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
             if (l == 1) {
                 if (optin(reinterpret_cast<const void*>(kb_edge<true>), lds)) return AETHER_EHIP;
                 kb_edge<true><<<dim3(egrid), dim3(256), lds, st>>>(
-                    P.l1_msg_w0, F1, P.l1_msg_b0, w2, b2, nullptr, nullptr, nullptr, wp(W.feat), send_s, recv_s,
-                    rowptr, wp(W.DN), wp(W.DE), 1, wp(W.G), wp(W.H1), wp(W.DP2), wp(W.DA), E);
+                    P.l1_msg_w0, F1, P.l1_msg_b0, w2, b2, WT.msg_w0t[0], WT.msg_w2t[0], nullptr, nullptr, nullptr,
+                    wp(W.feat), send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), 1, wp(W.G), wp(W.H1), wp(W.DP2),
+                    wp(W.DA), E);
             } else {
                 if (optin(reinterpret_cast<const void*>(kb_edge<false>), lds)) return AETHER_EHIP;
                 kb_edge<false><<<dim3(egrid), dim3(256), lds, st>>>(
-                    P.ln_msg_w0[l - 2], 0, nullptr, w2, b2, wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]),
-                    nullptr, send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), l < 4 ? 1 : 0, wp(W.G), wp(W.H1),
-                    wp(W.DP2), nullptr, E);
+                    P.ln_msg_w0[l - 2], 0, nullptr, w2, b2, WT.msg_w0t[l - 1] + 2 * H * H, WT.msg_w2t[l - 1],
+                    wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), nullptr, send_s, recv_s, rowptr, wp(W.DN),
+                    wp(W.DE), l < 4 ? 1 : 0, wp(W.G), wp(W.H1), wp(W.DP2), nullptr, E);
             }
             delete pse;
-            OuterList L;
             L.add(wp(W.DP2), H, H, wp(W.H1), H, H, E, gw2, H, gb2);
             if (l == 1) L.add(wp(W.G), H, H, wp(W.feat), FPAD, F1, E, Gr.l1_msg_w0, F1, Gr.l1_msg_b0);
             else L.add(wp(W.G), H, H, wp(W.e[l - 2]), H, H, E, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
-            run_outer(L, partial, st);
         } else {
             HIP_OK(hipMemsetAsync(gw2, 0, (size_t)H * H * 4, st));
             HIP_OK(hipMemsetAsync(gb2, 0, (size_t)H * 4, st));
+            HIP_OK(hipMemsetAsync(wp(W.G), 0, 256, st));
             if (l == 1) {
                 HIP_OK(hipMemsetAsync(Gr.l1_msg_w0, 0, (size_t)H * F1 * 4, st));
                 HIP_OK(hipMemsetAsync(Gr.l1_msg_b0, 0, (size_t)H * 4, st));
+            } else {
+                L.add(wp(W.DPS), H, H, wp(W.DPS), H, H, 0, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
             }
         }
         if (l >= 2) {
-            // ---- gather G onto nodes: dx_{l-1}
-            const size_t lds = (size_t)(2 * H * LDW) * 4;
-            if (optin(reinterpret_cast<const void*>(kb_gather), lds)) return AETHER_EHIP;
-            if (E == 0) HIP_OK(hipMemsetAsync(wp(W.G), 0, 4, st));
+            // ---- sums of G onto nodes, then dx_{l-1}
             { ProfScope ps(KB_GATHER, st);
-            kb_gather<<<dim3(ngrid), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], wp(W.G), rowptr, srowptr, sperm,
-                                                          wp(W.DN), wp(W.DX), wp(W.DPS), wp(W.DPR), Nn); }
-            OuterList L;
+            kb_sum_g<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(wp(W.G), rowptr, srowptr, sperm,
+                                                                          wp(W.DPS), wp(W.DPR), Nn);
+            kb_gather<<<dim3(ngrid), dim3(64), 0, st>>>(WT.msg_w0t[l - 1], wp(W.DPS), wp(W.DPR), wp(W.DN), dx_nxt,
+                                                       Nn); }
             L.add(wp(W.DPS), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
             L.add(wp(W.DPR), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
-            if (E == 0) L.add(wp(W.DPS), H, H, wp(W.DPS), H, H, 0, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
             run_outer(L, partial, st);
+            float* tmp = dx_cur; dx_cur = dx_nxt; dx_nxt = tmp;
         } else {
             // ---- res + field net
             { ProfScope ps(KB_FIELD, st);
-            kb_field<D><<<dim3((unsigned)((Nn + 255) / 256)), dim3(256), 0, st>>>(
+            kb_field<D><<<dim3((unsigned)((Nn + 7) / 8)), dim3(256), 0, st>>>(
                 P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
                 wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
                 wp(W.ONEHOT), Nn); }
-            OuterList L;
-            L.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
-            L.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
-            L.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
-            L.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
-            L.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
             run_outer(L, partial, st);
+            OuterList L2;
+            L2.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
+            L2.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
+            L2.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
+            L2.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
+            L2.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
+            run_outer(L2, partial, st);
         }
     }
     HIP_OK(hipGetLastError());

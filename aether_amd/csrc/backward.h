@@ -132,128 +132,126 @@ k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
     if (T.bias != nullptr && nb == 0 && c == 0 && m < T.M) T.bias[m] = sb;
 }
 
+// ------------------------------------------------------------------ transposed weight copies
+// One launch at the start of the backward writes W^T for every Linear whose input gradient is
+// needed, so that W^T g is `gemm_tile(A = W^T, ...)` with the same 16-byte fragment reads as the
+// forward.  dst[c][r] = src[r][col0 + c] for r < rows, c < cols; dst is [cols_pad][ldd], zero padded.
+struct TransposeTask { const float* src; float* dst; int rows, cols, src_ld, col0, ldd, cols_pad; };
+constexpr int TRANSPOSE_MAX_TASKS = 20;
+struct TransposeBatch { TransposeTask t[TRANSPOSE_MAX_TASKS]; int n_tasks; };
+
+__global__ void __launch_bounds__(256)
+k_transpose(TransposeBatch batch) {
+    const TransposeTask T = batch.t[blockIdx.y];
+    const int total = T.cols_pad * T.ldd;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int c = idx / T.ldd, r = idx - c * T.ldd;
+        T.dst[idx] = (c < T.cols && r < T.rows) ? T.src[(size_t)r * T.src_ld + T.col0 + c] : 0.0f;
+    }
+}
+
+// pointers into the transposed-weight region of the workspace
+struct BwdWT {
+    const float* out_w0t; const float* out_w3t; const float* out_w6t;      // [64][64], [64][64], [64][16]
+    const float* upd_w2t[4]; const float* upd_w0t[4];                       // W4^T [128][64], W3^T [64][128]
+    const float* msg_w2t[4];                                                // W2^T [64][64]
+    const float* msg_w0t[4];         // layer 1: W1^T [32][64]; layers 2-4: [192][64] = W_s^T | W_r^T | W_e^T
+};
+
 // ------------------------------------------------------------------ out MLP backward
 // forward (locs.py:160-168, local_to_global.py:12-13, aether.py:185):
 //   o1 = silu(Wo0 x4 + b), o2 = silu(Wo3 o1 + b), y = Wo6 o2 + b, out = p + R y
 // in: g = dL/dout.  out: dx4 and the row tensors of the weight gradients.
+// One wave per 16-node tile; weights are read from L2 in fragment shape.
 template <int D>
-__global__ void __launch_bounds__(256)
-kb_out(AetherParams P, const float* __restrict__ x4, const float* __restrict__ nodeinfo,
+__global__ void __launch_bounds__(64)
+kb_out(AetherParams P, BwdWT WT, const float* __restrict__ x4, const float* __restrict__ nodeinfo,
        const float* __restrict__ g_out, float* __restrict__ DX, float* __restrict__ O1,
        float* __restrict__ O2, float* __restrict__ DPO1, float* __restrict__ DPO2,
        float* __restrict__ DY, int64_t n_nodes) {
     using NI = NodeInfo<D>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* w0 = smem;                  // Wo0   [64][LDW]
-    float* w3 = w0 + H * LDW;          // Wo3
-    float* w0t = w3 + H * LDW;         // Wo0^T
-    float* w3t = w0t + H * LDW;        // Wo3^T
-    float* w6t = w3t + H * LDW;        // Wo6^T [64][24]: row m = hidden, col k = output dim (zero padded)
-    stage_weight64<256>(w0, P.out_w0, H);
-    stage_weight64<256>(w3, P.out_w3, H);
-    stage_weight_T(w0t, P.out_w0, H, H, H, 0, LDW, H);
-    stage_weight_T(w3t, P.out_w3, H, H, H, 0, LDW, H);
-    stage_weight_T(w6t, P.out_w6, D, H, H, 0, 24, H);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t tiles = (n_nodes + 15) >> 4;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t node = 16 * t + i;
-        const bool ok = node < n_nodes;
-        const int64_t nc = ok ? node : n_nodes - 1;
-        f32x4 xt[4], p1[4], p2[4], o1[4], o2[4];
-        load_tile64(xt, x4, nc, H, q);
+    const int64_t node = (int64_t)blockIdx.x * 16 + i;
+    const bool ok = node < n_nodes;
+    const int64_t nc = ok ? node : n_nodes - 1;
+    f32x4 xt[4], p1[4], p2[4], o1[4], o2[4];
+    load_tile64(xt, x4, nc, H, q);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(P.out_b0 + 16 * mb + 4 * q);
-        gemm_tile<4, 4>(w0, LDW, xt, p1, i, q);
+    for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(P.out_b0 + 16 * mb + 4 * q);
+    gemm_tile<4, 4>(P.out_w0, H, xt, p1, i, q);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) { o1[mb] = silu4(p1[mb]); p2[mb] = ld4(P.out_b3 + 16 * mb + 4 * q); }
-        gemm_tile<4, 4>(w3, LDW, o1, p2, i, q);
+    for (int mb = 0; mb < 4; ++mb) { o1[mb] = silu4(p1[mb]); p2[mb] = ld4(P.out_b3 + 16 * mb + 4 * q); }
+    gemm_tile<4, 4>(P.out_w3, H, o1, p2, i, q);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) o2[mb] = silu4(p2[mb]);
-        // dy = R^T g (rows 0..D-1 of a 16-row block: lanes q == 0, registers 0..D-1)
-        f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q == 0 && ok) {
-            const float* ni = nodeinfo + node * NI::STRIDE;
+    for (int mb = 0; mb < 4; ++mb) o2[mb] = silu4(p2[mb]);
+    // dy = R^T g (rows 0..D-1 of a 16-row block: lanes q == 0, registers 0..D-1)
+    f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q == 0 && ok) {
+        const float* ni = nodeinfo + node * NI::STRIDE;
 #pragma unroll
-            for (int a = 0; a < D; ++a) {
-                float s = 0.f;
+        for (int a = 0; a < D; ++a) {
+            float s = 0.f;
 #pragma unroll
-                for (int b = 0; b < D; ++b) s += ni[NI::R + b * D + a] * g_out[node * D + b];
-                dy[a] = s;
-            }
+            for (int b = 0; b < D; ++b) s += ni[NI::R + b * D + a] * g_out[node * D + b];
+            dy[a] = s;
         }
-        // do2 = Wo6^T dy  (K = 16, only k < D non-zero)
-        f32x4 d2[4], d1[4], dx[4];
+    }
+    // do2 = Wo6^T dy  (K = 16, only k < D non-zero)
+    f32x4 d2[4], d1[4], dx[4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 wv = ld4(w6t + (16 * mb + i) * 24 + 4 * q);
+    for (int mb = 0; mb < 4; ++mb) {
+        d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 wv = ld4(WT.out_w6t + (16 * mb + i) * 16 + 4 * q);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) d2[mb] = mfma16(wv[b], dy[b], d2[mb]);
-        }
+        for (int b = 0; b < 4; ++b) d2[mb] = mfma16(wv[b], dy[b], d2[mb]);
+    }
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) { d2[mb] = d2[mb] * dsilu4(p2[mb]); d1[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        gemm_tile<4, 4>(w3t, LDW, d2, d1, i, q);
+    for (int mb = 0; mb < 4; ++mb) { d2[mb] = d2[mb] * dsilu4(p2[mb]); d1[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    gemm_tile<4, 4>(WT.out_w3t, H, d2, d1, i, q);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) { d1[mb] = d1[mb] * dsilu4(p1[mb]); dx[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        gemm_tile<4, 4>(w0t, LDW, d1, dx, i, q);
-        if (ok) {
-            store_tile64(DX, node, H, q, dx);
-            store_tile64(O1, node, H, q, o1);
-            store_tile64(O2, node, H, q, o2);
-            store_tile64(DPO1, node, H, q, d1);
-            store_tile64(DPO2, node, H, q, d2);
-            st4(DY + node * 16 + 4 * q, dy);
-        }
+    for (int mb = 0; mb < 4; ++mb) { d1[mb] = d1[mb] * dsilu4(p1[mb]); dx[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    gemm_tile<4, 4>(WT.out_w0t, H, d1, dx, i, q);
+    if (ok) {
+        store_tile64(DX, node, H, q, dx);
+        store_tile64(O1, node, H, q, o1);
+        store_tile64(O2, node, H, q, o2);
+        store_tile64(DPO1, node, H, q, d1);
+        store_tile64(DPO2, node, H, q, d2);
+        st4(DY + node * 16 + 4 * q, dy);
     }
 }
 
 // ------------------------------------------------------------------ node update backward
 // forward (locs.py:240-241): u = silu(W3 n + b3), x = n + W4 u + b4.   in: dx.  out: dn, u, dpre_u.
-__global__ void __launch_bounds__(256)
-kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const float* __restrict__ w4g,
-        const float* __restrict__ nbuf, const float* __restrict__ DX, float* __restrict__ DN,
-        float* __restrict__ U, float* __restrict__ DPU, int64_t n_nodes) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* w3 = smem;                         // W3    [128][LDW]
-    float* w4t = w3 + 2 * H * LDW;            // W4^T  [128][LDW]   (row = u index, col = x index)
-    float* w3t = w4t + 2 * H * LDW;           // W3^T  [64][2H+8]   (row = n index, col = u index)
-    for (int idx = threadIdx.x; idx < 2 * H * (H / 4); idx += 256) {
-        const int r = idx >> 4, c = (idx & 15) * 4;
-        st4(w3 + r * LDW + c, ld4(w3g + (size_t)r * H + c));
-    }
-    stage_weight_T(w4t, w4g, H, 2 * H, 2 * H, 0, LDW, 2 * H);
-    stage_weight_T(w3t, w3g, 2 * H, H, H, 0, 2 * H + 8, H);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ void __launch_bounds__(64)
+kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const float* __restrict__ w4t,
+        const float* __restrict__ w3t, const float* __restrict__ nbuf, const float* __restrict__ DX,
+        float* __restrict__ DN, float* __restrict__ U, float* __restrict__ DPU, int64_t n_nodes) {
+    const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t tiles = (n_nodes + 15) >> 4;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t node = 16 * t + i;
-        const bool ok = node < n_nodes;
-        const int64_t nc = ok ? node : n_nodes - 1;
-        f32x4 nt[4], dx[4], pu[8], du[8], dn[4];
-        load_tile64(nt, nbuf, nc, H, q);
-        load_tile64(dx, DX, nc, H, q);
+    const int64_t node = (int64_t)blockIdx.x * 16 + i;
+    const bool ok = node < n_nodes;
+    const int64_t nc = ok ? node : n_nodes - 1;
+    f32x4 nt[4], dx[4], pu[8], du[8], dn[4];
+    load_tile64(nt, nbuf, nc, H, q);
+    load_tile64(dx, DX, nc, H, q);
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) { pu[mb] = ld4(b3g + 16 * mb + 4 * q); du[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        gemm_tile<8, 4>(w3, LDW, nt, pu, i, q);
-        gemm_tile<8, 4>(w4t, LDW, dx, du, i, q);
-        f32x4 u[8];
+    for (int mb = 0; mb < 8; ++mb) { pu[mb] = ld4(b3g + 16 * mb + 4 * q); du[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    gemm_tile<8, 4>(w3g, H, nt, pu, i, q);          // pre_u = W3 n + b3
+    gemm_tile<8, 4>(w4t, H, dx, du, i, q);          // du = W4^T dx
+    f32x4 u[8];
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) { u[mb] = silu4(pu[mb]); du[mb] = du[mb] * dsilu4(pu[mb]); }
+    for (int mb = 0; mb < 8; ++mb) { u[mb] = silu4(pu[mb]); du[mb] = du[mb] * dsilu4(pu[mb]); }
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) dn[mb] = dx[mb];
-        gemm_tile<4, 8>(w3t, 2 * H + 8, du, dn, i, q);
-        if (ok) {
-            store_tile64(DN, node, H, q, dn);
+    for (int mb = 0; mb < 4; ++mb) dn[mb] = dx[mb];
+    gemm_tile<4, 8>(w3t, 2 * H, du, dn, i, q);      // dn = dx + W3^T dpre_u
+    if (ok) {
+        store_tile64(DN, node, H, q, dn);
 #pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-                st4(U + node * 2 * H + 16 * mb + 4 * q, u[mb]);
-                st4(DPU + node * 2 * H + 16 * mb + 4 * q, du[mb]);
-            }
+        for (int mb = 0; mb < 8; ++mb) {
+            st4(U + node * 2 * H + 16 * mb + 4 * q, u[mb]);
+            st4(DPU + node * 2 * H + 16 * mb + 4 * q, du[mb]);
         }
     }
 }
@@ -263,29 +261,35 @@ kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const floa
 //   h = silu(pre1), pre2 = W2 h + b2, e = silu(pre2), aggr_i = mean_{k: recv = i} e_k.
 // de_k = DN[recv_k] / deg[recv_k] (+ DE[k], the gradient through the next layer's W_e)
 // out: G = dL/dpre1, H1 = h, DP2 = dL/dpre2, and  FIRST: DA = W1^T G   else: DE[k] <- W_e^T G.
+// Weights (forward and pre-transposed) are staged once per workgroup in LDS.
 template <bool FIRST>
 __global__ void __launch_bounds__(256)
 kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192]*/, int f1,
         const float* __restrict__ b_in, const float* __restrict__ w2g, const float* __restrict__ b2g,
-        const float* __restrict__ Ps, const float* __restrict__ Pr, const float* __restrict__ e_prev,
-        const float* __restrict__ feat, const int32_t* __restrict__ send_s,
-        const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
-        const float* __restrict__ DN, float* __restrict__ DE, int have_de, float* __restrict__ G,
-        float* __restrict__ H1, float* __restrict__ DP2, float* __restrict__ DA, int64_t n_edges) {
+        const float* __restrict__ w_in_t /*FIRST: W1^T [32][64] else W_e^T [64][64]*/,
+        const float* __restrict__ w2t, const float* __restrict__ Ps, const float* __restrict__ Pr,
+        const float* __restrict__ e_prev, const float* __restrict__ feat,
+        const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
+        const int32_t* __restrict__ rowptr, const float* __restrict__ DN, float* __restrict__ DE,
+        int have_de, float* __restrict__ G, float* __restrict__ H1, float* __restrict__ DP2,
+        float* __restrict__ DA, int64_t n_edges) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wi = smem;                  // W_in   [64][LDW]   (FIRST: K = 32 used)
     float* w2 = wi + H * LDW;          // W2
-    float* w2t = w2 + H * LDW;         // W2^T
-    float* wit = w2t + H * LDW;        // W_in^T [64 | 32][LDW]
+    float* w2ts = w2 + H * LDW;        // W2^T
+    float* wit = w2ts + H * LDW;       // W_in^T [64 | 32][LDW]
     if (FIRST) {
         stage_weight(wi, w_in, H, f1, f1, LDW);
-        stage_weight_T(wit, w_in, H, f1, f1, 0, LDW, FPAD);
+        for (int idx = threadIdx.x; idx < FPAD * (H / 4); idx += 256) {
+            const int r = idx >> 4, c = (idx & 15) * 4;
+            st4(wit + r * LDW + c, ld4(w_in_t + (size_t)r * H + c));
+        }
     } else {
         stage_weight64<256>(wi, w_in + 2 * H, 3 * H);
-        stage_weight_T(wit, w_in, H, H, 3 * H, 2 * H, LDW, H);
+        stage_weight64<256>(wit, w_in_t, H);
     }
     stage_weight64<256>(w2, w2g, H);
-    stage_weight_T(w2t, w2g, H, H, H, 0, LDW, H);
+    stage_weight64<256>(w2ts, w2t, H);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -325,7 +329,7 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
             d2[mb] = de * dsilu4(p2[mb]);
             dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        gemm_tile<4, 4>(w2t, LDW, d2, dh, i, q);
+        gemm_tile<4, 4>(w2ts, LDW, d2, dh, i, q);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu4(p1[mb]);
         if (FIRST) {
@@ -347,56 +351,76 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
     }
 }
 
-// ------------------------------------------------------------------ gather of G onto nodes
-// dP_r[i] = sum_{k: recv = i} G_k (contiguous run), dP_s[j] = sum_{k: send = j} G_k (sender list);
-// dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed).
+// ------------------------------------------------------------------ sums of G onto nodes
+// dP_r[i] = sum_{k: recv = i} G_k (contiguous run), dP_s[j] = sum_{k: send = j} G_k (sender list,
+// rows gathered through sperm).  One wave per node, lane = column, fixed order, 8 loads in flight.
 __global__ void __launch_bounds__(256)
-kb_gather(const float* __restrict__ w1g /*msg_w0 [64][192]*/, const float* __restrict__ G,
-          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ srowptr,
-          const int32_t* __restrict__ sperm, const float* __restrict__ DN, float* __restrict__ DX,
-          float* __restrict__ DPS, float* __restrict__ DPR, int64_t n_nodes) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wst = smem;                 // W_s^T [64][LDW]
-    float* wrt = wst + H * LDW;        // W_r^T
-    stage_weight_T(wst, w1g, H, H, 3 * H, 0, LDW, H);
-    stage_weight_T(wrt, w1g, H, H, 3 * H, H, LDW, H);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int64_t tiles = (n_nodes + 15) >> 4;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t node = 16 * t + i;
-        const bool ok = node < n_nodes;
-        const int64_t nc = ok ? node : n_nodes - 1;
-        f32x4 dps[4], dpr[4], dx[4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) { dps[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; dpr[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int k = rowptr[nc]; k < rowptr[nc + 1]; ++k) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) dpr[mb] += ld4(G + (int64_t)k * H + 16 * mb + 4 * q);
+kb_sum_g(const float* __restrict__ G, const int32_t* __restrict__ rowptr,
+         const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm,
+         float* __restrict__ DPS, float* __restrict__ DPR, int64_t n_nodes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n_nodes) return;
+    {
+        const int beg = rowptr[node], end = rowptr[node + 1];
+        const float* p = G + (int64_t)beg * H + lane;
+        float s = 0.f;
+        int k = beg;
+        for (; k + 8 <= end; k += 8, p += 8 * H) {
+            const float a0 = p[0], a1 = p[H], a2 = p[2 * H], a3 = p[3 * H], a4 = p[4 * H], a5 = p[5 * H],
+                        a6 = p[6 * H], a7 = p[7 * H];
+            s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
         }
-        for (int k = srowptr[nc]; k < srowptr[nc + 1]; ++k) {
-            const int64_t row = sperm[k];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) dps[mb] += ld4(G + row * H + 16 * mb + 4 * q);
+        for (; k < end; ++k, p += H) s += p[0];
+        DPR[node * H + lane] = s;
+    }
+    {
+        const int beg = srowptr[node], end = srowptr[node + 1];
+        float s = 0.f;
+        int k = beg;
+        for (; k + 4 <= end; k += 4) {
+            const int r0 = sperm[k], r1 = sperm[k + 1], r2 = sperm[k + 2], r3 = sperm[k + 3];
+            const float a0 = G[(int64_t)r0 * H + lane], a1 = G[(int64_t)r1 * H + lane],
+                        a2 = G[(int64_t)r2 * H + lane], a3 = G[(int64_t)r3 * H + lane];
+            s += a0; s += a1; s += a2; s += a3;
         }
-        load_tile64(dx, DN, nc, H, q);
-        gemm_tile<4, 4>(wst, LDW, dps, dx, i, q);
-        gemm_tile<4, 4>(wrt, LDW, dpr, dx, i, q);
-        if (ok) {
-            store_tile64(DX, node, H, q, dx);
-            store_tile64(DPS, node, H, q, dps);
-            store_tile64(DPR, node, H, q, dpr);
-        }
+        for (; k < end; ++k) s += G[(int64_t)sperm[k] * H + lane];
+        DPS[node * H + lane] = s;
     }
 }
 
+// dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed); wave per node tile
+__global__ void __launch_bounds__(64)
+kb_gather(const float* __restrict__ w1t /*[192][64]: W_s^T | W_r^T | W_e^T*/,
+          const float* __restrict__ DPS, const float* __restrict__ DPR, const float* __restrict__ DN,
+          float* __restrict__ DX, int64_t n_nodes) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t node = (int64_t)blockIdx.x * 16 + i;
+    const bool ok = node < n_nodes;
+    const int64_t nc = ok ? node : n_nodes - 1;
+    f32x4 dps[4], dpr[4], dx[4];
+    load_tile64(dps, DPS, nc, H, q);
+    load_tile64(dpr, DPR, nc, H, q);
+    load_tile64(dx, DN, nc, H, q);
+    gemm_tile<4, 4>(w1t, H, dps, dx, i, q);
+    gemm_tile<4, 4>(w1t + H * H, H, dpr, dx, i, q);
+    if (ok) store_tile64(DX, node, H, q, dx);
+}
+
 // ------------------------------------------------------------------ field net backward
-// One thread per node.  Gradient of the loss w.r.t. the field f of node j arrives through
+// 32 threads per node (8 nodes per workgroup).  Gradient of the loss w.r.t. the field f of node j
+// arrives through
 //   * the R_i^T f_j columns of its out-edges' features (DA columns RF, rotated back with R_recv),
 //   * the rel_feat[recv] columns R_j^T f_j of its in-edges' features (DA columns CF),
-//   * layer_1.res(rel_feat) (aether.py:39-48, locs.py:214-218): W_res^T dn_1, columns 2D..3D.
-// Then through the 3-layer field MLP (aether.py:113-119).  Leaves the row tensors for k_outer.
+//   * layer_1.res(rel_feat) (aether.py:39-48, locs.py:214-218): W_res^T dn_1, columns 2D..3D,
+// then through the 3-layer field MLP (aether.py:113-119).  Leaves the row tensors for k_outer.
+__device__ __forceinline__ float sum32(float v) {       // all-reduce over the 32 threads of a node
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 32);
+    return v;
+}
+
 template <int D>
 __global__ void __launch_bounds__(256)
 kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
@@ -412,32 +436,33 @@ kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ 
     constexpr int O = D * (D - 1) / 2;
     constexpr int C_RF = 3 * D + O;           // feature columns of R_i^T f_j
     constexpr int C_CF = 6 * D + O;           // feature columns of rel_feat[recv]'s R_i^T f_i part
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_nodes) return;
-    const float* ni = nodeinfo + n * NI::STRIDE;
-    // gradient w.r.t. cf_n = R_n^T f_n
+    __shared__ float sz[8][32], sh1[8][32], sd2[8][32], sd1[8][32];
+    const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
+    const int64_t n = (int64_t)blockIdx.x * 8 + g;
+    const bool ok = n < n_nodes;
+    const int64_t nc = ok ? n : n_nodes - 1;
+    const float* ni = nodeinfo + nc * NI::STRIDE;
+    // ---- dL/dcf, cf = R^T f
     float dcf[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) dcf[d] = 0.f;
-    for (int k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+    for (int k = rowptr[nc] + t; k < rowptr[nc + 1]; k += 32) {
 #pragma unroll
         for (int d = 0; d < D; ++d) dcf[d] += DA[(int64_t)k * FPAD + C_CF + d];
     }
-#pragma unroll 4
-    for (int o = 0; o < H; ++o) {
-        const float g = DN1[n * H + o];
 #pragma unroll
-        for (int d = 0; d < D; ++d) dcf[d] += P.l1_res_w[o * 3 * D + 2 * D + d] * g;
+    for (int o = t; o < H; o += 32) {
+        const float gg = DN1[nc * H + o];
+#pragma unroll
+        for (int d = 0; d < D; ++d) dcf[d] += P.l1_res_w[o * 3 * D + 2 * D + d] * gg;
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d) dcf[d] = sum32(dcf[d]);
+    // ---- dL/df = R dcf + sum over out-edges of R_recv d(rf)
     float df[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) {                              // f = R cf  ->  df = R dcf
-        float s = 0.f;
-#pragma unroll
-        for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * dcf[b];
-        df[a] = s;
-    }
-    for (int kk = srowptr[n]; kk < srowptr[n + 1]; ++kk) {     // out-edges: rf = R_recv^T f_n
+    for (int a = 0; a < D; ++a) df[a] = 0.f;
+    for (int kk = srowptr[nc] + t; kk < srowptr[nc + 1]; kk += 32) {
         const int64_t k = sperm[kk];
         const float* nr = nodeinfo + (int64_t)recv_s[k] * NI::STRIDE;
 #pragma unroll
@@ -446,66 +471,64 @@ kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ 
             for (int b = 0; b < D; ++b) df[a] += nr[NI::R + a * D + b] * DA[k * FPAD + C_RF + b];
         }
     }
-    // rel_feat row for dW_res (columns 0..3D-1 of a 16-wide row)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float v = 0.f;
-        if (c >= D && c < 2 * D) v = ni[NI::CV + c - D];
-        if (c >= 2 * D && c < 3 * D) v = ni[NI::CF + c - 2 * D];
-        RELF[n * 16 + c] = v;
+    for (int a = 0; a < D; ++a) {
+        float s = sum32(df[a]);
+#pragma unroll
+        for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * dcf[b];
+        df[a] = s;
     }
-    // recompute the field MLP
-    float z[FIN];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { z[d] = x[n * D + d]; z[D + d] = vel[n * D + d]; }
-    long ci = (long)(charges[n] + 1.0f);
+    // ---- recompute the field MLP: thread t owns hidden unit t
+    long ci = (long)(charges[nc] + 1.0f);
     ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
+    float zt = 0.f;
+    if (t < D) zt = x[nc * D + t];
+    else if (t < 2 * D) zt = vel[nc * D + t - D];
+    else if (t < FIN) zt = P.field_emb[ci * 16 + t - 2 * D];
+    sz[g][t] = zt;
+    __syncthreads();
+    float p1 = P.field_b0[t];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) z[2 * D + k] = P.field_emb[ci * 16 + k];
-    float p1[32], p2[32], h1[32], h2[32];
-#pragma unroll 4
-    for (int o = 0; o < 32; ++o) {
-        float s = P.field_b0[o];
+    for (int k = 0; k < FIN; ++k) p1 += P.field_w0[t * FIN + k] * sz[g][k];
+    const float h1 = silu(p1);
+    sh1[g][t] = h1;
+    __syncthreads();
+    float p2 = P.field_b2[t];
 #pragma unroll
-        for (int k = 0; k < FIN; ++k) s += P.field_w0[o * FIN + k] * z[k];
-        p1[o] = s; h1[o] = silu(s);
-    }
-#pragma unroll 4
-    for (int o = 0; o < 32; ++o) {
-        float s = P.field_b2[o];
+    for (int k = 0; k < 32; ++k) p2 += P.field_w2[t * 32 + k] * sh1[g][k];
+    const float h2 = silu(p2);
+    float d2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) s += P.field_w2[o * 32 + k] * h1[k];
-        p2[o] = s; h2[o] = silu(s);
-    }
-    float d2[32], d1[32];
-#pragma unroll 4
-    for (int k = 0; k < 32; ++k) {
-        float s = 0.f;
+    for (int d = 0; d < D; ++d) d2 += P.field_w4[d * 32 + t] * df[d];
+    d2 *= dsilu(p2);
+    sd2[g][t] = d2;
+    __syncthreads();
+    float d1 = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) s += P.field_w4[d * 32 + k] * df[d];
-        d2[k] = s * dsilu(p2[k]);
-    }
-#pragma unroll 4
-    for (int k = 0; k < 32; ++k) {
-        float s = 0.f;
+    for (int o = 0; o < 32; ++o) d1 += P.field_w2[o * 32 + t] * sd2[g][o];
+    d1 *= dsilu(p1);
+    sd1[g][t] = d1;
+    __syncthreads();
+    if (!ok) return;
+    Z[n * 32 + t] = zt;
+    H1f[n * 32 + t] = h1;
+    H2f[n * 32 + t] = h2;
+    DPH1[n * 32 + t] = d1;
+    DPH2[n * 32 + t] = d2;
+    if (t < 16) {
+        float rv = 0.f;                                       // rel_feat row for dW_res
+        if (t >= D && t < 2 * D) rv = ni[NI::CV + t - D];
+        if (t >= 2 * D && t < 3 * D) rv = ni[NI::CF + t - 2 * D];
+        RELF[n * 16 + t] = rv;
+        float dfv = 0.f;
 #pragma unroll
-        for (int o = 0; o < 32; ++o) s += P.field_w2[o * 32 + k] * d2[o];
-        d1[k] = s * dsilu(p1[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        Z[n * 32 + k] = k < FIN ? z[k] : 0.f;
-        H1f[n * 32 + k] = h1[k]; H2f[n * 32 + k] = h2[k];
-        DPH1[n * 32 + k] = d1[k]; DPH2[n * 32 + k] = d2[k];
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        DF[n * 16 + c] = c < D ? df[c] : 0.f;
-        ONEHOT[n * 16 + c] = c == (int)ci ? 1.f : 0.f;
-        float s = 0.f;                                          // d z[2D + c] (embedding columns)
+        for (int d = 0; d < D; ++d) if (t == d) dfv = df[d];
+        DF[n * 16 + t] = dfv;
+        ONEHOT[n * 16 + t] = t == (int)ci ? 1.f : 0.f;
+        float s = 0.f;                                        // d z[2D + t] (embedding columns)
 #pragma unroll 8
-        for (int o = 0; o < 32; ++o) s += P.field_w0[o * FIN + 2 * D + c] * d1[o];
-        DZE[n * 16 + c] = s;
+        for (int o = 0; o < 32; ++o) s += P.field_w0[o * FIN + 2 * D + t] * sd1[g][o];
+        DZE[n * 16 + t] = s;
     }
 }
 
