@@ -376,9 +376,9 @@ int run_outer(OuterList& L, float* partial, hipStream_t st) {
         int blocks = ((L.b.t[k].M + 15) / 16) * ((L.b.t[k].N + 15) / 16);
         if (blocks > max_blocks) max_blocks = blocks;
     }
-    int64_t chunks = (max_tiles + 31) / 32;             // >= 8 tiles per wave and chunk
+    int64_t chunks = (max_tiles + 63) / 64;             // >= 16 tiles per wave and chunk
     if (chunks < 1) chunks = 1;
-    if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
+    if (chunks > 32) chunks = 32;
     L.b.chunks = (int)chunks;
     ProfScope ps(KB_OUTER, st);
     k_outer<<<dim3((unsigned)max_blocks, (unsigned)chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);

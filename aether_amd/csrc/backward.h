@@ -76,20 +76,30 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     const bool am = 16 * mb + i < T.M, bn = 16 * nb + i < T.N;
     const bool want_bias = T.bias != nullptr && nb == 0;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, bacc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t t = t0 + wave; t < t1; t += 4) {
-        float av[4], bv[4];
+    // 4 tiles (32 loads) in flight per iteration; rows are consumed in ascending order
+    for (int64_t t = t0 + 4 * wave; t < t1; t += 16) {
+        float av[4][4], bv[4][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int64_t row = 16 * t + 4 * s + q;
-            const bool ok = row < T.rows;
-            av[s] = (ok && am) ? T.A[row * T.lda + 16 * mb + i] : 0.0f;
-            bv[s] = (ok && bn) ? T.B[row * T.ldb + 16 * nb + i] : 0.0f;
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int64_t row = 16 * (t + u) + 4 * s + q;
+                const bool ok = (t + u) < t1 && row < T.rows;
+                av[u][s] = (ok && am) ? T.A[row * T.lda + 16 * mb + i] : 0.0f;
+                bv[u][s] = (ok && bn) ? T.B[row * T.ldb + 16 * nb + i] : 0.0f;
+            }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma16(av[s], bv[s], acc);
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma16(av[u][s], bv[u][s], acc);
+        }
         if (want_bias) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bacc = mfma16(av[s], 1.0f, bacc);
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bacc = mfma16(av[u][s], 1.0f, bacc);
+            }
         }
     }
     // ordered cross-wave sum through LDS, then one partial block per (task, chunk, block)
@@ -122,8 +132,21 @@ k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
     const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     float s = 0.0f, sb = 0.0f;
-    for (int ch = 0; ch < batch.chunks; ++ch) {
-        const float* src = partial + (((size_t)blockIdx.y * batch.chunks + ch) * 64 + blockIdx.x) * 272;
+    const float* src0 = partial + ((size_t)blockIdx.y * batch.chunks * 64 + blockIdx.x) * 272;
+    int ch = 0;
+    for (; ch + 8 <= batch.chunks; ch += 8) {           // 8 chunk loads in flight, summed in chunk order
+        float v[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* src = src0 + (size_t)(ch + u) * 64 * 272;
+            v[u] = src[r * 16 + c];
+            vb[u] = c == 0 ? src[256 + r] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += v[u]; sb += vb[u]; }
+    }
+    for (; ch < batch.chunks; ++ch) {
+        const float* src = src0 + (size_t)ch * 64 * 272;
         s += src[r * 16 + c];
         if (c == 0) sb += src[256 + r];
     }
