@@ -181,7 +181,7 @@ struct GraphLayout {
     }
 };
 
-constexpr int OUTER_MAX_CHUNKS = 64;
+constexpr int OUTER_MAX_CHUNKS = 128;
 
 
 struct WsLayout {
@@ -214,7 +214,7 @@ struct WsLayout {
         DPS = take(nn * H); DPR = take(nn * H); RELF = take(nn * 16);
         Z = take(nn * 32); H1f = take(nn * 32); H2f = take(nn * 32); DPH1 = take(nn * 32); DPH2 = take(nn * 32);
         DF = take(nn * 16); DZE = take(nn * 16); ONEHOT = take(nn * 16);
-        partial = take((size_t)OUTER_MAX_TASKS * OUTER_MAX_CHUNKS * 64 * 272);
+        partial = take((size_t)OUTER_MAX_TASKS * OUTER_MAX_CHUNKS * 32 * 272);
         total = training ? off : fwd_total;
     }
 };
@@ -376,12 +376,12 @@ int run_outer(OuterList& L, float* partial, hipStream_t st) {
         int blocks = ((L.b.t[k].M + 15) / 16) * ((L.b.t[k].N + 15) / 16);
         if (blocks > max_blocks) max_blocks = blocks;
     }
-    int64_t chunks = (max_tiles + 63) / 64;             // >= 16 tiles per wave and chunk
+    int64_t chunks = (max_tiles + 7) / 8;               // >= 8 row tiles per workgroup
     if (chunks < 1) chunks = 1;
-    if (chunks > 32) chunks = 32;
+    if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
     L.b.chunks = (int)chunks;
     ProfScope ps(KB_OUTER, st);
-    k_outer<<<dim3((unsigned)max_blocks, (unsigned)chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
+    k_outer<<<dim3((unsigned)chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
     k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
     return AETHER_OK;
 }

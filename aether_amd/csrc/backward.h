@@ -61,64 +61,103 @@ struct OuterTask {
 constexpr int OUTER_MAX_TASKS = 8;
 struct OuterBatch { OuterTask t[OUTER_MAX_TASKS]; int n_tasks; int chunks; };
 
-// grid = (max blocks over tasks, chunks, n_tasks); partial[(task, chunk, block)][256 + 16]
+// grid = (chunks, n_tasks).  A workgroup owns a chunk of row tiles and computes EVERY 16x16 block of
+// its task's output for it: each row tile of A and B is read from global memory once (coalesced
+// 16-byte loads) into LDS, then read back transposed as MFMA operands.  Wave w owns the block rows
+// mb = w, w + 4.  Column sums of A (bias gradients) ride along in the staging threads.
+// partial[(task, chunk)][block][256 + 16]
+constexpr int LDO = 144;      // LDS row stride of a staged tile: 144 % 32 == 16 -> conflict-free b32 reads
 __global__ void __launch_bounds__(256)
 k_outer(OuterBatch batch, float* __restrict__ partial) {
-    const OuterTask T = batch.t[blockIdx.z];
+    const OuterTask T = batch.t[blockIdx.y];
     const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
-    if ((int)blockIdx.x >= MBn * NBn) return;
-    const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t tiles = (T.rows + 15) >> 4;
     const int64_t per = (tiles + batch.chunks - 1) / batch.chunks;
-    const int64_t t0 = per * blockIdx.y, t1 = t0 + per < tiles ? t0 + per : tiles;
-    const bool am = 16 * mb + i < T.M, bn = 16 * nb + i < T.N;
-    const bool want_bias = T.bias != nullptr && nb == 0;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, bacc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 4 tiles (32 loads) in flight per iteration; rows are consumed in ascending order
-    for (int64_t t = t0 + 4 * wave; t < t1; t += 16) {
-        float av[4][4], bv[4][4];
+    const int64_t t0 = per * blockIdx.x, t1 = t0 + per < tiles ? t0 + per : tiles;
+    __shared__ __attribute__((aligned(16))) float sa[16 * LDO], sb[16 * LDO];
+    __shared__ float scol[16][132];
+    f32x4 acc[2][8];              // block rows {wave, wave + 4} x up to 8 block columns
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int64_t row = 16 * (t + u) + 4 * s + q;
-                const bool ok = (t + u) < t1 && row < T.rows;
-                av[u][s] = (ok && am) ? T.A[row * T.lda + 16 * mb + i] : 0.0f;
-                bv[u][s] = (ok && bn) ? T.B[row * T.ldb + 16 * nb + i] : 0.0f;
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging map: thread -> (row, 4 columns); the same thread always serves the same columns, so
+    // its running sums are this chunk's column sums of A restricted to its row index
+    const int a4 = MBn * 4, b4 = NBn * 4;                 // float4 per row
+    f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int64_t t = t0; t < t1; ++t) {
+        __syncthreads();                                   // previous tile consumed
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            if (idx < 16 * a4) {
+                const int r = idx / a4, c = (idx - r * a4) * 4;
+                const int64_t row = 16 * t + r;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < T.rows) v = ld4(T.A + row * T.lda + c);
+                st4(sa + r * LDO + c, v);
+                csum[u] += v;
+            }
+            if (idx < 16 * b4) {
+                const int r = idx / b4, c = (idx - r * b4) * 4;
+                const int64_t row = 16 * t + r;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < T.rows) v = ld4(T.B + row * T.ldb + c);
+                st4(sb + r * LDO + c, v);
             }
         }
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int a = 0; a < 2; ++a) {
+            const int mb = wave + 4 * a;
+            if (mb < MBn) {
+                float av[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma16(av[u][s], bv[u][s], acc);
-        }
-        if (want_bias) {
+                for (int s4 = 0; s4 < 4; ++s4) av[s4] = sa[(4 * s4 + q) * LDO + 16 * mb + i];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+                for (int nb = 0; nb < 8; ++nb) {
+                    if (nb < NBn) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) bacc = mfma16(av[u][s], 1.0f, bacc);
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            acc[a][nb] = mfma16(av[s4], sb[(4 * s4 + q) * LDO + 16 * nb + i], acc[a][nb]);
+                    }
+                }
             }
         }
     }
-    // ordered cross-wave sum through LDS, then one partial block per (task, chunk, block)
-    __shared__ float red[4][64][8];
+    float* dst0 = partial + ((size_t)blockIdx.y * batch.chunks + blockIdx.x) * 32 * 272;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { red[wave][lane][r] = acc[r]; red[wave][lane][4 + r] = bacc[r]; }
-    __syncthreads();
-    if (wave == 0) {
-        float* dst = partial + (((size_t)blockIdx.z * batch.chunks + blockIdx.y) * 64 + blockIdx.x) * 272;
+    for (int a = 0; a < 2; ++a) {
+        const int mb = wave + 4 * a;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = ((red[0][lane][r] + red[1][lane][r]) + red[2][lane][r]) + red[3][lane][r];
-            dst[(4 * q + r) * 16 + i] = v;                            // block row 4q+r, col i
+        for (int nb = 0; nb < 8; ++nb) {
+            if (mb < MBn && nb < NBn) {
+                float* dst = dst0 + (size_t)(mb * NBn + nb) * 272;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(4 * q + r) * 16 + i] = acc[a][nb][r];
+            }
         }
-        if (want_bias && i == 0) {
+    }
+    if (T.bias != nullptr) {                               // column sums: reduce the 16 row indices in order
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                dst[256 + 4 * q + r] = ((red[0][lane][4 + r] + red[1][lane][4 + r]) + red[2][lane][4 + r]) +
-                                       red[3][lane][4 + r];
+        for (int u = 0; u < 2; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            if (idx < 16 * a4) {
+                const int r = idx / a4, c = (idx - r * a4) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) scol[r][c + j] = csum[u][j];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 16 * MBn) {
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += scol[r][threadIdx.x];
+            // bias of block row mb lives in the partial of block (mb, nb = 0), slots 256..271
+            dst0[(size_t)((threadIdx.x >> 4) * NBn) * 272 + 256 + (threadIdx.x & 15)] = sm;
         }
     }
 }
@@ -132,13 +171,13 @@ k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
     const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     float s = 0.0f, sb = 0.0f;
-    const float* src0 = partial + ((size_t)blockIdx.y * batch.chunks * 64 + blockIdx.x) * 272;
+    const float* src0 = partial + ((size_t)blockIdx.y * batch.chunks * 32 + blockIdx.x) * 272;
     int ch = 0;
     for (; ch + 8 <= batch.chunks; ch += 8) {           // 8 chunk loads in flight, summed in chunk order
         float v[8], vb[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float* src = src0 + (size_t)(ch + u) * 64 * 272;
+            const float* src = src0 + (size_t)(ch + u) * 32 * 272;
             v[u] = src[r * 16 + c];
             vb[u] = c == 0 ? src[256 + r] : 0.0f;
         }
@@ -146,7 +185,7 @@ k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
         for (int u = 0; u < 8; ++u) { s += v[u]; sb += vb[u]; }
     }
     for (; ch < batch.chunks; ++ch) {
-        const float* src = src0 + (size_t)ch * 64 * 272;
+        const float* src = src0 + (size_t)ch * 32 * 272;
         s += src[r * 16 + c];
         if (c == 0) sb += src[256 + r];
     }
