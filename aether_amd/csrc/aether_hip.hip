@@ -181,7 +181,7 @@ struct GraphLayout {
     }
 };
 
-constexpr int OUTER_MAX_CHUNKS = 128;
+constexpr int OUTER_MAX_CHUNKS = 256;
 
 
 struct WsLayout {

@@ -87,6 +87,29 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     // its running sums are this chunk's column sums of A restricted to its row index
     const int a4 = MBn * 4, b4 = NBn * 4;                 // float4 per row
     f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // register prefetch: the next tile's rows are in flight while the current tile is multiplied
+    f32x4 va[2], vb[2];
+    auto fetch = [&](int64_t t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            va[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < t1) {
+                if (idx < 16 * a4) {
+                    const int r = idx / a4, c = (idx - r * a4) * 4;
+                    const int64_t row = 16 * t + r;
+                    if (row < T.rows) va[u] = ld4(T.A + row * T.lda + c);
+                }
+                if (idx < 16 * b4) {
+                    const int r = idx / b4, c = (idx - r * b4) * 4;
+                    const int64_t row = 16 * t + r;
+                    if (row < T.rows) vb[u] = ld4(T.B + row * T.ldb + c);
+                }
+            }
+        }
+    };
+    fetch(t0);
     for (int64_t t = t0; t < t1; ++t) {
         __syncthreads();                                   // previous tile consumed
 #pragma unroll
@@ -94,20 +117,15 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
             const int idx = threadIdx.x + 256 * u;
             if (idx < 16 * a4) {
                 const int r = idx / a4, c = (idx - r * a4) * 4;
-                const int64_t row = 16 * t + r;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (row < T.rows) v = ld4(T.A + row * T.lda + c);
-                st4(sa + r * LDO + c, v);
-                csum[u] += v;
+                st4(sa + r * LDO + c, va[u]);
+                csum[u] += va[u];
             }
             if (idx < 16 * b4) {
                 const int r = idx / b4, c = (idx - r * b4) * 4;
-                const int64_t row = 16 * t + r;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (row < T.rows) v = ld4(T.B + row * T.ldb + c);
-                st4(sb + r * LDO + c, v);
+                st4(sb + r * LDO + c, vb[u]);
             }
         }
+        fetch(t + 1);
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
