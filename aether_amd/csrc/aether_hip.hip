@@ -376,13 +376,13 @@ int run_outer(OuterList& L, float* partial, hipStream_t st) {
         int blocks = ((L.b.t[k].M + 15) / 16) * ((L.b.t[k].N + 15) / 16);
         if (blocks > max_blocks) max_blocks = blocks;
     }
-    int64_t chunks = (max_tiles + 7) / 8;               // >= 8 row tiles per workgroup
+    int64_t chunks = (max_tiles + 15) / 16;             // >= 16 row tiles per workgroup
     if (chunks < 1) chunks = 1;
-    if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
+    if (chunks > 96) chunks = 96;
     L.b.chunks = (int)chunks;
     ProfScope ps(KB_OUTER, st);
     k_outer<<<dim3((unsigned)chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
-    k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
+    k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(1024), 0, st>>>(L.b, partial);
     return AETHER_OK;
 }
 
@@ -401,7 +401,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     float* partial = wp(W.partial);
     const int64_t ntile = (Nn + 15) / 16, etile = (E + 15) / 16;
     const unsigned ngrid = (unsigned)ntile;
-    const unsigned egrid = (unsigned)((etile + 3) / 4 < 1024 ? (etile + 3) / 4 : 1024);
+    const unsigned egrid = (unsigned)((etile + 3) / 4 < 512 ? (etile + 3) / 4 : 512);    // 2 workgroups per CU
     auto optin = [&](const void* k, size_t lds) -> int {     // once per kernel and process
         static std::vector<const void*> done;
         for (const void* d : done) if (d == k) return AETHER_OK;

@@ -180,18 +180,23 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     }
 }
 
-// grid = (64 blocks max, n_tasks): sums the chunk partials in chunk order and writes C / bias
-__global__ void __launch_bounds__(256)
+// grid = (blocks, n_tasks), 1024 threads: element (r, c) of one 16x16 block x 4 chunk groups.  Each
+// group adds its contiguous quarter of the chunks in order; the four group sums are combined in
+// order through LDS: a fixed summation tree, hence deterministic.
+__global__ void __launch_bounds__(1024)
 k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
     const OuterTask T = batch.t[blockIdx.y];
     const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
     if ((int)blockIdx.x >= MBn * NBn) return;
     const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
-    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 8, e = threadIdx.x & 255;
+    const int r = e >> 4, c = e & 15;
+    const int per = (batch.chunks + 3) / 4;
+    const int c0 = grp * per, c1 = c0 + per < batch.chunks ? c0 + per : batch.chunks;
     float s = 0.0f, sb = 0.0f;
     const float* src0 = partial + ((size_t)blockIdx.y * batch.chunks * 32 + blockIdx.x) * 272;
-    int ch = 0;
-    for (; ch + 8 <= batch.chunks; ch += 8) {           // 8 chunk loads in flight, summed in chunk order
+    int ch = c0;
+    for (; ch + 8 <= c1; ch += 8) {                     // 8 chunk loads in flight, summed in chunk order
         float v[8], vb[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -202,14 +207,22 @@ k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) { s += v[u]; sb += vb[u]; }
     }
-    for (; ch < batch.chunks; ++ch) {
+    for (; ch < c1; ++ch) {
         const float* src = src0 + (size_t)ch * 32 * 272;
         s += src[r * 16 + c];
         if (c == 0) sb += src[256 + r];
     }
-    const int m = 16 * mb + r, n = 16 * nb + c;
-    if (m < T.M && n < T.N) T.C[(size_t)m * T.ldc + n] = s;
-    if (T.bias != nullptr && nb == 0 && c == 0 && m < T.M) T.bias[m] = sb;
+    __shared__ float red[4][256], redb[4][16];
+    red[grp][e] = s;
+    if (c == 0) redb[grp][r] = sb;
+    __syncthreads();
+    if (grp == 0) {
+        const float tot = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        const int m = 16 * mb + r, n = 16 * nb + c;
+        if (m < T.M && n < T.N) T.C[(size_t)m * T.ldc + n] = tot;
+        if (T.bias != nullptr && nb == 0 && c == 0 && m < T.M)
+            T.bias[m] = ((redb[0][r] + redb[1][r]) + redb[2][r]) + redb[3][r];
+    }
 }
 
 // ------------------------------------------------------------------ transposed weight copies

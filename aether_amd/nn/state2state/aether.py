@@ -107,9 +107,20 @@ class _AetherStep(torch.autograd.Function):
             import torch.distributed as dist
             dist.all_reduce(flat, group=module.dp_group)
             flat.div_(dist.get_world_size(module.dp_group))
+        # Hand the gradients over as views of the flat buffer (no 47 small copies): a parameter whose
+        # .grad is unset gets the view itself (like DDP's gradient_as_bucket_view); an existing .grad
+        # is accumulated into, as torch.autograd would.
         need = ctx.needs_input_grad[_AetherStep.N_FIXED:]
-        grads = tuple(v.clone() if n else None for v, n in zip(views, need))
-        return (None,) * _AetherStep.N_FIXED + grads
+        out = []
+        for p, v, n in zip(module.parameters(), views, need):
+            if not n:
+                out.append(None)
+            elif module.grad_as_view and (p.grad is None or p.grad.data_ptr() == v.data_ptr()):
+                p.grad = v
+                out.append(None)
+            else:
+                out.append(v.clone())
+        return (None,) * _AetherStep.N_FIXED + tuple(out)
 
 
 class _FieldNetwork(nn.Module):
@@ -181,6 +192,7 @@ class Aether(nn.Module):
         self._graphs = GraphCache()
         self.flags = 0                    # _lib.FLAG_* bits passed to aether_forward
         self.dp_group = None              # set by aether_amd.parallel.attach_data_parallel
+        self.grad_as_view = True          # .grad tensors alias one flat buffer (see _AetherStep.backward)
         self._last_ws = None
         self._gbuf = None
         self._ws = None
