@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: all ranks use cuda:0 (with --backend gloo) to rehearse the N > 1 path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step (fwd+bwd+opt) figure")
     ap.add_argument("--streamed", action="store_true", help="force the layer-by-layer kernels")
@@ -104,11 +107,16 @@ def main():
     from aether_amd.synthetic import make_batch
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B, N, D = args.batch, args.nodes, args.dims
     torch.manual_seed(1)
