@@ -285,7 +285,8 @@ def main():
                  "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
                  "includes": "forward + HIP backward + " + ("RCCL grad all-reduce + " if world > 1 else "")
                              + "torch AdamW, " + train_launch + " launches"}
-        if rank == 0:       # per-kernel breakdown of one training step
+        if rank == 0:       # per-kernel breakdown of one training step (rank-local: no collective in here)
+            saved_group, model.dp_group = model.dp_group, None
             lib = _lib.load()
             nk = lib.aether_profile_kernels()
             lib.aether_profile_enable(1)
@@ -301,6 +302,9 @@ def main():
             lib.aether_profile_enable(0)
             train["kernels_us_per_step"] = {lib.aether_profile_kernel_name(k).decode(): 1e3 * ms[k] / ks
                                             for k in range(nk) if cnt[k]}
+            model.dp_group = saved_group
+        if world > 1:
+            dist.barrier()
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
