@@ -61,15 +61,16 @@ class _AetherStep(torch.autograd.Function):
     """aether_forward / aether_backward behind torch.autograd (parameters only get gradients:
     the runner detaches positions and edge attributes, experiments/lorentz/main.py:243-247)."""
 
-    N_FIXED = 7          # module, x, vel, edge_attr, charges, graph, n_edges precede the parameters
+    N_FIXED = 8          # module, train, x, vel, edge_attr, charges, graph, n_edges precede the parameters
 
     @staticmethod
-    def forward(ctx, module, x, vel, edge_attr, charges, graph, n_edges, *params):
+    def forward(ctx, module, train, x, vel, edge_attr, charges, graph, n_edges, *params):
         lib = _lib.load()
         graph, ginfo = graph
         D = module.num_dims
         n_nodes = x.shape[0]
-        train = any(ctx.needs_input_grad[_AetherStep.N_FIXED:])
+        # `train` is decided by the caller: inside Function.forward grad mode is always off, and
+        # needs_input_grad reflects requires_grad even under torch.no_grad()
         flags = module.flags | (_lib.FLAG_KEEP_INTERMEDIATES if train else 0)
         keep = bool(flags & _lib.FLAG_KEEP_INTERMEDIATES)
         ws_bytes = lib.aether_workspace_bytes(n_nodes, n_edges, D, 1 if keep else 0)
@@ -265,7 +266,8 @@ class Aether(nn.Module):
             raise ValueError("edge index / edge_attr / charges shapes do not match")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         graph = self.prepare_graph((send, recv), n_nodes)
-        return _AetherStep.apply(self, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E,
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return _AetherStep.apply(self, train, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E,
                                  *self.parameters())
 
     # -- test hook -------------------------------------------------------------------
