@@ -47,12 +47,19 @@ template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static constexpr int FIELD_H1 = FIELD_Z + FUSED_MAX_NODES * 24;    // [32][32]
     static constexpr int FIELD_H2 = FIELD_H1 + FUSED_MAX_NODES * 32;   // [32][32]
     static constexpr int FIELD_F = FIELD_H2 + FUSED_MAX_NODES * 32;    // [32][4]
+    static constexpr int FIELD_W = FIELD_F + FUSED_MAX_NODES * 4;      // field-net parameters (2,080 floats)
+    static constexpr int FW0 = FIELD_W;                                // [32][22]
+    static constexpr int FW2 = FW0 + 32 * 22;                          // [32][32]
+    static constexpr int FW4 = FW2 + 32 * 32;                          // [3][32]
+    static constexpr int FB = FW4 + 3 * 32;                            // b0[32] b2[32] b4[4]
+    static constexpr int FEMB = FB + 68;                               // [3][16]
+    static constexpr int FIELD_END = FEMB + 48;
     static constexpr int FEAT = SCRATCH;                               // [NW waves][FEAT_ROWS][LDF]
     static constexpr int WSTAGE = SCRATCH;                             // [NW waves][16][LDST] tile staging
     static constexpr int UBUF = SCRATCH;                               // [32][LDU]
     static constexpr int OBUF1 = SCRATCH;                              // [32][LDW]
     static constexpr int OBUF2 = SCRATCH + FUSED_MAX_NODES * LDW;      // [32][LDW]
-    static_assert(FIELD_F + FUSED_MAX_NODES * 4 <= TOTAL, "field scratch");
+    static_assert(FIELD_END <= TOTAL, "field scratch");
     static_assert(UBUF + FUSED_MAX_NODES * LDU <= TOTAL, "ubuf");
     static_assert(OBUF2 + FUSED_MAX_NODES * LDW <= TOTAL, "obuf");
     static_assert(TOTAL * 4 <= 160 * 1024, "LDS budget");
@@ -191,6 +198,19 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         float* h1 = smem + L::FIELD_H1;
         float* h2 = smem + L::FIELD_H2;
         float* ff = smem + L::FIELD_F;
+        float* fw0 = smem + L::FW0;
+        float* fw2 = smem + L::FW2;
+        float* fw4 = smem + L::FW4;
+        float* fb = smem + L::FB;
+        float* femb = smem + L::FEMB;
+        // the 2,080 field-net parameters go to LDS once; the per-(node, unit) loops below read them there
+        for (int idx = tid; idx < 32 * FIN; idx += THREADS) fw0[idx] = P.field_w0[idx];
+        for (int idx = tid; idx < 32 * 32; idx += THREADS) fw2[idx] = P.field_w2[idx];
+        if (tid < D * 32) fw4[tid] = P.field_w4[tid];
+        if (tid < 32) { fb[tid] = P.field_b0[tid]; fb[32 + tid] = P.field_b2[tid]; }
+        if (tid < D) fb[64 + tid] = P.field_b4[tid];
+        if (tid < 48) femb[tid] = P.field_emb[tid];
+        __syncthreads();
         for (int idx = tid; idx < nv * FIN; idx += THREADS) {
             int node = idx / FIN, k = idx - node * FIN;
             float val;
@@ -199,32 +219,32 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             else {
                 long ci = (long)(charges[vb + node] + 1.0f);
                 ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
-                val = P.field_emb[ci * 16 + (k - 2 * D)];
+                val = femb[ci * 16 + (k - 2 * D)];
             }
             z[node * 24 + k] = val;
         }
         __syncthreads();
         for (int idx = tid; idx < nv * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
-            float s = P.field_b0[o];
+            float s = fb[o];
 #pragma unroll
-            for (int k = 0; k < FIN; ++k) s += P.field_w0[o * FIN + k] * z[node * 24 + k];
+            for (int k = 0; k < FIN; ++k) s += fw0[o * FIN + k] * z[node * 24 + k];
             h1[node * 32 + o] = silu(s);
         }
         __syncthreads();
         for (int idx = tid; idx < nv * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
-            float s = P.field_b2[o];
+            float s = fb[32 + o];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) s += P.field_w2[o * 32 + k] * h1[node * 32 + k];
+            for (int k = 0; k < 32; ++k) s += fw2[o * 32 + k] * h1[node * 32 + k];
             h2[node * 32 + o] = silu(s);
         }
         __syncthreads();
         for (int idx = tid; idx < nv * D; idx += THREADS) {
             int node = idx / D, d = idx - node * D;
-            float s = P.field_b4[d];
+            float s = fb[64 + d];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) s += P.field_w4[d * 32 + k] * h2[node * 32 + k];
+            for (int k = 0; k < 32; ++k) s += fw4[d * 32 + k] * h2[node * 32 + k];
             ff[node * 4 + d] = s;
         }
         __syncthreads();
@@ -408,13 +428,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         };
         {
             const int nvalid = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;    // wave-uniform
-            if (ROUNDS == 2 && nvalid == 2) {
-                f32x4 ha[4], hb[4];
-                front(0, ha);
-                front(1, hb);
-                back(0, ha);
-                back(1, hb);
-            } else {
+            {
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) {
                     if (r < nvalid) {
@@ -439,6 +453,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         const int mb3 = wave & 3, tn3 = (wave >> 2) & 1;  // steps 3, 4: rows 16*mb3.. of node tile tn3
         const bool act3 = wave < 8;                       // step 3 / out MLP: 8 units
         const int sel4 = NW == 16 ? wave >> 3 : 0;        // step 4 (NW=16): 0 -> P_s, 1 -> P_r
+        // step 4 with one node tile (split mode): waves 0-3 compute P_s, waves 4-7 P_r, tile 0
+        const bool one_tile = NW == 8 && n <= 16;
+        const int tn4 = one_tile ? 0 : tn3;
+        const bool do_s = NW == 16 ? sel4 == 0 : (one_tile ? wave < 4 : true);
+        const bool do_r = NW == 16 ? sel4 == 1 : (one_tile ? wave >= 4 : true);
         // Issue every L2 load of the node phase now, so that their latency hides behind the barrier
         // and the earlier steps: W3 / W4 / next-layer W_s, W_r fragments and the next layer's edge
         // weights (W_e = W1[:, 128:192], W2) that go to LDS once every wave has left the edge tiles.
@@ -454,8 +473,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                if (NW == 8 || sel4 == 0) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
-                if (NW == 8 || sel4 == 1) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+                if (do_s) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
+                if (do_r) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
             }
 #pragma unroll
             for (int j = 0; j < STG; ++j) {
@@ -527,19 +546,19 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // step 4: next layer's node terms P_s = W_s x, P_r = W_r x + b1 (locs.py:233 split)
         if (layer < 4) {
             const float* b1n = P.ln_msg_b0[layer - 1];
-            if (16 * tn3 < n) {
+            if (16 * tn4 < n) {
                 f32x4 xv[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) xv[a] = ld4(xbuf + (16 * tn3 + i) * LDW + 16 * a + 4 * q);
-                if (NW == 8 || sel4 == 0) {
+                for (int a = 0; a < 4; ++a) xv[a] = ld4(xbuf + (16 * tn4 + i) * LDW + 16 * a + 4 * q);
+                if (do_s) {
                     f32x4 accs = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) accs = mfma16(wsv[a][b], xv[a][b], accs);
-                    if (16 * tn3 + i < n) {      // sender rows live in the visible numbering
-                        st4(psb + (off + 16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accs);
-                        float* gps = dbg.ps[layer - 1] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q;
+                    if (16 * tn4 + i < n) {      // sender rows live in the visible numbering
+                        st4(psb + (off + 16 * tn4 + i) * LDW + 16 * mb3 + 4 * q, accs);
+                        float* gps = dbg.ps[layer - 1] + (int64_t)(nb + 16 * tn4 + i) * H + 16 * mb3 + 4 * q;
                         if (wg.partner >= 0) {       // write-through (sc1) payload: no release fence needed
                             typedef unsigned long long u64;
                             const u64 lo = ((u64)__float_as_uint(accs[1]) << 32) | __float_as_uint(accs[0]);
