@@ -570,15 +570,15 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                         }
                     }
                 }
-                if (NW == 8 || sel4 == 1) {
+                if (do_r) {
                     f32x4 accr = ld4(b1n + 16 * mb3 + 4 * q);
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) accr = mfma16(wrv[a][b], xv[a][b], accr);
-                    st4(prb + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, accr);
-                    if (keep && 16 * tn3 + i < n)
-                        st4(dbg.pr[layer - 1] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, accr);
+                    st4(prb + (16 * tn4 + i) * LDW + 16 * mb3 + 4 * q, accr);
+                    if (keep && 16 * tn4 + i < n)
+                        st4(dbg.pr[layer - 1] + (int64_t)(nb + 16 * tn4 + i) * H + 16 * mb3 + 4 * q, accr);
                 }
             }
             if (wg.partner >= 0) {
