@@ -35,10 +35,21 @@ __device__ __forceinline__ float silu(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// Four values at once: the three plain multiplies / adds are written on 2-wide vectors so that they
+// become v_pk_mul_f32 / v_pk_add_f32 (fp32 MFMA shares the VALU: every instruction saved is
+// matrix-pipe time).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 silu4(f32x4 v) {
-    f32x4 o;
-    o[0] = silu(v[0]); o[1] = silu(v[1]); o[2] = silu(v[2]); o[3] = silu(v[3]);
-    return o;
+    const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    const f32x2 tl = lo * -1.44269504088896340736f, th = hi * -1.44269504088896340736f;
+    f32x2 el = {__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])};
+    f32x2 eh = {__builtin_amdgcn_exp2f(th[0]), __builtin_amdgcn_exp2f(th[1])};
+    el = el + 1.0f;
+    eh = eh + 1.0f;
+    const f32x2 rl = {__builtin_amdgcn_rcpf(el[0]), __builtin_amdgcn_rcpf(el[1])};
+    const f32x2 rh = {__builtin_amdgcn_rcpf(eh[0]), __builtin_amdgcn_rcpf(eh[1])};
+    const f32x2 ol = lo * rl, oh = hi * rh;
+    return f32x4{ol[0], ol[1], oh[0], oh[1]};
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
