@@ -345,18 +345,16 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     }
     FUSED_STAMP(3);
 
-    // node sums (step 1 of the node phase): lane (node i of node tile tn) adds the node's partial
-    // rows `part[node + tile]`, tiles nt0..nt1-1, in tile order.
-    int nt0[2], nt1[2];
-    float ndeg[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int slot = 16 * tn + i;
-        int beg = 0, end = 0;
-        if (slot < n) { beg = rowptr[nb + slot] - eb; end = rowptr[nb + slot + 1] - eb; }
-        nt0[tn] = beg >> 4;
-        nt1[tn] = end > beg ? ((end - 1) >> 4) + 1 : nt0[tn];
-        ndeg[tn] = (float)(end - beg > 1 ? end - beg : 1);
+    // node-sum ownership (step 1 of the node phase): thread -> (node slot, 4 columns).  The in-edge
+    // sum of a node arrives as per-(receiver, tile) partial rows `part[node + tile]`.
+    const int aslot = (tid >> 4) & (FUSED_MAX_NODES - 1), ac4 = (tid & 15) * 4;
+    int at0 = 0, at1 = 0;
+    float adeg = 1.0f;
+    if (aslot < n) {
+        const int beg = rowptr[nb + aslot] - eb, end = rowptr[nb + aslot + 1] - eb;
+        at0 = beg >> 4;
+        at1 = end > beg ? ((end - 1) >> 4) + 1 : at0;
+        adeg = (float)(end - beg > 1 ? end - beg : 1);
     }
 
 #ifdef AETHER_FUSED_PRIO
@@ -487,6 +485,14 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         __syncthreads();       // all partial rows are published; wA / wB are idle
         FUSED_STAMP(4 + 8 * (layer - 1) + 3);
+        // step 1: n = x_prev + (sum of the node's partial rows, in tile order) / max(deg, 1)
+        if (tid < FUSED_MAX_NODES * 16) {
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = at0; t < at1; ++t) sum += ld4(part + (aslot + t) * LDW + ac4);
+            const f32x4 nv = ld4(xbuf + aslot * LDW + ac4) + sum / adeg;
+            st4(nbuf + aslot * LDW + ac4, nv);
+            if (keep && aslot < n) st4(dbg.n[layer - 1] + (int64_t)(nb + aslot) * H + ac4, nv);
+        }
         if (layer < 4) {       // next layer's edge weights -> LDS (loads were issued above)
 #pragma unroll
             for (int j = 0; j < STG; ++j) {
@@ -496,10 +502,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
             if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
         }
-        // steps 1 + 2: n = x_prev + (sum of the node's partial rows, in tile order) / max(deg, 1) is
-        // built by every wave straight into its B operand (no separate pass, no barrier);
-        // u = SiLU(W3 n + b3): rows 16*mb2.. of u for node tile(s).  Waves 0-3 also leave their
-        // quarter of n in nbuf for step 3's residual.
+        __syncthreads();       // n complete
+        FUSED_STAMP(4 + 8 * (layer - 1) + 7);
+        // step 2: u = SiLU(W3 n + b3): rows 16*mb2.. of u for node tile(s)
         {
             float* ubuf = smem + L::UBUF;
             const f32x4 bv = ld4(b3 + 16 * mb2 + 4 * q);
@@ -507,31 +512,14 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             for (int t2 = 0; t2 < (NW == 8 ? 2 : 1); ++t2) {
                 const int tn = NW == 8 ? t2 : wave >> 3;
                 if (16 * tn < n) {
-                    const int slot = 16 * tn + i;
-                    f32x4 nv[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) nv[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    for (int t = nt0[tn]; t < nt1[tn]; ++t) {
-                        const float* pr_ = part + (slot + t) * LDW + 4 * q;
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) nv[a] += ld4(pr_ + 16 * a);
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        nv[a] = ld4(xbuf + slot * LDW + 16 * a + 4 * q) + nv[a] / ndeg[tn];
-                    if (wave < 4) {
-                        const f32x4 mine = wave == 0 ? nv[0] : (wave == 1 ? nv[1] : (wave == 2 ? nv[2] : nv[3]));
-                        st4(nbuf + slot * LDW + 16 * wave + 4 * q, mine);
-                        if (keep && slot < n)
-                            st4(dbg.n[layer - 1] + (int64_t)(nb + slot) * H + 16 * wave + 4 * q, mine);
-                    }
                     f32x4 acc = bv;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
+                        const f32x4 nv = ld4(nbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) acc = mfma16(w3v[a][b], nv[a][b], acc);
+                        for (int b = 0; b < 4; ++b) acc = mfma16(w3v[a][b], nv[b], acc);
                     }
-                    st4(ubuf + slot * LDU + 16 * mb2 + 4 * q, silu4(acc));
+                    st4(ubuf + (16 * tn + i) * LDU + 16 * mb2 + 4 * q, silu4(acc));
                 }
             }
         }
