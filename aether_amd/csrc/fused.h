@@ -357,9 +357,6 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         adeg = (float)(end - beg > 1 ? end - beg : 1);
     }
 
-#ifdef AETHER_FUSED_PRIO
-    if (__builtin_amdgcn_readfirstlane(tid) >= AETHER_FUSED_PRIO) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
         // ------------------------------------------------------------ edge tiles (locs.py:227-238)

@@ -13,6 +13,12 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The tests bind the in-tree libaether_hip.so.  If a fresh checkout has not been built yet,
+    # build it once with hipcc (cross-compiles without a GPU); a missing compiler is an error
+    # of the environment, not something to fall back from.
+    from aether_amd import build as _b
+    if not os.path.exists(_b.LIB):
+        _b.build_library(force=True, verbose=False)
 
 
 def load_case(name):
