@@ -145,8 +145,8 @@ constexpr int64_t FUSED_TABLE_MAX_EDGES = 4 << 20;
 int g_fused_split = 1;        // aether_set_option("fused_split", 0|1): two workgroups per group when CUs are idle
 
 struct GraphLayout {
-    size_t perm, send_s, recv_s, rowptr, wgdesc, tdesc, tsel, tdst, sperm, srowptr, keys, vals, diff, cross, flag,
-        cub, total, cub_bytes;
+    size_t perm, send_s, recv_s, rowptr, gsel, wgdesc, tdesc, tsel, tdst, sperm, srowptr, keys, vals, diff, cross,
+        flag, cub, total, cub_bytes;
     int64_t max_wgs, max_tiles;
     GraphLayout(int64_t E, int64_t Nn, bool with_sort_scratch = true) {
         size_t off = 0;
@@ -154,6 +154,7 @@ struct GraphLayout {
         size_t e4 = (size_t)(E > 0 ? E : 1) * 4;
         perm = take(e4); send_s = take(e4); recv_s = take(e4);
         rowptr = take((size_t)(Nn + 1) * 4);
+        gsel = take((size_t)((E + 15) / 16) * 64 * 4 + 4);     // tile structure for tile_receiver_sums
         // fused-path tables; skipped for graphs far beyond what the fused kernel serves
         const bool tables = E <= FUSED_TABLE_MAX_EDGES;
         max_wgs = tables ? 2 * Nn : 0;
@@ -186,7 +187,7 @@ constexpr int OUTER_MAX_CHUNKS = 256;
 
 struct WsLayout {
     // forward (always)
-    size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, stamps, flags, fwd_total;
+    size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, part, stamps, flags, fwd_total;
     // saved by the forward under KEEP_INTERMEDIATES for the backward
     size_t n[4], feat;
     // backward temporaries
@@ -203,6 +204,7 @@ struct WsLayout {
         for (auto& v : pr) v = take(nn * H);
         for (auto& v : e) v = take(ee * H);
         aggr = take(nn * H);
+        part = take((nn + (ee + 15) / 16 + 1) * H);   // per-(receiver, tile) sums of the streamed edge kernels
         stamps = take((size_t)4096 * FUSED_STAMPS);
         flags = take(2 * nn + 64);              // split-mode hand-off flags, one int per workgroup
         fwd_total = off;
@@ -305,16 +307,25 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     const int64_t n_chunks = (E + 255) / 256;
     const int64_t n_tiles = (E + 15) / 16;
     const unsigned node_grid = (unsigned)((Nn + 15) / 16);
+    const uint32_t* gsel = reinterpret_cast<const uint32_t*>(graph + G.gsel);
     if (E > 0) {
-        const size_t lds1 = (size_t)(H * LDF + H * LDW + 2 * H + 256 * LDF) * 4;
-        unsigned g1 = (unsigned)(n_chunks < 2048 ? n_chunks : 2048);
+        const size_t lds1 = (size_t)(H * LDF + H * LDW + 2 * H + 128 * LDF + 4 * 16 * LDST) * 4;
+        static bool attr1 = false;
+        if (!attr1) {
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_layer1<D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            attr1 = true;
+        }
+        const int64_t n_chunks1 = (E + 127) / 128;
+        unsigned g1 = (unsigned)(n_chunks1 < 2048 ? n_chunks1 : 2048);
         ProfScope ps(K_EDGE_L1, st);
-        k_edge_layer1<D><<<dim3(g1), dim3(256), lds1, st>>>(P, nodeinfo, ea, perm, send_s, recv_s,
-                                                           wp(W.e[0]), keep ? wp(W.feat) : nullptr, E);
+        k_edge_layer1<D><<<dim3(g1), dim3(256), lds1, st>>>(P, nodeinfo, ea, perm, send_s, recv_s, gsel,
+                                                           wp(W.part), wp(W.e[0]), keep ? wp(W.feat) : nullptr,
+                                                           E);
     }
     auto seg_mean = [&](int l) {
         ProfScope ps(K_SEGMEAN, st);
-        k_segment_mean<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(wp(W.e[l - 1]), rowptr, wp(W.aggr), Nn);
+        k_segment_mean<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(wp(W.part), rowptr, wp(W.aggr), Nn);
     };
     seg_mean(1);
     {
@@ -325,14 +336,16 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     }
     for (int l = 2; l <= 4; ++l) {
         if (E > 0) {
-            const size_t lds = (size_t)(2 * H * LDW + H) * 4;
+            const size_t lds = (size_t)(2 * H * LDW + H + 4 * 16 * LDST) * 4;
             int64_t wgs = (n_tiles + 3) / 4;
             unsigned g = (unsigned)(wgs < 1024 ? wgs : 1024);
             ProfScope ps(K_EDGE_LN, st);
             auto launch = [&](auto kern) {
+                // layer 4's messages are only needed as receiver sums (locs.py:190-193) unless kept
+                float* eo = (l == 4 && !keep) ? nullptr : wp(W.e[l - 1]);
                 kern<<<dim3(g), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2],
                                                      P.ln_msg_b2[l - 2], wp(W.ps[l - 2]), wp(W.pr[l - 2]),
-                                                     wp(W.e[l - 2]), send_s, recv_s, wp(W.e[l - 1]), E);
+                                                     wp(W.e[l - 2]), send_s, recv_s, gsel, wp(W.part), eo, E);
             };
             if (g_edge_variant == 1) launch(k_edge_layer<false>);
             else launch(k_edge_layer<true>);
@@ -623,6 +636,8 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
                                               (int)n_edges, 0, bits_for(n_nodes), st));
     k_graph_finish<<<dim3(blocks), dim3(256), 0, st>>>(send, recv_s, perm, n_edges, n_nodes,
                                                       (int32_t*)(g + G.send_s), rowptr);
+    k_graph_gtiles<<<dim3((unsigned)((n_edges + 15) / 16)), dim3(64), 0, st>>>(recv_s, n_edges,
+                                                                              (uint32_t*)(g + G.gsel));
     // sender lists for the backward: stable sort of the receiver-sorted positions by sender
     {
         int32_t* send_s = (int32_t*)(g + G.send_s);

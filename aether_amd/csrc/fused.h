@@ -145,6 +145,42 @@ k_graph_tiles(const FusedTile* __restrict__ tdesc, const int32_t* __restrict__ r
     tdst[(size_t)blockIdx.x * 64 + lane] = dp;
 }
 
+// The same structure for the whole receiver-sorted edge list (tile t = sorted positions 16t..16t+15),
+// one word per lane, for the streamed edge kernels (streamed.h::tile_receiver_sums):
+// bits 0-3 segment-matrix column; per result register r4: first row of segment 4q+r4 (4 bits), valid (1 bit).
+__global__ void __launch_bounds__(64)
+k_graph_gtiles(const int32_t* __restrict__ recv_s, int64_t n_edges, uint32_t* __restrict__ gsel) {
+    const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+    const int64_t k = (int64_t)blockIdx.x * 16 + i;
+    const bool valid = k < n_edges;
+    const int rcv = valid ? recv_s[k] : -1;
+    const int prev = __shfl_up(rcv, 1, 16);
+    const unsigned smask = (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;
+    const unsigned vmask = (unsigned)__ballot(q == 0 && valid) & 0xFFFFu;
+    unsigned w = 0;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int edge = 4 * s4 + q;
+        const int seg_of_edge = __popc(smask & ((2u << edge) - 1u));
+        if (((vmask >> edge) & 1u) && seg_of_edge == i) w |= 1u << s4;
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int seg = 4 * q + r4;
+        unsigned mm = smask;
+        int s0 = 0;
+        bool exists = true;
+        for (int t = 0; t < seg; ++t) {
+            if (mm == 0) { exists = false; break; }
+            s0 = __ffs(mm) - 1;
+            mm &= mm - 1;
+        }
+        const unsigned ok = (exists && ((vmask >> s0) & 1u)) ? 16u : 0u;
+        w |= ((unsigned)s0 | ok) << (4 + 5 * r4);
+    }
+    gsel[(size_t)blockIdx.x * 64 + lane] = w;
+}
+
 template <int D, int NW, int ROUNDS, bool KEEP>
 __global__ void __launch_bounds__(NW * 64)
 k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,

@@ -73,6 +73,40 @@ k_node_prep(AetherParams P, const float* __restrict__ x, const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ per-tile receiver sums
+// Same matrix-core segment sum as the fused kernel (fused.h), with the partial rows going to
+// global memory: row (receiver + tile) of `part` gets the sum of the tile's messages for that
+// receiver.  `gs` is this lane's word of the graph's tile table (k_graph_gtiles): bits 0-3 the 0/1
+// column of the segment matrix, then per result register (first row : 4 bits, valid : 1 bit).
+// `wst` = 16 wave-private LDS rows of LDST floats; `rcv` = receiver of this lane's edge.
+__device__ __forceinline__ void tile_receiver_sums(const f32x4 (&e)[4], float* wst, unsigned gs, int rcv,
+                                                   int64_t tile, float* __restrict__ part, int i, int q,
+                                                   int lane) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) st4(wst + i * LDST + 16 * mb + 4 * q, e[mb]);
+    __builtin_amdgcn_wave_barrier();
+    f32x4 red[4];
+#pragma unroll
+    for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float sel = (gs >> s4) & 1u ? 1.0f : 0.0f;
+        const float* erow = wst + (4 * s4 + q) * LDST + i;
+#pragma unroll
+        for (int nbk = 0; nbk < 4; ++nbk) red[nbk] = mfma16(sel, erow[16 * nbk], red[nbk]);
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const unsigned f = gs >> (4 + 5 * r4);
+        const int node = __shfl(rcv, (lane & 48) + (int)(f & 15u));     // receiver of the segment's first row
+        if (f & 16u) {
+            float* dst = part + ((int64_t)node + tile) * H + i;
+            dst[0] = red[0][r4]; dst[16] = red[1][r4]; dst[32] = red[2][r4]; dst[48] = red[3][r4];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------ K1: layer-1 edge kernel
 // Phase A (one thread per edge): local-frame edge features, aether.py:52-100 +
 // geometry.py:76-101, followed by [rel_feat[recv] | edge_attr_orig] (aether.py:99,177).
@@ -82,14 +116,17 @@ __global__ void __launch_bounds__(256)
 k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
               const float* __restrict__ edge_attr_orig, const int32_t* __restrict__ perm,
               const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
-              float* __restrict__ e_out, float* __restrict__ feat_dbg, int64_t n_edges) {
+              const uint32_t* __restrict__ gsel, float* __restrict__ part, float* __restrict__ e_out,
+              float* __restrict__ feat_dbg, int64_t n_edges) {
     using NI = NodeInfo<D>;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+    constexpr int CH = 128;                 // edges per workgroup iteration (2 tiles per wave)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* w1 = smem;                       // [64][LDF]
     float* w2 = w1 + H * LDF;               // [64][LDW]
     float* bias = w2 + H * LDW;             // [128]: b1 | b2
-    float* feat = bias + 2 * H;             // [256][LDF]
+    float* feat = bias + 2 * H;             // [CH][LDF]
+    float* wstage = feat + CH * LDF;        // [4 waves][16][LDST]
     stage_weight(w1, P.l1_msg_w0, H, F1, F1, LDF);
     stage_weight64<256>(w2, P.l1_msg_w2, H);
     if (threadIdx.x < H) {
@@ -98,11 +135,12 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t n_chunks = (n_edges + 255) / 256;
+    float* wst = wstage + wave * (16 * LDST);
+    const int64_t n_chunks = (n_edges + CH - 1) / CH;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         __syncthreads();                    // weights staged / previous chunk's feat consumed
-        {
-            int64_t k = chunk * 256 + threadIdx.x;
+        if (threadIdx.x < CH) {
+            int64_t k = chunk * CH + threadIdx.x;
             float o[FPAD];
             if (k < n_edges) {
                 const float* nj = nodeinfo + (int64_t)send_s[k] * NI::STRIDE;
@@ -131,10 +169,11 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
         }
         __syncthreads();
 #pragma unroll 1
-        for (int t = 0; t < 4; ++t) {
-            const int local = wave * 64 + t * 16 + i;
-            const int64_t k = chunk * 256 + local;
-            if (chunk * 256 + wave * 64 + t * 16 >= n_edges) break;     // wave-uniform
+        for (int t = 0; t < 2; ++t) {
+            const int local = wave * 32 + t * 16 + i;
+            const int64_t k = chunk * CH + local;
+            if (chunk * CH + wave * 32 + t * 16 >= n_edges) break;      // wave-uniform
+            const int64_t tile = (chunk * CH + wave * 32 + t * 16) >> 4;
             f32x4 bop[2];
             bop[0] = ld4(feat + local * LDF + 4 * q);
             bop[1] = ld4(feat + local * LDF + 16 + 4 * q);
@@ -149,10 +188,15 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
             gemm_tile<4, 4>(w2, LDW, h1, acc2, i, q);
+            f32x4 eo[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
             if (k < n_edges) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, silu4(acc2[mb]));
+                for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, eo[mb]);
             }
+            const int rcv = recv_s[k < n_edges ? k : n_edges - 1];
+            tile_receiver_sums(eo, wst, gsel[tile * 64 + lane], rcv, tile, part, i, q, lane);
         }
     }
 }
@@ -173,11 +217,14 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
              const float* __restrict__ b_msg2, const float* __restrict__ Ps,
              const float* __restrict__ Pr, const float* __restrict__ e_prev,
              const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
-             float* __restrict__ e_out, int64_t n_edges) {
+             const uint32_t* __restrict__ gsel, float* __restrict__ part,
+             float* __restrict__ e_out /* null: the messages themselves are not needed (layer 4) */,
+             int64_t n_edges) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* we = smem;                       // [64][LDW]  = W1[:, 128:192]
     float* w2 = we + H * LDW;               // [64][LDW]
     float* bias = w2 + H * LDW;             // [64] b2
+    float* wst = bias + H + (threadIdx.x >> 6) * (16 * LDST);     // [4 waves][16][LDST] tile staging
     stage_weight64<256>(we, w_msg0 + 2 * H, 3 * H);
     stage_weight64<256>(w2, w_msg2, H);
     if (threadIdx.x < H) bias[threadIdx.x] = b_msg2[threadIdx.x];
@@ -215,6 +262,7 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
     }
     int64_t kn = clampk(tile + stride < n_tiles ? tile + stride : tile);
     int32_t s1 = send_s[kn], r1 = recv_s[kn];
+    int32_t rcur = r0;                      // receiver of this lane's edge in the current tile
     f32x4 eo[4];
     int64_t ko = -1;
     for (; tile < n_tiles; tile += stride) {
@@ -230,11 +278,13 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
             prv[mb] = ld4(Pr + (int64_t)r1 * H + 16 * mb + 4 * q);
             ev[mb] = ld4(e_prev + kn * H + 16 * mb + 4 * q);
         }
+        const int32_t rnext = r1;
+        const unsigned gs = gsel[tile * 64 + lane];
         kn = kn2;
         s1 = send_s[kn2];
         r1 = recv_s[kn2];
         if constexpr (!REGW) {
-            if (ko >= 0 && ko < n_edges) {
+            if (e_out != nullptr && ko >= 0 && ko < n_edges) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) st4(e_out + ko * H + 16 * mb + 4 * q, eo[mb]);
             }
@@ -266,19 +316,21 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
             asm volatile("" : "+v"(z));
             gemm_tile<4, 4>(w2 + z, LDW, h1, acc2, i, q);
         }
-        if constexpr (REGW) {
-            if (k < n_edges) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, silu4(acc2[mb]));
+        for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
+        if constexpr (REGW) {
+            if (e_out != nullptr && k < n_edges) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, eo[mb]);
             }
         } else {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
             ko = k;
         }
+        tile_receiver_sums(eo, wst, gs, rcur, tile, part, i, q, lane);
+        rcur = rnext;
     }
     if constexpr (!REGW) {
-        if (ko >= 0 && ko < n_edges) {
+        if (e_out != nullptr && ko >= 0 && ko < n_edges) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) st4(e_out + ko * H + 16 * mb + 4 * q, eo[mb]);
         }
@@ -287,15 +339,18 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
 
 // ------------------------------------------------------------------ segmented mean by receiver
 // torch_scatter.scatter(e, recv, reduce="mean") (locs.py:236-238) on the receiver-sorted messages:
-// one wave per node, lane = column, rows added in edge order (deterministic); 8 row loads in flight.
+// one wave per node, lane = column, rows added in tile (= edge) order (deterministic); 8 row loads in flight.
+// The edge kernels have already reduced every 16-edge tile per receiver (tile_receiver_sums): a
+// node's partial rows are rows node + t0 .. node + t1 of `part` (t = tiles its run touches).
 __global__ void __launch_bounds__(256)
-k_segment_mean(const float* __restrict__ e, const int32_t* __restrict__ rowptr,
+k_segment_mean(const float* __restrict__ part, const int32_t* __restrict__ rowptr,
                float* __restrict__ aggr, int64_t n_nodes) {
     const int lane = threadIdx.x & 63;
     const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= n_nodes) return;
-    const int beg = rowptr[node], end = rowptr[node + 1];
-    const float* p = e + (int64_t)beg * H + lane;
+    const int ebeg = rowptr[node], eend = rowptr[node + 1];
+    const int beg = ebeg >> 4, end = eend > ebeg ? ((eend - 1) >> 4) + 1 : beg;    // tiles of the run
+    const float* p = part + (node + (int64_t)beg) * H + lane;
     float s = 0.f;
     int k = beg;
     for (; k + 8 <= end; k += 8, p += 8 * H) {
@@ -304,7 +359,7 @@ k_segment_mean(const float* __restrict__ e, const int32_t* __restrict__ rowptr,
         s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
     }
     for (; k < end; ++k, p += H) s += p[0];
-    const float deg = (float)(end - beg > 1 ? end - beg : 1);    // count clamped to >= 1
+    const float deg = (float)(eend - ebeg > 1 ? eend - ebeg : 1);    // count clamped to >= 1
     aggr[node * H + lane] = s / deg;
 }
 
