@@ -309,15 +309,15 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     const unsigned node_grid = (unsigned)((Nn + 15) / 16);
     const uint32_t* gsel = reinterpret_cast<const uint32_t*>(graph + G.gsel);
     if (E > 0) {
-        const size_t lds1 = (size_t)(H * LDF + H * LDW + 2 * H + 128 * LDF + 4 * 16 * LDST) * 4;
+        const size_t lds1 = (size_t)(H * LDF + H * LDW + 2 * H + 4 * 64 * LDF) * 4;
         static bool attr1 = false;
         if (!attr1) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_layer1<D>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
             attr1 = true;
         }
-        const int64_t n_chunks1 = (E + 127) / 128;
-        unsigned g1 = (unsigned)(n_chunks1 < 2048 ? n_chunks1 : 2048);
+        const int64_t n_wg1 = ((E + 63) / 64 + 3) / 4;
+        unsigned g1 = (unsigned)(n_wg1 < 512 ? n_wg1 : 512);              // 2 workgroups per CU
         ProfScope ps(K_EDGE_L1, st);
         k_edge_layer1<D><<<dim3(g1), dim3(256), lds1, st>>>(P, nodeinfo, ea, perm, send_s, recv_s, gsel,
                                                            wp(W.part), wp(W.e[0]), keep ? wp(W.feat) : nullptr,

@@ -120,27 +120,28 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
               float* __restrict__ feat_dbg, int64_t n_edges) {
     using NI = NodeInfo<D>;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
-    constexpr int CH = 128;                 // edges per workgroup iteration (2 tiles per wave)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* w1 = smem;                       // [64][LDF]
     float* w2 = w1 + H * LDF;               // [64][LDW]
     float* bias = w2 + H * LDW;             // [128]: b1 | b2
-    float* feat = bias + 2 * H;             // [CH][LDF]
-    float* wstage = feat + CH * LDF;        // [4 waves][16][LDST]
+    float* scratch = bias + 2 * H;          // [4 waves][64][LDF]: features of the wave's 64 edges, then
+                                            // (once they sit in registers) its 16 tile-staging rows
     stage_weight(w1, P.l1_msg_w0, H, F1, F1, LDF);
     stage_weight64<256>(w2, P.l1_msg_w2, H);
     if (threadIdx.x < H) {
         bias[threadIdx.x] = P.l1_msg_b0[threadIdx.x];
         bias[H + threadIdx.x] = P.l1_msg_b2[threadIdx.x];
     }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    float* wst = wstage + wave * (16 * LDST);
-    const int64_t n_chunks = (n_edges + CH - 1) / CH;
-    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        __syncthreads();                    // weights staged / previous chunk's feat consumed
-        if (threadIdx.x < CH) {
-            int64_t k = chunk * CH + threadIdx.x;
+    float* wfeat = scratch + wave * (64 * LDF);
+    // each wave works on its own 64-edge batches: every lane builds one edge's features, then the
+    // wave runs the batch's four 16-edge tiles; no workgroup barrier in the loop
+    const int64_t n_batches = (n_edges + 63) / 64;
+    for (int64_t batch = (int64_t)blockIdx.x * 4 + wave; batch < n_batches; batch += (int64_t)gridDim.x * 4) {
+        {
+            const int64_t k = batch * 64 + lane;
             float o[FPAD];
             if (k < n_edges) {
                 const float* nj = nodeinfo + (int64_t)send_s[k] * NI::STRIDE;
@@ -163,40 +164,44 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
 #pragma unroll
                 for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
             }
-            float* fr = feat + threadIdx.x * LDF;
+            float* fr = wfeat + lane * LDF;
 #pragma unroll
             for (int t = 0; t < FPAD; t += 4) st4(fr + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
         }
-        __syncthreads();
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {
-            const int local = wave * 32 + t * 16 + i;
-            const int64_t k = chunk * CH + local;
-            if (chunk * CH + wave * 32 + t * 16 >= n_edges) break;      // wave-uniform
-            const int64_t tile = (chunk * CH + wave * 32 + t * 16) >> 4;
-            f32x4 bop[2];
-            bop[0] = ld4(feat + local * LDF + 4 * q);
-            bop[1] = ld4(feat + local * LDF + 16 + 4 * q);
-            f32x4 acc[4], acc2[4];
+        __builtin_amdgcn_wave_barrier();
+        f32x4 bop[4][2];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                acc[mb] = ld4(bias + 16 * mb + 4 * q);
-                acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
+        for (int t = 0; t < 4; ++t) {
+            bop[t][0] = ld4(wfeat + (16 * t + i) * LDF + 4 * q);
+            bop[t][1] = ld4(wfeat + (16 * t + i) * LDF + 16 + 4 * q);
+        }
+        __builtin_amdgcn_wave_barrier();    // features are in registers: the rows become tile staging
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t k = batch * 64 + 16 * t + i;
+            if (batch * 64 + 16 * t < n_edges) {                       // wave-uniform
+                const int64_t tile = batch * 4 + t;
+                f32x4 acc[4], acc2[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    acc[mb] = ld4(bias + 16 * mb + 4 * q);
+                    acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
+                }
+                gemm_tile<4, 2>(w1, LDF, bop[t], acc, i, q);
+                f32x4 h1[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
+                gemm_tile<4, 4>(w2, LDW, h1, acc2, i, q);
+                f32x4 eo[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
+                if (k < n_edges) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, eo[mb]);
+                }
+                const int rcv = recv_s[k < n_edges ? k : n_edges - 1];
+                tile_receiver_sums(eo, wfeat, gsel[tile * 64 + lane], rcv, tile, part, i, q, lane);
             }
-            gemm_tile<4, 2>(w1, LDF, bop, acc, i, q);
-            f32x4 h1[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
-            gemm_tile<4, 4>(w2, LDW, h1, acc2, i, q);
-            f32x4 eo[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
-            if (k < n_edges) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, eo[mb]);
-            }
-            const int rcv = recv_s[k < n_edges ? k : n_edges - 1];
-            tile_receiver_sums(eo, wst, gsel[tile * 64 + lane], rcv, tile, part, i, q, lane);
         }
     }
 }
