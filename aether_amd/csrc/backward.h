@@ -356,7 +356,7 @@ kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const floa
 // out: G = dL/dpre1, H1 = h, DP2 = dL/dpre2, and  FIRST: DA = W1^T G   else: DE[k] <- W_e^T G.
 // Weights (forward and pre-transposed) are staged once per workgroup in LDS.
 template <bool FIRST>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192]*/, int f1,
         const float* __restrict__ b_in, const float* __restrict__ w2g, const float* __restrict__ b2g,
         const float* __restrict__ w_in_t /*FIRST: W1^T [32][64] else W_e^T [64][64]*/,
@@ -388,6 +388,9 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
     const int i = lane & 15, q = lane >> 4;
     const int64_t tiles = (n_edges + 15) >> 4;
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+        int z = 0;
+        asm volatile("" : "+v"(z));      // opaque offset: weight fragments are re-read from LDS per tile
+                                         // instead of being hoisted into ~256 registers (1 wave per SIMD)
         const int64_t k = 16 * t + i;
         const bool ok = k < n_edges;
         const int64_t kc = ok ? k : n_edges - 1;
@@ -399,18 +402,18 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
             bop[1] = ld4(feat + kc * FPAD + 16 + 4 * q);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(b_in + 16 * mb + 4 * q);
-            gemm_tile<4, 2>(wi, LDW, bop, p1, i, q);
+            gemm_tile<4, 2>(wi + z, LDW, bop, p1, i, q);
         } else {
             f32x4 bop[4];
             load_tile64(bop, e_prev, kc, H, q);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
                 p1[mb] = ld4(Ps + s * H + 16 * mb + 4 * q) + ld4(Pr + r * H + 16 * mb + 4 * q);
-            gemm_tile<4, 4>(wi, LDW, bop, p1, i, q);
+            gemm_tile<4, 4>(wi + z, LDW, bop, p1, i, q);
         }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) { h[mb] = silu4(p1[mb]); p2[mb] = ld4(b2g + 16 * mb + 4 * q); }
-        gemm_tile<4, 4>(w2, LDW, h, p2, i, q);
+        gemm_tile<4, 4>(w2 + z, LDW, h, p2, i, q);
         // de = dn[recv] / deg (+ gradient through the next layer's edge input)
         const int deg = rowptr[r + 1] - rowptr[r];
         const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
@@ -422,18 +425,18 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
             d2[mb] = de * dsilu4(p2[mb]);
             dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        gemm_tile<4, 4>(w2ts, LDW, d2, dh, i, q);
+        gemm_tile<4, 4>(w2ts + z, LDW, d2, dh, i, q);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu4(p1[mb]);
         if (FIRST) {
             f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            gemm_tile<2, 4>(wit, LDW, g, da, i, q);
+            gemm_tile<2, 4>(wit + z, LDW, g, da, i, q);
             if (ok) { st4(DA + k * FPAD + 4 * q, da[0]); st4(DA + k * FPAD + 16 + 4 * q, da[1]); }
         } else {
             f32x4 dep[4];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_tile<4, 4>(wit, LDW, g, dep, i, q);
+            gemm_tile<4, 4>(wit + z, LDW, g, dep, i, q);
             if (ok) store_tile64(DE, k, H, q, dep);
         }
         if (ok) {

@@ -241,7 +241,7 @@ def main():
         if use_graph and world == 1:
             # whole training step (forward, HIP backward, AdamW) as one hipGraph replay
             try:
-                opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12, capturable=True)
+                opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12, capturable=True, fused=True)
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
