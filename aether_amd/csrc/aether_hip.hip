@@ -375,26 +375,28 @@ struct OuterList {
              float* bias) {
         OuterTask& t = b.t[b.n_tasks++];
         t.A = A; t.B = B; t.C = C; t.bias = bias; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.M = M; t.N = N;
+        t.chunks = 1;
         t.rows = rows;
     }
 };
 
 int run_outer(OuterList& L, float* partial, hipStream_t st) {
     if (L.b.n_tasks == 0) return AETHER_OK;
-    int64_t max_tiles = 1;
-    int max_blocks = 1;
+    int max_chunks = 1, max_blocks = 1;
     for (int k = 0; k < L.b.n_tasks; ++k) {
-        int64_t tiles = (L.b.t[k].rows + 15) / 16;
-        if (tiles > max_tiles) max_tiles = tiles;
-        int blocks = ((L.b.t[k].M + 15) / 16) * ((L.b.t[k].N + 15) / 16);
+        OuterTask& t = L.b.t[k];
+        int64_t tiles = (t.rows + 15) / 16;
+        int64_t chunks = (tiles + 15) / 16;             // >= 16 row tiles per workgroup
+        if (chunks < 1) chunks = 1;
+        if (chunks > 96) chunks = 96;
+        t.chunks = (int)chunks;
+        if (t.chunks > max_chunks) max_chunks = t.chunks;
+        int blocks = ((t.M + 15) / 16) * ((t.N + 15) / 16);
         if (blocks > max_blocks) max_blocks = blocks;
     }
-    int64_t chunks = (max_tiles + 15) / 16;             // >= 16 row tiles per workgroup
-    if (chunks < 1) chunks = 1;
-    if (chunks > 96) chunks = 96;
-    L.b.chunks = (int)chunks;
+    L.b.chunks = max_chunks;
     ProfScope ps(KB_OUTER, st);
-    k_outer<<<dim3((unsigned)chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
+    k_outer<<<dim3((unsigned)max_chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
     k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(1024), 0, st>>>(L.b, partial);
     return AETHER_OK;
 }

@@ -56,6 +56,7 @@ __device__ __forceinline__ void store_tile64(float* __restrict__ p, int64_t row,
 struct OuterTask {
     const float* A; const float* B; float* C; float* bias;
     int lda, ldb, ldc, M, N;        // M, N = valid output extents (blocks of 16 cover them)
+    int chunks;                     // row chunks of this task (<= batch.chunks)
     int64_t rows;
 };
 constexpr int OUTER_MAX_TASKS = 8;
@@ -73,8 +74,9 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
+    if ((int)blockIdx.x >= T.chunks) return;
     const int64_t tiles = (T.rows + 15) >> 4;
-    const int64_t per = (tiles + batch.chunks - 1) / batch.chunks;
+    const int64_t per = (tiles + T.chunks - 1) / T.chunks;
     const int64_t t0 = per * blockIdx.x, t1 = t0 + per < tiles ? t0 + per : tiles;
     __shared__ __attribute__((aligned(16))) float sa[16 * LDO], sb[16 * LDO];
     __shared__ float scol[16][132];
@@ -191,8 +193,8 @@ k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
     const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
     const int grp = threadIdx.x >> 8, e = threadIdx.x & 255;
     const int r = e >> 4, c = e & 15;
-    const int per = (batch.chunks + 3) / 4;
-    const int c0 = grp * per, c1 = c0 + per < batch.chunks ? c0 + per : batch.chunks;
+    const int per = (T.chunks + 3) / 4;
+    const int c0 = grp * per, c1 = c0 + per < T.chunks ? c0 + per : T.chunks;
     float s = 0.0f, sb = 0.0f;
     const float* src0 = partial + ((size_t)blockIdx.y * batch.chunks * 32 + blockIdx.x) * 272;
     int ch = c0;
