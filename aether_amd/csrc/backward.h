@@ -89,45 +89,45 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     // its running sums are this chunk's column sums of A restricted to its row index
     const int a4 = MBn * 4, b4 = NBn * 4;                 // float4 per row
     f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    // register prefetch: the next tile's rows are in flight while the current tile is multiplied
-    f32x4 va[2], vb[2];
-    auto fetch = [&](int64_t t) {
+    // register prefetch, two tiles deep: rows of tiles t+1 and t+2 are in flight while tile t is multiplied
+    f32x4 va[2][2], vb[2][2];              // [stage][u]
+    auto fetch = [&](int64_t t, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int idx = threadIdx.x + 256 * u;
-            va[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < t1) {
                 if (idx < 16 * a4) {
                     const int r = idx / a4, c = (idx - r * a4) * 4;
                     const int64_t row = 16 * t + r;
-                    if (row < T.rows) va[u] = ld4(T.A + row * T.lda + c);
+                    if (row < T.rows) xa[u] = ld4(T.A + row * T.lda + c);
                 }
                 if (idx < 16 * b4) {
                     const int r = idx / b4, c = (idx - r * b4) * 4;
                     const int64_t row = 16 * t + r;
-                    if (row < T.rows) vb[u] = ld4(T.B + row * T.ldb + c);
+                    if (row < T.rows) xb[u] = ld4(T.B + row * T.ldb + c);
                 }
             }
         }
     };
-    fetch(t0);
-    for (int64_t t = t0; t < t1; ++t) {
+    auto consume = [&](const f32x4 (&xa)[2], const f32x4 (&xb)[2]) {
         __syncthreads();                                   // previous tile consumed
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int idx = threadIdx.x + 256 * u;
             if (idx < 16 * a4) {
                 const int r = idx / a4, c = (idx - r * a4) * 4;
-                st4(sa + r * LDO + c, va[u]);
-                csum[u] += va[u];
+                st4(sa + r * LDO + c, xa[u]);
+                csum[u] += xa[u];
             }
             if (idx < 16 * b4) {
                 const int r = idx / b4, c = (idx - r * b4) * 4;
-                st4(sb + r * LDO + c, vb[u]);
+                st4(sb + r * LDO + c, xb[u]);
             }
         }
-        fetch(t + 1);
+    };
+    auto multiply = [&]() {
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -145,6 +145,18 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
                     }
                 }
             }
+        }
+    };
+    fetch(t0, va[0], vb[0]);
+    fetch(t0 + 1, va[1], vb[1]);
+    for (int64_t t = t0; t < t1; t += 2) {
+        consume(va[0], vb[0]);
+        fetch(t + 2, va[0], vb[0]);
+        multiply();
+        if (t + 1 < t1) {
+            consume(va[1], vb[1]);
+            fetch(t + 3, va[1], vb[1]);
+            multiply();
         }
     }
     float* dst0 = partial + ((size_t)blockIdx.y * batch.chunks + blockIdx.x) * 32 * 272;
