@@ -386,9 +386,9 @@ int run_outer(OuterList& L, float* partial, hipStream_t st) {
     for (int k = 0; k < L.b.n_tasks; ++k) {
         OuterTask& t = L.b.t[k];
         int64_t tiles = (t.rows + 15) / 16;
-        int64_t chunks = (tiles + 15) / 16;             // >= 16 row tiles per workgroup
+        int64_t chunks = (tiles + 7) / 8;               // >= 8 row tiles per workgroup (serial chain)
         if (chunks < 1) chunks = 1;
-        if (chunks > 96) chunks = 96;
+        if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
         t.chunks = (int)chunks;
         if (t.chunks > max_chunks) max_chunks = t.chunks;
         int blocks = ((t.M + 15) / 16) * ((t.N + 15) / 16);
