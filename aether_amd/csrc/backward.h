@@ -89,25 +89,27 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     // its running sums are this chunk's column sums of A restricted to its row index
     const int a4 = MBn * 4, b4 = NBn * 4;                 // float4 per row
     f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // staging coordinates of this thread (tile independent): hoisted out of the loop -- the runtime
+    // integer divisions were most of the per-tile instruction count
+    int ra[2], ca[2], rb[2], cb[2];
+    bool oka[2], okb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = threadIdx.x + 256 * u;
+        oka[u] = idx < 16 * a4; okb[u] = idx < 16 * b4;
+        ra[u] = idx / a4; ca[u] = (idx - ra[u] * a4) * 4;
+        rb[u] = idx / b4; cb[u] = (idx - rb[u] * b4) * 4;
+    }
     // register prefetch, two tiles deep: rows of tiles t+1 and t+2 are in flight while tile t is multiplied
     f32x4 va[2][2], vb[2][2];              // [stage][u]
     auto fetch = [&](int64_t t, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int idx = threadIdx.x + 256 * u;
             xa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             xb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < t1) {
-                if (idx < 16 * a4) {
-                    const int r = idx / a4, c = (idx - r * a4) * 4;
-                    const int64_t row = 16 * t + r;
-                    if (row < T.rows) xa[u] = ld4(T.A + row * T.lda + c);
-                }
-                if (idx < 16 * b4) {
-                    const int r = idx / b4, c = (idx - r * b4) * 4;
-                    const int64_t row = 16 * t + r;
-                    if (row < T.rows) xb[u] = ld4(T.B + row * T.ldb + c);
-                }
+                if (oka[u] && 16 * t + ra[u] < T.rows) xa[u] = ld4(T.A + (16 * t + ra[u]) * T.lda + ca[u]);
+                if (okb[u] && 16 * t + rb[u] < T.rows) xb[u] = ld4(T.B + (16 * t + rb[u]) * T.ldb + cb[u]);
             }
         }
     };
@@ -115,16 +117,8 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
         __syncthreads();                                   // previous tile consumed
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int idx = threadIdx.x + 256 * u;
-            if (idx < 16 * a4) {
-                const int r = idx / a4, c = (idx - r * a4) * 4;
-                st4(sa + r * LDO + c, xa[u]);
-                csum[u] += xa[u];
-            }
-            if (idx < 16 * b4) {
-                const int r = idx / b4, c = (idx - r * b4) * 4;
-                st4(sb + r * LDO + c, xb[u]);
-            }
+            if (oka[u]) { st4(sa + ra[u] * LDO + ca[u], xa[u]); csum[u] += xa[u]; }
+            if (okb[u]) st4(sb + rb[u] * LDO + cb[u], xb[u]);
         }
     };
     auto multiply = [&]() {
