@@ -396,7 +396,16 @@ int run_outer(OuterList& L, float* partial, hipStream_t st) {
     }
     L.b.chunks = max_chunks;
     ProfScope ps(KB_OUTER, st);
-    k_outer<<<dim3((unsigned)max_chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
+    bool any_big = false, any_small = false;
+    for (int k = 0; k < L.b.n_tasks; ++k) {
+        const bool big = (L.b.t[k].M + 15) / 16 > 4 || (L.b.t[k].N + 15) / 16 > 4;
+        any_big |= big;
+        any_small |= !big;
+    }
+    if (any_small)
+        k_outer<false><<<dim3((unsigned)max_chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
+    if (any_big)
+        k_outer<true><<<dim3((unsigned)max_chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
     k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(1024), 0, st>>>(L.b, partial);
     return AETHER_OK;
 }

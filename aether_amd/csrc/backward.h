@@ -68,9 +68,13 @@ struct OuterBatch { OuterTask t[OUTER_MAX_TASKS]; int n_tasks; int chunks; };
 // mb = w, w + 4.  Column sums of A (bias gradients) ride along in the staging threads.
 // partial[(task, chunk)][block][256 + 16]
 constexpr int LDO = 144;      // LDS row stride of a staged tile: 144 % 32 == 16 -> conflict-free b32 reads
+// BIG = false serves tasks of at most 64 x 64 (16 accumulator registers instead of 64: more resident
+// workgroups hide the row-load latency of the [E, 64] tasks); tasks of the other class exit at once.
+template <bool BIG>
 __global__ void __launch_bounds__(256)
 k_outer(OuterBatch batch, float* __restrict__ partial) {
     const OuterTask T = batch.t[blockIdx.y];
+    if ((((T.M + 15) >> 4) > 4 || ((T.N + 15) >> 4) > 4) != BIG) return;
     const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -80,11 +84,12 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     const int64_t t0 = per * blockIdx.x, t1 = t0 + per < tiles ? t0 + per : tiles;
     __shared__ __attribute__((aligned(16))) float sa[16 * LDO], sb[16 * LDO];
     __shared__ float scol[16][132];
-    f32x4 acc[2][8];              // block rows {wave, wave + 4} x up to 8 block columns
+    constexpr int AM = BIG ? 2 : 1, NBM = BIG ? 8 : 4;
+    f32x4 acc[AM][NBM];           // block rows {wave, wave + 4} x up to 8 block columns
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AM; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NBM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     // staging map: thread -> (row, 4 columns); the same thread always serves the same columns, so
     // its running sums are this chunk's column sums of A restricted to its row index
     const int a4 = MBn * 4, b4 = NBn * 4;                 // float4 per row
@@ -124,14 +129,14 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     auto multiply = [&]() {
         __syncthreads();
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < AM; ++a) {
             const int mb = wave + 4 * a;
             if (mb < MBn) {
                 float av[4];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) av[s4] = sa[(4 * s4 + q) * LDO + 16 * mb + i];
 #pragma unroll
-                for (int nb = 0; nb < 8; ++nb) {
+                for (int nb = 0; nb < NBM; ++nb) {
                     if (nb < NBn) {
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4)
@@ -155,10 +160,10 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
     }
     float* dst0 = partial + ((size_t)blockIdx.y * batch.chunks + blockIdx.x) * 32 * 272;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < AM; ++a) {
         const int mb = wave + 4 * a;
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
+        for (int nb = 0; nb < NBM; ++nb) {
             if (mb < MBn && nb < NBn) {
                 float* dst = dst0 + (size_t)(mb * NBn + nb) * 272;
 #pragma unroll
