@@ -182,7 +182,10 @@ struct GraphLayout {
     }
 };
 
-constexpr int OUTER_MAX_CHUNKS = 256;
+constexpr int OUTER_MAX_CHUNKS = 256;      // workgroups (= partials) per task
+// Up to this many edges the backward keeps the operands of every layer's weight gradients alive and
+// multiplies all of them in one launch at the end (12 more [E, 64] buffers: 3 KiB per edge).
+int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defer_max_edges", n)
 
 
 struct WsLayout {
@@ -191,8 +194,12 @@ struct WsLayout {
     // saved by the forward under KEEP_INTERMEDIATES for the backward
     size_t n[4], feat;
     // backward temporaries
-    size_t DX, DX2, wt, DN, U, DPU, O1, O2, DPO1, DPO2, DY, DE, G, H1, DP2, DA, DPS, DPR, RELF, Z, H1f, H2f, DPH1,
-        DPH2, DF, DZE, ONEHOT, partial;
+    // Operands of the weight-gradient outer products are per layer when `defer` (all of them are then
+    // multiplied in ONE launch at the end of the backward); otherwise the layers share one set.
+    size_t DXl[5], Ul[4], DPUl[4], Gl[4], H1l[4], DP2l[4], DPSl[4], DPRl[4];
+    size_t wt, DN, O1, O2, DPO1, DPO2, DY, DE, DA, RELF, Z, H1f, H2f, DPH1, DPH2, DF, DZE, ONEHOT, partial;
+    bool defer;
+    size_t partial_cap;             // partials (OUTER_PART floats each)
     size_t total;
     WsLayout(int64_t Nn, int64_t E, int D, bool training) {
         size_t off = 0;
@@ -210,13 +217,33 @@ struct WsLayout {
         fwd_total = off;
         for (auto& v : n) v = take(nn * H);
         feat = take(ee * FPAD);
-        DX = take(nn * H); DX2 = take(nn * H); wt = take((size_t)160 * 1024); DN = take(nn * H); U = take(nn * 2 * H); DPU = take(nn * 2 * H);
+        defer = E <= g_outer_defer_max_edges;
+        const int sets = defer ? 4 : 1;
+        for (int k = 0; k < 5; ++k) DXl[k] = (defer || k < 2) ? take(nn * H) : DXl[k - 2];
+        for (int k = 0; k < 4; ++k) {
+            const bool own = k < sets;
+            Ul[k] = own ? take(nn * 2 * H) : Ul[0];
+            DPUl[k] = own ? take(nn * 2 * H) : DPUl[0];
+            DPSl[k] = own ? take(nn * H) : DPSl[0];
+            DPRl[k] = own ? take(nn * H) : DPRl[0];
+            Gl[k] = own ? take(ee * H) : Gl[0];
+            H1l[k] = own ? take(ee * H) : H1l[0];
+            DP2l[k] = own ? take(ee * H) : DP2l[0];
+        }
+        wt = take((size_t)160 * 1024); DN = take(nn * H);
         O1 = take(nn * H); O2 = take(nn * H); DPO1 = take(nn * H); DPO2 = take(nn * H); DY = take(nn * 16);
-        DE = take(ee * H); G = take(ee * H); H1 = take(ee * H); DP2 = take(ee * H); DA = take(ee * FPAD);
-        DPS = take(nn * H); DPR = take(nn * H); RELF = take(nn * 16);
+        DE = take(ee * H); DA = take(ee * FPAD);
+        RELF = take(nn * 16);
         Z = take(nn * 32); H1f = take(nn * 32); H2f = take(nn * 32); DPH1 = take(nn * 32); DPH2 = take(nn * 32);
         DF = take(nn * 16); DZE = take(nn * 16); ONEHOT = take(nn * 16);
-        partial = take((size_t)OUTER_MAX_TASKS * OUTER_MAX_CHUNKS * 32 * 272);
+        {   // at most 9 edge-level and 32 node-level tasks share the partial buffer
+            auto chunks_of = [](size_t rows) {
+                size_t c = ((rows + 15) / 16 + 3) / 4;
+                return c < 1 ? (size_t)1 : (c > (size_t)OUTER_MAX_CHUNKS ? (size_t)OUTER_MAX_CHUNKS : c);
+            };
+            partial_cap = 9 * chunks_of(ee) + 32 * chunks_of(nn);
+            partial = take(partial_cap * OUTER_PART);
+        }
         total = training ? off : fwd_total;
     }
 };
@@ -369,44 +396,58 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
 
 // ------------------------------------------------------------------ backward orchestration
 struct OuterList {
-    OuterBatch b;
-    OuterList() { b.n_tasks = 0; b.chunks = 1; }
+    std::vector<OuterTask> tasks;
     void add(const float* A, int lda, int M, const float* B, int ldb, int N, int64_t rows, float* C, int ldc,
              float* bias) {
-        OuterTask& t = b.t[b.n_tasks++];
+        OuterTask t;
         t.A = A; t.B = B; t.C = C; t.bias = bias; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.M = M; t.N = N;
-        t.chunks = 1;
+        t.chunks = 1; t.part0 = 0;
         t.rows = rows;
+        tasks.push_back(t);
     }
 };
 
-int run_outer(OuterList& L, float* partial, hipStream_t st) {
-    if (L.b.n_tasks == 0) return AETHER_OK;
-    int max_chunks = 1, max_blocks = 1;
-    for (int k = 0; k < L.b.n_tasks; ++k) {
-        OuterTask& t = L.b.t[k];
+// Multiplies every task of the list: one k_outer launch per block class (<4,4>, <8,4>, <4,8>) and
+// one k_outer_reduce per launch; then empties the list.
+int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st) {
+    if (L.tasks.empty()) return AETHER_OK;
+    size_t next_part = 0;
+    std::vector<OuterTask> cls[2][2];
+    for (OuterTask& t : L.tasks) {
         int64_t tiles = (t.rows + 15) / 16;
-        int64_t chunks = (tiles + 7) / 8;               // >= 8 row tiles per workgroup (serial chain)
+        int64_t chunks = (tiles + 3) / 4;               // one row tile per wave until the chunk cap: short MFMA chains
         if (chunks < 1) chunks = 1;
         if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
         t.chunks = (int)chunks;
-        if (t.chunks > max_chunks) max_chunks = t.chunks;
-        int blocks = ((t.M + 15) / 16) * ((t.N + 15) / 16);
-        if (blocks > max_blocks) max_blocks = blocks;
+        t.part0 = (int)next_part;
+        next_part += (size_t)chunks;
+        const int mbn = (t.M + 15) / 16, nbn = (t.N + 15) / 16;
+        if (mbn > 8 || nbn > 8 || (mbn > 4 && nbn > 4)) return fail(AETHER_EINVAL, "k_outer: unsupported block shape");
+        cls[mbn > 4][nbn > 4].push_back(t);
     }
-    L.b.chunks = max_chunks;
+    if (next_part > partial_cap) return fail(AETHER_EINVAL, "k_outer: partial buffer too small");
     ProfScope ps(KB_OUTER, st);
-    bool any_big = false, any_small = false;
-    for (int k = 0; k < L.b.n_tasks; ++k) {
-        const bool big = (L.b.t[k].M + 15) / 16 > 4 || (L.b.t[k].N + 15) / 16 > 4;
-        any_big |= big;
-        any_small |= !big;
-    }
-    if (any_small)
-        k_outer<false><<<dim3((unsigned)max_chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
-    if (any_big)
-        k_outer<true><<<dim3((unsigned)max_chunks, (unsigned)L.b.n_tasks), dim3(256), 0, st>>>(L.b, partial);
-    k_outer_reduce<<<dim3((unsigned)max_blocks, (unsigned)L.b.n_tasks), dim3(1024), 0, st>>>(L.b, partial);
+    for (int cm = 0; cm < 2; ++cm)
+        for (int cn = 0; cn < 2; ++cn) {
+            const std::vector<OuterTask>& v = cls[cm][cn];
+            for (size_t k0 = 0; k0 < v.size(); k0 += OUTER_MAX_TASKS) {
+                OuterBatch b;
+                b.n_tasks = (int)(v.size() - k0 < (size_t)OUTER_MAX_TASKS ? v.size() - k0 : (size_t)OUTER_MAX_TASKS);
+                int max_chunks = 1;
+                for (int k = 0; k < b.n_tasks; ++k) {
+                    b.t[k] = v[k0 + k];
+                    if (b.t[k].chunks > max_chunks) max_chunks = b.t[k].chunks;
+                }
+                const dim3 grid((unsigned)max_chunks, (unsigned)b.n_tasks);
+                const int mp = cm ? 128 : 64, np = cn ? 128 : 64;
+                const size_t lds = (size_t)4 * 16 * (mp + 16 + np + 16) * sizeof(float);
+                if (!cm && !cn) k_outer<4, 4><<<grid, dim3(256), lds, st>>>(b, partial);
+                else if (cm) k_outer<8, 4><<<grid, dim3(256), lds, st>>>(b, partial);
+                else k_outer<4, 8><<<grid, dim3(256), lds, st>>>(b, partial);
+                k_outer_reduce<<<dim3((unsigned)(mp * np / 256 + 1), (unsigned)b.n_tasks), dim3(1024), 0, st>>>(b, partial);
+            }
+        }
+    L.tasks.clear();
     return AETHER_OK;
 }
 
@@ -423,6 +464,8 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     const int32_t *send_s = gp(G.send_s), *recv_s = gp(G.recv_s), *rowptr = gp(G.rowptr);
     const int32_t *sperm = gp(G.sperm), *srowptr = gp(G.srowptr);
     float* partial = wp(W.partial);
+    OuterList L;                     // pending weight-gradient products
+    auto flush = [&]() -> int { return W.defer ? AETHER_OK : run_outer(L, partial, W.partial_cap, st); };
     const int64_t ntile = (Nn + 15) / 16, etile = (E + 15) / 16;
     const unsigned ngrid = (unsigned)ntile;
     const unsigned egrid = (unsigned)((etile + 3) / 4 < 512 ? (etile + 3) / 4 : 512);    // 2 workgroups per CU
@@ -464,17 +507,18 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     // ---- out MLP
     {
         { ProfScope ps(KB_OUT, st);
-        kb_out<D><<<dim3(ngrid), dim3(64), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DX), wp(W.O1),
+        kb_out<D><<<dim3(ngrid), dim3(64), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
                                                    wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
-        OuterList L;
         L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
         L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
         L.add(wp(W.DY), 16, D, wp(W.O2), H, H, Nn, Gr.out_w6, H, Gr.out_b6);
-        run_outer(L, partial, st);
+        if (flush()) return AETHER_EHIP;
     }
-    float* dx_cur = wp(W.DX);       // dL/dx_l; kb_gather writes dL/dx_{l-1} into the other buffer
-    float* dx_nxt = wp(W.DX2);
     for (int l = 4; l >= 1; --l) {
+        float* dx_cur = wp(W.DXl[l]);        // dL/dx_l; kb_gather writes dL/dx_{l-1}
+        float* dx_nxt = wp(W.DXl[l - 1]);
+        float *bU = wp(W.Ul[l - 1]), *bDPU = wp(W.DPUl[l - 1]), *bG = wp(W.Gl[l - 1]), *bH1 = wp(W.H1l[l - 1]);
+        float *bDP2 = wp(W.DP2l[l - 1]), *bDPS = wp(W.DPSl[l - 1]), *bDPR = wp(W.DPRl[l - 1]);
         const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
         const float* b3 = l == 1 ? P.l1_upd_b0 : P.ln_upd_b0[l - 2];
         float* gw3 = l == 1 ? Gr.l1_upd_w0 : Gr.ln_upd_w0[l - 2];
@@ -485,13 +529,12 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         const float* b2 = l == 1 ? P.l1_msg_b2 : P.ln_msg_b2[l - 2];
         float* gw2 = l == 1 ? Gr.l1_msg_w2 : Gr.ln_msg_w2[l - 2];
         float* gb2 = l == 1 ? Gr.l1_msg_b2 : Gr.ln_msg_b2[l - 2];
-        OuterList L;                 // all weight gradients of this layer: one k_outer launch
         // ---- node update: dx_l -> dn_l
         { ProfScope ps(KB_NODE, st);
         kb_node<<<dim3(ngrid), dim3(64), 0, st>>>(w3, b3, WT.upd_w2t[l - 1], WT.upd_w0t[l - 1], wp(W.n[l - 1]),
-                                                 dx_cur, wp(W.DN), wp(W.U), wp(W.DPU), Nn); }
-        L.add(dx_cur, H, H, wp(W.U), 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
-        L.add(wp(W.DPU), 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
+                                                 dx_cur, wp(W.DN), bU, bDPU, Nn); }
+        L.add(dx_cur, H, H, bU, 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
+        L.add(bDPU, 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
         // ---- edge MLP
         if (E > 0) {
             const size_t lds = (size_t)(4 * H * LDW) * 4;
@@ -500,41 +543,40 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
                 if (optin(reinterpret_cast<const void*>(kb_edge<true>), lds)) return AETHER_EHIP;
                 kb_edge<true><<<dim3(egrid), dim3(256), lds, st>>>(
                     P.l1_msg_w0, F1, P.l1_msg_b0, w2, b2, WT.msg_w0t[0], WT.msg_w2t[0], nullptr, nullptr, nullptr,
-                    wp(W.feat), send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), 1, wp(W.G), wp(W.H1), wp(W.DP2),
+                    wp(W.feat), send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), 1, bG, bH1, bDP2,
                     wp(W.DA), E);
             } else {
                 if (optin(reinterpret_cast<const void*>(kb_edge<false>), lds)) return AETHER_EHIP;
                 kb_edge<false><<<dim3(egrid), dim3(256), lds, st>>>(
                     P.ln_msg_w0[l - 2], 0, nullptr, w2, b2, WT.msg_w0t[l - 1] + 2 * H * H, WT.msg_w2t[l - 1],
                     wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), nullptr, send_s, recv_s, rowptr, wp(W.DN),
-                    wp(W.DE), l < 4 ? 1 : 0, wp(W.G), wp(W.H1), wp(W.DP2), nullptr, E);
+                    wp(W.DE), l < 4 ? 1 : 0, bG, bH1, bDP2, nullptr, E);
             }
             delete pse;
-            L.add(wp(W.DP2), H, H, wp(W.H1), H, H, E, gw2, H, gb2);
-            if (l == 1) L.add(wp(W.G), H, H, wp(W.feat), FPAD, F1, E, Gr.l1_msg_w0, F1, Gr.l1_msg_b0);
-            else L.add(wp(W.G), H, H, wp(W.e[l - 2]), H, H, E, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
+            L.add(bDP2, H, H, bH1, H, H, E, gw2, H, gb2);
+            if (l == 1) L.add(bG, H, H, wp(W.feat), FPAD, F1, E, Gr.l1_msg_w0, F1, Gr.l1_msg_b0);
+            else L.add(bG, H, H, wp(W.e[l - 2]), H, H, E, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
         } else {
             HIP_OK(hipMemsetAsync(gw2, 0, (size_t)H * H * 4, st));
             HIP_OK(hipMemsetAsync(gb2, 0, (size_t)H * 4, st));
-            HIP_OK(hipMemsetAsync(wp(W.G), 0, 256, st));
+            HIP_OK(hipMemsetAsync(bG, 0, 256, st));
             if (l == 1) {
                 HIP_OK(hipMemsetAsync(Gr.l1_msg_w0, 0, (size_t)H * F1 * 4, st));
                 HIP_OK(hipMemsetAsync(Gr.l1_msg_b0, 0, (size_t)H * 4, st));
             } else {
-                L.add(wp(W.DPS), H, H, wp(W.DPS), H, H, 0, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
+                L.add(bDPS, H, H, bDPS, H, H, 0, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
             }
         }
         if (l >= 2) {
             // ---- sums of G onto nodes, then dx_{l-1}
             { ProfScope ps(KB_GATHER, st);
-            kb_sum_g<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(wp(W.G), rowptr, srowptr, sperm,
-                                                                          wp(W.DPS), wp(W.DPR), Nn);
-            kb_gather<<<dim3(ngrid), dim3(64), 0, st>>>(WT.msg_w0t[l - 1], wp(W.DPS), wp(W.DPR), wp(W.DN), dx_nxt,
+            kb_sum_g<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(bG, rowptr, srowptr, sperm,
+                                                                          bDPS, bDPR, Nn);
+            kb_gather<<<dim3(ngrid), dim3(64), 0, st>>>(WT.msg_w0t[l - 1], bDPS, bDPR, wp(W.DN), dx_nxt,
                                                        Nn); }
-            L.add(wp(W.DPS), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
-            L.add(wp(W.DPR), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
-            run_outer(L, partial, st);
-            float* tmp = dx_cur; dx_cur = dx_nxt; dx_nxt = tmp;
+            L.add(bDPS, H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
+            L.add(bDPR, H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
+            if (flush()) return AETHER_EHIP;
         } else {
             // ---- res + field net
             { ProfScope ps(KB_FIELD, st);
@@ -542,16 +584,14 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
                 P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
                 wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
                 wp(W.ONEHOT), Nn); }
-            run_outer(L, partial, st);
-            OuterList L2;
-            L2.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
-            L2.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
-            L2.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
-            L2.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
-            L2.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
-            run_outer(L2, partial, st);
+            L.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
+            L.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
+            L.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
+            L.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
+            L.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
         }
     }
+    if (run_outer(L, partial, W.partial_cap, st)) return AETHER_EHIP;
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }
@@ -574,6 +614,11 @@ int aether_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "fused_split")) {      // takes effect at the next aether_graph_build
         g_fused_split = value != 0;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces
+        if (value < 0) return fail(AETHER_EINVAL, "set_option: outer_defer_max_edges must be >= 0");
+        g_outer_defer_max_edges = value;
         return AETHER_OK;
     }
     if (!strcmp(name, "edge_variant")) {

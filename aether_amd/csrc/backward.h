@@ -56,185 +56,182 @@ __device__ __forceinline__ void store_tile64(float* __restrict__ p, int64_t row,
 struct OuterTask {
     const float* A; const float* B; float* C; float* bias;
     int lda, ldb, ldc, M, N;        // M, N = valid output extents (blocks of 16 cover them)
-    int chunks;                     // row chunks of this task (<= batch.chunks)
+    int chunks;                     // row chunks (= workgroups = partials) of this task
+    int part0;                      // index of its first partial
     int64_t rows;
 };
-constexpr int OUTER_MAX_TASKS = 8;
-struct OuterBatch { OuterTask t[OUTER_MAX_TASKS]; int n_tasks; int chunks; };
+constexpr int OUTER_MAX_TASKS = 48;  // 48 x 72 bytes of kernel arguments
+struct OuterBatch { OuterTask t[OUTER_MAX_TASKS]; int n_tasks; };
 
-// grid = (chunks, n_tasks).  A workgroup owns a chunk of row tiles and computes EVERY 16x16 block of
-// its task's output for it: each row tile of A and B is read from global memory once (coalesced
-// 16-byte loads) into LDS, then read back transposed as MFMA operands.  Wave w owns the block rows
-// mb = w, w + 4.  Column sums of A (bias gradients) ride along in the staging threads.
-// partial[(task, chunk)][block][256 + 16]
-constexpr int LDO = 144;      // LDS row stride of a staged tile: 144 % 32 == 16 -> conflict-free b32 reads
-// BIG = false serves tasks of at most 64 x 64 (16 accumulator registers instead of 64: more resident
-// workgroups hide the row-load latency of the [E, 64] tasks); tasks of the other class exit at once.
-template <bool BIG>
+// Weight gradients C[M, N] = A[rows, M]^T B[rows, N] (+ column sums of A as the bias gradient).
+// grid = (chunks, n_tasks), 4 waves per workgroup.  Every wave owns whole 16-row tiles (t = t0 + wave,
+// + 4, ..): it parks the 16 rows of A and B in its private LDS rows (coalesced 16-byte loads, the next
+// tile prefetched into registers) and reads them back as MFMA operands.  Output block (mb, nb) holds
+// the elements m = MB*i' + mb, n = NB*i + nb, so ONE 16-byte LDS read per k-step yields the A (resp. B)
+// operands of four blocks: 8 reads feed the 64 MFMAs of a <4,4> tile.  No workgroup barrier in the
+// loop; at the end the four waves add their accumulators in wave order through LDS (deterministic)
+// and write one partial per workgroup: partial[task.part0 + chunk] = [16MB][16NB] row-major + bias at 8192.
+// Tasks of another block class than <MB, NB> exit at once.
+constexpr int OUTER_PART = 32 * 272;        // floats per partial (>= 128*64 + 128)
+template <int MB, int NB>
 __global__ void __launch_bounds__(256)
 k_outer(OuterBatch batch, float* __restrict__ partial) {
     const OuterTask T = batch.t[blockIdx.y];
-    if ((((T.M + 15) >> 4) > 4 || ((T.N + 15) >> 4) > 4) != BIG) return;
     const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
+    if ((MBn > 4 ? 8 : 4) != MB || (NBn > 4 ? 8 : 4) != NB) return;
+    if ((int)blockIdx.x >= T.chunks) return;
+    constexpr int SA = 16 * MB + 16, SB = 16 * NB + 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    if ((int)blockIdx.x >= T.chunks) return;
-    const int64_t tiles = (T.rows + 15) >> 4;
-    const int64_t per = (tiles + T.chunks - 1) / T.chunks;
-    const int64_t t0 = per * blockIdx.x, t1 = t0 + per < tiles ? t0 + per : tiles;
-    __shared__ __attribute__((aligned(16))) float sa[16 * LDO], sb[16 * LDO];
-    __shared__ float scol[16][132];
-    constexpr int AM = BIG ? 2 : 1, NBM = BIG ? 8 : 4;
-    f32x4 acc[AM][NBM];           // block rows {wave, wave + 4} x up to 8 block columns
+    float* sa = smem + wave * (16 * (SA + SB));
+    float* sb = sa + 16 * SA;
+    const int tiles = (int)((T.rows + 15) >> 4);
+    const int per = (tiles + T.chunks - 1) / T.chunks;
+    const int t0 = per * blockIdx.x, t1 = t0 + per < tiles ? t0 + per : tiles;
+    f32x4 acc[MB][NB];
 #pragma unroll
-    for (int a = 0; a < AM; ++a)
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < NBM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // staging map: thread -> (row, 4 columns); the same thread always serves the same columns, so
-    // its running sums are this chunk's column sums of A restricted to its row index
-    const int a4 = MBn * 4, b4 = NBn * 4;                 // float4 per row
-    f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    // staging coordinates of this thread (tile independent): hoisted out of the loop -- the runtime
-    // integer divisions were most of the per-tile instruction count
-    int ra[2], ca[2], rb[2], cb[2];
-    bool oka[2], okb[2];
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging coordinates (tile independent): float4 number f = lane + 64 j -> (row, 4 columns)
+    f32x4 va[MB], vb[NB], csum[MB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int idx = threadIdx.x + 256 * u;
-        oka[u] = idx < 16 * a4; okb[u] = idx < 16 * b4;
-        ra[u] = idx / a4; ca[u] = (idx - ra[u] * a4) * 4;
-        rb[u] = idx / b4; cb[u] = (idx - rb[u] * b4) * 4;
+    for (int j = 0; j < MB; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int f = lane + 64 * j, r = f / (4 * MB), c = (f % (4 * MB)) * 4;
+            const int64_t row = 16 * (int64_t)t + r;
+            va[j] = (t < t1 && row < T.rows && c < 16 * MBn) ? ld4(T.A + row * T.lda + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int f = lane + 64 * j, r = f / (4 * NB), c = (f % (4 * NB)) * 4;
+            const int64_t row = 16 * (int64_t)t + r;
+            vb[j] = (t < t1 && row < T.rows && c < 16 * NBn) ? ld4(T.B + row * T.ldb + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(t0 + wave);
+    for (int t = t0 + wave; t < t1; t += 4) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int f = lane + 64 * j, r = f / (4 * MB), c = (f % (4 * MB)) * 4;
+            st4(sa + r * SA + c, va[j]);
+            csum[j] += va[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int f = lane + 64 * j, r = f / (4 * NB), c = (f % (4 * NB)) * 4;
+            st4(sb + r * SB + c, vb[j]);
+        }
+        fetch(t + 4);                                      // next tile of this wave: in flight under the MFMAs
+        __builtin_amdgcn_wave_barrier();
+        f32x4 av[4][MB / 4], bv[4][NB / 4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int h = 0; h < MB / 4; ++h) av[s4][h] = ld4(sa + (4 * s4 + q) * SA + MB * i + 4 * h);
+#pragma unroll
+            for (int h = 0; h < NB / 4; ++h) bv[s4][h] = ld4(sb + (4 * s4 + q) * SB + NB * i + 4 * h);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = mfma16(av[s4][mb >> 2][mb & 3], bv[s4][nb >> 2][nb & 3], acc[mb][nb]);
+        __builtin_amdgcn_wave_barrier();
     }
-    // register prefetch, two tiles deep: rows of tiles t+1 and t+2 are in flight while tile t is multiplied
-    f32x4 va[2][2], vb[2][2];              // [stage][u]
-    auto fetch = [&](int64_t t, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
+    // ---- the four waves add up in wave order: red[m][n], m = MB*(4q + r) + mb, n = NB*i + nb
+    constexpr int LDP = 16 * NB;
+    float* red = smem;
+    float* redb = smem + 16 * MB * LDP;
+    if (T.bias != nullptr) {          // column sums within the wave: lanes with equal columns differ in row
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            xa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            xb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t < t1) {
-                if (oka[u] && 16 * t + ra[u] < T.rows) xa[u] = ld4(T.A + (16 * t + ra[u]) * T.lda + ca[u]);
-                if (okb[u] && 16 * t + rb[u] < T.rows) xb[u] = ld4(T.B + (16 * t + rb[u]) * T.ldb + cb[u]);
-            }
+        for (int j = 0; j < MB; ++j) {
+            const int f = lane + 64 * j, r = f / (4 * MB), c = (f % (4 * MB)) * 4;
+            st4(sa + r * SA + c, csum[j]);
         }
-    };
-    auto consume = [&](const f32x4 (&xa)[2], const f32x4 (&xb)[2]) {
-        __syncthreads();                                   // previous tile consumed
+        __builtin_amdgcn_wave_barrier();
+    }
+    float bsum[(16 * MB + 63) / 64];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (oka[u]) { st4(sa + ra[u] * LDO + ca[u], xa[u]); csum[u] += xa[u]; }
-            if (okb[u]) st4(sb + rb[u] * LDO + cb[u], xb[u]);
-        }
-    };
-    auto multiply = [&]() {
+    for (int u = 0; u < (16 * MB + 63) / 64; ++u) {
+        const int c = lane + 64 * u;
+        float sm = 0.f;
+        if (T.bias != nullptr && c < 16 * MB)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += sa[r * SA + c];
+        bsum[u] = sm;
+    }
+    for (int w = 0; w < 4; ++w) {
         __syncthreads();
+        if (wave == w) {
 #pragma unroll
-        for (int a = 0; a < AM; ++a) {
-            const int mb = wave + 4 * a;
-            if (mb < MBn) {
-                float av[4];
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) av[s4] = sa[(4 * s4 + q) * LDO + 16 * mb + i];
+                for (int r = 0; r < 4; ++r) {
+                    float* dst = red + (MB * (4 * q + r) + mb) * LDP + NB * i;
 #pragma unroll
-                for (int nb = 0; nb < NBM; ++nb) {
-                    if (nb < NBn) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4)
-                            acc[a][nb] = mfma16(av[s4], sb[(4 * s4 + q) * LDO + 16 * nb + i], acc[a][nb]);
+                    for (int h = 0; h < NB / 4; ++h) {
+                        f32x4 v = f32x4{acc[mb][4 * h][r], acc[mb][4 * h + 1][r], acc[mb][4 * h + 2][r], acc[mb][4 * h + 3][r]};
+                        if (w > 0) v += ld4(dst + 4 * h);
+                        st4(dst + 4 * h, v);
                     }
                 }
-            }
-        }
-    };
-    fetch(t0, va[0], vb[0]);
-    fetch(t0 + 1, va[1], vb[1]);
-    for (int64_t t = t0; t < t1; t += 2) {
-        consume(va[0], vb[0]);
-        fetch(t + 2, va[0], vb[0]);
-        multiply();
-        if (t + 1 < t1) {
-            consume(va[1], vb[1]);
-            fetch(t + 3, va[1], vb[1]);
-            multiply();
-        }
-    }
-    float* dst0 = partial + ((size_t)blockIdx.y * batch.chunks + blockIdx.x) * 32 * 272;
 #pragma unroll
-    for (int a = 0; a < AM; ++a) {
-        const int mb = wave + 4 * a;
-#pragma unroll
-        for (int nb = 0; nb < NBM; ++nb) {
-            if (mb < MBn && nb < NBn) {
-                float* dst = dst0 + (size_t)(mb * NBn + nb) * 272;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(4 * q + r) * 16 + i] = acc[a][nb][r];
+            for (int u = 0; u < (16 * MB + 63) / 64; ++u) {
+                const int c = lane + 64 * u;
+                if (c < 16 * MB) redb[c] = w > 0 ? redb[c] + bsum[u] : bsum[u];
             }
         }
     }
-    if (T.bias != nullptr) {                               // column sums: reduce the 16 row indices in order
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = threadIdx.x + 256 * u;
-            if (idx < 16 * a4) {
-                const int r = idx / a4, c = (idx - r * a4) * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) scol[r][c + j] = csum[u][j];
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < 16 * MBn) {
-            float sm = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sm += scol[r][threadIdx.x];
-            // bias of block row mb lives in the partial of block (mb, nb = 0), slots 256..271
-            dst0[(size_t)((threadIdx.x >> 4) * NBn) * 272 + 256 + (threadIdx.x & 15)] = sm;
-        }
-    }
+    __syncthreads();
+    float* dst = partial + ((size_t)T.part0 + blockIdx.x) * OUTER_PART;
+    for (int f = threadIdx.x; f < 16 * MB * LDP / 4; f += 256) st4(dst + 4 * f, ld4(red + 4 * f));
+    if (T.bias != nullptr && (int)threadIdx.x < 16 * MB) dst[8192 + threadIdx.x] = redb[threadIdx.x];
 }
 
-// grid = (blocks, n_tasks), 1024 threads: element (r, c) of one 16x16 block x 4 chunk groups.  Each
-// group adds its contiguous quarter of the chunks in order; the four group sums are combined in
-// order through LDS: a fixed summation tree, hence deterministic.
+// grid = (1 + 16MB*16NB/256, n_tasks), 1024 threads: 256 elements x 4 chunk groups.  Each group adds
+// its contiguous quarter of the chunks in order; the four group sums are combined in order through
+// LDS: a fixed summation tree, hence deterministic.  The last block of a task reduces the bias row.
 __global__ void __launch_bounds__(1024)
 k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
     const OuterTask T = batch.t[blockIdx.y];
     const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
-    if ((int)blockIdx.x >= MBn * NBn) return;
-    const int mb = blockIdx.x / NBn, nb = blockIdx.x - mb * NBn;
+    const int ldp = NBn > 4 ? 128 : 64, mpad = MBn > 4 ? 128 : 64;
+    const int nblk = mpad * ldp / 256;
+    if ((int)blockIdx.x > nblk) return;
+    const bool is_bias = (int)blockIdx.x == nblk;
+    if (is_bias && T.bias == nullptr) return;
     const int grp = threadIdx.x >> 8, e = threadIdx.x & 255;
-    const int r = e >> 4, c = e & 15;
+    const int off = is_bias ? 8192 + e : (int)blockIdx.x * 256 + e;
+    const int m = is_bias ? e : off / ldp, n = is_bias ? 0 : off % ldp;
+    const bool valid = is_bias ? e < T.M : (m < T.M && n < T.N);
     const int per = (T.chunks + 3) / 4;
     const int c0 = grp * per, c1 = c0 + per < T.chunks ? c0 + per : T.chunks;
-    float s = 0.0f, sb = 0.0f;
-    const float* src0 = partial + ((size_t)blockIdx.y * batch.chunks * 32 + blockIdx.x) * 272;
-    int ch = c0;
-    for (; ch + 8 <= c1; ch += 8) {                     // 8 chunk loads in flight, summed in chunk order
-        float v[8], vb[8];
+    const float* src0 = partial + (size_t)T.part0 * OUTER_PART + off;
+    float s = 0.0f;
+    if (valid) {
+        int ch = c0;
+        for (; ch + 8 <= c1; ch += 8) {                     // 8 chunk loads in flight, summed in chunk order
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float* src = src0 + (size_t)(ch + u) * 32 * 272;
-            v[u] = src[r * 16 + c];
-            vb[u] = c == 0 ? src[256 + r] : 0.0f;
+            for (int u = 0; u < 8; ++u) v[u] = src0[(size_t)(ch + u) * OUTER_PART];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s += v[u]; sb += vb[u]; }
+        for (; ch < c1; ++ch) s += src0[(size_t)ch * OUTER_PART];
     }
-    for (; ch < c1; ++ch) {
-        const float* src = src0 + (size_t)ch * 32 * 272;
-        s += src[r * 16 + c];
-        if (c == 0) sb += src[256 + r];
-    }
-    __shared__ float red[4][256], redb[4][16];
+    __shared__ float red[4][256];
     red[grp][e] = s;
-    if (c == 0) redb[grp][r] = sb;
     __syncthreads();
-    if (grp == 0) {
+    if (grp == 0 && valid) {
         const float tot = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-        const int m = 16 * mb + r, n = 16 * nb + c;
-        if (m < T.M && n < T.N) T.C[(size_t)m * T.ldc + n] = tot;
-        if (T.bias != nullptr && nb == 0 && c == 0 && m < T.M)
-            T.bias[m] = ((redb[0][r] + redb[1][r]) + redb[2][r]) + redb[3][r];
+        if (is_bias) T.bias[e] = tot;
+        else T.C[(size_t)m * T.ldc + n] = tot;
     }
 }
 

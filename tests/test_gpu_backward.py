@@ -66,6 +66,24 @@ def test_gradients_vs_oracle_autograd_fresh_inputs(D):
             assert scale_rel_err(g, sdg[k].grad) <= GTOL, (B, N, k)
 
 
+@pytest.mark.parametrize("D", [2, 3])
+def test_per_layer_weight_gradient_launches_match_deferred(D):
+    """Above `outer_defer_max_edges` the backward multiplies each layer's weight gradients before the
+    next layer overwrites their operands; below it everything is deferred to one launch at the end.
+    Both orders run the same kernels on the same rows: identical bits."""
+    lib = _lib.load()
+    inp = make_batch(9, 12, D, seed=71)
+    m = _model(D, "fused")
+    _, deferred = _loss_backward(m, inp)
+    try:
+        _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 0), "set_option")
+        _, per_layer = _loss_backward(m, inp)
+    finally:
+        _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 1 << 20), "set_option")
+    for k in deferred:
+        assert torch.equal(deferred[k], per_layer[k]), k
+
+
 def test_backward_is_deterministic_and_optimizer_step_runs():
     D = 2
     m = _model(D, "fused")
