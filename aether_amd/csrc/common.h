@@ -23,6 +23,12 @@ constexpr float TWO_PI_F = 6.28318548202514648f;   // float(2*np.pi)
 constexpr float EPS_F = 1e-7f;                     // nn/utils/geometry.py:62
 
 // ------------------------------------------------------------------ device helpers
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() on gfx950 also drains vmcnt (loads
+// and stores share one counter), i.e. it waits for every global load in flight: weight prefetches
+// issued before a barrier would be exposed at it.  Use where no thread reads, through global memory,
+// what another thread of the workgroup wrote.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

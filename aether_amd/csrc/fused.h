@@ -246,7 +246,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         if (tid < 32) { fb[tid] = P.field_b0[tid]; fb[32 + tid] = P.field_b2[tid]; }
         if (tid < D) fb[64 + tid] = P.field_b4[tid];
         if (tid < 48) femb[tid] = P.field_emb[tid];
-        __syncthreads();
+        lds_barrier();
         for (int idx = tid; idx < nv * FIN; idx += THREADS) {
             int node = idx / FIN, k = idx - node * FIN;
             float val;
@@ -259,7 +259,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
             z[node * 24 + k] = val;
         }
-        __syncthreads();
+        lds_barrier();
         for (int idx = tid; idx < nv * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
             float s = fb[o];
@@ -267,7 +267,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             for (int k = 0; k < FIN; ++k) s += fw0[o * FIN + k] * z[node * 24 + k];
             h1[node * 32 + o] = silu(s);
         }
-        __syncthreads();
+        lds_barrier();
         for (int idx = tid; idx < nv * 32; idx += THREADS) {
             int node = idx >> 5, o = idx & 31;
             float s = fb[32 + o];
@@ -275,7 +275,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             for (int k = 0; k < 32; ++k) s += fw2[o * 32 + k] * h1[node * 32 + k];
             h2[node * 32 + o] = silu(s);
         }
-        __syncthreads();
+        lds_barrier();
         for (int idx = tid; idx < nv * D; idx += THREADS) {
             int node = idx / D, d = idx - node * D;
             float s = fb[64 + d];
@@ -283,7 +283,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             for (int k = 0; k < 32; ++k) s += fw4[d * 32 + k] * h2[node * 32 + k];
             ff[node * 4 + d] = s;
         }
-        __syncthreads();
+        lds_barrier();
         // frames + rel_feat (geometry.py:7-73, aether.py:33-50): one thread per node
         if (tid < nv) {
             float v[D], f[D], R[D][D], cv[D], cf[D];
@@ -304,7 +304,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 for (int t = 0; t < NI::STRIDE; ++t) g[t] = t < NI::CF + D ? ni[t] : 0.0f;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // x0 = layer_1.res(rel_feat) (locs.py:214-218); rows of unused node slots are zero
         for (int idx = tid; idx < FUSED_MAX_NODES * H; idx += THREADS) {
             int node = idx >> 6, o = idx & 63;
@@ -320,7 +320,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
             xbuf[node * LDW + o] = acc;
         }
-        __syncthreads();       // field scratch (aliases SCRATCH) is dead from here on
+        lds_barrier();       // field scratch (aliases SCRATCH) is dead from here on
     }
     FUSED_STAMP(2);
 
@@ -377,7 +377,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             selbits[r] = have ? tsel[(size_t)(wg.tile0 + tile) * 64 + lane] : 0u;
             destpack[r] = have ? tdst[(size_t)(wg.tile0 + tile) * 64 + lane] : 0xFFFFFFFFu;
         }
-        __syncthreads();       // feature scratch (aliases SCRATCH) is dead from here on
+        lds_barrier();       // feature scratch (aliases SCRATCH) is dead from here on
     }
     FUSED_STAMP(3);
 
@@ -399,6 +399,53 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // No workgroup barrier in here.  A wave with K tiles runs them through one branch-free block
         // (front = first Linear + SiLU, back = second Linear + SiLU + per-receiver sums) so that the
         // compiler can overlap one tile's VALU / LDS tail with the next tile's MFMAs.
+        const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
+        const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
+        const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
+        const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
+        // work split: step 2 has 16 (row block, node tile) units, step 3 has 8, step 4 has 16
+        const int mb2 = wave & 7;                         // step 2: rows 16*mb2.. of the 128
+        const int mb3 = wave & 3, tn3 = (wave >> 2) & 1;  // steps 3, 4: rows 16*mb3.. of node tile tn3
+        const bool act3 = wave < 8;                       // step 3 / out MLP: 8 units
+        const int sel4 = NW == 16 ? wave >> 3 : 0;        // step 4 (NW=16): 0 -> P_s, 1 -> P_r
+        // step 4 with one node tile (split mode): waves 0-3 compute P_s, waves 4-7 P_r, tile 0
+        const bool one_tile = NW == 8 && n <= 16;
+        const int tn4 = one_tile ? 0 : tn3;
+        const bool do_s = NW == 16 ? sel4 == 0 : (one_tile ? wave < 4 : true);
+        const bool do_r = NW == 16 ? sel4 == 1 : (one_tile ? wave >= 4 : true);
+        // Every L2 load of the node phase is issued BEFORE the wave's last edge tile, so that the
+        // ~130 KB of weights a workgroup needs per layer (all 256 workgroups ask at the same moment)
+        // stream in under the tile's MFMAs: next layer's edge weights (W_e = W1[:, 128:192], W2: they
+        // go to LDS once every wave has left the edge tiles), then W3 / W4 / next-layer W_s, W_r fragments.
+        constexpr int STG = (H * H / 4) / THREADS;        // float4 per thread per staged matrix
+        f32x4 w3v[4], w4v[8], wsv[4], wrv[4], stA[STG], stB[STG];
+        float b2n = 0.0f;
+        auto issue_loads = [&]() {
+            if (layer < 4) {
+                const float* w1n = P.ln_msg_w0[layer - 1];
+#pragma unroll
+                for (int j = 0; j < STG; ++j) {
+                    const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+                    stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
+                    stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
+                }
+                if (tid < H) b2n = P.ln_msg_b2[layer - 1][tid];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * mb2 + i) * H + 16 * a + 4 * q);
+            if (act3 && 16 * tn3 < n) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * a + 4 * q);
+            }
+            if (layer < 4) {
+                const float* w1n = P.ln_msg_w0[layer - 1];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (do_s) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
+                    if (do_r) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+                }
+            }
+        };
         auto front = [&](int r, f32x4 (&h1)[4]) {
             f32x4 acc[4];
             if (layer == 1) {
@@ -461,62 +508,23 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         };
         {
             const int nvalid = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;    // wave-uniform
-            {
+            if (nvalid == 0) issue_loads();
 #pragma unroll
-                for (int r = 0; r < ROUNDS; ++r) {
-                    if (r < nvalid) {
-                        FUSED_WSTAMP(layer, r, 0);
-                        f32x4 h1[4];
-                        front(r, h1);
-                        FUSED_WSTAMP(layer, r, 2);
-                        back(r, h1);
-                        FUSED_WSTAMP(layer, r, 5);
-                    }
+            for (int r = 0; r < ROUNDS; ++r) {
+                if (r < nvalid) {
+                    if (r == nvalid - 1) issue_loads();
+                    FUSED_WSTAMP(layer, r, 0);
+                    f32x4 h1[4];
+                    front(r, h1);
+                    FUSED_WSTAMP(layer, r, 2);
+                    back(r, h1);
+                    FUSED_WSTAMP(layer, r, 5);
                 }
             }
         }
         FUSED_STAMP(4 + 8 * (layer - 1) + 2);
         // ------------------------------------------------------------ node phase (locs.py:240-241)
-        const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
-        const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
-        const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
-        const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
-        // work split: step 2 has 16 (row block, node tile) units, step 3 has 8, step 4 has 16
-        const int mb2 = wave & 7;                         // step 2: rows 16*mb2.. of the 128
-        const int mb3 = wave & 3, tn3 = (wave >> 2) & 1;  // steps 3, 4: rows 16*mb3.. of node tile tn3
-        const bool act3 = wave < 8;                       // step 3 / out MLP: 8 units
-        const int sel4 = NW == 16 ? wave >> 3 : 0;        // step 4 (NW=16): 0 -> P_s, 1 -> P_r
-        // step 4 with one node tile (split mode): waves 0-3 compute P_s, waves 4-7 P_r, tile 0
-        const bool one_tile = NW == 8 && n <= 16;
-        const int tn4 = one_tile ? 0 : tn3;
-        const bool do_s = NW == 16 ? sel4 == 0 : (one_tile ? wave < 4 : true);
-        const bool do_r = NW == 16 ? sel4 == 1 : (one_tile ? wave >= 4 : true);
-        // Issue every L2 load of the node phase now, so that their latency hides behind the barrier
-        // and the earlier steps: W3 / W4 / next-layer W_s, W_r fragments and the next layer's edge
-        // weights (W_e = W1[:, 128:192], W2) that go to LDS once every wave has left the edge tiles.
-        constexpr int STG = (H * H / 4) / THREADS;        // float4 per thread per staged matrix
-        f32x4 w3v[4], w4v[8], wsv[4], wrv[4], stA[STG], stB[STG];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * mb2 + i) * H + 16 * a + 4 * q);
-        if (act3) {
-#pragma unroll
-            for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * a + 4 * q);
-        }
-        if (layer < 4) {
-            const float* w1n = P.ln_msg_w0[layer - 1];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (do_s) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
-                if (do_r) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
-            }
-#pragma unroll
-            for (int j = 0; j < STG; ++j) {
-                const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
-                stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
-                stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
-            }
-        }
-        __syncthreads();       // all partial rows are published; wA / wB are idle
+        lds_barrier();       // all partial rows are published; wA / wB are idle
         FUSED_STAMP(4 + 8 * (layer - 1) + 3);
         // step 1: n = x_prev + (sum of the node's partial rows, in tile order) / max(deg, 1)
         if (tid < FUSED_MAX_NODES * 16) {
@@ -533,9 +541,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 st4(wA + rr * LDW + cc, stA[j]);
                 st4(wB + rr * LDW + cc, stB[j]);
             }
-            if (tid < H) bias[H + tid] = P.ln_msg_b2[layer - 1][tid];
+            if (tid < H) bias[H + tid] = b2n;
         }
-        __syncthreads();       // n complete
+        lds_barrier();       // n complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 7);
         // step 2: u = SiLU(W3 n + b3): rows 16*mb2.. of u for node tile(s)
         {
@@ -556,7 +564,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
         }
-        __syncthreads();       // u complete
+        lds_barrier();       // u complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 4);
 
         // step 3: x = n + W4 u + b4: rows 16*mb3.. of node tile tn3
@@ -574,7 +582,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             if (keep && 16 * tn3 + i < n)
                 st4(dbg.x[layer] + (int64_t)(nb + 16 * tn3 + i) * H + 16 * mb3 + 4 * q, acc);
         }
-        __syncthreads();
+        lds_barrier();
         FUSED_STAMP(4 + 8 * (layer - 1) + 5);
         // step 4: next layer's node terms P_s = W_s x, P_r = W_r x + b1 (locs.py:233 split)
         if (layer < 4) {
@@ -646,7 +654,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     psb[slot * LDW + c + 1] = __uint_as_float((unsigned)(v >> 32));
                 }
             }
-            __syncthreads();   // P_s / P_r and the staged weights are visible to the next edge tiles
+            lds_barrier();   // P_s / P_r and the staged weights are visible to the next edge tiles
             FUSED_STAMP(4 + 8 * (layer - 1) + 6);
         }
     }
@@ -671,7 +679,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
             st4(o1 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
         }
-        __syncthreads();
+        lds_barrier();
         if (act) {
             f32x4 acc = ld4(P.out_b3 + 16 * mb + 4 * q);
 #pragma unroll
@@ -683,7 +691,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
             st4(o2 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
         }
-        __syncthreads();
+        lds_barrier();
         if (wave < 2 && 16 * wave < n) {
             const int tn2 = wave;
             const int row = i < D ? i : D - 1;       // rows >= D of the 16-row block are discarded
