@@ -228,99 +228,126 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     if (tid < H) { bias[tid] = P.l1_msg_b0[tid]; bias[H + tid] = P.l1_msg_b2[tid]; }
     FUSED_STAMP(1);
 
-    // ---------------------------------------------------------------- P1: field net (aether.py:108-134)
+    // ---------------------------------------------------------------- P1: field net, frames, x0 on the matrix core
+    // aether.py:108-134 (field), geometry.py:7-73 + aether.py:33-50 (frames), locs.py:214-218 (x0).
+    // Wave t owns the visible nodes 16t .. 16t+15 as the 16 columns of its MFMA tiles; the three
+    // Linear layers chain in accumulator layout, lanes q == 0 end up with the node's force and build
+    // its frame, and x0 = res(rel_feat) is one more tile product: no workgroup barrier in between,
+    // every global load (inputs, 2,080 field parameters, res weights) issued up front.
     {
-        float* z = smem + L::FIELD_Z;
-        float* h1 = smem + L::FIELD_H1;
-        float* h2 = smem + L::FIELD_H2;
-        float* ff = smem + L::FIELD_F;
-        float* fw0 = smem + L::FW0;
-        float* fw2 = smem + L::FW2;
-        float* fw4 = smem + L::FW4;
-        float* fb = smem + L::FB;
-        float* femb = smem + L::FEMB;
-        // the 2,080 field-net parameters go to LDS once; the per-(node, unit) loops below read them there
-        for (int idx = tid; idx < 32 * FIN; idx += THREADS) fw0[idx] = P.field_w0[idx];
-        for (int idx = tid; idx < 32 * 32; idx += THREADS) fw2[idx] = P.field_w2[idx];
-        if (tid < D * 32) fw4[tid] = P.field_w4[tid];
-        if (tid < 32) { fb[tid] = P.field_b0[tid]; fb[32 + tid] = P.field_b2[tid]; }
-        if (tid < D) fb[64 + tid] = P.field_b4[tid];
-        if (tid < 48) femb[tid] = P.field_emb[tid];
-        lds_barrier();
-        for (int idx = tid; idx < nv * FIN; idx += THREADS) {
-            int node = idx / FIN, k = idx - node * FIN;
-            float val;
-            if (k < D) val = x[(int64_t)(vb + node) * D + k];
-            else if (k < 2 * D) val = vel[(int64_t)(vb + node) * D + (k - D)];
-            else {
-                long ci = (long)(charges[vb + node] + 1.0f);
-                ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
-                val = femb[ci * 16 + (k - 2 * D)];
+        const int vtiles = (nv + 15) >> 4;
+        if (wave < vtiles) {
+            const int node = 16 * wave + i;                    // visible slot
+            const bool live = node < nv;
+            const int64_t g = vb + (live ? node : 0);
+            float pz[D], vz[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { pz[d] = x[g * D + d]; vz[d] = vel[g * D + d]; }
+            const float ch = charges[g];
+            // layer-1 operands: B = z[k][node], A = W0[16mb + i][k], k = 4s + q (FIN = 2D + 16 <= 24)
+            float zc[6][3], a1[2][6];
+#pragma unroll
+            for (int s4 = 0; s4 < 6; ++s4) {
+                const int k = 4 * s4 + q;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    zc[s4][c] = (k >= 2 * D && k < FIN) ? P.field_emb[c * 16 + (k - 2 * D)] : 0.0f;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) a1[mb][s4] = k < FIN ? P.field_w0[(16 * mb + i) * FIN + k] : 0.0f;
             }
-            z[node * 24 + k] = val;
-        }
-        lds_barrier();
-        for (int idx = tid; idx < nv * 32; idx += THREADS) {
-            int node = idx >> 5, o = idx & 31;
-            float s = fb[o];
+            f32x4 w2f[2][2], w4f[2], acc1[2], acc2[2];
 #pragma unroll
-            for (int k = 0; k < FIN; ++k) s += fw0[o * FIN + k] * z[node * 24 + k];
-            h1[node * 32 + o] = silu(s);
-        }
-        lds_barrier();
-        for (int idx = tid; idx < nv * 32; idx += THREADS) {
-            int node = idx >> 5, o = idx & 31;
-            float s = fb[32 + o];
+            for (int mb = 0; mb < 2; ++mb) {
+                acc1[mb] = ld4(P.field_b0 + 16 * mb + 4 * q);
+                acc2[mb] = ld4(P.field_b2 + 16 * mb + 4 * q);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) s += fw2[o * 32 + k] * h1[node * 32 + k];
-            h2[node * 32 + o] = silu(s);
-        }
-        lds_barrier();
-        for (int idx = tid; idx < nv * D; idx += THREADS) {
-            int node = idx / D, d = idx - node * D;
-            float s = fb[64 + d];
-#pragma unroll
-            for (int k = 0; k < 32; ++k) s += fw4[d * 32 + k] * h2[node * 32 + k];
-            ff[node * 4 + d] = s;
-        }
-        lds_barrier();
-        // frames + rel_feat (geometry.py:7-73, aether.py:33-50): one thread per node
-        if (tid < nv) {
-            float v[D], f[D], R[D][D], cv[D], cf[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) { v[d] = z[tid * 24 + D + d]; f[d] = ff[tid * 4 + d]; }
-            node_frame<D>(v, f, R, cv, cf);
-            float* ni = ninfo + tid * 24;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                ni[NI::P + d] = z[tid * 24 + d]; ni[NI::V + d] = v[d]; ni[NI::F + d] = f[d];
-                ni[NI::CV + d] = cv[d]; ni[NI::CF + d] = cf[d];
-#pragma unroll
-                for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
+                for (int a = 0; a < 2; ++a) w2f[mb][a] = ld4(P.field_w2 + (16 * mb + i) * 32 + 16 * a + 4 * q);
             }
-            if (keep && tid >= off && tid < off + n) {
-                float* g = dbg.nodeinfo + (int64_t)(vb + tid) * NI::STRIDE;
 #pragma unroll
-                for (int t = 0; t < NI::STRIDE; ++t) g[t] = t < NI::CF + D ? ni[t] : 0.0f;
+            for (int a = 0; a < 2; ++a)
+                w4f[a] = i < D ? ld4(P.field_w4 + i * 32 + 16 * a + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc3[r] = (4 * q + r < D) ? P.field_b4[4 * q + r] : 0.0f;
+            // x0 operands: A = W_res[16mb + i][D + k], k = 4s + q < 2D (the first D inputs of rel_feat are zero)
+            float ar[4][2];
+            f32x4 acc0[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                acc0[mb] = ld4(P.l1_res_b + 16 * mb + 4 * q);
+#pragma unroll
+                for (int s4 = 0; s4 < 2; ++s4)
+                    ar[mb][s4] = 4 * s4 + q < 2 * D ? P.l1_res_w[(16 * mb + i) * 3 * D + D + 4 * s4 + q] : 0.0f;
             }
-        }
-        lds_barrier();
-        // x0 = layer_1.res(rel_feat) (locs.py:214-218); rows of unused node slots are zero
-        for (int idx = tid; idx < FUSED_MAX_NODES * H; idx += THREADS) {
-            int node = idx >> 6, o = idx & 63;
-            float acc = 0.0f;
-            if (node < n) {
-                acc = P.l1_res_b[o];
+            long ci = (long)(ch + 1.0f);                        // charge_to_index: (q + 1).long(), aether.py:127-129
+            ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
+#pragma unroll
+            for (int s4 = 0; s4 < 6; ++s4) {
+                const int k = 4 * s4 + q;
+                float zk = ci == 0 ? zc[s4][0] : (ci == 1 ? zc[s4][1] : zc[s4][2]);
+#pragma unroll
+                for (int d = 0; d < D; ++d) { zk = k == d ? pz[d] : zk; zk = k == D + d ? vz[d] : zk; }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc1[mb] = mfma16(a1[mb][s4], zk, acc1[mb]);
+            }
+            f32x4 hh[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) hh[mb] = silu4(acc1[mb]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) acc2[mb] = mfma16(w2f[mb][a][b], hh[a][b], acc2[mb]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) hh[mb] = silu4(acc2[mb]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc3 = mfma16(w4f[a][b], hh[a][b], acc3);
+            // lanes q == 0: acc3[d] = force component d of node i -> frame + NodeInfo record
+            if (q == 0 && live) {
+                float f[D], R[D][D], cv[D], cf[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) f[d] = acc3[d];
+                node_frame<D>(vz, f, R, cv, cf);
+                float* ni = ninfo + node * 24;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    acc += P.l1_res_w[o * 3 * D + D + d] * ninfo[(off + node) * 24 + NI::CV + d];
-                    acc += P.l1_res_w[o * 3 * D + 2 * D + d] * ninfo[(off + node) * 24 + NI::CF + d];
+                    ni[NI::P + d] = pz[d]; ni[NI::V + d] = vz[d]; ni[NI::F + d] = f[d];
+                    ni[NI::CV + d] = cv[d]; ni[NI::CF + d] = cf[d];
+#pragma unroll
+                    for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
                 }
-                if (keep) dbg.x[0][(int64_t)(nb + node) * H + o] = acc;
+                if (keep && node >= off && node < off + n) {
+                    float* gni = dbg.nodeinfo + (int64_t)(vb + node) * NI::STRIDE;
+#pragma unroll
+                    for (int t = 0; t < NI::STRIDE; ++t) gni[t] = t < NI::CF + D ? ni[t] : 0.0f;
+                }
             }
-            xbuf[node * LDW + o] = acc;
+            __builtin_amdgcn_wave_barrier();
+            // x0 = W_res[:, D:] [cv | cf] + b (own nodes only; cv, cf are contiguous in the record)
+#pragma unroll
+            for (int s4 = 0; s4 < 2; ++s4) {
+                const int k = 4 * s4 + q;
+                const float rk = (live && k < 2 * D) ? ninfo[node * 24 + NI::CV + k] : 0.0f;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc0[mb] = mfma16(ar[mb][s4], rk, acc0[mb]);
+            }
+            const int own = node - off;
+            if (own >= 0 && own < n) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    st4(xbuf + own * LDW + 16 * mb + 4 * q, acc0[mb]);
+                    if (keep) st4(dbg.x[0] + (int64_t)(nb + own) * H + 16 * mb + 4 * q, acc0[mb]);
+                }
+            }
+        } else {
+            // rows of unused node slots are zero
+            for (int idx = tid - 64 * vtiles; idx < (FUSED_MAX_NODES - n) * (H / 4); idx += THREADS - 64 * vtiles)
+                st4(xbuf + (n + (idx >> 4)) * LDW + (idx & 15) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
         }
-        lds_barrier();       // field scratch (aliases SCRATCH) is dead from here on
+        lds_barrier();
     }
     FUSED_STAMP(2);
 
@@ -420,8 +447,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         constexpr int STG = (H * H / 4) / THREADS;        // float4 per thread per staged matrix
         f32x4 w3v[4], w4v[8], wsv[4], wrv[4], stA[STG], stB[STG];
         float b2n = 0.0f;
-        auto issue_loads = [&]() {
-            if (layer < 4) {
+        // part 0: staged matrices; 1: W3; 2, 3: W4 halves; 4: W_s / W_r.  A wave spreads the parts over
+        // its last tile (a burst of ~20 loads per wave blocks at issue until the L2 returns drain).
+        auto issue_loads = [&](int part) {
+            if (part == 0 && layer < 4) {
                 const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
                 for (int j = 0; j < STG; ++j) {
@@ -431,13 +460,16 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
                 if (tid < H) b2n = P.ln_msg_b2[layer - 1][tid];
             }
+            if (part == 1) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * mb2 + i) * H + 16 * a + 4 * q);
-            if (act3 && 16 * tn3 < n) {
-#pragma unroll
-                for (int a = 0; a < 8; ++a) w4v[a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * a + 4 * q);
+                for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * mb2 + i) * H + 16 * a + 4 * q);
             }
-            if (layer < 4) {
+            if ((part == 2 || part == 3) && act3 && 16 * tn3 < n) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    w4v[4 * (part - 2) + a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * (4 * (part - 2) + a) + 4 * q);
+            }
+            if (part == 4 && layer < 4) {
                 const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -446,8 +478,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
         };
-        auto front = [&](int r, f32x4 (&h1)[4]) {
+        auto front = [&](int r, f32x4 (&h1)[4], bool last) {
             f32x4 acc[4];
+            if (last) issue_loads(0);
             if (layer == 1) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb] = ld4(bias + 16 * mb + 4 * q);
@@ -459,15 +492,18 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     acc[mb] = ld4(psb + sl[r] * LDW + 16 * mb + 4 * q) + ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
                 gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
             }
+            if (last) issue_loads(1);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
         };
-        auto back = [&](int r, const f32x4 (&h1)[4]) {
+        auto back = [&](int r, const f32x4 (&h1)[4], bool last) {
             const int tile = NW * r + wave;
             f32x4 acc2[4];
+            if (last) issue_loads(2);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
             gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
+            if (last) issue_loads(3);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
             if (keep) {
@@ -505,19 +541,23 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (last) issue_loads(4);
         };
         {
             const int nvalid = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;    // wave-uniform
-            if (nvalid == 0) issue_loads();
+            if (nvalid == 0) {
+#pragma unroll
+                for (int part = 0; part < 5; ++part) issue_loads(part);
+            }
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 if (r < nvalid) {
-                    if (r == nvalid - 1) issue_loads();
+                    const bool last = r == nvalid - 1;
                     FUSED_WSTAMP(layer, r, 0);
                     f32x4 h1[4];
-                    front(r, h1);
+                    front(r, h1, last);
                     FUSED_WSTAMP(layer, r, 2);
-                    back(r, h1);
+                    back(r, h1, last);
                     FUSED_WSTAMP(layer, r, 5);
                 }
             }
