@@ -57,6 +57,7 @@ class AetherGraphInfo(C.Structure):
 FLAG_KEEP_INTERMEDIATES = 1
 FLAG_FORCE_STREAMED = 2
 FLAG_FORCE_FUSED = 4
+FLAG_WORKSPACE_REUSED = 8
 
 # name -> (restype, argtypes); every symbol include/aether_hip.h declares
 SIGNATURES = {

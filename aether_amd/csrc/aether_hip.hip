@@ -276,7 +276,7 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
 template <int D>
 int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphInfo& info, const float* x,
                const float* vel, const float* charges, const float* ea, const char* graph, char* ws,
-               float* out, bool keep, hipStream_t st) {
+               float* out, bool keep, bool ws_reused, hipStream_t st) {
     GraphLayout G(E, Nn, false);
     WsLayout W(Nn, E, D, keep);
     auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
@@ -293,7 +293,7 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     const FusedWG* wgd = reinterpret_cast<const FusedWG*>(graph + G.wgdesc);
     const uint32_t* tsel = reinterpret_cast<const uint32_t*>(graph + G.tsel);
     const uint32_t* tdst = reinterpret_cast<const uint32_t*>(graph + G.tdst);
-    if (info.reserved & 1)      // split mode: every polled word is zero before the launch
+    if ((info.reserved & 1) && !ws_reused)      // split mode: every polled word is zero before the launch
         HIP_OK(hipMemsetAsync(dbg.flags, 0, (size_t)info.n_groups * 4, st));
     const int tiles = (info.max_group_edges + 15) / 16;
     const int nw = g_fused_waves;
@@ -843,12 +843,13 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
     if ((flags & AETHER_FLAG_FORCE_FUSED) && !fused)
         return fail(AETHER_EINVAL, "forward: fused path requested but the graph has no groups");
     const bool keep = (flags & AETHER_FLAG_KEEP_INTERMEDIATES) != 0;
+    const bool reused = (flags & AETHER_FLAG_WORKSPACE_REUSED) != 0;
     if (fused) {
         if (num_dims == 2)
             return fused_impl<2>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,
-                                 (const char*)graph, (char*)workspace, out, keep, st);
+                                 (const char*)graph, (char*)workspace, out, keep, reused, st);
         return fused_impl<3>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,
-                             (const char*)graph, (char*)workspace, out, keep, st);
+                             (const char*)graph, (char*)workspace, out, keep, reused, st);
     }
     if (num_dims == 2)
         return streamed_impl<2>(*params, n_nodes, n_edges, x, vel, charges, edge_attr_orig,

@@ -78,6 +78,13 @@ class _AetherStep(torch.autograd.Function):
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         else:
             ws = module._workspace(ws_bytes, x.device)
+            # same buffer, same layout as the last completed inference call: the fused kernel left its
+            # hand-off words re-armed, the library need not zero them again (AETHER_FLAG_WORKSPACE_REUSED)
+            fused = ginfo.n_groups > 0 and n_edges > 0 and not (flags & _lib.FLAG_FORCE_STREAMED)
+            ws_key = (ws.data_ptr(), n_nodes, n_edges, D, keep, graph.data_ptr()) if fused else None
+            if ws_key is not None and module._ws_key == ws_key:
+                flags |= _lib.FLAG_WORKSPACE_REUSED
+            module._ws_key = None
         out = torch.empty_like(x)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         st = lib.aether_forward(C.byref(module._param_struct()), D, n_nodes, n_edges,
@@ -88,6 +95,8 @@ class _AetherStep(torch.autograd.Function):
         if train:
             ctx.module = module
             ctx.saved = (x, vel, charges, graph, ginfo, ws, n_edges)
+        if not train:
+            module._ws_key = ws_key
         module._last_ws = ws
         return out
 
@@ -195,6 +204,7 @@ class Aether(nn.Module):
         self.dp_group = None              # set by aether_amd.parallel.attach_data_parallel
         self.grad_as_view = True          # .grad tensors alias one flat buffer (see _AetherStep.backward)
         self._last_ws = None
+        self._ws_key = None               # (workspace, shape, graph) of the last completed inference call
         self._gbuf = None
         self._ws = None
         self._pstruct = None

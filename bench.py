@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
+    ap.add_argument("--graph-steps", type=int, default=10,
+                    help="consecutive forward steps captured per hipGraph (1: one replay per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (with --backend gloo) to rehearse the N > 1 path on one GPU")
@@ -152,8 +154,26 @@ def main():
             with torch.cuda.graph(g):
                 out = call()
             step = g.replay
+            # `graph_steps` consecutive steps per hipGraph (as a rollout would be captured): the
+            # launch gap between two graph replays is paid once per group instead of once per step
+            S = max(1, min(args.graph_steps, args.steps))
+            if S > 1:
+                gs = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs):
+                    for _ in range(S):
+                        out = call()
+                group = gs.replay
         else:
             step = call
+            S = 1
+
+        def run_steps(k):
+            if S > 1:
+                for _ in range(k // S):
+                    group()
+                k = k % S
+            for _ in range(k):
+                step()
 
         for _ in range(args.warmup):
             step()
@@ -162,8 +182,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run_steps(args.steps)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -317,7 +336,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD["name"] if (B, N, D) == (128, 20, 2) else f"D{D}-N{N}-B{B}",
                        "num_dims": D, "nodes_per_graph": N, "graphs_per_gpu": B, "edges_per_gpu": E,
-                       "hidden": 64, "launch": "hipgraph" if use_graph else "eager",
+                       "hidden": 64, "launch": (f"hipgraph ({S} steps per replay)" if use_graph else "eager"),
                        "parallelism": f"graphs sharded over {world} rank(s), no forward collective"},
             "edges_per_s": E * world / (dt / args.steps),
             "step_algorithmic_tflops": step_flops * world / (dt / args.steps) / 1e12,

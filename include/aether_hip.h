@@ -72,6 +72,11 @@ typedef struct AetherGraphInfo {
 #define AETHER_FLAG_KEEP_INTERMEDIATES 1  /* also write nodeinfo, x0..x4, e1..e4 to the workspace */
 #define AETHER_FLAG_FORCE_STREAMED 2      /* use the layer-by-layer kernels even for small graphs */
 #define AETHER_FLAG_FORCE_FUSED 4         /* fail instead of falling back to the streamed kernels */
+/* The caller passes the workspace of an earlier, COMPLETED aether_forward call with the same n_nodes,
+ * n_edges, num_dims and KEEP flag, and nothing else has written to it since.  The fused kernel leaves
+ * its inter-workgroup hand-off words re-armed (zero) when it finishes, so the library can skip zeroing
+ * them again (one memset node less per step).  Never set it for a fresh or re-purposed buffer. */
+#define AETHER_FLAG_WORKSPACE_REUSED 8
 
 /* Library / build identification (host string, static storage). */
 const char* aether_version(void);

@@ -142,3 +142,33 @@ def test_full_size_multi_rank_shards_are_independent():
             ea = prepare_edge_attr(inp["x"][sl], e, q[e[0]] * q[e[1]])
             part = m(None, inp["x"][sl], e, inp["vel"][sl], ea, q)
             assert scale_rel_err(part, full[sl]) <= 2e-6
+
+
+def test_workspace_reuse_keeps_split_mode_handoff_armed():
+    """Inference reuses one workspace; from the second call on the module passes
+    AETHER_FLAG_WORKSPACE_REUSED and the library no longer zeroes the hand-off words of the split
+    (two workgroups per graph) kernel.  Outputs must stay bit-identical call after call, also when
+    another shape or the streamed path used the buffer in between."""
+    D = 2
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    m.load_state_dict(load_state_dict(D))
+    a = make_batch(16, 20, D, seed=5, device="cuda")       # 16 graphs on 256 CUs: split mode
+    b = make_batch(7, 9, D, seed=6, device="cuda")
+
+    def run(inp, flags=0):
+        m.flags = flags
+        with torch.no_grad():
+            return m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]).clone()
+
+    ref_a, ref_b = run(a), run(b)
+    want = O.aether_forward(load_state_dict(D), a["x"].cpu(), a["vel"].cpu(), [e.cpu() for e in a["edges"]],
+                            a["edge_attr"].cpu(), a["charges"].cpu())
+    assert scale_rel_err(ref_a.cpu(), want) <= 1e-5
+    for _ in range(3):
+        assert torch.equal(run(a), ref_a)                  # reused, flags left armed by the kernel
+    assert m._ws_key is not None
+    assert torch.equal(run(b), ref_b)                      # other layout in the same buffer
+    assert torch.equal(run(a), ref_a)
+    run(a, _lib.FLAG_FORCE_STREAMED)                       # streamed kernels in between
+    assert torch.equal(run(a), ref_a)
+    assert torch.equal(run(a), ref_a)
