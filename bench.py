@@ -229,6 +229,8 @@ def main():
                         tj = json.load(open(tpath))
                         if tj.get("workload") == WORKLOAD["name"] and (B, N, D) == (128, 20, 2):
                             traffic = tj.get(dom_name + "_hbm_bytes_per_launch")
+                            if executed is None:       # PMC SQ_INSTS_MFMA x 2,048 FLOP, same separate passes
+                                executed = tj.get(dom_name + "_executed_flop_per_launch")
                     except Exception:
                         traffic = None
                 roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
