@@ -250,9 +250,8 @@ struct WsLayout {
 
 inline int bits_for(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
-int g_fused_waves = 8;
 int g_edge_variant = 1;       // aether_set_option("edge_variant", 0|1): 0 = weights in registers, 2 waves/SIMD;
-                              // 1 = weights re-read from LDS, 3 waves/SIMD, deferred stores (faster: 411 vs 457 us @2.5M edges)        // aether_set_option("fused_waves", 8 | 16)
+                              // 1 = weights re-read from LDS, 3 waves/SIMD, deferred stores (faster: 411 vs 457 us @2.5M edges)
 
 template <int D, int NW, int ROUNDS, bool KEEP>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
@@ -296,7 +295,6 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     if ((info.reserved & 1) && !ws_reused)      // split mode: every polled word is zero before the launch
         HIP_OK(hipMemsetAsync(dbg.flags, 0, (size_t)info.n_groups * 4, st));
     const int tiles = (info.max_group_edges + 15) / 16;
-    const int nw = g_fused_waves;
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
@@ -305,8 +303,7 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
               : fused_launch<D, NWV, R, false>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),      \
                                                gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,           \
                                                info.n_groups, dbg, out, st)
-    if (nw == 16 && tiles <= 16) { AETHER_FUSED_CASE(16, 1); }
-    else if (tiles <= 8) { AETHER_FUSED_CASE(8, 1); }
+    if (tiles <= 8) { AETHER_FUSED_CASE(8, 1); }
     else if (tiles <= 16) { AETHER_FUSED_CASE(8, 2); }
     else { AETHER_FUSED_CASE(8, 3); }
 #undef AETHER_FUSED_CASE
@@ -606,12 +603,6 @@ const char* aether_last_error(void) { return g_err; }
 
 int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");
-    if (!strcmp(name, "fused_waves")) {
-        // 16 waves (4 per SIMD, one tile per wave) is used only when a workgroup owns <= 16 tiles
-        if (value != 8 && value != 16) return fail(AETHER_EINVAL, "set_option: fused_waves must be 8 or 16");
-        g_fused_waves = value;
-        return AETHER_OK;
-    }
     if (!strcmp(name, "fused_split")) {      // takes effect at the next aether_graph_build
         g_fused_split = value != 0;
         return AETHER_OK;

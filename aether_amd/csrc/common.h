@@ -91,18 +91,17 @@ __device__ __forceinline__ void stage_weight(float* lds, const float* __restrict
 // LDS [64][LDW]: all global loads are issued before the first LDS store.
 template <int THREADS>
 __device__ __forceinline__ void stage_weight64(float* lds, const float* __restrict__ w, int src_ld) {
-    constexpr int PER = (H * H / 4) / THREADS;
-    static_assert(PER * THREADS * 4 == H * H, "thread count must divide 1024");
+    constexpr int PER = (H * H / 4 + THREADS - 1) / THREADS;
     f32x4 v[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int idx = threadIdx.x + THREADS * j, r = idx >> 4, c = (idx & 15) * 4;
-        v[j] = ld4(w + (size_t)r * src_ld + c);
+        if (idx < H * H / 4) v[j] = ld4(w + (size_t)r * src_ld + c);
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int idx = threadIdx.x + THREADS * j, r = idx >> 4, c = (idx & 15) * 4;
-        st4(lds + r * LDW + c, v[j]);
+        if (idx < H * H / 4) st4(lds + r * LDW + c, v[j]);
     }
 }
 

@@ -195,7 +195,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     constexpr int THREADS = NW * 64;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
     constexpr int FIN = 2 * D + 16;
-    static_assert(NW == 8 || NW == 16, "node-phase decomposition is written for 8 or 16 waves");
+    static_assert(NW == 8 || NW == 12, "waves 0-7 run the node phase; more waves only add edge-tile slots");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wA = smem + L::WA;
     float* wB = smem + L::WB;
@@ -222,10 +222,25 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #endif
     FUSED_STAMP(0);
 
-    // ---------------------------------------------------------------- P0: stage layer-1 weights
-    stage_weight(wA, P.l1_msg_w0, H, F1, F1, LDF);
-    stage_weight64<THREADS>(wB, P.l1_msg_w2, H);
-    if (tid < H) { bias[tid] = P.l1_msg_b0[tid]; bias[H + tid] = P.l1_msg_b2[tid]; }
+    // ---------------------------------------------------------------- P0: layer-1 weights, loads only
+    // (W1 [64][F1] zero padded to [64][LDF], W2, biases); they land in LDS after the prologue, so their
+    // latency hides behind the field net.
+    constexpr int P0A = (H * LDF + THREADS - 1) / THREADS;
+    constexpr int P0B = (H * H / 4 + THREADS - 1) / THREADS;
+    float p0a[P0A];
+    f32x4 p0b[P0B];
+    float p0bias = 0.0f;
+#pragma unroll
+    for (int j = 0; j < P0A; ++j) {
+        const int idx = tid + THREADS * j, r = idx / LDF, c = idx - r * LDF;
+        p0a[j] = (idx < H * LDF && c < F1) ? P.l1_msg_w0[r * F1 + c] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < P0B; ++j) {
+        const int idx = tid + THREADS * j;
+        if (idx < H * H / 4) p0b[j] = ld4(P.l1_msg_w2 + (size_t)(idx >> 4) * H + (idx & 15) * 4);
+    }
+    if (tid < 2 * H) p0bias = tid < H ? P.l1_msg_b0[tid] : P.l1_msg_b2[tid - H];
     FUSED_STAMP(1);
 
     // ---------------------------------------------------------------- P1: field net, frames, x0 on the matrix core
@@ -347,6 +362,18 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             for (int idx = tid - 64 * vtiles; idx < (FUSED_MAX_NODES - n) * (H / 4); idx += THREADS - 64 * vtiles)
                 st4(xbuf + (n + (idx >> 4)) * LDW + (idx & 15) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
         }
+        // P0, second half: the layer-1 weights go to LDS
+#pragma unroll
+        for (int j = 0; j < P0A; ++j) {
+            const int idx = tid + THREADS * j;
+            if (idx < H * LDF) wA[idx] = p0a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < P0B; ++j) {
+            const int idx = tid + THREADS * j;
+            if (idx < H * H / 4) st4(wB + (idx >> 4) * LDW + (idx & 15) * 4, p0b[j]);
+        }
+        if (tid < 2 * H) bias[tid] = p0bias;
         lds_barrier();
     }
     FUSED_STAMP(2);
@@ -420,6 +447,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         adeg = (float)(end - beg > 1 ? end - beg : 1);
     }
 
+    f32x4 wsv[4], wrv[4];        // next layer's W_s / W_r fragments; after layer 4: out_w0 / out_w3
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
         // ------------------------------------------------------------ edge tiles (locs.py:227-238)
@@ -433,34 +461,38 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // work split: step 2 has 16 (row block, node tile) units, step 3 has 8, step 4 has 16
         const int mb2 = wave & 7;                         // step 2: rows 16*mb2.. of the 128
         const int mb3 = wave & 3, tn3 = (wave >> 2) & 1;  // steps 3, 4: rows 16*mb3.. of node tile tn3
-        const bool act3 = wave < 8;                       // step 3 / out MLP: 8 units
-        const int sel4 = NW == 16 ? wave >> 3 : 0;        // step 4 (NW=16): 0 -> P_s, 1 -> P_r
+        const bool act3 = wave < 8;                       // steps 2 - 4 / out MLP: waves 0-7
         // step 4 with one node tile (split mode): waves 0-3 compute P_s, waves 4-7 P_r, tile 0
-        const bool one_tile = NW == 8 && n <= 16;
+        const bool one_tile = n <= 16;
         const int tn4 = one_tile ? 0 : tn3;
-        const bool do_s = NW == 16 ? sel4 == 0 : (one_tile ? wave < 4 : true);
-        const bool do_r = NW == 16 ? sel4 == 1 : (one_tile ? wave >= 4 : true);
+        const bool do_s = act3 && (one_tile ? wave < 4 : true);
+        const bool do_r = act3 && (one_tile ? wave >= 4 : true);
         // Every L2 load of the node phase is issued BEFORE the wave's last edge tile, so that the
         // ~130 KB of weights a workgroup needs per layer (all 256 workgroups ask at the same moment)
         // stream in under the tile's MFMAs: next layer's edge weights (W_e = W1[:, 128:192], W2: they
         // go to LDS once every wave has left the edge tiles), then W3 / W4 / next-layer W_s, W_r fragments.
-        constexpr int STG = (H * H / 4) / THREADS;        // float4 per thread per staged matrix
-        f32x4 w3v[4], w4v[8], wsv[4], wrv[4], stA[STG], stB[STG];
+        constexpr int STG = (H * H / 4 + THREADS - 1) / THREADS;      // float4 per thread per staged matrix
+        f32x4 w3v[4], w4v[8], stA[STG], stB[STG];
         float b2n = 0.0f;
+        // layer 4 has no next edge layer: wsv / wrv carry the out-MLP fragments (out_w0, out_w3) instead
         // part 0: staged matrices; 1: W3; 2, 3: W4 halves; 4: W_s / W_r.  A wave spreads the parts over
         // its last tile (a burst of ~20 loads per wave blocks at issue until the L2 returns drain).
+        // With 12 waves (168 VGPRs) only parts 0 and 1 fit next to a tile; the rest follows the tile.
+        constexpr bool LATE = NW > 8;
         auto issue_loads = [&](int part) {
             if (part == 0 && layer < 4) {
                 const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
                 for (int j = 0; j < STG; ++j) {
                     const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
-                    stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
-                    stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
+                    if (idx < H * H / 4) {
+                        stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
+                        stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
+                    }
                 }
                 if (tid < H) b2n = P.ln_msg_b2[layer - 1][tid];
             }
-            if (part == 1) {
+            if (part == 1 && act3) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * mb2 + i) * H + 16 * a + 4 * q);
             }
@@ -475,6 +507,13 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 for (int a = 0; a < 4; ++a) {
                     if (do_s) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
                     if (do_r) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+                }
+            }
+            if (part == 4 && layer == 4 && act3) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    wsv[a] = ld4(P.out_w0 + (16 * mb3 + i) * H + 16 * a + 4 * q);
+                    wrv[a] = ld4(P.out_w3 + (16 * mb3 + i) * H + 16 * a + 4 * q);
                 }
             }
         };
@@ -499,11 +538,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         auto back = [&](int r, const f32x4 (&h1)[4], bool last) {
             const int tile = NW * r + wave;
             f32x4 acc2[4];
-            if (last) issue_loads(2);
+            if (last && !LATE) issue_loads(2);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
             gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
-            if (last) issue_loads(3);
+            if (last && !LATE) issue_loads(3);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
             if (keep) {
@@ -541,7 +580,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (last) issue_loads(4);
+            if (last && !LATE) issue_loads(4);
         };
         {
             const int nvalid = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;    // wave-uniform
@@ -561,6 +600,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     FUSED_WSTAMP(layer, r, 5);
                 }
             }
+            if (LATE && nvalid > 0) {
+#pragma unroll
+                for (int part = 2; part < 5; ++part) issue_loads(part);
+            }
         }
         FUSED_STAMP(4 + 8 * (layer - 1) + 2);
         // ------------------------------------------------------------ node phase (locs.py:240-241)
@@ -578,20 +621,21 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
             for (int j = 0; j < STG; ++j) {
                 const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
-                st4(wA + rr * LDW + cc, stA[j]);
-                st4(wB + rr * LDW + cc, stB[j]);
+                if (idx < H * H / 4) {
+                    st4(wA + rr * LDW + cc, stA[j]);
+                    st4(wB + rr * LDW + cc, stB[j]);
+                }
             }
             if (tid < H) bias[H + tid] = b2n;
         }
         lds_barrier();       // n complete
         FUSED_STAMP(4 + 8 * (layer - 1) + 7);
-        // step 2: u = SiLU(W3 n + b3): rows 16*mb2.. of u for node tile(s)
-        {
+        // step 2: u = SiLU(W3 n + b3): rows 16*mb2.. of u for both node tiles
+        if (act3) {
             float* ubuf = smem + L::UBUF;
             const f32x4 bv = ld4(b3 + 16 * mb2 + 4 * q);
 #pragma unroll
-            for (int t2 = 0; t2 < (NW == 8 ? 2 : 1); ++t2) {
-                const int tn = NW == 8 ? t2 : wave >> 3;
+            for (int tn = 0; tn < 2; ++tn) {
                 if (16 * tn < n) {
                     f32x4 acc = bv;
 #pragma unroll
@@ -708,14 +752,18 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         float* o2 = smem + L::OBUF2;
         const int mb = wave & 3, tn = (wave >> 2) & 1;
         const bool act = wave < 8 && 16 * tn < n;
+        f32x4 w6v[4];                                    // last Linear: rows >= D of the block are discarded
+        if (wave < 2) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) w6v[a] = ld4(P.out_w6 + (i < D ? i : D - 1) * H + 16 * a + 4 * q);
+        }
         if (act) {
             f32x4 acc = ld4(P.out_b0 + 16 * mb + 4 * q);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const f32x4 wv = ld4(P.out_w0 + (16 * mb + i) * H + 16 * a + 4 * q);
                 const f32x4 xv = ld4(xbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc = mfma16(wv[b], xv[b], acc);
+                for (int b = 0; b < 4; ++b) acc = mfma16(wsv[a][b], xv[b], acc);
             }
             st4(o1 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
         }
@@ -724,24 +772,21 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             f32x4 acc = ld4(P.out_b3 + 16 * mb + 4 * q);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const f32x4 wv = ld4(P.out_w3 + (16 * mb + i) * H + 16 * a + 4 * q);
                 const f32x4 xv = ld4(o1 + (16 * tn + i) * LDW + 16 * a + 4 * q);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc = mfma16(wv[b], xv[b], acc);
+                for (int b = 0; b < 4; ++b) acc = mfma16(wrv[a][b], xv[b], acc);
             }
             st4(o2 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
         }
         lds_barrier();
         if (wave < 2 && 16 * wave < n) {
             const int tn2 = wave;
-            const int row = i < D ? i : D - 1;       // rows >= D of the 16-row block are discarded
             f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const f32x4 wv = ld4(P.out_w6 + row * H + 16 * a + 4 * q);
                 const f32x4 xv = ld4(o2 + (16 * tn2 + i) * LDW + 16 * a + 4 * q);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) y = mfma16(wv[b], xv[b], y);
+                for (int b = 0; b < 4; ++b) y = mfma16(w6v[a][b], xv[b], y);
             }
             const int node = 16 * tn2 + i;
             if (q == 0 && node < n) {

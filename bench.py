@@ -92,7 +92,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step (fwd+bwd+opt) figure")
     ap.add_argument("--streamed", action="store_true", help="force the layer-by-layer kernels")
-    ap.add_argument("--fused-waves", type=int, default=0, help="8 or 16 (tuning; 0 = library default)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to aether_set_option")
     ap.add_argument("--dims", type=int, default=WORKLOAD["D"], help="2 (headline) or 3 (cfg3)")
     ap.add_argument("--batch", type=int, default=WORKLOAD["B"])
@@ -127,8 +126,6 @@ def main():
         model = Aether(2 * D, 64, 0.0, D, device=dev)
     if args.streamed:
         model.flags = _lib.FLAG_FORCE_STREAMED
-    if args.fused_waves:
-        _lib.check(_lib.load().aether_set_option(b"fused_waves", args.fused_waves), "set_option")
     for kv in args.opt:
         k, v = kv.split("=")
         _lib.check(_lib.load().aether_set_option(k.encode(), int(v)), "set_option " + kv)

@@ -10,10 +10,9 @@ sys.path.insert(0, REPO)
 from aether_amd import build as B, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--dims", type=int, default=2); ap.add_argument("--batch", type=int, default=128)
-ap.add_argument("--nodes", type=int, default=20); ap.add_argument("--waves", type=int, default=8)
+ap.add_argument("--nodes", type=int, default=20)
 a = ap.parse_args()
 _lib.LIB_PATH = B.build_diagnostic()
-_lib.check(_lib.load().aether_set_option(b"fused_waves", a.waves), "set_option")
 from aether_amd.nn.state2state.aether import Aether
 from aether_amd.synthetic import make_batch
 torch.manual_seed(1)
@@ -54,7 +53,7 @@ clk = np.median(st[:, 41] / st[:, 40])
 print(f"  shader clock during the kernel: {clk:.0f} MHz (s_memtime cycles / wall us)")
 print("  layer-2 per-wave tile timeline, cycles since kernel entry (median over workgroups):")
 print("   wave round   start   gemm1   silu1   gemm2  silu2+stage  reduce   | total")
-for w in range(a.waves):
+for w in range(8):
     for r in range(3):
         v = med[64 + w * 24 + r * 8: 64 + w * 24 + r * 8 + 6]
         if v[5] == 0: continue
