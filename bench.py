@@ -47,8 +47,10 @@ def _dist_env():
     return rank, world, local
 
 
-def _cpu_baseline(sd, inp, budget_s=15.0):
-    """Oracle forward on the host cores; bounded sample of the same workload."""
+def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0):
+    """Oracle forward on the host cores; bounded sample of the same workload.  With `model`, the
+    oracle also serves as the checker of the HIP path on this very batch (one step and the 20-step
+    rollout of SURVEY.md 8d, scale-relative max error: the 1e-5 bar of the north star)."""
     from oracle import aether_oracle as O
     cores = os.cpu_count() or 1
     try:
@@ -70,11 +72,32 @@ def _cpu_baseline(sd, inp, budget_s=15.0):
             if el > budget_s or n >= 400:
                 break
     E = inp["edges"][0].numel()
+    parity = None
+    if model is not None:
+        from aether_amd.rollout import rollout
+        with torch.no_grad():
+            want = O.aether_forward(*args)
+            d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items() if k != "edges"}
+            edges_d = [e.to(dev) for e in inp["edges"]]
+            got = model(d["h"], d["x"], edges_d, d["vel"], d["edge_attr"], d["charges"]).cpu()
+            traj_w = O.rollout(sd, inp["x"], inp["vel"], inp["edges"], inp["charges"], 20)
+            traj_g = rollout(model, d["x"], d["vel"], edges_d, d["charges"], 20).cpu()
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+        mse = float(((traj_g - traj_w) ** 2).mean())
+        parity = {"step_max_rel_err": rel(got, want), "step_tolerance": 1e-5,
+                  "rollout20_mse_between_paths": mse,
+                  "rollout20_rel_mse": mse / float((traj_w ** 2).mean()),
+                  "rollout20_max_rel_err": rel(traj_g, traj_w),
+                  "note": "single step: the 1e-5 bar; rollout: fp32 round-off of step 1 fed back through 20 "
+                          "autoregressive steps of a random-init model (the MSE between the two paths is the "
+                          "quantity SURVEY 8d bounds by 1e-5)",
+                  "checker": "oracle/aether_oracle.py (pinned to the reference's golden vectors)"}
     return {
         "value": 4.0 * E * n / el, "unit": "edge-messages/s", "cores": cores, "kind": "port",
         "ms_per_step": 1e3 * el / n,
         "sample": f"{n} forward steps of the same B=128 N=20 D=2 batch in {el:.1f} s, "
                   f"torch CPU fp32, {cores} threads",
+        "parity": parity,
     }
 
 
@@ -343,7 +366,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            line["cpu_baseline"] = _cpu_baseline(sd, host)
+            line["cpu_baseline"] = _cpu_baseline(sd, host, model, dev)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         else:
             line["cpu_baseline"] = None
