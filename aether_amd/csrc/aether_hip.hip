@@ -190,7 +190,7 @@ int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defe
 
 struct WsLayout {
     // forward (always)
-    size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, part, stamps, flags, fwd_total;
+    size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, part, stamps, flags, velbuf[2], fwd_total;
     // saved by the forward under KEEP_INTERMEDIATES for the backward
     size_t n[4], feat;
     // backward temporaries
@@ -214,6 +214,7 @@ struct WsLayout {
         part = take((nn + (ee + 15) / 16 + 1) * H);   // per-(receiver, tile) sums of the streamed edge kernels
         stamps = take((size_t)4096 * FUSED_STAMPS);
         flags = take(2 * nn + 64);              // split-mode hand-off flags, one int per workgroup
+        for (auto& v : velbuf) v = take(nn * 4);    // aether_rollout: velocities of the steps, ping-pong
         fwd_total = off;
         for (auto& v : n) v = take(nn * H);
         feat = take(ee * FPAD);
@@ -275,7 +276,7 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
 template <int D>
 int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphInfo& info, const float* x,
                const float* vel, const float* charges, const float* ea, const char* graph, char* ws,
-               float* out, bool keep, bool ws_reused, hipStream_t st) {
+               float* out, bool keep, bool ws_reused, StepExtras step, hipStream_t st) {
     GraphLayout G(E, Nn, false);
     WsLayout W(Nn, E, D, keep);
     auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
@@ -289,6 +290,7 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     dbg.feat = wp(W.feat);
     dbg.stamps = wp(W.stamps);
     dbg.flags = reinterpret_cast<int*>(ws + W.flags);
+    dbg.step = step;
     const FusedWG* wgd = reinterpret_cast<const FusedWG*>(graph + G.wgdesc);
     const uint32_t* tsel = reinterpret_cast<const uint32_t*>(graph + G.tsel);
     const uint32_t* tdst = reinterpret_cast<const uint32_t*>(graph + G.tdst);
@@ -315,7 +317,7 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
 template <int D>
 int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, const float* vel,
                   const float* charges, const float* ea, const char* graph, char* ws, float* out,
-                  bool keep, hipStream_t st) {
+                  bool keep, StepExtras step, hipStream_t st) {
     GraphLayout G(E, Nn, false);
     WsLayout W(Nn, E, D, keep);
     auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
@@ -345,7 +347,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
         ProfScope ps(K_EDGE_L1, st);
         k_edge_layer1<D><<<dim3(g1), dim3(256), lds1, st>>>(P, nodeinfo, ea, perm, send_s, recv_s, gsel,
                                                            wp(W.part), wp(W.e[0]), keep ? wp(W.feat) : nullptr,
-                                                           E);
+                                                           step.qattr, E);
     }
     auto seg_mean = [&](int l) {
         ProfScope ps(K_SEGMEAN, st);
@@ -356,7 +358,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
         ProfScope ps(K_NODE_UPDATE, st);
         k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
         P, 1, wp(W.x[0]), wp(W.aggr), wp(W.x[1]), wp(W.ps[0]), wp(W.pr[0]), nodeinfo, x, out,
-        keep ? wp(W.n[0]) : nullptr, Nn);
+        keep ? wp(W.n[0]) : nullptr, nullptr, 1.0f, Nn);
     }
     for (int l = 2; l <= 4; ++l) {
         if (E > 0) {
@@ -379,12 +381,12 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
             ProfScope ps(K_NODE_UPDATE, st);
             k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.aggr), wp(W.x[l]), wp(W.ps[l - 1]), wp(W.pr[l - 1]),
-                nodeinfo, x, out, keep ? wp(W.n[l - 1]) : nullptr, Nn);
+                nodeinfo, x, out, keep ? wp(W.n[l - 1]) : nullptr, nullptr, 1.0f, Nn);
         } else {
             ProfScope ps(K_NODE_LAST, st);
             k_node_update<D, true><<<dim3(node_grid), dim3(64), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.aggr), wp(W.x[l]), nullptr, nullptr, nodeinfo, x,
-                out, keep ? wp(W.n[l - 1]) : nullptr, Nn);
+                out, keep ? wp(W.n[l - 1]) : nullptr, step.vel_out, step.dt, Nn);
         }
     }
     HIP_OK(hipGetLastError());
@@ -835,18 +837,62 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
         return fail(AETHER_EINVAL, "forward: fused path requested but the graph has no groups");
     const bool keep = (flags & AETHER_FLAG_KEEP_INTERMEDIATES) != 0;
     const bool reused = (flags & AETHER_FLAG_WORKSPACE_REUSED) != 0;
+    const StepExtras no_extras{nullptr, nullptr, 1.0f};
     if (fused) {
         if (num_dims == 2)
             return fused_impl<2>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,
-                                 (const char*)graph, (char*)workspace, out, keep, reused, st);
+                                 (const char*)graph, (char*)workspace, out, keep, reused, no_extras, st);
         return fused_impl<3>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,
-                             (const char*)graph, (char*)workspace, out, keep, reused, st);
+                             (const char*)graph, (char*)workspace, out, keep, reused, no_extras, st);
     }
     if (num_dims == 2)
         return streamed_impl<2>(*params, n_nodes, n_edges, x, vel, charges, edge_attr_orig,
-                                (const char*)graph, (char*)workspace, out, keep, st);
+                                (const char*)graph, (char*)workspace, out, keep, no_extras, st);
     return streamed_impl<3>(*params, n_nodes, n_edges, x, vel, charges, edge_attr_orig,
-                            (const char*)graph, (char*)workspace, out, keep, st);
+                            (const char*)graph, (char*)workspace, out, keep, no_extras, st);
+}
+
+int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x0,
+                   const float* vel0, const float* charges, const void* graph, const AetherGraphInfo* info,
+                   void* workspace, size_t workspace_bytes, float* trajectory, int steps, float dt,
+                   int flags, void* stream) {
+    if (!params || !x0 || !vel0 || !charges || !graph || !info || !workspace || !trajectory)
+        return fail(AETHER_EINVAL, "rollout: null pointer");
+    if (info->n_nodes != n_nodes || info->n_edges != n_edges)
+        return fail(AETHER_EINVAL, "rollout: graph info does not match n_nodes / n_edges");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "rollout: num_dims must be 2 or 3");
+    if (n_nodes <= 0 || n_edges < 0 || steps < 0) return fail(AETHER_EINVAL, "rollout: bad sizes");
+    if (!(dt != 0.0f)) return fail(AETHER_EINVAL, "rollout: dt must be non-zero");
+    if (flags & AETHER_FLAG_KEEP_INTERMEDIATES) return fail(AETHER_EINVAL, "rollout: inference only");
+    if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 0))
+        return fail(AETHER_ESPACE, "rollout: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const bool fused = info->n_groups > 0 && n_edges > 0 && !(flags & AETHER_FLAG_FORCE_STREAMED);
+    if ((flags & AETHER_FLAG_FORCE_FUSED) && !fused)
+        return fail(AETHER_EINVAL, "rollout: fused path requested but the graph has no groups");
+    WsLayout W(n_nodes, n_edges, num_dims, false);
+    char* ws = (char*)workspace;
+    const size_t stride = (size_t)n_nodes * num_dims;
+    for (int t = 0; t < steps; ++t) {
+        const float* x = t == 0 ? x0 : trajectory + (size_t)(t - 1) * stride;
+        const float* v = t == 0 ? vel0 : reinterpret_cast<const float*>(ws + W.velbuf[(t - 1) & 1]);
+        float* out = trajectory + (size_t)t * stride;
+        StepExtras ex{charges, reinterpret_cast<float*>(ws + W.velbuf[t & 1]), dt};
+        const bool reused = t > 0 || (flags & AETHER_FLAG_WORKSPACE_REUSED);   // the step before re-armed the flags
+        int rc;
+        if (fused)
+            rc = num_dims == 2 ? fused_impl<2>(*params, n_nodes, n_edges, *info, x, v, charges, nullptr, (const char*)graph,
+                                               ws, out, false, reused, ex, st)
+                               : fused_impl<3>(*params, n_nodes, n_edges, *info, x, v, charges, nullptr, (const char*)graph,
+                                               ws, out, false, reused, ex, st);
+        else
+            rc = num_dims == 2 ? streamed_impl<2>(*params, n_nodes, n_edges, x, v, charges, nullptr, (const char*)graph, ws,
+                                                  out, false, ex, st)
+                               : streamed_impl<3>(*params, n_nodes, n_edges, x, v, charges, nullptr, (const char*)graph, ws,
+                                                  out, false, ex, st);
+        if (rc != AETHER_OK) return rc;
+    }
+    return AETHER_OK;
 }
 
 int aether_backward(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,

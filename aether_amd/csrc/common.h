@@ -105,6 +105,12 @@ __device__ __forceinline__ void stage_weight64(float* lds, const float* __restri
     }
 }
 
+// Rollout extras of one step (aether_rollout): `qattr` != nullptr makes the kernels derive
+// edge_attr_orig = [q_send * q_recv, |x_send - x_recv|] themselves (the runner's per-batch prep,
+// experiments/lorentz/main.py:243-246) instead of reading it; `vel_out` != nullptr also writes the
+// next velocity (x_next - x) / dt next to the output.
+struct StepExtras { const float* qattr; float* vel_out; float dt; };
+
 template <int D> struct NodeInfo {
     // [p(D) v(D) f(D) R(D*D row-major) cv(D) cf(D)], padded to a multiple of 4 floats
     static constexpr int P = 0, V = D, F = 2 * D, R = 3 * D, CV = 3 * D + D * D, CF = CV + D;

@@ -72,6 +72,7 @@ struct FusedDebug {
     float* n[4]; float* ps[3]; float* pr[3]; float* feat;     // saved for the backward
     int* flags;             // [workgroups] split mode: layer whose P_s rows this workgroup has published
     float* stamps;          // [groups][FUSED_STAMPS] diagnostic build only
+    StepExtras step;        // rollout: derived edge attributes, next velocity
 };
 constexpr int FUSED_STAMPS = 512;
 
@@ -399,8 +400,20 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 float njl[NI::STRIDE], nrl[NI::STRIDE];
 #pragma unroll
                 for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
-                const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
-                float eal[2] = {ea[0], ea[1]};
+                float eal[2];
+                if (dbg.step.qattr) {          // main.py:243-246: [q_i q_j, sqrt(sum((x_i - x_j)^2))]
+                    float d2 = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const float df = njl[NI::P + d] - nrl[NI::P + d];
+                        d2 += df * df;
+                    }
+                    eal[0] = dbg.step.qattr[send_s[k]] * dbg.step.qattr[recv_s[k]];
+                    eal[1] = sqrtf(d2);
+                } else {
+                    const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                    eal[0] = ea[0]; eal[1] = ea[1];
+                }
                 edge_features<D>(njl, nrl, eal, o);
                 if (keep) {
 #pragma unroll
@@ -799,7 +812,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     float s = 0.f;
 #pragma unroll
                     for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * yl[b];
-                    out[(int64_t)(nb + node) * D + a] = ni[NI::P + a] + s;
+                    const float xn = ni[NI::P + a] + s;
+                    out[(int64_t)(nb + node) * D + a] = xn;
+                    if (dbg.step.vel_out)
+                        dbg.step.vel_out[(int64_t)(nb + node) * D + a] = (xn - ni[NI::P + a]) / dbg.step.dt;
                 }
             }
         }

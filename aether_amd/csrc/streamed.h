@@ -117,7 +117,7 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
               const float* __restrict__ edge_attr_orig, const int32_t* __restrict__ perm,
               const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
               const uint32_t* __restrict__ gsel, float* __restrict__ part, float* __restrict__ e_out,
-              float* __restrict__ feat_dbg, int64_t n_edges) {
+              float* __restrict__ feat_dbg, const float* __restrict__ qattr, int64_t n_edges) {
     using NI = NodeInfo<D>;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -153,8 +153,20 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { njl[t + u] = a[u]; nrl[t + u] = b[u]; }
                 }
-                const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
-                float eal[2] = {ea[0], ea[1]};
+                float eal[2];
+                if (qattr) {                   // main.py:243-246: [q_i q_j, sqrt(sum((x_i - x_j)^2))]
+                    float d2 = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const float df = njl[NI::P + d] - nrl[NI::P + d];
+                        d2 += df * df;
+                    }
+                    eal[0] = qattr[send_s[k]] * qattr[recv_s[k]];
+                    eal[1] = sqrtf(d2);
+                } else {
+                    const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                    eal[0] = ea[0]; eal[1] = ea[1];
+                }
                 edge_features<D>(njl, nrl, eal, o);
                 if (feat_dbg) {
 #pragma unroll
@@ -380,7 +392,8 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
               const float* __restrict__ aggr,
               float* __restrict__ x_out, float* __restrict__ Ps, float* __restrict__ Pr,
               const float* __restrict__ nodeinfo, const float* __restrict__ pos,
-              float* __restrict__ out, float* __restrict__ nsave, int64_t n_nodes) {
+              float* __restrict__ out, float* __restrict__ nsave, float* __restrict__ vel_out, float dt,
+              int64_t n_nodes) {
     using NI = NodeInfo<D>;
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
@@ -464,7 +477,9 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
                 float s = 0.f;
 #pragma unroll
                 for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * yl[b];   // R y
-                out[node * D + a] = pos[node * D + a] + s;
+                const float xn = pos[node * D + a] + s;
+                out[node * D + a] = xn;
+                if (vel_out) vel_out[node * D + a] = (xn - pos[node * D + a]) / dt;
             }
         }
     }

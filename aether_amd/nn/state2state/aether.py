@@ -280,6 +280,47 @@ class Aether(nn.Module):
         return _AetherStep.apply(self, train, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E,
                                  *self.parameters())
 
+    # -- device rollout ---------------------------------------------------------------
+    @torch.no_grad()
+    def rollout(self, x, vel, edges, charges, steps, dt=1.0):
+        """``steps`` autoregressive steps on the device (``aether_rollout``): positions
+        ``[steps, n_nodes, D]``.  x_{t+1} = self(x_t, v_t), v_{t+1} = (x_{t+1} - x_t) / dt, with
+        ``edge_attr = [q_i q_j, |x_i - x_j|]`` rebuilt inside the kernels every step
+        (experiments/lorentz/main.py:243-246); one kernel launch per step, no host-side gathers."""
+        if not x.is_cuda:
+            raise _lib.AetherHipError("aether_amd.Aether runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        lib = _lib.load()
+        send, recv = edges
+        if send.dtype != torch.int64 or recv.dtype != torch.int64:
+            raise TypeError("edges must be int64 (torch.LongTensor), as in the reference")
+        n_nodes, D = x.shape
+        if D != self.num_dims or vel.shape != x.shape or charges.numel() != n_nodes:
+            raise ValueError(f"x/vel must be [n_nodes, {self.num_dims}], charges [n_nodes, 1]")
+        E = send.numel()
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        x, vel, charges = f32(x), f32(vel), f32(charges)
+        graph, ginfo = self.prepare_graph((send, recv), n_nodes)
+        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 0)
+        ws = self._workspace(ws_bytes, x.device)
+        flags = self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES
+        fused = ginfo.n_groups > 0 and E > 0 and not (flags & _lib.FLAG_FORCE_STREAMED)
+        ws_key = (ws.data_ptr(), n_nodes, E, D, False, graph.data_ptr()) if fused else None
+        if ws_key is not None and self._ws_key == ws_key:
+            flags |= _lib.FLAG_WORKSPACE_REUSED
+        self._ws_key = None
+        traj = torch.empty(int(steps), n_nodes, D, dtype=torch.float32, device=x.device)
+        if int(steps) <= 0:
+            return traj
+        st = lib.aether_rollout(C.byref(self._param_struct()), D, n_nodes, E, x.data_ptr(), vel.data_ptr(),
+                                charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(), ws.numel(),
+                                traj.data_ptr(), int(steps), float(dt), flags,
+                                torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(st, "aether_rollout")
+        self._ws_key = ws_key
+        self._last_ws = ws
+        return traj
+
     # -- test hook -------------------------------------------------------------------
     def debug_fetch(self, name, n_nodes, n_edges, cols):
         lib = _lib.load()

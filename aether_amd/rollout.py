@@ -5,16 +5,24 @@ protocol used for the "20-step rollout MSE" figure is the one SURVEY.md defines 
 restates (oracle/aether_oracle.py::rollout): x_{t+1} = Aether(x_t, v_t), v_{t+1} = (x_{t+1} - x_t) / dt,
 with ``edge_attr = [q_i q_j, |x_i - x_j|]`` rebuilt from the current positions every step
 (experiments/lorentz/main.py:243-246).  Everything stays on the device; the edge index (and therefore
-the receiver-sorted graph view) is reused across steps.
+the receiver-sorted graph view) is reused across steps.  ``rollout`` runs the loop inside the library
+(``aether_rollout``); ``rollout_stepwise`` is the loop of module calls it replaces.
 """
 from __future__ import annotations
 
 import torch
 
 
-@torch.no_grad()
 def rollout(model, x, vel, edges, charges, steps: int, dt: float = 1.0):
-    """Returns the predicted positions, ``[steps, n_nodes, D]``."""
+    """Predicted positions ``[steps, n_nodes, D]``: the device rollout (``aether_rollout``, one kernel
+    launch per step, edge attributes derived in the kernels)."""
+    return model.rollout(x, vel, edges, charges, steps, dt)
+
+
+@torch.no_grad()
+def rollout_stepwise(model, x, vel, edges, charges, steps: int, dt: float = 1.0):
+    """The same protocol as a loop of module calls with the runner's tensor ops in between (how a
+    reference user would write it; kept as the cross-check of ``rollout``)."""
     rows, cols = edges
     qprod = charges[rows] * charges[cols]
     traj = []

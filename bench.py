@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the 20-step device rollout timing")
     ap.add_argument("--graph-steps", type=int, default=10,
                     help="consecutive forward steps captured per hipGraph (1: one replay per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
@@ -259,6 +260,27 @@ def main():
                         "avg_launch_us": dom["avg_us"], "algorithmic_flop_per_launch": flops,
                         "executed_flop_per_launch": executed}
 
+    # ---- 20-step device rollout (aether_rollout): metric 2's protocol, one launch per step ------------
+    roll = None
+    if rank == 0 and not args.no_rollout:
+        from aether_amd.rollout import rollout, rollout_stepwise
+        T, R = 20, 10
+        rargs = (model, inp["x"], inp["vel"], inp["edges"], inp["charges"], T)
+        def timed(fn):
+            for _ in range(2):
+                fn(*rargs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(R):
+                fn(*rargs)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / R
+        ms_dev, ms_loop = timed(rollout), timed(rollout_stepwise)
+        roll = {"steps": T, "ms_per_rollout": ms_dev, "ms_per_step": ms_dev / T,
+                "value": 4.0 * E * T / (ms_dev * 1e-3), "unit": "edge-messages/s",
+                "loop_of_module_calls_ms": ms_loop,
+                "includes": "edge attributes and velocities derived in the kernels, eager launches"}
+
     # ---- training step: forward + HIP backward + gradient all-reduce (N > 1) + AdamW ----------------
     train = None
     if not args.no_train:
@@ -362,7 +384,7 @@ def main():
                        "parallelism": f"graphs sharded over {world} rank(s), no forward collective"},
             "edges_per_s": E * world / (dt / args.steps),
             "step_algorithmic_tflops": step_flops * world / (dt / args.steps) / 1e12,
-            "roofline": roof, "kernels": kernels, "train": train,
+            "roofline": roof, "kernels": kernels, "rollout": roll, "train": train,
         }
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

@@ -125,6 +125,25 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
                    void* workspace, size_t workspace_bytes, float* out, int flags, void* stream);
 
 /*
+ * Autoregressive rollout, all on the device: `steps` forward steps back to back,
+ *   x_{t+1} = Aether(x_t, v_t),  v_{t+1} = (x_{t+1} - x_t) / dt,
+ * with edge_attr_orig = [q_i q_j, |x_i - x_j|] derived inside the kernels from the current positions
+ * (the runner's per-batch prep, experiments/lorentz/main.py:243-246) -- the protocol of the
+ * "20-step rollout MSE" metric (oracle/aether_oracle.py::rollout restates it).  Replaces a
+ * Python loop of model calls, gathers and concatenations (about 2/3 of the time of such a loop at
+ * N=20, batch=128) by one kernel launch per step.
+ *   x0, vel0   : float[n_nodes][D], state at t = 0 (not modified)
+ *   trajectory : float[steps][n_nodes][D], positions x_1 .. x_steps
+ *   workspace  : aether_workspace_bytes(n_nodes, n_edges, D, 0) bytes
+ *   flags      : AETHER_FLAG_FORCE_* / AETHER_FLAG_WORKSPACE_REUSED as for aether_forward
+ * Stream-ordered; capture it in a hipGraph to replay a whole rollout with one launch.
+ */
+int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
+                   const float* x0, const float* vel0, const float* charges, const void* graph,
+                   const AetherGraphInfo* info, void* workspace, size_t workspace_bytes,
+                   float* trajectory, int steps, float dt, int flags, void* stream);
+
+/*
  * Backward step: gradients of a scalar loss w.r.t. every parameter, given grad_out = dL/d(out).
  * Replaces torch.autograd through Aether.forward (the runner's loss.backward(),
  * experiments/lorentz/main.py:289-291).  Inputs (x, vel, charges, edge attributes) are data and

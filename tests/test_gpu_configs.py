@@ -11,7 +11,7 @@ from conftest import GOLDEN, load_state_dict, scale_rel_err
 from aether_amd import _lib
 from aether_amd.edges import get_edges, prepare_edge_attr
 from aether_amd.nn.state2state.aether import Aether
-from aether_amd.rollout import rollout, rollout_mse
+from aether_amd.rollout import rollout, rollout_mse, rollout_stepwise
 from aether_amd.synthetic import make_batch
 from oracle import aether_oracle as O
 
@@ -41,6 +41,22 @@ def test_rollout_20_steps_matches_reference(D, flags):
     truth = ref + 0.1 * torch.randn(ref.shape, generator=g)
     a, b = rollout_mse(traj, truth), rollout_mse(ref, truth)
     assert float(((a - b).abs() / b).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_FORCE_STREAMED])
+@pytest.mark.parametrize("D", [2, 3])
+def test_device_rollout_equals_loop_of_module_calls(D, flags):
+    """aether_rollout (edge attributes and velocities derived in the kernels) vs the loop a user of
+    the reference would write around forward(); also at a non-unit dt and at the headline shape."""
+    m = _model(D, flags)
+    for (B, N, T, dt, seed) in [(4, 5, 20, 1.0, 3), (128, 20, 6, 0.25, 4), (3, 9, 5, 2.0, 5)]:
+        inp = make_batch(B, N, D, seed=seed, device="cuda")
+        a = rollout(m, inp["x"], inp["vel"], inp["edges"], inp["charges"], T, dt)
+        b = rollout_stepwise(m, inp["x"], inp["vel"], inp["edges"], inp["charges"], T, dt)
+        assert a.shape == (T, B * N, D)
+        assert scale_rel_err(a[0].cpu(), b[0].cpu()) <= 1e-6          # one step: same arithmetic up to fma contraction
+        assert scale_rel_err(a.cpu(), b.cpu()) <= TOL
+    assert rollout(m, inp["x"], inp["vel"], inp["edges"], inp["charges"], 0).shape == (0, 27, D)
 
 
 def _knn_scene_batch(n_scenes, D, k, seed):
