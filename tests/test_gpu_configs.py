@@ -188,3 +188,46 @@ def test_workspace_reuse_keeps_split_mode_handoff_armed():
     run(a, _lib.FLAG_FORCE_STREAMED)                       # streamed kernels in between
     assert torch.equal(run(a), ref_a)
     assert torch.equal(run(a), ref_a)
+
+
+def _random_multigraph_batch(seed, D):
+    """Arbitrary edge lists as the reference's scatter accepts them: components of 1..40 nodes,
+    random edges with self loops and duplicates, some nodes without in-edges (the last node of the
+    batch always receives one, so that scatter's output has n_nodes rows), unsorted."""
+    g = torch.Generator().manual_seed(seed)
+    n_comp = int(torch.randint(1, 12, (1,), generator=g))
+    send, recv, off = [], [], 0
+    for _ in range(n_comp):
+        n = int(torch.randint(1, 41, (1,), generator=g))
+        m = int(torch.randint(0, 6 * n + 1, (1,), generator=g))
+        if m:
+            send.append(torch.randint(0, n, (m,), generator=g) + off)
+            recv.append(torch.randint(0, n, (m,), generator=g) + off)
+        off += n
+    send.append(torch.tensor([max(off - 2, 0)])); recv.append(torch.tensor([off - 1]))
+    edges = [torch.cat(send).long(), torch.cat(recv).long()]
+    perm = torch.randperm(edges[0].numel(), generator=g)
+    edges = [edges[0][perm], edges[1][perm]]
+    x = torch.randn(off, D, generator=g) * 2.0
+    v = torch.randn(off, D, generator=g)
+    q = torch.randint(-1, 2, (off, 1), generator=g).float()
+    ea = prepare_edge_attr(x, edges, q[edges[0]] * q[edges[1]])
+    return dict(x=x, vel=v, charges=q, edges=edges, edge_attr=ea, h=v.norm(dim=-1, keepdim=True))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("D", [2, 3])
+def test_random_multigraphs_match_oracle(D, seed):
+    sd = load_state_dict(D)
+    inp = _random_multigraph_batch(seed, D)
+    want = O.aether_forward(sd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+    assert torch.isfinite(want).all()
+    dev = "cuda"
+    edges = [e.to(dev) for e in inp["edges"]]
+    outs = {}
+    for name, flags in (("default", 0), ("streamed", _lib.FLAG_FORCE_STREAMED)):
+        m = _model(D, flags)
+        with torch.no_grad():
+            outs[name] = m(inp["h"].to(dev), inp["x"].to(dev), edges, inp["vel"].to(dev),
+                           inp["edge_attr"].to(dev), inp["charges"].to(dev)).cpu()
+        assert scale_rel_err(outs[name], want) <= TOL, (name, seed)
