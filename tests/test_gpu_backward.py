@@ -27,7 +27,7 @@ def _loss_backward(m, inp):
     loss = torch.nn.functional.mse_loss(out, inp["target"].to(dev))
     loss.backward()
     torch.cuda.synchronize()
-    return float(loss), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    return float(loss.detach()), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
 
 
 @pytest.mark.parametrize("path", ["fused", "streamed"])
@@ -64,6 +64,29 @@ def test_gradients_vs_oracle_autograd_fresh_inputs(D):
         _, grads = _loss_backward(m, inp)
         for k, g in grads.items():
             assert scale_rel_err(g, sdg[k].grad) <= GTOL, (B, N, k)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+@pytest.mark.parametrize("D", [2, 3])
+def test_gradients_on_random_multigraphs(D, seed):
+    """Self loops, duplicate edges, nodes without in-edges, components of 1..40 nodes: gradients of both
+    dispatch paths against the oracle's autograd."""
+    from test_gpu_configs import _random_multigraph_batch
+    sd = load_state_dict(D)
+    inp = _random_multigraph_batch(seed, D)
+    g = torch.Generator().manual_seed(seed)
+    inp["target"] = inp["x"] + 0.1 * torch.randn(inp["x"].shape, generator=g)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.aether_forward(sdg, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+    torch.nn.functional.mse_loss(out, inp["target"]).backward()
+    for path in ("default", "streamed"):
+        m = _model(D, "streamed")
+        if path == "default":
+            m.flags = 0
+        _, grads = _loss_backward(m, inp)
+        for k, gk in grads.items():
+            assert torch.isfinite(gk).all(), (path, k)
+            assert scale_rel_err(gk, sdg[k].grad) <= GTOL, (path, k)
 
 
 @pytest.mark.parametrize("D", [2, 3])
