@@ -530,8 +530,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
         };
-        auto front = [&](int r, f32x4 (&h1)[4], bool last) {
-            f32x4 acc[4];
+        // Split mode, layers 2-4: the partner workgroup's P_s rows arrive while the FIRST tile's first
+        // Linear runs.  `late` tiles start from P_r and the own senders' P_s only; the partner's rows
+        // are fetched into LDS after that GEMM (receive_partner_rows) and added before the SiLU.
+        const bool xch = wg.partner >= 0 && layer > 1;
+        auto front_gemm = [&](int r, f32x4 (&acc)[4], bool last, bool late) {
             if (last) issue_loads(0);
             if (layer == 1) {
 #pragma unroll
@@ -539,10 +542,45 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 f32x4 bop[2] = {e[r][0], e[r][1]};
                 gemm_tile<4, 2>(wA, LDF, bop, acc, i, q);
             } else {
+                const bool own_s = !late || (sl[r] >= off && sl[r] < off + n);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-                    acc[mb] = ld4(psb + sl[r] * LDW + 16 * mb + 4 * q) + ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
+                for (int mb = 0; mb < 4; ++mb) {
+                    acc[mb] = ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
+                    if (own_s) acc[mb] += ld4(psb + sl[r] * LDW + 16 * mb + 4 * q);
+                }
                 gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
+            }
+        };
+        auto receive_partner_rows = [&]() {
+            // second half of the hand-off (first half: end of the previous node phase): one lane polls the
+            // partner's flag (bounded), then every wave reads its share of the partner's rows with sc1
+            // (L1-bypassing) 8-byte loads -- the only loads of those bytes in this launch.
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(dbg.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < layer - 1) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) break;           // partner not resident: give up, never hang
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            lds_barrier();
+            const int np = nv - n;                              // partner rows = visible slots outside [off, off + n)
+            for (int idx = tid; idx < np * 32; idx += THREADS) {
+                typedef unsigned long long u64;
+                int slot = idx >> 5;
+                if (slot >= off) slot += n;
+                const int c = (idx & 31) * 2;
+                const u64 v = __hip_atomic_load((const u64*)(dbg.ps[layer - 2] + (int64_t)(vb + slot) * H + c),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                psb[slot * LDW + c] = __uint_as_float((unsigned)v);
+                psb[slot * LDW + c + 1] = __uint_as_float((unsigned)(v >> 32));
+            }
+            lds_barrier();
+        };
+        auto front_act = [&](int r, f32x4 (&acc)[4], f32x4 (&h1)[4], bool last, bool late) {
+            if (late && !(sl[r] >= off && sl[r] < off + n)) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb] += ld4(psb + sl[r] * LDW + 16 * mb + 4 * q);
             }
             if (last) issue_loads(1);
 #pragma unroll
@@ -606,13 +644,17 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 if (r < nvalid) {
                     const bool last = r == nvalid - 1;
                     FUSED_WSTAMP(layer, r, 0);
-                    f32x4 h1[4];
-                    front(r, h1, last);
+                    f32x4 acc[4], h1[4];
+                    const bool late = xch && r == 0;
+                    front_gemm(r, acc, last, late);
+                    if (late) receive_partner_rows();           // every wave passes here exactly once per layer
+                    front_act(r, acc, h1, last, late);
                     FUSED_WSTAMP(layer, r, 2);
                     back(r, h1, last);
                     FUSED_WSTAMP(layer, r, 5);
                 }
             }
+            if (xch && nvalid == 0) receive_partner_rows();
             if (LATE && nvalid > 0) {
 #pragma unroll
                 for (int part = 2; part < 5; ++part) issue_loads(part);
@@ -719,39 +761,16 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                         st4(dbg.pr[layer - 1] + (int64_t)(nb + 16 * tn4 + i) * H + 16 * mb3 + 4 * q, accr);
                 }
             }
-            if (wg.partner >= 0) {
-                // Hand the own P_s rows to the partner workgroup and fetch its rows
-                // (cdna_hip_programming.md Guideline 16, form R1 with write-through payload): every
-                // byte of the payload is stored sc1 (8-byte agent-scope stores above) and every storing
-                // wave drains its stores before the barrier; one lane then raises the flag and polls the
-                // partner's (bounded); after the second barrier every wave reads the partner's rows with
-                // sc1 (L1-bypassing) 8-byte loads -- the only loads of those bytes in this launch.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    __hip_atomic_store(dbg.flags + blockIdx.x, layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(dbg.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < layer) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 24)) break;           // partner not resident: give up, never hang
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-                __syncthreads();
-                // partner rows = visible slots outside [off, off + n)
-                const int np = nv - n;
-                for (int idx = tid; idx < np * 32; idx += THREADS) {
-                    typedef unsigned long long u64;
-                    int slot = idx >> 5;
-                    if (slot >= off) slot += n;
-                    const int c = (idx & 31) * 2;
-                    const u64 v = __hip_atomic_load((const u64*)(dbg.ps[layer - 1] + (int64_t)(vb + slot) * H + c),
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    psb[slot * LDW + c] = __uint_as_float((unsigned)v);
-                    psb[slot * LDW + c + 1] = __uint_as_float((unsigned)(v >> 32));
-                }
-            }
+            // First half of the hand-off of the own P_s rows to the partner workgroup
+            // (cdna_hip_programming.md Guideline 16, form R1 with write-through payload): every byte of
+            // the payload was stored sc1 (8-byte agent-scope stores above); every wave drains its stores
+            // before the barrier, then one lane raises the flag.  The partner picks the rows up after
+            // the first GEMM of its next edge phase (receive_partner_rows), as this workgroup does with
+            // the partner's: the flag's flight time hides behind those 64 MFMAs.
+            if (wg.partner >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();   // P_s / P_r and the staged weights are visible to the next edge tiles
+            if (wg.partner >= 0 && tid == 0)
+                __hip_atomic_store(dbg.flags + blockIdx.x, layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             FUSED_STAMP(4 + 8 * (layer - 1) + 6);
         }
     }
