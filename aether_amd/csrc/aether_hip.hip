@@ -752,11 +752,10 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
         if (G.max_wgs >= 2 * (int64_t)n_grp) {
             // Workgroup descriptors.  With fewer groups than half the CUs, each group is split over two
             // workgroups by receiver range (balanced by in-edge count); see FusedWG.
-            int cus = 256;
-            hipDeviceProp_t prop;
-            int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cus = prop.multiProcessorCount;
+            int cus = 256, dev = 0;       // (hipGetDeviceProperties takes ~100 ms per call: one attribute instead)
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
             bool split = g_fused_split && 2 * n_grp <= cus;
             for (int k = 0; k < n_grp && split; ++k) if (grp[k + 1] - grp[k] < 2) split = false;
             std::vector<FusedWG> wgs;

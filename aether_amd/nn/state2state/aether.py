@@ -41,6 +41,13 @@ class GraphCache:
         if hit is not None:
             self._d.move_to_end(key)
             return hit[0]
+        # Same index in new tensors (the runner rebuilds it every batch, main.py:211-212): two
+        # element-wise comparisons on the device are far cheaper than sorting again.
+        for k2, (val, s2, r2) in reversed(list(self._d.items())):
+            if (k2[2], k2[3], k2[6]) == (key[2], key[3], key[6]) and torch.equal(s2, send) and torch.equal(r2, recv):
+                self._d[key] = (val, send, recv)
+                self._trim()
+                return val
         lib = _lib.load()
         E = send.numel()
         nbytes = lib.aether_graph_bytes(E, n_nodes)
@@ -52,9 +59,12 @@ class GraphCache:
                    "aether_graph_build")
         # keep the index tensors alive so the key (their addresses) stays unique
         self._d[key] = ((buf, info), send, recv)
+        self._trim()
+        return buf, info
+
+    def _trim(self):
         while len(self._d) > self.max_entries:
             self._d.popitem(last=False)
-        return buf, info
 
 
 class _AetherStep(torch.autograd.Function):
