@@ -71,19 +71,19 @@ class _AetherStep(torch.autograd.Function):
     """aether_forward / aether_backward behind torch.autograd (parameters only get gradients:
     the runner detaches positions and edge attributes, experiments/lorentz/main.py:243-247)."""
 
-    N_FIXED = 8          # module, train, x, vel, edge_attr, charges, graph, n_edges precede the parameters
+    N_FIXED = 7          # module, x, vel, edge_attr, charges, graph, n_edges precede the parameters
 
     @staticmethod
-    def forward(ctx, module, train, x, vel, edge_attr, charges, graph, n_edges, *params):
+    def launch(module, train, x, vel, edge_attr, charges, graph, n_edges):
+        """One aether_forward call; returns (out, saved-for-backward or None)."""
         lib = _lib.load()
         graph, ginfo = graph
         D = module.num_dims
         n_nodes = x.shape[0]
-        # `train` is decided by the caller: inside Function.forward grad mode is always off, and
-        # needs_input_grad reflects requires_grad even under torch.no_grad()
         flags = module.flags | (_lib.FLAG_KEEP_INTERMEDIATES if train else 0)
         keep = bool(flags & _lib.FLAG_KEEP_INTERMEDIATES)
-        ws_bytes = lib.aether_workspace_bytes(n_nodes, n_edges, D, 1 if keep else 0)
+        ws_bytes = module._workspace_bytes(n_nodes, n_edges, keep)
+        ws_key = None
         if train:        # the backward reads this forward's intermediates: one workspace per call
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         else:
@@ -97,17 +97,22 @@ class _AetherStep(torch.autograd.Function):
             module._ws_key = None
         out = torch.empty_like(x)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        st = lib.aether_forward(C.byref(module._param_struct()), D, n_nodes, n_edges,
+        st = lib.aether_forward(module._param_struct_ref(), D, n_nodes, n_edges,
                                 x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
                                 edge_attr.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
                                 ws.numel(), out.data_ptr(), flags, stream)
         _lib.check(st, "aether_forward")
-        if train:
-            ctx.module = module
-            ctx.saved = (x, vel, charges, graph, ginfo, ws, n_edges)
-        if not train:
-            module._ws_key = ws_key
+        module._ws_key = ws_key
         module._last_ws = ws
+        return out, ((x, vel, charges, graph, ginfo, ws, n_edges) if train else None)
+
+    @staticmethod
+    def forward(ctx, module, x, vel, edge_attr, charges, graph, n_edges, *params):
+        # only the training path comes through here (inside Function.forward grad mode is always off and
+        # needs_input_grad reflects requires_grad even under torch.no_grad(): the caller decides)
+        out, saved = _AetherStep.launch(module, True, x, vel, edge_attr, charges, graph, n_edges)
+        ctx.module = module
+        ctx.saved = saved
         return out
 
     @staticmethod
@@ -218,6 +223,8 @@ class Aether(nn.Module):
         self._gbuf = None
         self._ws = None
         self._pstruct = None
+        self._plist = None
+        self._ws_bytes = {}
         self.to(device)
         self.params = self.__str__()
 
@@ -229,18 +236,38 @@ class Aether(nn.Module):
     # -- plumbing ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         self._pstruct = None              # parameter storage may move (.to / .cuda / .float)
+        self._plist = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._pstruct = None
+        self._plist = None
         return super().load_state_dict(*a, **k)
 
     def _param_struct(self):
-        sd = dict(self.named_parameters())
-        key = tuple(p.data_ptr() for p in sd.values())
+        if self._plist is None:
+            self._plist = [p for _, p in self.named_parameters()]
+        key = tuple([p.data_ptr() for p in self._plist])
         if self._pstruct is None or self._pstruct[0] != key:
-            self._pstruct = (key, _lib.params_struct(sd))
+            struct = _lib.params_struct(dict(self.named_parameters()))
+            self._pstruct = (key, struct, C.byref(struct))
         return self._pstruct[1]
+
+    def _param_struct_ref(self):
+        self._param_struct()
+        return self._pstruct[2]
+
+    def _workspace_bytes(self, n_nodes, n_edges, keep):
+        if keep:         # the training layout depends on a library option (outer_defer_max_edges): always ask
+            return _lib.load().aether_workspace_bytes(n_nodes, n_edges, self.num_dims, 1)
+        key = (n_nodes, n_edges)
+        nbytes = self._ws_bytes.get(key)
+        if nbytes is None:
+            nbytes = _lib.load().aether_workspace_bytes(n_nodes, n_edges, self.num_dims, 0)
+            if len(self._ws_bytes) > 64:
+                self._ws_bytes.clear()
+            self._ws_bytes[key] = nbytes
+        return nbytes
 
     def _grad_buffers(self):
         """Flat fp32 gradient buffer + an AetherParams struct and per-parameter views into it."""
@@ -287,7 +314,9 @@ class Aether(nn.Module):
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         graph = self.prepare_graph((send, recv), n_nodes)
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        return _AetherStep.apply(self, train, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E,
+        if not train:           # inference: no autograd node, no parameter list to marshal
+            return _AetherStep.launch(self, False, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E)[0]
+        return _AetherStep.apply(self, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E,
                                  *self.parameters())
 
     # -- device rollout ---------------------------------------------------------------
