@@ -397,47 +397,69 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t tiles = (n_edges + 15) >> 4;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= tiles) return;
+    // One memory round trip per tile: the indices (and the receiver's in-degree) of the NEXT tile are
+    // fetched while this one computes, and every row this tile needs is requested at the top of the
+    // iteration; each sigmoid is evaluated once and serves both SiLU and its derivative.
+    auto clampk = [&](int64_t tt) { const int64_t k = 16 * tt + i; return k < n_edges ? k : n_edges - 1; };
+    int64_t kc = clampk(t);
+    int32_t s = send_s[kc], r = recv_s[kc];
+    int deg = rowptr[r + 1] - rowptr[r];
+    for (; t < tiles; t += stride) {
         int z = 0;
         asm volatile("" : "+v"(z));      // opaque offset: weight fragments are re-read from LDS per tile
                                          // instead of being hoisted into ~256 registers (1 wave per SIMD)
         const int64_t k = 16 * t + i;
         const bool ok = k < n_edges;
-        const int64_t kc = ok ? k : n_edges - 1;
-        const int64_t s = send_s[kc], r = recv_s[kc];
-        f32x4 p1[4], p2[4], h[4];
+        // ---- this tile's rows
+        f32x4 bop[4], p1[4], dnv[4], dev[4];
         if (FIRST) {
-            f32x4 bop[2];
             bop[0] = ld4(feat + kc * FPAD + 4 * q);
             bop[1] = ld4(feat + kc * FPAD + 16 + 4 * q);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(b_in + 16 * mb + 4 * q);
-            gemm_tile<4, 2>(wi + z, LDW, bop, p1, i, q);
         } else {
-            f32x4 bop[4];
             load_tile64(bop, e_prev, kc, H, q);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
-                p1[mb] = ld4(Ps + s * H + 16 * mb + 4 * q) + ld4(Pr + r * H + 16 * mb + 4 * q);
+                p1[mb] = ld4(Ps + (int64_t)s * H + 16 * mb + 4 * q) + ld4(Pr + (int64_t)r * H + 16 * mb + 4 * q);
+        }
+        load_tile64(dnv, DN, r, H, q);
+        if (have_de) load_tile64(dev, DE, kc, H, q);
+        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        // ---- next tile's indices
+        const int64_t kn = clampk(t + stride < tiles ? t + stride : t);
+        const int32_t s_n = send_s[kn], r_n = recv_s[kn];
+        const int deg_n = rowptr[r_n + 1] - rowptr[r_n];
+        // ---- forward recompute: pre1, h = silu(pre1), pre2
+        f32x4 p2[4], h[4], sg1[4];
+        if (FIRST) {
+            f32x4 b2[2] = {bop[0], bop[1]};
+            gemm_tile<4, 2>(wi + z, LDW, b2, p1, i, q);
+        } else {
             gemm_tile<4, 4>(wi + z, LDW, bop, p1, i, q);
         }
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) { h[mb] = silu4(p1[mb]); p2[mb] = ld4(b2g + 16 * mb + 4 * q); }
+        for (int mb = 0; mb < 4; ++mb) {
+            sg1[mb] = sigmoid4(p1[mb]);
+            h[mb] = p1[mb] * sg1[mb];
+            p2[mb] = ld4(b2g + 16 * mb + 4 * q);
+        }
         gemm_tile<4, 4>(w2 + z, LDW, h, p2, i, q);
-        // de = dn[recv] / deg (+ gradient through the next layer's edge input)
-        const int deg = rowptr[r + 1] - rowptr[r];
-        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
         f32x4 d2[4], dh[4], g[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            f32x4 de = ld4(DN + r * H + 16 * mb + 4 * q) * inv;
-            if (have_de) de += ld4(DE + kc * H + 16 * mb + 4 * q);
-            d2[mb] = de * dsilu4(p2[mb]);
+            f32x4 de = dnv[mb] * inv;
+            if (have_de) de += dev[mb];
+            d2[mb] = de * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
             dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         gemm_tile<4, 4>(w2ts + z, LDW, d2, dh, i, q);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu4(p1[mb]);
+        for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu_from_sigmoid(p1[mb], sg1[mb]);
         if (FIRST) {
             f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             gemm_tile<2, 4>(wit + z, LDW, g, da, i, q);
@@ -454,6 +476,7 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
             store_tile64(H1, k, H, q, h);
             store_tile64(DP2, k, H, q, d2);
         }
+        kc = kn; s = s_n; r = r_n; deg = deg_n;
     }
 }
 

@@ -57,6 +57,18 @@ __device__ __forceinline__ f32x4 silu4(f32x4 v) {
     const f32x2 ol = lo * rl, oh = hi * rh;
     return f32x4{ol[0], ol[1], oh[0], oh[1]};
 }
+// sigmoid of four values (same hardware ops as silu4); silu = x * s, d silu / dx = s * (1 + x * (1 - s))
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+    const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    const f32x2 tl = lo * -1.44269504088896340736f, th = hi * -1.44269504088896340736f;
+    f32x2 el = {__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])};
+    f32x2 eh = {__builtin_amdgcn_exp2f(th[0]), __builtin_amdgcn_exp2f(th[1])};
+    el = el + 1.0f;
+    eh = eh + 1.0f;
+    return f32x4{__builtin_amdgcn_rcpf(el[0]), __builtin_amdgcn_rcpf(el[1]), __builtin_amdgcn_rcpf(eh[0]),
+                 __builtin_amdgcn_rcpf(eh[1])};
+}
+__device__ __forceinline__ f32x4 dsilu_from_sigmoid(f32x4 x, f32x4 s) { return s * (1.0f + x * (1.0f - s)); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
