@@ -530,7 +530,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         float* gb2 = l == 1 ? Gr.l1_msg_b2 : Gr.ln_msg_b2[l - 2];
         // ---- node update: dx_l -> dn_l
         { ProfScope ps(KB_NODE, st);
-        kb_node<<<dim3(ngrid), dim3(64), 0, st>>>(w3, b3, WT.upd_w2t[l - 1], WT.upd_w0t[l - 1], wp(W.n[l - 1]),
+        kb_node<<<dim3(ngrid), dim3(256), 0, st>>>(w3, b3, WT.upd_w2t[l - 1], WT.upd_w0t[l - 1], wp(W.n[l - 1]),
                                                  dx_cur, wp(W.DN), bU, bDPU, Nn); }
         L.add(dx_cur, H, H, bU, 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
         L.add(bDPU, 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
@@ -569,10 +569,8 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         if (l >= 2) {
             // ---- sums of G onto nodes, then dx_{l-1}
             { ProfScope ps(KB_GATHER, st);
-            kb_sum_g<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(bG, rowptr, srowptr, sperm,
-                                                                          bDPS, bDPR, Nn);
-            kb_gather<<<dim3(ngrid), dim3(64), 0, st>>>(WT.msg_w0t[l - 1], bDPS, bDPR, wp(W.DN), dx_nxt,
-                                                       Nn); }
+            kb_gather<<<dim3(ngrid), dim3(1024), 0, st>>>(bG, rowptr, srowptr, sperm, WT.msg_w0t[l - 1], wp(W.DN),
+                                                         bDPS, bDPR, dx_nxt, Nn); }
             L.add(bDPS, H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
             L.add(bDPR, H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
             if (flush()) return AETHER_EHIP;

@@ -325,38 +325,69 @@ kb_out(AetherParams P, BwdWT WT, const float* __restrict__ x4, const float* __re
     }
 }
 
-// ------------------------------------------------------------------ node update backward
-// forward (locs.py:240-241): u = silu(W3 n + b3), x = n + W4 u + b4.   in: dx.  out: dn, u, dpre_u.
-__global__ void __launch_bounds__(64)
+// Node update backward of one layer (locs.py:240-241): x = n + W4 silu(W3 n + b3) + b4.
+// One workgroup of 4 waves per 16-node tile, output rows split over the waves (a single wave would
+// chain 384 dependent-latency MFMAs behind 96 weight-fragment loads: 15 us per launch at 2,560 nodes):
+//   stage A: wave w owns rows 32w .. 32w+31 of pre_u = W3 n + b3 and of du = W4^T dx
+//            -> U = silu(pre_u), DPU = du * silu'(pre_u) (to global for the weight gradients, to LDS for B)
+//   stage B: wave w owns rows 16w .. 16w+15 of dn = dx + W3^T dpre_u
+// Every weight fragment is requested before the first MFMA.
+__global__ void __launch_bounds__(256)
 kb_node(const float* __restrict__ w3g, const float* __restrict__ b3g, const float* __restrict__ w4t,
         const float* __restrict__ w3t, const float* __restrict__ nbuf, const float* __restrict__ DX,
         float* __restrict__ DN, float* __restrict__ U, float* __restrict__ DPU, int64_t n_nodes) {
-    const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float dpu_s[16 * LDU];     // [node][128 + 8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t node = (int64_t)blockIdx.x * 16 + i;
     const bool ok = node < n_nodes;
     const int64_t nc = ok ? node : n_nodes - 1;
-    f32x4 nt[4], dx[4], pu[8], du[8], dn[4];
+    f32x4 nt[4], dx[4], w3f[2][4], w4f[2][4], w3tf[8], pu[2], du[2];
     load_tile64(nt, nbuf, nc, H, q);
     load_tile64(dx, DX, nc, H, q);
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) { pu[mb] = ld4(b3g + 16 * mb + 4 * q); du[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    gemm_tile<8, 4>(w3g, H, nt, pu, i, q);          // pre_u = W3 n + b3
-    gemm_tile<8, 4>(w4t, H, dx, du, i, q);          // du = W4^T dx
-    f32x4 u[8];
+    for (int m = 0; m < 2; ++m) {
+        const int mb = 2 * wave + m;
+        pu[m] = ld4(b3g + 16 * mb + 4 * q);
+        du[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) { u[mb] = silu4(pu[mb]); du[mb] = du[mb] * dsilu4(pu[mb]); }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) dn[mb] = dx[mb];
-    gemm_tile<4, 8>(w3t, 2 * H, du, dn, i, q);      // dn = dx + W3^T dpre_u
-    if (ok) {
-        store_tile64(DN, node, H, q, dn);
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            st4(U + node * 2 * H + 16 * mb + 4 * q, u[mb]);
-            st4(DPU + node * 2 * H + 16 * mb + 4 * q, du[mb]);
+        for (int a = 0; a < 4; ++a) {
+            w3f[m][a] = ld4(w3g + (size_t)(16 * mb + i) * H + 16 * a + 4 * q);
+            w4f[m][a] = ld4(w4t + (size_t)(16 * mb + i) * H + 16 * a + 4 * q);
         }
     }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) w3tf[a] = ld4(w3t + (size_t)(16 * wave + i) * (2 * H) + 16 * a + 4 * q);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                pu[m] = mfma16(w3f[m][a][b], nt[a][b], pu[m]);
+                du[m] = mfma16(w4f[m][a][b], dx[a][b], du[m]);
+            }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int mb = 2 * wave + m;
+        const f32x4 sg = sigmoid4(pu[m]);
+        const f32x4 u = pu[m] * sg;
+        const f32x4 dpu = du[m] * dsilu_from_sigmoid(pu[m], sg);
+        st4(dpu_s + i * LDU + 16 * mb + 4 * q, dpu);
+        if (ok) {
+            st4(U + node * 2 * H + 16 * mb + 4 * q, u);
+            st4(DPU + node * 2 * H + 16 * mb + 4 * q, dpu);
+        }
+    }
+    __syncthreads();
+    f32x4 dn = dx[wave];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const f32x4 bv = ld4(dpu_s + i * LDU + 16 * a + 4 * q);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dn = mfma16(w3tf[a][b], bv[b], dn);
+    }
+    if (ok) st4(DN + node * H + 16 * wave + 4 * q, dn);
 }
 
 // ------------------------------------------------------------------ edge MLP backward
@@ -480,61 +511,76 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
     }
 }
 
-// ------------------------------------------------------------------ sums of G onto nodes
-// dP_r[i] = sum_{k: recv = i} G_k (contiguous run), dP_s[j] = sum_{k: send = j} G_k (sender list,
-// rows gathered through sperm).  One wave per node, lane = column, fixed order, 8 loads in flight.
-__global__ void __launch_bounds__(256)
-kb_sum_g(const float* __restrict__ G, const int32_t* __restrict__ rowptr,
-         const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm,
-         float* __restrict__ DPS, float* __restrict__ DPR, int64_t n_nodes) {
-    const int lane = threadIdx.x & 63;
-    const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (node >= n_nodes) return;
-    {
-        const int beg = rowptr[node], end = rowptr[node + 1];
-        const float* p = G + (int64_t)beg * H + lane;
-        float s = 0.f;
-        int k = beg;
-        for (; k + 8 <= end; k += 8, p += 8 * H) {
-            const float a0 = p[0], a1 = p[H], a2 = p[2 * H], a3 = p[3 * H], a4 = p[4 * H], a5 = p[5 * H],
-                        a6 = p[6 * H], a7 = p[7 * H];
-            s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
-        }
-        for (; k < end; ++k, p += H) s += p[0];
-        DPR[node * H + lane] = s;
-    }
-    {
-        const int beg = srowptr[node], end = srowptr[node + 1];
-        float s = 0.f;
-        int k = beg;
-        for (; k + 4 <= end; k += 4) {
-            const int r0 = sperm[k], r1 = sperm[k + 1], r2 = sperm[k + 2], r3 = sperm[k + 3];
-            const float a0 = G[(int64_t)r0 * H + lane], a1 = G[(int64_t)r1 * H + lane],
-                        a2 = G[(int64_t)r2 * H + lane], a3 = G[(int64_t)r3 * H + lane];
-            s += a0; s += a1; s += a2; s += a3;
-        }
-        for (; k < end; ++k) s += G[(int64_t)sperm[k] * H + lane];
-        DPS[node * H + lane] = s;
-    }
-}
-
-// dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed); wave per node tile
-__global__ void __launch_bounds__(64)
-kb_gather(const float* __restrict__ w1t /*[192][64]: W_s^T | W_r^T | W_e^T*/,
-          const float* __restrict__ DPS, const float* __restrict__ DPR, const float* __restrict__ DN,
-          float* __restrict__ DX, int64_t n_nodes) {
-    const int lane = threadIdx.x & 63;
+// dL/dx_{l-1} of layers 2-4 in one launch per 16-node tile (16 waves):
+//   phase 1, wave w = node 16*tile + w: DPR = sum of G over the node's in-edges (contiguous rows of the
+//            receiver-sorted G), DPS = sum over its out-edges (rows listed by sperm / srowptr); lane =
+//            column, 8 / 4 row loads in flight, fixed order -> deterministic.  Both go to global memory
+//            (operands of the weight gradients) and to LDS.
+//   phase 2, waves 0-3 (rows 16w .. 16w+15): dx = dn + W_s^T DPS + W_r^T DPR (locs.py:233 split), the
+//            weight fragments were requested before phase 1.
+__global__ void __launch_bounds__(1024)
+kb_gather(const float* __restrict__ G, const int32_t* __restrict__ rowptr,
+          const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm,
+          const float* __restrict__ w1t /*[192][64]: W_s^T | W_r^T | W_e^T*/, const float* __restrict__ DN,
+          float* __restrict__ DPS, float* __restrict__ DPR, float* __restrict__ DX, int64_t n_nodes) {
+    __shared__ __attribute__((aligned(16))) float sums[2][16 * LDW];      // [DPS | DPR][node][64 + 8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t node = (int64_t)blockIdx.x * 16 + i;
-    const bool ok = node < n_nodes;
-    const int64_t nc = ok ? node : n_nodes - 1;
-    f32x4 dps[4], dpr[4], dx[4];
-    load_tile64(dps, DPS, nc, H, q);
-    load_tile64(dpr, DPR, nc, H, q);
-    load_tile64(dx, DN, nc, H, q);
-    gemm_tile<4, 4>(w1t, H, dps, dx, i, q);
-    gemm_tile<4, 4>(w1t + H * H, H, dpr, dx, i, q);
-    if (ok) store_tile64(DX, node, H, q, dx);
+    f32x4 wsf[4], wrf[4], dx;
+    const int64_t tnode = (int64_t)blockIdx.x * 16 + i;
+    const int64_t tc = tnode < n_nodes ? tnode : n_nodes - 1;
+    if (wave < 4) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            wsf[a] = ld4(w1t + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
+            wrf[a] = ld4(w1t + (size_t)H * H + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
+        }
+        dx = ld4(DN + tc * H + 16 * wave + 4 * q);
+    }
+    const int64_t node = (int64_t)blockIdx.x * 16 + wave;
+    float sr = 0.f, ss = 0.f;
+    if (node < n_nodes) {
+        {
+            const int beg = rowptr[node], end = rowptr[node + 1];
+            const float* p = G + (int64_t)beg * H + lane;
+            int k = beg;
+            for (; k + 8 <= end; k += 8, p += 8 * H) {
+                const float a0 = p[0], a1 = p[H], a2 = p[2 * H], a3 = p[3 * H], a4 = p[4 * H], a5 = p[5 * H],
+                            a6 = p[6 * H], a7 = p[7 * H];
+                sr += a0; sr += a1; sr += a2; sr += a3; sr += a4; sr += a5; sr += a6; sr += a7;
+            }
+            for (; k < end; ++k, p += H) sr += p[0];
+            DPR[node * H + lane] = sr;
+        }
+        {
+            const int beg = srowptr[node], end = srowptr[node + 1];
+            int k = beg;
+            for (; k + 4 <= end; k += 4) {
+                const int r0 = sperm[k], r1 = sperm[k + 1], r2 = sperm[k + 2], r3 = sperm[k + 3];
+                const float a0 = G[(int64_t)r0 * H + lane], a1 = G[(int64_t)r1 * H + lane],
+                            a2 = G[(int64_t)r2 * H + lane], a3 = G[(int64_t)r3 * H + lane];
+                ss += a0; ss += a1; ss += a2; ss += a3;
+            }
+            for (; k < end; ++k) ss += G[(int64_t)sperm[k] * H + lane];
+            DPS[node * H + lane] = ss;
+        }
+    }
+    sums[0][wave * LDW + lane] = ss;
+    sums[1][wave * LDW + lane] = sr;
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 bs = ld4(sums[0] + i * LDW + 16 * a + 4 * q);
+            const f32x4 br = ld4(sums[1] + i * LDW + 16 * a + 4 * q);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                dx = mfma16(wsf[a][b], bs[b], dx);
+                dx = mfma16(wrf[a][b], br[b], dx);
+            }
+        }
+        if (tnode < n_nodes) st4(DX + tnode * H + 16 * wave + 4 * q, dx);
+    }
 }
 
 // ------------------------------------------------------------------ field net backward
