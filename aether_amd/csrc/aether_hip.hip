@@ -237,12 +237,12 @@ struct WsLayout {
         RELF = take(nn * 16);
         Z = take(nn * 32); H1f = take(nn * 32); H2f = take(nn * 32); DPH1 = take(nn * 32); DPH2 = take(nn * 32);
         DF = take(nn * 16); DZE = take(nn * 16); ONEHOT = take(nn * 16);
-        {   // at most 9 edge-level and 32 node-level tasks share the partial buffer
+        {   // at most 9 edge-level and 48 node-level tasks (64 x 64 pieces) share the partial buffer
             auto chunks_of = [](size_t rows) {
                 size_t c = ((rows + 15) / 16 + 3) / 4;
                 return c < 1 ? (size_t)1 : (c > (size_t)OUTER_MAX_CHUNKS ? (size_t)OUTER_MAX_CHUNKS : c);
             };
-            partial_cap = 9 * chunks_of(ee) + 32 * chunks_of(nn);
+            partial_cap = 9 * chunks_of(ee) + 48 * chunks_of(nn);     // 64 x 64 pieces
             partial = take(partial_cap * OUTER_PART);
         }
         total = training ? off : fwd_total;
@@ -396,22 +396,31 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
 // ------------------------------------------------------------------ backward orchestration
 struct OuterList {
     std::vector<OuterTask> tasks;
+    // Products wider than 64 x 64 are entered as 64 x 64 pieces (column slices of A / B, the matching
+    // block of C): every task is then of the <4,4> class and one k_outer + one k_outer_reduce launch
+    // serves a whole backward (the 128-wide classes cost two more launch pairs, ~36 us per step at cfg2).
     void add(const float* A, int lda, int M, const float* B, int ldb, int N, int64_t rows, float* C, int ldc,
              float* bias) {
-        OuterTask t;
-        t.A = A; t.B = B; t.C = C; t.bias = bias; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.M = M; t.N = N;
-        t.chunks = 1; t.part0 = 0;
-        t.rows = rows;
-        tasks.push_back(t);
+        for (int m0 = 0; m0 < M; m0 += 64)
+            for (int n0 = 0; n0 < N; n0 += 64) {
+                OuterTask t;
+                t.A = A + m0; t.B = B + n0; t.C = C + (size_t)m0 * ldc + n0;
+                t.bias = (bias != nullptr && n0 == 0) ? bias + m0 : nullptr;
+                t.lda = lda; t.ldb = ldb; t.ldc = ldc;
+                t.M = M - m0 < 64 ? M - m0 : 64;
+                t.N = N - n0 < 64 ? N - n0 : 64;
+                t.chunks = 1; t.part0 = 0;
+                t.rows = rows;
+                tasks.push_back(t);
+            }
     }
 };
 
-// Multiplies every task of the list: one k_outer launch per block class (<4,4>, <8,4>, <4,8>) and
-// one k_outer_reduce per launch; then empties the list.
+// Multiplies every task of the list (all of them 64 x 64 or smaller: OuterList::add): one k_outer and
+// one k_outer_reduce launch per OUTER_MAX_TASKS tasks; then empties the list.
 int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st) {
     if (L.tasks.empty()) return AETHER_OK;
     size_t next_part = 0;
-    std::vector<OuterTask> cls[2][2];
     for (OuterTask& t : L.tasks) {
         int64_t tiles = (t.rows + 15) / 16;
         int64_t chunks = (tiles + 3) / 4;               // one row tile per wave until the chunk cap: short MFMA chains
@@ -420,32 +429,22 @@ int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st) 
         t.chunks = (int)chunks;
         t.part0 = (int)next_part;
         next_part += (size_t)chunks;
-        const int mbn = (t.M + 15) / 16, nbn = (t.N + 15) / 16;
-        if (mbn > 8 || nbn > 8 || (mbn > 4 && nbn > 4)) return fail(AETHER_EINVAL, "k_outer: unsupported block shape");
-        cls[mbn > 4][nbn > 4].push_back(t);
+        if (t.M > 64 || t.N > 64) return fail(AETHER_EINVAL, "k_outer: task wider than 64 x 64");
     }
     if (next_part > partial_cap) return fail(AETHER_EINVAL, "k_outer: partial buffer too small");
     ProfScope ps(KB_OUTER, st);
-    for (int cm = 0; cm < 2; ++cm)
-        for (int cn = 0; cn < 2; ++cn) {
-            const std::vector<OuterTask>& v = cls[cm][cn];
-            for (size_t k0 = 0; k0 < v.size(); k0 += OUTER_MAX_TASKS) {
-                OuterBatch b;
-                b.n_tasks = (int)(v.size() - k0 < (size_t)OUTER_MAX_TASKS ? v.size() - k0 : (size_t)OUTER_MAX_TASKS);
-                int max_chunks = 1;
-                for (int k = 0; k < b.n_tasks; ++k) {
-                    b.t[k] = v[k0 + k];
-                    if (b.t[k].chunks > max_chunks) max_chunks = b.t[k].chunks;
-                }
-                const dim3 grid((unsigned)max_chunks, (unsigned)b.n_tasks);
-                const int mp = cm ? 128 : 64, np = cn ? 128 : 64;
-                const size_t lds = (size_t)4 * 16 * (mp + 16 + np + 16) * sizeof(float);
-                if (!cm && !cn) k_outer<4, 4><<<grid, dim3(256), lds, st>>>(b, partial);
-                else if (cm) k_outer<8, 4><<<grid, dim3(256), lds, st>>>(b, partial);
-                else k_outer<4, 8><<<grid, dim3(256), lds, st>>>(b, partial);
-                k_outer_reduce<<<dim3((unsigned)(mp * np / 256 + 1), (unsigned)b.n_tasks), dim3(1024), 0, st>>>(b, partial);
-            }
+    for (size_t k0 = 0; k0 < L.tasks.size(); k0 += OUTER_MAX_TASKS) {
+        OuterBatch b;
+        b.n_tasks = (int)(L.tasks.size() - k0 < (size_t)OUTER_MAX_TASKS ? L.tasks.size() - k0 : (size_t)OUTER_MAX_TASKS);
+        int max_chunks = 1;
+        for (int k = 0; k < b.n_tasks; ++k) {
+            b.t[k] = L.tasks[k0 + k];
+            if (b.t[k].chunks > max_chunks) max_chunks = b.t[k].chunks;
         }
+        const size_t lds = (size_t)4 * 16 * (64 + 16 + 64 + 16) * sizeof(float);
+        k_outer<4, 4><<<dim3((unsigned)max_chunks, (unsigned)b.n_tasks), dim3(256), lds, st>>>(b, partial);
+        k_outer_reduce<<<dim3((unsigned)(64 * 64 / 256 + 1), (unsigned)b.n_tasks), dim3(1024), 0, st>>>(b, partial);
+    }
     L.tasks.clear();
     return AETHER_OK;
 }
@@ -569,8 +568,13 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         if (l >= 2) {
             // ---- sums of G onto nodes, then dx_{l-1}
             { ProfScope ps(KB_GATHER, st);
-            kb_gather<<<dim3(ngrid), dim3(1024), 0, st>>>(bG, rowptr, srowptr, sperm, WT.msg_w0t[l - 1], wp(W.DN),
-                                                         bDPS, bDPR, dx_nxt, Nn); }
+            if (E <= 64 * Nn) {
+                kb_gather<<<dim3(ngrid), dim3(1024), 0, st>>>(bG, rowptr, srowptr, sperm, WT.msg_w0t[l - 1],
+                                                             wp(W.DN), bDPS, bDPR, dx_nxt, Nn);
+            } else {
+                kb_sum_g<<<dim3((unsigned)((Nn + 3) / 4)), dim3(256), 0, st>>>(bG, rowptr, srowptr, sperm, bDPS, bDPR, Nn);
+                kb_gather_rows<<<dim3(ngrid), dim3(64), 0, st>>>(WT.msg_w0t[l - 1], bDPS, bDPR, wp(W.DN), dx_nxt, Nn);
+            } }
             L.add(bDPS, H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
             L.add(bDPR, H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
             if (flush()) return AETHER_EHIP;

@@ -511,7 +511,65 @@ kb_edge(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192
     }
 }
 
-// dL/dx_{l-1} of layers 2-4 in one launch per 16-node tile (16 waves):
+// ------------------------------------------------------------------ sums of G onto nodes
+// dP_r[i] = sum_{k: recv = i} G_k (contiguous run), dP_s[j] = sum_{k: send = j} G_k (sender list,
+// rows gathered through sperm).  One wave per node, lane = column, fixed order, 8 loads in flight.
+__global__ void __launch_bounds__(256)
+kb_sum_g(const float* __restrict__ G, const int32_t* __restrict__ rowptr,
+         const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm,
+         float* __restrict__ DPS, float* __restrict__ DPR, int64_t n_nodes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n_nodes) return;
+    {
+        const int beg = rowptr[node], end = rowptr[node + 1];
+        const float* p = G + (int64_t)beg * H + lane;
+        float s = 0.f;
+        int k = beg;
+        for (; k + 8 <= end; k += 8, p += 8 * H) {
+            const float a0 = p[0], a1 = p[H], a2 = p[2 * H], a3 = p[3 * H], a4 = p[4 * H], a5 = p[5 * H],
+                        a6 = p[6 * H], a7 = p[7 * H];
+            s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
+        }
+        for (; k < end; ++k, p += H) s += p[0];
+        DPR[node * H + lane] = s;
+    }
+    {
+        const int beg = srowptr[node], end = srowptr[node + 1];
+        float s = 0.f;
+        int k = beg;
+        for (; k + 4 <= end; k += 4) {
+            const int r0 = sperm[k], r1 = sperm[k + 1], r2 = sperm[k + 2], r3 = sperm[k + 3];
+            const float a0 = G[(int64_t)r0 * H + lane], a1 = G[(int64_t)r1 * H + lane],
+                        a2 = G[(int64_t)r2 * H + lane], a3 = G[(int64_t)r3 * H + lane];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; k < end; ++k) s += G[(int64_t)sperm[k] * H + lane];
+        DPS[node * H + lane] = s;
+    }
+}
+
+// dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed); wave per node tile
+__global__ void __launch_bounds__(64)
+kb_gather_rows(const float* __restrict__ w1t /*[192][64]: W_s^T | W_r^T | W_e^T*/,
+          const float* __restrict__ DPS, const float* __restrict__ DPR, const float* __restrict__ DN,
+          float* __restrict__ DX, int64_t n_nodes) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t node = (int64_t)blockIdx.x * 16 + i;
+    const bool ok = node < n_nodes;
+    const int64_t nc = ok ? node : n_nodes - 1;
+    f32x4 dps[4], dpr[4], dx[4];
+    load_tile64(dps, DPS, nc, H, q);
+    load_tile64(dpr, DPR, nc, H, q);
+    load_tile64(dx, DN, nc, H, q);
+    gemm_tile<4, 4>(w1t, H, dps, dx, i, q);
+    gemm_tile<4, 4>(w1t + H * H, H, dpr, dx, i, q);
+    if (ok) store_tile64(DX, node, H, q, dx);
+}
+
+// dL/dx_{l-1} of layers 2-4 in one launch per 16-node tile (16 waves); used up to an average degree of
+// 64 (above it the row sums dominate and the two kernels above, with 4-wave workgroups, stream better):
 //   phase 1, wave w = node 16*tile + w: DPR = sum of G over the node's in-edges (contiguous rows of the
 //            receiver-sorted G), DPS = sum over its out-edges (rows listed by sperm / srowptr); lane =
 //            column, 8 / 4 row loads in flight, fixed order -> deterministic.  Both go to global memory

@@ -53,13 +53,15 @@ def test_parameter_gradients_match_reference(D, case, path):
 @pytest.mark.parametrize("D", [2, 3])
 def test_gradients_vs_oracle_autograd_fresh_inputs(D):
     sd = load_state_dict(D)
-    for (B, N, seed, path) in [(5, 7, 51, "fused"), (3, 40, 52, "streamed"), (130, 20, 53, "fused")]:
+    # (2, 70): average degree 69 > 64 -> the backward's row sums run as their own kernel
+    for (B, N, seed, path) in [(5, 7, 51, "fused"), (3, 40, 52, "streamed"), (130, 20, 53, "fused"),
+                               (2, 70, 54, "streamed")]:
         inp = make_batch(B, N, D, seed=seed)
         sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         out = O.aether_forward(sdg, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
         torch.nn.functional.mse_loss(out, inp["target"]).backward()
         m = _model(D, path)
-        if path == "streamed" and N == 40:
+        if path == "streamed" and N >= 40:
             m.flags = 0                      # too big for a fused group: default dispatch must cope
         _, grads = _loss_backward(m, inp)
         for k, g in grads.items():
