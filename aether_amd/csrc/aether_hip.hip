@@ -356,7 +356,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     seg_mean(1);
     {
         ProfScope ps(K_NODE_UPDATE, st);
-        k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
+        k_node_update<D, false><<<dim3(node_grid), dim3(256), 0, st>>>(
         P, 1, wp(W.x[0]), wp(W.aggr), wp(W.x[1]), wp(W.ps[0]), wp(W.pr[0]), nodeinfo, x, out,
         keep ? wp(W.n[0]) : nullptr, nullptr, 1.0f, Nn);
     }
@@ -379,12 +379,12 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
         seg_mean(l);
         if (l < 4) {
             ProfScope ps(K_NODE_UPDATE, st);
-            k_node_update<D, false><<<dim3(node_grid), dim3(64), 0, st>>>(
+            k_node_update<D, false><<<dim3(node_grid), dim3(256), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.aggr), wp(W.x[l]), wp(W.ps[l - 1]), wp(W.pr[l - 1]),
                 nodeinfo, x, out, keep ? wp(W.n[l - 1]) : nullptr, nullptr, 1.0f, Nn);
         } else {
             ProfScope ps(K_NODE_LAST, st);
-            k_node_update<D, true><<<dim3(node_grid), dim3(64), 0, st>>>(
+            k_node_update<D, true><<<dim3(node_grid), dim3(256), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.aggr), wp(W.x[l]), nullptr, nullptr, nodeinfo, x,
                 out, keep ? wp(W.n[l - 1]) : nullptr, step.vel_out, step.dt, Nn);
         }

@@ -380,14 +380,16 @@ k_segment_mean(const float* __restrict__ part, const int32_t* __restrict__ rowpt
     aggr[node * H + lane] = s / deg;
 }
 
-// ------------------------------------------------------------------ K2: node update kernel
-// n = x_prev + mean_{j->i} e (locs.py:236-240); x = n + W4 SiLU(W3 n + b3) + b4 (:241);
-// then either the next layer's node terms P_s, P_r, or (LAST) the out MLP (locs.py:160-168),
-// globalise (local_to_global.py:12-13) and the residual x + pred (aether.py:185).
-// One wave per 16-node tile; weights are read from L2 in fragment shape (used once per wave).
-// The mean over in-edges comes from k_segment_mean.
+// Node update of one layer (locs.py:240-241) for a 16-node tile, output rows split over the 4 waves of
+// the workgroup (a single wave would chain ~400 MFMAs behind a hundred weight-fragment loads):
+//   A: u = SiLU(W3 n + b3), n = x_prev + mean        wave w: rows 32w .. 32w+31 of the 128     -> LDS
+//   B: x = n + W4 u + b4                              wave w: rows 16w .. 16w+15                -> LDS, x_out
+//   C: next layer's P_s = W_s x, P_r = W_r x + b1     wave w: rows 16w .. of both               (locs.py:233 split)
+//      LAST: out MLP (locs.py:160-168,193), rows 16w .. of each hidden layer, then wave 0 globalises
+//      (local_to_global.py:12-13) and adds the residual (aether.py:185).
+// Every weight fragment a wave needs is requested before its first MFMA.
 template <int D, bool LAST>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_prev,
               const float* __restrict__ aggr,
               float* __restrict__ x_out, float* __restrict__ Ps, float* __restrict__ Pr,
@@ -395,91 +397,128 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
               float* __restrict__ out, float* __restrict__ nsave, float* __restrict__ vel_out, float dt,
               int64_t n_nodes) {
     using NI = NodeInfo<D>;
-    const int lane = threadIdx.x & 63;
+    constexpr int LDUU = 2 * H + 8;
+    __shared__ __attribute__((aligned(16))) float ubuf[16 * LDUU];       // u, later o1 | o2 (cols 0-63 | 64-127)
+    __shared__ __attribute__((aligned(16))) float xbuf[16 * LDW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t node = (int64_t)blockIdx.x * 16 + i;
-    const int64_t nc = node < n_nodes ? node : n_nodes - 1;
+    const bool ok = node < n_nodes;
+    const int64_t nc = ok ? node : n_nodes - 1;
     const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
     const float* b3 = layer == 1 ? P.l1_upd_b0 : P.ln_upd_b0[layer - 2];
     const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
     const float* b4 = layer == 1 ? P.l1_upd_b2 : P.ln_upd_b2[layer - 2];
-    // n = x_prev + mean over in-edges (k_segment_mean)
-    f32x4 n[4];
+    // ---- all loads of the kernel
+    f32x4 n[4], w3f[2][4], w4f[8], wcf[2][4], u[2], xn, c0v, c1v, w6f[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
         n[mb] = ld4(x_prev + nc * H + 16 * mb + 4 * q) + ld4(aggr + nc * H + 16 * mb + 4 * q);
-    if (nsave != nullptr && node < n_nodes) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) st4(nsave + node * H + 16 * mb + 4 * q, n[mb]);
+    for (int m = 0; m < 2; ++m) {
+        u[m] = ld4(b3 + 16 * (2 * wave + m) + 4 * q);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) w3f[m][a] = ld4(w3 + (size_t)(16 * (2 * wave + m) + i) * H + 16 * a + 4 * q);
     }
-    f32x4 u[8];
+    xn = ld4(b4 + 16 * wave + 4 * q);
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) u[mb] = ld4(b3 + 16 * mb + 4 * q);
-    gemm_tile<8, 4>(w3, H, n, u, i, q);
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) u[mb] = silu4(u[mb]);
-    f32x4 xn[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) xn[mb] = ld4(b4 + 16 * mb + 4 * q);
-    gemm_tile<4, 8>(w4, 2 * H, u, xn, i, q);
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) xn[mb] += n[mb];
-    if (node < n_nodes) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) st4(x_out + node * H + 16 * mb + 4 * q, xn[mb]);
-    }
+    for (int a = 0; a < 8; ++a) w4f[a] = ld4(w4 + (size_t)(16 * wave + i) * (2 * H) + 16 * a + 4 * q);
     if constexpr (!LAST) {
         const float* w1n = P.ln_msg_w0[layer - 1];            // next layer's W1 [64][192]
-        const float* b1n = P.ln_msg_b0[layer - 1];
-        f32x4 ps[4], pr[4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            ps[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pr[mb] = ld4(b1n + 16 * mb + 4 * q);
-        }
-        gemm_tile<4, 4>(w1n, 3 * H, xn, ps, i, q);
-        gemm_tile<4, 4>(w1n + H, 3 * H, xn, pr, i, q);
-        if (node < n_nodes) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                st4(Ps + node * H + 16 * mb + 4 * q, ps[mb]);
-                st4(Pr + node * H + 16 * mb + 4 * q, pr[mb]);
-            }
-        }
-    } else {
-        f32x4 o1[4], o2[4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) o1[mb] = ld4(P.out_b0 + 16 * mb + 4 * q);
-        gemm_tile<4, 4>(P.out_w0, H, xn, o1, i, q);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) { o1[mb] = silu4(o1[mb]); o2[mb] = ld4(P.out_b3 + 16 * mb + 4 * q); }
-        gemm_tile<4, 4>(P.out_w3, H, o1, o2, i, q);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) o2[mb] = silu4(o2[mb]);
-        // last Linear has D (2|3) output rows: rows >= D of the 16-row block read row D-1
-        // (in bounds) and are discarded.
-        const int row = i < D ? i : D - 1;
-        f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+        c0v = f32x4{0.f, 0.f, 0.f, 0.f};
+        c1v = ld4(P.ln_msg_b0[layer - 1] + 16 * wave + 4 * q);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            f32x4 wv = ld4(P.out_w6 + row * H + 16 * a + 4 * q);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) y = mfma16(wv[b], o2[a][b], y);
+            wcf[0][a] = ld4(w1n + (size_t)(16 * wave + i) * (3 * H) + 16 * a + 4 * q);
+            wcf[1][a] = ld4(w1n + (size_t)(16 * wave + i) * (3 * H) + H + 16 * a + 4 * q);
         }
-        // rows 0..D-1 of y sit in lanes q == 0, registers 0..D-1, for node (lane & 15)
-        if (q == 0 && node < n_nodes) {
-            float yl[D];
+    } else {
+        c0v = ld4(P.out_b0 + 16 * wave + 4 * q);
+        c1v = ld4(P.out_b3 + 16 * wave + 4 * q);
 #pragma unroll
-            for (int d = 0; d < D; ++d) yl[d] = y[d] + P.out_b6[d];
-            const float* ni = nodeinfo + node * NI::STRIDE;
+        for (int a = 0; a < 4; ++a) {
+            wcf[0][a] = ld4(P.out_w0 + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
+            wcf[1][a] = ld4(P.out_w3 + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
+            // last Linear has D (2|3) output rows: rows >= D of the 16-row block read row D-1 and are discarded
+            if (wave == 0) w6f[a] = ld4(P.out_w6 + (size_t)(i < D ? i : D - 1) * H + 16 * a + 4 * q);
+        }
+    }
+    if (nsave != nullptr && ok) st4(nsave + node * H + 16 * wave + 4 * q, n[wave]);
+    // ---- A
 #pragma unroll
-            for (int a = 0; a < D; ++a) {
-                float s = 0.f;
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * yl[b];   // R y
-                const float xn = pos[node * D + a] + s;
-                out[node * D + a] = xn;
-                if (vel_out) vel_out[node * D + a] = (xn - pos[node * D + a]) / dt;
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) u[m] = mfma16(w3f[m][a][b], n[a][b], u[m]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) st4(ubuf + i * LDUU + 16 * (2 * wave + m) + 4 * q, silu4(u[m]));
+    __syncthreads();
+    // ---- B
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const f32x4 uv = ld4(ubuf + i * LDUU + 16 * a + 4 * q);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xn = mfma16(w4f[a][b], uv[b], xn);
+    }
+    xn += n[wave];
+    st4(xbuf + i * LDW + 16 * wave + 4 * q, xn);
+    if (ok) st4(x_out + node * H + 16 * wave + 4 * q, xn);
+    __syncthreads();
+    // ---- C
+    f32x4 xv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) xv[a] = ld4(xbuf + i * LDW + 16 * a + 4 * q);
+    if constexpr (!LAST) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                c0v = mfma16(wcf[0][a][b], xv[a][b], c0v);
+                c1v = mfma16(wcf[1][a][b], xv[a][b], c1v);
+            }
+        if (ok) {
+            st4(Ps + node * H + 16 * wave + 4 * q, c0v);
+            st4(Pr + node * H + 16 * wave + 4 * q, c1v);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) c0v = mfma16(wcf[0][a][b], xv[a][b], c0v);
+        st4(ubuf + i * LDUU + 16 * wave + 4 * q, silu4(c0v));            // o1 (u is dead: all waves passed B)
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 ov = ld4(ubuf + i * LDUU + 16 * a + 4 * q);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) c1v = mfma16(wcf[1][a][b], ov[b], c1v);
+        }
+        st4(ubuf + i * LDUU + H + 16 * wave + 4 * q, silu4(c1v));        // o2
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 ov = ld4(ubuf + i * LDUU + H + 16 * a + 4 * q);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) y = mfma16(w6f[a][b], ov[b], y);
+            }
+            // rows 0..D-1 of y sit in lanes q == 0, registers 0..D-1, for node (lane & 15)
+            if (q == 0 && ok) {
+                float yl[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) yl[d] = y[d] + P.out_b6[d];
+                const float* ni = nodeinfo + node * NI::STRIDE;
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * yl[b];   // R y
+                    const float xnew = pos[node * D + a] + s;
+                    out[node * D + a] = xnew;
+                    if (vel_out) vel_out[node * D + a] = (xnew - pos[node * D + a]) / dt;
+                }
             }
         }
     }
