@@ -327,7 +327,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
 
     {
         ProfScope ps(K_NODE_PREP, st);
-        k_node_prep<D><<<dim3((unsigned)((Nn + 255) / 256)), dim3(256), 0, st>>>(P, x, vel, charges,
+        k_node_prep<D><<<dim3((unsigned)((Nn + 15) / 16)), dim3(64), 0, st>>>(P, x, vel, charges,
                                                                               nodeinfo, wp(W.x[0]), Nn);
     }
     const int64_t n_chunks = (E + 255) / 256;

@@ -5,71 +5,117 @@
 
 namespace {
 
-// ------------------------------------------------------------------ K0: per-node prep
-// field net (aether.py:108-134), frame R from velocity (geometry.py:7-73),
-// rel_feat = [0 | R^T v | R^T f] (aether.py:33-50), and x0 = layer_1.res(rel_feat)
-// (locs.py:214-218,240).  One thread per node; the weights are wave-uniform (scalar loads).
+// ------------------------------------------------------------------ K1: node preparation
+// Field query (aether.py:108-134), frame + canonical velocity / force (geometry.py:7-73,
+// aether.py:33-50) and x0 = layer_1.res(rel_feat) (locs.py:214-218) on the matrix core: a wave owns 16
+// nodes as the columns of its MFMA tiles; the three Linear layers of the field net chain in accumulator
+// layout, lanes q == 0 end up with the node's force and build its NodeInfo record, x0 is one more
+// tile product.  Every global load (inputs, the 2,080 field parameters, res weights) is issued up front.
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_node_prep(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
             const float* __restrict__ charges, float* __restrict__ nodeinfo,
             float* __restrict__ x0, int64_t n_nodes) {
     using NI = NodeInfo<D>;
     constexpr int FIN = 2 * D + 16;
-    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_nodes) return;
-    float z[FIN];
+    __shared__ float rel[16 * 8];                              // [node][cv | cf] for the x0 operand
+    const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+    const int64_t node = (int64_t)blockIdx.x * 16 + i;
+    const bool live = node < n_nodes;
+    const int64_t g = live ? node : n_nodes - 1;
+    float pz[D], vz[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) { z[d] = x[n * D + d]; z[D + d] = vel[n * D + d]; }
-    long ci = (long)(charges[n] + 1.0f);                      // aether.py:122-124 (truncation)
+    for (int d = 0; d < D; ++d) { pz[d] = x[g * D + d]; vz[d] = vel[g * D + d]; }
+    const float ch = charges[g];
+    // layer-1 operands: B = z[k][node], A = W0[16mb + i][k], k = 4s + q (FIN = 2D + 16 <= 24)
+    float zc[6][3], a1[2][6];
+#pragma unroll
+    for (int s4 = 0; s4 < 6; ++s4) {
+        const int k = 4 * s4 + q;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) zc[s4][c] = (k >= 2 * D && k < FIN) ? P.field_emb[c * 16 + (k - 2 * D)] : 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) a1[mb][s4] = k < FIN ? P.field_w0[(16 * mb + i) * FIN + k] : 0.0f;
+    }
+    f32x4 w2f[2][2], w4f[2], acc1[2], acc2[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        acc1[mb] = ld4(P.field_b0 + 16 * mb + 4 * q);
+        acc2[mb] = ld4(P.field_b2 + 16 * mb + 4 * q);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) w2f[mb][a] = ld4(P.field_w2 + (16 * mb + i) * 32 + 16 * a + 4 * q);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) w4f[a] = i < D ? ld4(P.field_w4 + i * 32 + 16 * a + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc3[r] = (4 * q + r < D) ? P.field_b4[4 * q + r] : 0.0f;
+    // x0 operands: A = W_res[16mb + i][D + k], k = 4s + q < 2D (the first D inputs of rel_feat are zero)
+    float ar[4][2];
+    f32x4 acc0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        acc0[mb] = ld4(P.l1_res_b + 16 * mb + 4 * q);
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4)
+            ar[mb][s4] = 4 * s4 + q < 2 * D ? P.l1_res_w[(16 * mb + i) * 3 * D + D + 4 * s4 + q] : 0.0f;
+    }
+    long ci = (long)(ch + 1.0f);                               // charge_to_index: (q + 1).long(), aether.py:122-124
     ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) z[2 * D + k] = P.field_emb[ci * 16 + k];
-    float h1[32], h2[32];
-#pragma unroll 4
-    for (int o = 0; o < 32; ++o) {
-        float s = P.field_b0[o];
+    for (int s4 = 0; s4 < 6; ++s4) {
+        const int k = 4 * s4 + q;
+        float zk = ci == 0 ? zc[s4][0] : (ci == 1 ? zc[s4][1] : zc[s4][2]);
 #pragma unroll
-        for (int k = 0; k < FIN; ++k) s += P.field_w0[o * FIN + k] * z[k];
-        h1[o] = silu(s);
+        for (int d = 0; d < D; ++d) { zk = k == d ? pz[d] : zk; zk = k == D + d ? vz[d] : zk; }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) acc1[mb] = mfma16(a1[mb][s4], zk, acc1[mb]);
     }
-#pragma unroll 4
-    for (int o = 0; o < 32; ++o) {
-        float s = P.field_b2[o];
+    f32x4 hh[2];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) s += P.field_w2[o * 32 + k] * h1[k];
-        h2[o] = silu(s);
-    }
-    float f[D], v[D];
+    for (int mb = 0; mb < 2; ++mb) hh[mb] = silu4(acc1[mb]);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        float s = P.field_b4[d];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int k = 0; k < 32; ++k) s += P.field_w4[d * 32 + k] * h2[k];
-        f[d] = s;
-        v[d] = z[D + d];
-    }
-    float R[D][D], cv[D], cf[D];
-    node_frame<D>(v, f, R, cv, cf);
-    float* ni = nodeinfo + n * NI::STRIDE;
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        ni[NI::P + d] = z[d]; ni[NI::V + d] = v[d]; ni[NI::F + d] = f[d];
-        ni[NI::CV + d] = cv[d]; ni[NI::CF + d] = cf[d];
+            for (int mb = 0; mb < 2; ++mb) acc2[mb] = mfma16(w2f[mb][a][b], hh[a][b], acc2[mb]);
 #pragma unroll
-        for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
-    }
-    // x0 = W_res [0 | cv | cf] + b_res
-    float* xo = x0 + n * H;
-#pragma unroll 4
-    for (int o = 0; o < H; ++o) {
-        float acc = P.l1_res_b[o];
+    for (int mb = 0; mb < 2; ++mb) hh[mb] = silu4(acc2[mb]);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            acc += P.l1_res_w[o * 3 * D + D + d] * cv[d];
-            acc += P.l1_res_w[o * 3 * D + 2 * D + d] * cf[d];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc3 = mfma16(w4f[a][b], hh[a][b], acc3);
+    // lanes q == 0: acc3[d] = force component d of node i -> frame + NodeInfo record
+    if (q == 0) {
+        float f[D], R[D][D], cv[D], cf[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) f[d] = acc3[d];
+        node_frame<D>(vz, f, R, cv, cf);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { rel[i * 8 + d] = cv[d]; rel[i * 8 + D + d] = cf[d]; }
+        if (live) {
+            float* ni = nodeinfo + node * NI::STRIDE;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                ni[NI::P + d] = pz[d]; ni[NI::V + d] = vz[d]; ni[NI::F + d] = f[d];
+                ni[NI::CV + d] = cv[d]; ni[NI::CF + d] = cf[d];
+#pragma unroll
+                for (int e = 0; e < D; ++e) ni[NI::R + d * D + e] = R[d][e];
+            }
         }
-        xo[o] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();                           // one wave: its LDS operations execute in order
+#pragma unroll
+    for (int s4 = 0; s4 < 2; ++s4) {
+        const int k = 4 * s4 + q;
+        const float rk = k < 2 * D ? rel[i * 8 + k] : 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc0[mb] = mfma16(ar[mb][s4], rk, acc0[mb]);
+    }
+    if (live) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) st4(x0 + node * H + 16 * mb + 4 * q, acc0[mb]);
     }
 }
 
