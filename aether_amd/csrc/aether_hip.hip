@@ -251,8 +251,6 @@ struct WsLayout {
 
 inline int bits_for(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
-int g_edge_variant = 1;       // aether_set_option("edge_variant", 0|1): 0 = weights in registers, 2 waves/SIMD;
-                              // 1 = weights re-read from LDS, 3 waves/SIMD, deferred stores (faster: 411 vs 457 us @2.5M edges)
 
 template <int D, int NW, int ROUNDS, bool KEEP>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
@@ -366,15 +364,11 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
             int64_t wgs = (n_tiles + 3) / 4;
             unsigned g = (unsigned)(wgs < 1024 ? wgs : 1024);
             ProfScope ps(K_EDGE_LN, st);
-            auto launch = [&](auto kern) {
-                // layer 4's messages are only needed as receiver sums (locs.py:190-193) unless kept
-                float* eo = (l == 4 && !keep) ? nullptr : wp(W.e[l - 1]);
-                kern<<<dim3(g), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2],
-                                                     P.ln_msg_b2[l - 2], wp(W.ps[l - 2]), wp(W.pr[l - 2]),
-                                                     wp(W.e[l - 2]), send_s, recv_s, gsel, wp(W.part), eo, E);
-            };
-            if (g_edge_variant == 1) launch(k_edge_layer<false>);
-            else launch(k_edge_layer<true>);
+            // layer 4's messages are only needed as receiver sums (locs.py:190-193) unless kept
+            float* eo = (l == 4 && !keep) ? nullptr : wp(W.e[l - 1]);
+            k_edge_layer<<<dim3(g), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2], P.ln_msg_b2[l - 2],
+                                                         wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), send_s,
+                                                         recv_s, gsel, wp(W.part), eo, E);
         }
         seg_mean(l);
         if (l < 4) {
@@ -614,11 +608,6 @@ int aether_set_option(const char* name, int value) {
     if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces
         if (value < 0) return fail(AETHER_EINVAL, "set_option: outer_defer_max_edges must be >= 0");
         g_outer_defer_max_edges = value;
-        return AETHER_OK;
-    }
-    if (!strcmp(name, "edge_variant")) {
-        if (value < 0 || value > 2) return fail(AETHER_EINVAL, "set_option: edge_variant must be 0..2");
-        g_edge_variant = value;
         return AETHER_OK;
     }
     return fail(AETHER_EINVAL, "set_option: unknown option");

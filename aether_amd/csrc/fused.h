@@ -196,7 +196,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     constexpr int THREADS = NW * 64;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
     constexpr int FIN = 2 * D + 16;
-    static_assert(NW == 8 || NW == 12, "waves 0-7 run the node phase; more waves only add edge-tile slots");
+    static_assert(NW == 8, "waves 0-7 run the node phase (12 and 16 waves per workgroup were measured: DESIGN.md 4.1)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wA = smem + L::WA;
     float* wB = smem + L::WB;
@@ -490,8 +490,6 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // layer 4 has no next edge layer: wsv / wrv carry the out-MLP fragments (out_w0, out_w3) instead
         // part 0: staged matrices; 1: W3; 2, 3: W4 halves; 4: W_s / W_r.  A wave spreads the parts over
         // its last tile (a burst of ~20 loads per wave blocks at issue until the L2 returns drain).
-        // With 12 waves (168 VGPRs) only parts 0 and 1 fit next to a tile; the rest follows the tile.
-        constexpr bool LATE = NW > 8;
         auto issue_loads = [&](int part) {
             if (part == 0 && layer < 4) {
                 const float* w1n = P.ln_msg_w0[layer - 1];
@@ -589,11 +587,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         auto back = [&](int r, const f32x4 (&h1)[4], bool last) {
             const int tile = NW * r + wave;
             f32x4 acc2[4];
-            if (last && !LATE) issue_loads(2);
+            if (last) issue_loads(2);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
             gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
-            if (last && !LATE) issue_loads(3);
+            if (last) issue_loads(3);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
             if (keep) {
@@ -631,7 +629,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (last && !LATE) issue_loads(4);
+            if (last) issue_loads(4);
         };
         {
             const int nvalid = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;    // wave-uniform
@@ -655,10 +653,6 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
             if (xch && nvalid == 0) receive_partner_rows();
-            if (LATE && nvalid > 0) {
-#pragma unroll
-                for (int part = 2; part < 5; ++part) issue_loads(part);
-            }
         }
         FUSED_STAMP(4 + 8 * (layer - 1) + 2);
         // ------------------------------------------------------------ node phase (locs.py:240-241)

@@ -267,15 +267,13 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
 // ------------------------------------------------------------------ K3: layers 2-4 edge kernel
 // e_l = SiLU(W2 SiLU(W_s x_s + W_r x_r + b1 + W_e e_{l-1}) + b2), locs.py:227-235 with the
 // node terms P_s = W_s x, P_r = W_r x + b1 gathered as the accumulator's initial value.
-// Weights are staged once per workgroup in LDS.  REGW: each wave keeps its MFMA A fragments of W_e
-// and W2 in registers (128 VGPRs, 2 waves per SIMD); otherwise the fragments are re-read from LDS
-// per tile (3 waves per SIMD).  Inputs of the next tile (indices two tiles ahead, gathered rows one
+// Weights are staged once per workgroup in LDS and their fragments re-read per tile (3 waves per SIMD;
+// keeping them in 128 registers at 2 waves per SIMD was 11 % slower).  Inputs of the next tile (indices two tiles ahead, gathered rows one
 // tile ahead) are in flight while the current tile's 128 MFMAs issue, and the finished tile is
 // stored one iteration late, right after the next loads are issued: LLVM waits vmcnt(0) whenever
 // loads and stores are both pending (they may retire out of order), so a store issued just before
 // the loop-top wait would expose its full write latency on every tile.
-template <bool REGW>
-__global__ void __launch_bounds__(256, REGW ? 2 : 3)
+__global__ void __launch_bounds__(256, 3)
 k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
              const float* __restrict__ b_msg2, const float* __restrict__ Ps,
              const float* __restrict__ Pr, const float* __restrict__ e_prev,
@@ -296,17 +294,7 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
     const int i = lane & 15, q = lane >> 4;
     const int64_t n_tiles = (n_edges + 15) / 16;
     const int64_t stride = (int64_t)gridDim.x * 4;
-    f32x4 wef[REGW ? 4 : 1][4], w2f[REGW ? 4 : 1][4], b2v[4];     // [a][mb] fragments
-    if constexpr (REGW) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                wef[a][mb] = ld4(we + (16 * mb + i) * LDW + 16 * a + 4 * q);
-                w2f[a][mb] = ld4(w2 + (16 * mb + i) * LDW + 16 * a + 4 * q);
-            }
-        }
-    }
+    f32x4 b2v[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) b2v[mb] = ld4(bias + 16 * mb + 4 * q);
 
@@ -346,57 +334,27 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
         kn = kn2;
         s1 = send_s[kn2];
         r1 = recv_s[kn2];
-        if constexpr (!REGW) {
-            if (e_out != nullptr && ko >= 0 && ko < n_edges) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) st4(e_out + ko * H + 16 * mb + 4 * q, eo[mb]);
-            }
-        }
-        if constexpr (REGW) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma16(wef[a][mb][b], bop[a][b], acc[mb]);
-        } else {
-            int z = 0;
-            asm volatile("" : "+v"(z));      // opaque offset: keeps the fragment reads inside the loop
-            gemm_tile<4, 4>(we + z, LDW, bop, acc, i, q);
-        }
-        f32x4 h1[4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
-        if constexpr (REGW) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc2[mb] = mfma16(w2f[a][mb][b], h1[a][b], acc2[mb]);
-        } else {
-            int z = 0;
-            asm volatile("" : "+v"(z));
-            gemm_tile<4, 4>(w2 + z, LDW, h1, acc2, i, q);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
-        if constexpr (REGW) {
-            if (e_out != nullptr && k < n_edges) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) st4(e_out + k * H + 16 * mb + 4 * q, eo[mb]);
-            }
-        } else {
-            ko = k;
-        }
-        tile_receiver_sums(eo, wst, gs, rcur, tile, part, i, q, lane);
-        rcur = rnext;
-    }
-    if constexpr (!REGW) {
         if (e_out != nullptr && ko >= 0 && ko < n_edges) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) st4(e_out + ko * H + 16 * mb + 4 * q, eo[mb]);
         }
+        int z = 0;
+        asm volatile("" : "+v"(z));      // opaque offset: keeps the fragment reads inside the loop
+        gemm_tile<4, 4>(we + z, LDW, bop, acc, i, q);
+        f32x4 h1[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
+        asm volatile("" : "+v"(z));
+        gemm_tile<4, 4>(w2 + z, LDW, h1, acc2, i, q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
+        ko = k;
+        tile_receiver_sums(eo, wst, gs, rcur, tile, part, i, q, lane);
+        rcur = rnext;
+    }
+    if (e_out != nullptr && ko >= 0 && ko < n_edges) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) st4(e_out + ko * H + 16 * mb + 4 * q, eo[mb]);
     }
 }
 

@@ -171,8 +171,7 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
 
 /*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
- * there are fewer groups than half the CUs; read by aether_graph_build), "edge_variant" 0|1
- * (streamed edge kernel: weights in registers | re-read from LDS with 3 waves per SIMD),
+ * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and
  * multiplies them in one launch when n_edges <= n, default 2^20; changes aether_workspace_bytes).
  */
