@@ -8,7 +8,8 @@
  * each one names the reference interface it replaces.  Plain pointers and sizes only:
  * every pointer is a DEVICE pointer (HIP) unless it says "host"; `stream` is a
  * hipStream_t passed as void*.  No call allocates, frees or synchronises except
- * aether_graph_build (which synchronises `stream` once to report bad indices).
+ * aether_graph_build (which synchronises `stream` to report bad indices and to size the
+ * fused kernel's groups on the host).
  * All functions return 0 on success, a negative AETHER_E* code on error;
  * aether_last_error() returns a host string for the calling thread's last error.
  */
