@@ -1,0 +1,93 @@
+"""End-to-end training parity: the runner's loop (forward, MSE loss, backward, Adam; experiments/lorentz/
+main.py:247-291) driven through the HIP module vs the same loop on the oracle with torch autograd on the
+CPU, from the same initial parameters; plus the error behaviour of the drop-in surface."""
+import ctypes as C
+
+import pytest
+import torch
+
+from conftest import load_state_dict, scale_rel_err
+from aether_amd import _lib
+from aether_amd.edges import get_edges
+from aether_amd.nn.state2state.aether import Aether
+from aether_amd.synthetic import make_batch
+from oracle import aether_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_five_adam_steps_track_the_oracle(D):
+    steps, lr = 5, 5e-4                                  # the runner's learning rate (main.py:33)
+    batches = [make_batch(8, 20, D, seed=200 + t) for t in range(steps)]
+    # --- oracle side: functional parameters + torch.optim.Adam on the CPU
+    sd = {k: v.clone().requires_grad_(True) for k, v in load_state_dict(D).items()}
+    opt_o = torch.optim.Adam(list(sd.values()), lr=lr)
+    losses_o = []
+    for b in batches:
+        opt_o.zero_grad()
+        out = O.aether_forward(sd, b["x"], b["vel"], b["edges"], b["edge_attr"], b["charges"])
+        loss = torch.nn.functional.mse_loss(out, b["target"])
+        loss.backward()
+        opt_o.step()
+        losses_o.append(float(loss.detach()))
+    # --- HIP module
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    m.load_state_dict(load_state_dict(D))
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    losses = []
+    for b in batches:
+        d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items() if k != "edges"}
+        edges = [e.cuda() for e in b["edges"]]
+        opt.zero_grad()
+        out = m(d["h"], d["x"], edges, d["vel"], d["edge_attr"], d["charges"])
+        loss = torch.nn.functional.mse_loss(out, d["target"])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    for a, b_ in zip(losses, losses_o):
+        assert abs(a - b_) <= 2e-5 * abs(b_), (losses, losses_o)
+    # Adam divides by sqrt(v): parameters whose gradient is ~0 amplify round-off, so compare the update
+    # of every tensor at the scale of the largest update (lr per step)
+    init = load_state_dict(D)
+    for k, p in m.state_dict().items():
+        upd, upd_o = p.cpu() - init[k], sd[k].detach() - init[k]
+        assert float((upd - upd_o).abs().max()) <= 0.05 * steps * lr, k
+        assert scale_rel_err(p.cpu(), sd[k].detach()) <= 1e-3, k
+
+
+def test_drop_in_error_behaviour():
+    D = 2
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    inp = make_batch(2, 5, D, seed=1, device="cuda")
+    args = lambda **kw: [kw.get(k, inp[k]) for k in ("h", "x", "edges", "vel", "edge_attr", "charges")]
+    with pytest.raises(_lib.AetherHipError, match="no CPU fallback"):
+        m(*args(x=inp["x"].cpu()))
+    with pytest.raises(TypeError):
+        m(*args(edges=[e.int() for e in inp["edges"]]))
+    with pytest.raises(ValueError):
+        m(*args(vel=inp["vel"][:-1]))
+    bad = [inp["edges"][0].clone(), inp["edges"][1].clone()]
+    bad[1][3] = inp["x"].shape[0]                       # receiver out of range
+    with pytest.raises(_lib.AetherHipError, match="outside"):
+        m(*args(edges=bad))
+    for ctor in (lambda: Aether(4, 32, 0.0, 2), lambda: Aether(4, 64, 0.1, 2), lambda: Aether(4, 64, 0.0, 4)):
+        with pytest.raises(ValueError):
+            ctor()
+    # C ABI: a workspace that is too small is refused, nothing is launched
+    lib = _lib.load()
+    send, recv = get_edges(2, 5, device="cuda")
+    graph, info = m.prepare_graph((send, recv), 10)
+    need = lib.aether_workspace_bytes(10, 40, D, 0)
+    ws = torch.empty(need - 256, dtype=torch.uint8, device="cuda")
+    out = torch.empty_like(inp["x"])
+    rc = lib.aether_forward(C.byref(m._param_struct()), D, 10, 40, inp["x"].data_ptr(), inp["vel"].data_ptr(),
+                            inp["charges"].data_ptr(), inp["edge_attr"].data_ptr(), graph.data_ptr(),
+                            C.byref(info), ws.data_ptr(), ws.numel(), out.data_ptr(), 0,
+                            torch.cuda.current_stream().cuda_stream)
+    assert rc == -4 and b"workspace" in lib.aether_last_error(), (rc, lib.aether_last_error())
+    rc = lib.aether_forward(C.byref(m._param_struct()), 4, 10, 40, inp["x"].data_ptr(), inp["vel"].data_ptr(),
+                            inp["charges"].data_ptr(), inp["edge_attr"].data_ptr(), graph.data_ptr(),
+                            C.byref(info), ws.data_ptr(), ws.numel(), out.data_ptr(), 0,
+                            torch.cuda.current_stream().cuda_stream)
+    assert rc == -1
