@@ -1,0 +1,87 @@
+"""world_size = 2 on ONE GPU (gloo): the HIP step under attach_data_parallel.  Each rank runs the module
+on its block of graphs; the all-reduced flat gradient buffer must equal the full-batch gradients of a
+single process, and both ranks must hold identical parameters after an optimizer step."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO, load_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aether_amd.edges import get_edges, prepare_edge_attr
+    from aether_amd.nn.state2state.aether import Aether
+    from aether_amd.parallel import attach_data_parallel, shard_graphs
+    from aether_amd.synthetic import make_batch
+    D, B, N = 2, 8, 20
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(100 + rank)                        # ranks start from different weights
+    m = Aether(2 * D, 64, 0.0, D, device=dev)
+    if rank == 0:
+        m.load_state_dict(load_state_dict(D))
+    attach_data_parallel(m)                              # broadcast from rank 0
+    full = make_batch(B, N, D, seed=9)
+    lo, hi = shard_graphs(B, rank, world)
+    sl = slice(lo * N, hi * N)
+    edges = get_edges(hi - lo, N, device=dev)
+    x, v, q_, tgt = (full[k][sl].to(dev) for k in ("x", "vel", "charges", "target"))
+    ea = prepare_edge_attr(x, edges, q_[edges[0]] * q_[edges[1]])
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    out = m(v.norm(dim=-1, keepdim=True), x, edges, v, ea, q_)
+    torch.nn.functional.mse_loss(out, tgt).backward()    # all-reduce + mean happen inside the backward
+    grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+    opt.step()
+    torch.cuda.synchronize()
+    params = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+    q.put((rank, grads, params, out.detach().cpu().numpy().copy(), (lo, hi)))      # numpy: pickled by value
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_on_one_gpu_match_single_process_gradients():
+    from aether_amd.nn.state2state.aether import Aether
+    from aether_amd.synthetic import make_batch
+    from conftest import scale_rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    D, B, N = 2, 8, 20
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    m.load_state_dict(load_state_dict(D))
+    full = make_batch(B, N, D, seed=9, device="cuda")
+    out = m(full["h"], full["x"], full["edges"], full["vel"], full["edge_attr"], full["charges"])
+    torch.nn.functional.mse_loss(out, full["target"]).backward()
+    for rank, grads, params, out_r, (lo, hi) in res:
+        assert torch.allclose(torch.from_numpy(out_r), out.detach().cpu()[lo * N:hi * N], atol=2e-6)   # no forward collective
+        for k, p in m.named_parameters():
+            assert scale_rel_err(torch.from_numpy(grads[k]), p.grad.cpu()) <= 5e-5, (rank, k)
+    for k in res[0][2]:
+        assert (res[0][2][k] == res[1][2][k]).all(), k                                      # replicas stay in sync
