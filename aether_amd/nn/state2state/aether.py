@@ -237,6 +237,7 @@ class Aether(nn.Module):
     def _apply(self, fn, *a, **k):
         self._pstruct = None              # parameter storage may move (.to / .cuda / .float)
         self._plist = None
+        self._gbuf = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -271,6 +272,8 @@ class Aether(nn.Module):
 
     def _grad_buffers(self):
         """Flat fp32 gradient buffer + an AetherParams struct and per-parameter views into it."""
+        if self._gbuf is not None and self._plist is not None and self._gbuf[0].device == self._plist[0].device:
+            return self._gbuf                 # parameter set and device unchanged (both reset _plist / _gbuf)
         named = list(self.named_parameters())
         total = sum(p.numel() for _, p in named)
         dev = named[0][1].device
@@ -313,11 +316,13 @@ class Aether(nn.Module):
             raise ValueError("edge index / edge_attr / charges shapes do not match")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         graph = self.prepare_graph((send, recv), n_nodes)
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self._plist is None:         # nn.Module.parameters() walks the module tree: 0.15 ms per call
+            self._plist = [p for _, p in self.named_parameters()]
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
         if not train:           # inference: no autograd node, no parameter list to marshal
             return _AetherStep.launch(self, False, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E)[0]
         return _AetherStep.apply(self, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E,
-                                 *self.parameters())
+                                 *self._plist)
 
     # -- device rollout ---------------------------------------------------------------
     @torch.no_grad()
