@@ -32,6 +32,8 @@
 #include "fused.h"
 #include "backward.h"
 
+#include <mutex>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -81,6 +83,19 @@ struct ProfScope {
     }
     ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st); }
 };
+
+// Kernels that use more than 64 KiB of dynamic LDS need an explicit opt-in, once per (kernel, device).
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& d : done) if (d.first == kernel && d.second == dev) return AETHER_OK;
+    HIP_OK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.emplace_back(kernel, dev);
+    return AETHER_OK;
+}
 
 // ------------------------------------------------------------------ graph build kernels
 __global__ void k_graph_keys(const int64_t* __restrict__ send, const int64_t* __restrict__ recv,
@@ -259,12 +274,7 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
                  int n_groups, const FusedDebug& dbg, float* out, hipStream_t st) {
     auto kern = k_fused<D, NW, ROUNDS, KEEP>;
     constexpr size_t lds = (size_t)FusedLds<NW, ROUNDS>::TOTAL * 4;
-    static bool attr_set = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
-    if (!attr_set) {
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return AETHER_EHIP;
     ProfScope ps(K_FUSED, st);
     kern<<<dim3((unsigned)n_groups), dim3(NW * 64), lds, st>>>(P, x, vel, charges, ea, perm, send_s, recv_s,
                                                               rowptr, wgdesc, tsel, tdst, dbg, out);
@@ -334,12 +344,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     const uint32_t* gsel = reinterpret_cast<const uint32_t*>(graph + G.gsel);
     if (E > 0) {
         const size_t lds1 = (size_t)(H * LDF + H * LDW + 2 * H + 4 * 64 * LDF) * 4;
-        static bool attr1 = false;
-        if (!attr1) {
-            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_layer1<D>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-            attr1 = true;
-        }
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_edge_layer1<D>), lds1)) return AETHER_EHIP;
         const int64_t n_wg1 = ((E + 63) / 64 + 3) / 4;
         unsigned g1 = (unsigned)(n_wg1 < 512 ? n_wg1 : 512);              // 2 workgroups per CU
         ProfScope ps(K_EDGE_L1, st);
@@ -461,13 +466,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     const int64_t ntile = (Nn + 15) / 16, etile = (E + 15) / 16;
     const unsigned ngrid = (unsigned)ntile;
     const unsigned egrid = (unsigned)((etile + 3) / 4 < 512 ? (etile + 3) / 4 : 512);    // 2 workgroups per CU
-    auto optin = [&](const void* k, size_t lds) -> int {     // once per kernel and process
-        static std::vector<const void*> done;
-        for (const void* d : done) if (d == k) return AETHER_OK;
-        HIP_OK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done.push_back(k);
-        return AETHER_OK;
-    };
+    auto optin = [&](const void* k, size_t lds) -> int { return ensure_dynamic_lds(k, lds); };
     // ---- transposed weight copies (one launch)
     BwdWT WT;
     {
