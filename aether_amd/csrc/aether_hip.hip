@@ -31,6 +31,7 @@
 #include "streamed.h"
 #include "fused.h"
 #include "backward.h"
+#include "seq2seq.h"
 
 #include <mutex>
 #include <utility>
@@ -597,6 +598,38 @@ extern "C" {
 
 const char* aether_version(void) { return "aether_hip 0.2 (gfx950, fp32 MFMA 16x16x4, fused + streamed)"; }
 const char* aether_last_error(void) { return g_err; }
+
+size_t aether_s2s_field_workspace_bytes(int64_t n_points, int hidden) {
+    if (n_points <= 0 || hidden <= 0) return 0;
+    return (size_t)3 * (size_t)n_points * (size_t)hidden * sizeof(float) + 768;
+}
+
+int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, int64_t n_points, const float* x,
+                     int x_stride, void* workspace, size_t workspace_bytes, float* field, void* stream) {
+    if (!p || !x || !workspace || !field || !p->B || !p->w0 || !p->b0 || !p->w2 || !p->b2 || !p->w4 || !p->b4)
+        return fail(AETHER_EINVAL, "s2s_field: null pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_field: num_dims must be 2 or 3");
+    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "s2s_field: hidden must be a multiple of 32");
+    if (n_points <= 0 || x_stride < num_dims) return fail(AETHER_EINVAL, "s2s_field: bad sizes");
+    if (workspace_bytes < aether_s2s_field_workspace_bytes(n_points, hidden))
+        return fail(AETHER_ESPACE, "s2s_field: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plane = align_up((size_t)n_points * hidden * sizeof(float), 256);
+    float* gamma = reinterpret_cast<float*>(workspace);
+    float* h1 = reinterpret_cast<float*>((char*)workspace + plane);
+    float* h2 = reinterpret_cast<float*>((char*)workspace + 2 * plane);
+    const int half = hidden / 2;
+    const unsigned rb = (unsigned)((n_points * half + 255) / 256);
+    if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
+    else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
+    const dim3 gh((unsigned)((n_points + 63) / 64), (unsigned)((hidden + 63) / 64));
+    k_s2s_linear<true><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, n_points, hidden);
+    k_s2s_linear<true><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, n_points, hidden);
+    const dim3 go((unsigned)((n_points + 63) / 64), 1);
+    k_s2s_linear<false><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, n_points, num_dims);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
 
 int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");

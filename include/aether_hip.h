@@ -171,6 +171,28 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
                            const void* workspace, float* dst, void* stream);
 
 /*
+ * seq2seq Aether, field query: replaces Aether.predict_field
+ * (nn/seq2seq/aether.py:86-90) = FourierFeatureMapper (nn/nn/fourier_feature_mapper.py:7-21) followed by
+ * field_net (aether.py:72-78).  Unlike the state2state field it sees positions only.
+ *   B      : float[D][hidden/2]    buffer coordinate_embedding.B
+ *   w0..b4 : field_net.{0,2,4}.{weight,bias}: [h][h],[h],[h][h],[h],[D][h],[D]
+ *   x      : float[n_points][x_stride], the first D columns are the coordinates (x[..., :D], :87)
+ *   field  : float[n_points][D]
+ *   workspace : aether_s2s_field_workspace_bytes(n_points, hidden) bytes
+ * Stream-ordered; four launches (features, three Linear layers on the matrix core).
+ */
+typedef struct AetherS2SFieldParams {
+    const float* B;
+    const float* w0; const float* b0;
+    const float* w2; const float* b2;
+    const float* w4; const float* b4;
+} AetherS2SFieldParams;
+size_t aether_s2s_field_workspace_bytes(int64_t n_points, int hidden);
+int aether_s2s_field(const AetherS2SFieldParams* params, int num_dims, int hidden, int64_t n_points,
+                     const float* x, int x_stride, void* workspace, size_t workspace_bytes, float* field,
+                     void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the seq2seq field query from the imported reference.
+
+TEST INFRASTRUCTURE ONLY; runs in the build container where /root/reference is mounted.  Imported,
+unmodified: ``nn.nn.fourier_feature_mapper.FourierFeatureMapper`` (its ``B`` buffer and forward).
+``field_net`` is the plain ``torch.nn.Sequential`` the reference builds inline in
+``nn/seq2seq/aether.py:72-78`` (constructing the whole seq2seq ``Aether`` needs a params dictionary of
+~40 flags and torch_scatter; the five-layer Sequential itself is generic torch) -- created here under
+``torch.manual_seed(SEED)`` in the same order, so the tests can recreate the identical parameters
+from the seed; a checksum of every tensor is stored to detect drift.  Positions are a batch of
+trajectories ``[B, N, T, 2D]`` as ``predict_field`` receives them in ``predict_future`` (:161-162).
+
+Usage:  python oracle/make_golden_seq2seq.py [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+from torch import nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("AETHER_REFERENCE", "/root/reference")
+SEED, HIDDEN = 1234, 512
+
+
+def build_reference_field(num_dims: int):
+    sys.path.insert(0, REF)
+    from nn.nn.fourier_feature_mapper import FourierFeatureMapper          # the reference class
+    torch.manual_seed(SEED)
+    field_net = nn.Sequential(nn.Linear(HIDDEN, HIDDEN), nn.SiLU(), nn.Linear(HIDDEN, HIDDEN), nn.SiLU(),
+                              nn.Linear(HIDDEN, num_dims))                   # aether.py:72-78
+    emb = FourierFeatureMapper(num_dims, HIDDEN // 2, std=1.0)              # aether.py:83-84
+    return field_net, emb
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    args = ap.parse_args()
+    for D in (2, 3):
+        field_net, emb = build_reference_field(D)
+        g = torch.Generator().manual_seed(77 + D)
+        x = torch.randn(3, 5, 7, 2 * D, generator=g) * 1.5                   # [B, N, T, pos | vel]
+        with torch.no_grad():
+            coords = x[..., :D]                                               # aether.py:87
+            rff = emb(coords)                                                 # :88
+            field = field_net(rff)                                            # :89
+            field64 = field_net.double()(emb.double()(coords.double()))
+        sd = {"coordinate_embedding.B": emb.B}
+        sd.update({"field_net." + k: v for k, v in field_net.float().state_dict().items()})
+        out = {"in.x": x.numpy(), "ref.rff": rff.numpy(), "ref.field": field.numpy(),
+               "ref64.field": field64.numpy(), "B": emb.B.numpy(), "seed": np.int64(SEED),
+               "hidden": np.int64(HIDDEN)}
+        for k, v in sd.items():
+            out["sum." + k] = np.float64(v.double().sum().item())
+            out["abs." + k] = np.float64(v.double().abs().sum().item())
+        np.savez(os.path.join(args.out, f"s2s_field_D{D}.npz"), **out)
+        print("wrote s2s_field_D%d.npz" % D, {k: tuple(v.shape) for k, v in sd.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -47,3 +47,21 @@ def scale_rel_err(a, b):
 
 CASES = ["B1N5", "B3N5", "B2N20", "B2N2", "sparse"]
 GRAD_CASES = ["B3N5", "B2N20", "sparse"]
+
+
+def load_s2s_field(D):
+    """Golden fixture of the seq2seq field query (oracle/make_golden_seq2seq.py) + its parameters,
+    recreated from the stored seed exactly as the generator made them (checksums verified)."""
+    import numpy as _np
+    import torch as _torch
+    from torch import nn as _nn
+    d = _np.load(os.path.join(GOLDEN, f"s2s_field_D{D}.npz"))
+    hidden = int(d["hidden"])
+    _torch.manual_seed(int(d["seed"]))
+    net = _nn.Sequential(_nn.Linear(hidden, hidden), _nn.SiLU(), _nn.Linear(hidden, hidden), _nn.SiLU(),
+                         _nn.Linear(hidden, D))
+    sd = {"coordinate_embedding.B": _torch.from_numpy(d["B"])}
+    sd.update({"field_net." + k: v.detach() for k, v in net.state_dict().items()})
+    for k, v in sd.items():
+        assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
+    return d, sd

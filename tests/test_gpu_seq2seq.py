@@ -1,0 +1,49 @@
+"""seq2seq Aether, row A8: the HIP field query vs the golden vectors captured from the reference and
+vs the oracle on fresh inputs."""
+import pytest
+import torch
+
+from conftest import load_s2s_field, scale_rel_err
+from aether_amd.nn.seq2seq.field import FieldQuery
+from oracle import seq2seq_oracle as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _module(D, sd, hidden):
+    m = FieldQuery(D, hidden, 1.0, device="cuda")
+    missing = m.load_state_dict(sd, strict=True)
+    return m
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_field_query_matches_reference(D):
+    d, sd = load_s2s_field(D)
+    m = _module(D, sd, int(d["hidden"]))
+    assert list(m.state_dict().keys()) == ["field_net.0.weight", "field_net.0.bias", "field_net.2.weight",
+                                           "field_net.2.bias", "field_net.4.weight", "field_net.4.bias",
+                                           "coordinate_embedding.B"]                     # reference key order
+    x = torch.from_numpy(d["in.x"]).cuda()
+    field, coords = m(x)
+    assert field.shape == x.shape[:-1] + (D,) and torch.equal(coords, x[..., :D])
+    ref, ref64 = torch.from_numpy(d["ref.field"]), torch.from_numpy(d["ref64.field"]).float()
+    assert scale_rel_err(field.cpu(), ref) <= TOL
+    # not further from the fp64 evaluation of the reference than the reference's own fp32 run (x2)
+    assert scale_rel_err(field.cpu(), ref64) <= max(2 * scale_rel_err(ref, ref64), 2e-6)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_field_query_fresh_inputs_and_ragged_sizes(D):
+    d, sd = load_s2s_field(D)
+    m = _module(D, sd, int(d["hidden"]))
+    g = torch.Generator().manual_seed(5)
+    for shape in [(1, D), (63, 2 * D), (4, 20, 49, 2 * D), (130, 2 * D), (0, 2 * D)]:
+        x = torch.randn(*shape, generator=g) * 2.0
+        field, _ = m(x.cuda())
+        want = S.predict_field(sd, x, D)
+        assert field.shape == want.shape
+        if x.numel():
+            assert scale_rel_err(field.cpu(), want) <= TOL, shape
+    with pytest.raises(Exception):
+        m(torch.zeros(3, 2 * D))                      # CPU tensor: no fallback

@@ -76,7 +76,7 @@ def test_cpu_tensor_fails_loudly():
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports what include/aether_hip.h declares."""
     hdr = open(os.path.join(REPO, "include", "aether_hip.h")).read()
-    declared = set(re.findall(r"\b(aether_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(aether_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()

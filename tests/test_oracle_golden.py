@@ -140,3 +140,19 @@ def test_frame_maps_axis_to_heading(D):
     axis = R[..., :, 0] if D == 2 else R[..., :, 2]
     # 3-D: acos(z/(rho+1e-7)) carries the reference's EPS, so ~1e-7/rho_min slack
     assert torch.allclose(axis, v / v.norm(dim=-1, keepdim=True), atol=1e-5)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_seq2seq_field(D):
+    """Row A8: Fourier features + field MLP of the seq2seq model vs the imported reference."""
+    from conftest import load_s2s_field
+    from oracle import seq2seq_oracle as S
+    d, sd = load_s2s_field(D)
+    x = torch.from_numpy(d["in.x"])
+    assert torch.equal(S.rff_matrix(D, int(d["hidden"]) // 2), sd["coordinate_embedding.B"])
+    rff = S.fourier_features(x[..., :D], sd["coordinate_embedding.B"])
+    assert scale_rel_err(rff, torch.from_numpy(d["ref.rff"])) <= 1e-6
+    field = S.predict_field(sd, x, D)
+    assert scale_rel_err(field, torch.from_numpy(d["ref.field"])) <= 1e-6
+    sd64 = {k: v.double() for k, v in sd.items()}
+    assert scale_rel_err(S.predict_field(sd64, x.double(), D), torch.from_numpy(d["ref64.field"])) <= 1e-12

@@ -10,7 +10,7 @@ sys.path.insert(0, REPO)
 from aether_amd import build as B, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--dims", type=int, default=2); ap.add_argument("--batch", type=int, default=128)
-ap.add_argument("--nodes", type=int, default=20)
+ap.add_argument("--nodes", type=int, default=20); ap.add_argument("--keep", action="store_true", help="time the save-for-backward variant")
 a = ap.parse_args()
 _lib.LIB_PATH = B.build_diagnostic()
 from aether_amd.nn.state2state.aether import Aether
@@ -19,6 +19,8 @@ torch.manual_seed(1)
 with contextlib.redirect_stdout(io.StringIO()):
     m = Aether(2 * a.dims, 64, 0.0, a.dims, device="cuda")
 inp = make_batch(a.batch, a.nodes, a.dims, seed=0, device="cuda")
+if a.keep:
+    m.flags = _lib.FLAG_KEEP_INTERMEDIATES
 Nn, E = inp["x"].shape[0], inp["edges"][0].numel()
 with torch.no_grad():
     for _ in range(20):
