@@ -622,11 +622,11 @@ int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, in
     const unsigned rb = (unsigned)((n_points * half + 255) / 256);
     if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
-    const dim3 gh((unsigned)((n_points + 63) / 64), (unsigned)((hidden + 63) / 64));
-    k_s2s_linear<true><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, n_points, hidden);
-    k_s2s_linear<true><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, n_points, hidden);
+    const dim3 gh((unsigned)((n_points + 63) / 64), (unsigned)((hidden + 127) / 128));
+    k_s2s_linear<true, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, n_points, hidden);
+    k_s2s_linear<true, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, n_points, hidden);
     const dim3 go((unsigned)((n_points + 63) / 64), 1);
-    k_s2s_linear<false><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, n_points, num_dims);
+    k_s2s_linear<false, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, n_points, num_dims);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }

@@ -5,8 +5,8 @@
 // MFMA-bound (1.05 MFLOP per point).  Activations are point-major [N][h], which is at once the
 // B-operand layout (k = 16a + 4q + b: one 16-byte load feeds four k-steps) and, transposed back by the
 // store, the accumulator layout -- the same trick as the rest of the library, so no LDS is needed:
-// a wave owns a 32 x 32 output block (2 x 2 MFMA tiles), reads W and X fragments straight from L2 one
-// k-group ahead, and issues 16 MFMAs per four 1-KiB loads.
+// a wave owns a 64 x 32 output block (4 x 2 MFMA tiles), reads W and X fragments straight from L2 two
+// k-groups ahead, and issues 32 MFMAs per six 1-KiB loads.
 #pragma once
 #include "common.h"
 
@@ -31,57 +31,80 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
 }
 
 // Y[n][m] = act(sum_k W[m][k] X[n][k] + b[m]); W [M][K] row-major (nn.Linear), X [N][K], Y [N][ldy].
-// K % 16 == 0.  grid = (ceil(N / 64), ceil(M / 64)), 4 waves = 2 (m) x 2 (n) blocks of 32 x 32.
-template <bool SILU>
+// K % 16 == 0.  grid = (ceil(N / 64), ceil(M / (32 MT))), 4 waves = 2 (m) x 2 (n); a wave owns
+// MT x 2 MFMA tiles (16 MT rows x 32 points) and keeps the fragments of the next PF k-groups in flight
+// (4 waves per SIMD at MT = 4: the kernel is bound by the latency of its L2 reads, occupancy matters
+// more than a deeper ring or whole-line fragment pairs -- both were measured slower).
+template <bool SILU, int MT>
 __global__ void __launch_bounds__(256)
 k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ X,
              float* __restrict__ Y, int M, int K, int64_t N, int ldy) {
+    constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int m0 = (int)blockIdx.y * 64 + 32 * (wave >> 1);
+    const int m0 = (int)blockIdx.y * (32 * MT) + 16 * MT * (wave >> 1);
     const int64_t n0 = (int64_t)blockIdx.x * 64 + 32 * (wave & 1);
     if (m0 >= M || n0 >= N) return;
     // rows / points past the end are clamped for the loads and masked at the store
-    const float* wrow[2];
+    const float* wrow[MT];
     const float* xrow[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < MT; ++t) {
         const int m = m0 + 16 * t + i;
-        const int64_t n = n0 + 16 * t + i;
         wrow[t] = W + (size_t)(m < M ? m : M - 1) * K + 4 * q;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t n = n0 + 16 * t + i;
         xrow[t] = X + (size_t)(n < N ? n : N - 1) * K + 4 * q;
     }
-    f32x4 acc[2][2];
+    f32x4 acc[MT][2];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < MT; ++mb) {
         f32x4 b4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int m = m0 + 16 * mb + 4 * q + r; b4[r] = m < M ? bias[m] : 0.0f; }
         acc[mb][0] = b4; acc[mb][1] = b4;
     }
-    f32x4 wv[2], xv[2], wn[2], xn[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { wv[t] = ld4(wrow[t]); xv[t] = ld4(xrow[t]); }
     const int steps = K >> 4;
-    for (int a = 0; a < steps; ++a) {
-        const int an = a + 1 < steps ? a + 1 : a;
+    f32x4 wq[PF][MT], xq[PF][2];                      // ring of prefetched fragments
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { wn[t] = ld4(wrow[t] + 16 * an); xn[t] = ld4(xrow[t] + 16 * an); }
+    for (int p = 0; p < PF; ++p) {
+        const int a = p < steps ? p : steps - 1;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * a);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+        for (int t = 0; t < 2; ++t) xq[p][t] = ld4(xrow[t] + 16 * a);
+    }
+    for (int a0 = 0; a0 < steps; a0 += PF) {
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma16(wv[mb][b], xv[nb][b], acc[mb][nb]);
+        for (int p = 0; p < PF; ++p) {
+            if (a0 + p < steps) {
+                f32x4 wv[MT], xv[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { wv[t] = wn[t]; xv[t] = xn[t]; }
+                for (int t = 0; t < MT; ++t) wv[t] = wq[p][t];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) xv[t] = xq[p][t];
+                const int an = a0 + p + PF < steps ? a0 + p + PF : steps - 1;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * an);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) xq[p][t] = ld4(xrow[t] + 16 * an);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma16(wv[mb][b], xv[nb][b], acc[mb][nb]);
+            }
+        }
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int64_t n = n0 + 16 * nb + i;
         if (n >= N) continue;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < MT; ++mb) {
             const int m = m0 + 16 * mb + 4 * q;
             f32x4 v = acc[mb][nb];
             if (SILU) v = silu4(v);
