@@ -631,6 +631,29 @@ int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, in
     return AETHER_OK;
 }
 
+int aether_s2s_localize(int num_dims, int64_t n_nodes, int64_t n_edges, const float* x, const int64_t* send,
+                        const int64_t* recv, int polar, float* rel_feat, float* Rinv, float* edge_attr,
+                        float* edge_pos, void* stream) {
+    if (!x || !rel_feat || !Rinv) return fail(AETHER_EINVAL, "s2s_localize: null pointer");
+    if (n_edges > 0 && (!send || !recv || !edge_attr || !edge_pos))
+        return fail(AETHER_EINVAL, "s2s_localize: null edge pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_localize: num_dims must be 2 or 3");
+    if (n_nodes <= 0 || n_edges < 0) return fail(AETHER_EINVAL, "s2s_localize: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = (unsigned)((n_nodes + 255) / 256), eb = (unsigned)((n_edges + 255) / 256);
+    if (num_dims == 2) {
+        k_s2s_aug_nodes<2><<<dim3(nb), dim3(256), 0, st>>>(x, rel_feat, Rinv, n_nodes);
+        if (n_edges > 0)
+            k_s2s_aug_edges<2><<<dim3(eb), dim3(256), 0, st>>>(x, send, recv, rel_feat, polar, edge_attr, edge_pos, n_edges);
+    } else {
+        k_s2s_aug_nodes<3><<<dim3(nb), dim3(256), 0, st>>>(x, rel_feat, Rinv, n_nodes);
+        if (n_edges > 0)
+            k_s2s_aug_edges<3><<<dim3(eb), dim3(256), 0, st>>>(x, send, recv, rel_feat, polar, edge_attr, edge_pos, n_edges);
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
 int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");
     if (!strcmp(name, "fused_split")) {      // takes effect at the next aether_graph_build

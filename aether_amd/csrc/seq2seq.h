@@ -119,3 +119,149 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
 }
 
 }  // namespace
+
+// =====================================================================================================
+// Row A9: augmented local frames of the seq2seq model
+//   AugmentedLocalizer.forward            nn/utils/augmented_global_to_local.py:52-68
+//   canonicalize_augmented_inputs         nn/utils/canonicalization.py:33-56
+//   create_augmented_edge_attr_pos_vel    canonicalization.py:111-140 (2-D), :143-172 (3-D)
+//   angle helpers                         nn/utils/geometry.py:7-66,76-127
+// Per node: canonical state, frame Rinv and the features of the edge from the virtual origin node
+// (pos 0, vel e1, force 0: augmented_global_to_local.py:41).  Per edge j -> i: the features in i's
+// frame followed by the receiver's node row.  Element-wise work with a handful of transcendentals per
+// item: a thread per node / edge, every output row written contiguously (HBM-bound: 4 (2 NF + 3 D)
+// bytes of output per edge against two node rows that stay in L2).
+namespace {
+
+constexpr float PI_S2S = 3.14159274101257324219f;         // float32(pi), as the reference's fp32 ops see it
+constexpr float TWO_PI_A9 = 6.28318548202514648438f;
+
+template <int D> struct AugDims {
+    static constexpr int O = D * (D - 1) / 2, NF = 4 * D + O, RF = 3 * D + NF, EA = NF + RF, EP = D + O;
+};
+
+// rho, theta in [0, 2 pi), phi of a 3-vector (geometry.py:37-66, symmetric_theta = False)
+__device__ __forceinline__ void spherical3(const float* v, float& rho, float& theta, float& phi) {
+    rho = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    theta = atan2f(v[1], v[0]);
+    if (theta < 0.0f) theta += TWO_PI_A9;
+    phi = acosf(fminf(fmaxf(v[2] / (rho + 1e-7f), -1.0f), 1.0f));
+}
+__device__ __forceinline__ void rot3(float theta, float phi, float (&R)[3][3]) {      // geometry.py:24-34
+    const float c = cosf(theta), s = sinf(theta), cp = cosf(phi), sp = sinf(phi);
+    R[0][0] = cp * c; R[0][1] = -s;  R[0][2] = sp * c;
+    R[1][0] = cp * s; R[1][1] = c;   R[1][2] = sp * s;
+    R[2][0] = -sp;    R[2][1] = 0.f; R[2][2] = cp;
+}
+
+// features of the edge j -> i in i's frame; xj, xi = [pos | vel | force]
+template <int D>
+__device__ __forceinline__ void aug_edge(const float* xj, const float* xi, float* o) {
+    if constexpr (D == 2) {
+        const float yaw_i = atan2f(xi[3], xi[2]);
+        const float c = cosf(yaw_i), s = sinf(yaw_i);                  // r = R(yaw_i)^T = [[c, s], [-s, c]]
+        const float dx = xj[0] - xi[0], dy = xj[1] - xi[1];
+        float dyaw = atan2f(xj[3], xj[2]) - yaw_i;                     // angle_diff, geometry.py:116-127
+        if (dyaw >= PI_S2S) dyaw -= TWO_PI_A9;
+        if (dyaw < -PI_S2S) dyaw += TWO_PI_A9;
+        float dth = atan2f(dy, dx) - yaw_i;                            // wrap_angles(normalize=True), :108-113
+        if (dth <= -PI_S2S) dth += TWO_PI_A9;
+        if (dth > PI_S2S) dth -= TWO_PI_A9;
+        o[0] = c * dx + s * dy; o[1] = -s * dx + c * dy;
+        o[2] = dyaw / PI_S2S;
+        o[3] = sqrtf(dx * dx + dy * dy);
+        o[4] = dth / PI_S2S;
+        o[5] = c * xj[2] + s * xj[3]; o[6] = -s * xj[2] + c * xj[3];
+        o[7] = c * xj[4] + s * xj[5]; o[8] = -s * xj[4] + c * xj[5];
+    } else {
+        float rho, yj, pj, yi, pi_;
+        spherical3(xj + 3, rho, yj, pj);
+        spherical3(xi + 3, rho, yi, pi_);
+        float Ri[3][3], Rj[3][3];
+        rot3(yi, pi_, Ri);
+        rot3(yj, pj, Rj);
+        const float dp[3] = {xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2]};
+        // M = Ri^T Rj^T (canonicalization.py:153-154: the sender matrix is transposed as well)
+        auto Mel = [&](int a, int b) { return Ri[0][a] * Rj[b][0] + Ri[1][a] * Rj[b][1] + Ri[2][a] * Rj[b][2]; };
+        float rdp[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            rdp[a] = Ri[0][a] * dp[0] + Ri[1][a] * dp[1] + Ri[2][a] * dp[2];
+            o[a] = rdp[a];
+            o[9 + a] = Ri[0][a] * xj[3] + Ri[1][a] * xj[4] + Ri[2][a] * xj[5];
+            o[12 + a] = Ri[0][a] * xj[6] + Ri[1][a] * xj[7] + Ri[2][a] * xj[8];
+        }
+        o[3] = atan2f(Mel(1, 0), Mel(0, 0));                           // ZYX, not normalised (geometry.py:87-100)
+        o[4] = asinf(-Mel(2, 0));
+        o[5] = atan2f(Mel(2, 1), Mel(2, 2));
+        float dth, dph;
+        spherical3(dp, o[6], dth, dph);                                // node distance
+        spherical3(rdp, rho, o[7], o[8]);
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+k_s2s_aug_nodes(const float* __restrict__ x, float* __restrict__ rel_feat, float* __restrict__ Rinv,
+                int64_t n_nodes) {
+    using A = AugDims<D>;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_nodes) return;
+    float xi[3 * D];
+#pragma unroll
+    for (int t = 0; t < 3 * D; ++t) xi[t] = x[n * 3 * D + t];
+    float row[A::RF];
+    float R[D][D];
+    if constexpr (D == 2) {
+        const float ang = atan2f(xi[3], xi[2]);
+        const float c = cosf(ang), s = sinf(ang);
+        R[0][0] = c; R[0][1] = -s; R[1][0] = s; R[1][1] = c;
+        row[0] = 0.f; row[1] = 0.f; row[2] = sqrtf(xi[2] * xi[2] + xi[3] * xi[3]); row[3] = 0.f;
+        row[4] = c * xi[4] + s * xi[5]; row[5] = -s * xi[4] + c * xi[5];
+    } else {
+        float rho, th, ph;
+        spherical3(xi + 3, rho, th, ph);
+        rot3(th, ph, R);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            row[a] = 0.f;
+            row[3 + a] = R[0][a] * xi[3] + R[1][a] * xi[4] + R[2][a] * xi[5];
+            row[6 + a] = R[0][a] * xi[6] + R[1][a] * xi[7] + R[2][a] * xi[8];
+        }
+    }
+    float origin[3 * D];
+#pragma unroll
+    for (int t = 0; t < 3 * D; ++t) origin[t] = t == D ? 1.0f : 0.0f;
+    aug_edge<D>(origin, xi, row + 3 * D);
+#pragma unroll
+    for (int t = 0; t < A::RF; ++t) rel_feat[n * A::RF + t] = row[t];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) Rinv[n * D * D + a * D + b] = R[a][b];
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, const int64_t* __restrict__ recv,
+                const float* __restrict__ rel_feat, int polar, float* __restrict__ edge_attr,
+                float* __restrict__ edge_pos, int64_t n_edges) {
+    using A = AugDims<D>;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t j = send[e], i = recv[e];
+    float xj[3 * D], xi[3 * D], o[A::NF];
+#pragma unroll
+    for (int t = 0; t < 3 * D; ++t) { xj[t] = x[j * 3 * D + t]; xi[t] = x[i * 3 * D + t]; }
+    aug_edge<D>(xj, xi, o);
+    float* out = edge_attr + e * A::EA;
+#pragma unroll
+    for (int t = 0; t < A::NF; ++t) out[t] = o[t];
+#pragma unroll
+    for (int t = 0; t < A::RF; ++t) out[A::NF + t] = rel_feat[i * A::RF + t];
+    const int p0 = polar ? (D == 2 ? 2 : 3) : 0;                      // augmented_global_to_local.py:19-24
+#pragma unroll
+    for (int t = 0; t < A::EP; ++t) edge_pos[e * A::EP + t] = o[p0 + t];
+}
+
+}  // namespace

@@ -193,6 +193,24 @@ int aether_s2s_field(const AetherS2SFieldParams* params, int num_dims, int hidde
                      void* stream);
 
 /*
+ * seq2seq Aether, augmented local frames: replaces AugmentedLocalizer.forward
+ * (nn/utils/augmented_global_to_local.py:52-68; canonicalize_augmented_inputs and
+ * create_augmented[_3d]_edge_attr_pos_vel, nn/utils/canonicalization.py:33-56,111-172) on a flattened
+ * batch: nodes of all graphs in one array, edges as global node indices (no out-of-range check).
+ *   x         : float[n_nodes][3D]           pos | vel | force
+ *   send/recv : int64[n_edges]               edge j -> i, features in i's frame
+ *   polar     : 1 = pos_representation 'polar', 0 = 'cart' (columns picked for edge_pos, :19-24)
+ *   rel_feat  : float[n_nodes][7D+O]         canonical state | features of the edge from the virtual origin node
+ *   Rinv      : float[n_nodes][D][D]         un-transposed frame, as the reference returns it
+ *   edge_attr : float[n_edges][2(4D+O)+3D]   edge features | rel_feat[recv]      (24 | 39 columns)
+ *   edge_pos  : float[n_edges][D+O]
+ * O = D(D-1)/2.  Stream-ordered; two launches.
+ */
+int aether_s2s_localize(int num_dims, int64_t n_nodes, int64_t n_edges, const float* x,
+                        const int64_t* send, const int64_t* recv, int polar, float* rel_feat,
+                        float* Rinv, float* edge_attr, float* edge_pos, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

@@ -62,5 +62,35 @@ def main():
         print("wrote s2s_field_D%d.npz" % D, {k: tuple(v.shape) for k, v in sd.items()})
 
 
+def localizer_fixtures(out_dir):
+    """Row A9: the imported reference AugmentedLocalizer on random states and on degenerate ones."""
+    sys.path.insert(0, REF)
+    from nn.utils.augmented_global_to_local import AugmentedLocalizer
+    for use_3d in (False, True):
+        D = 3 if use_3d else 2
+        for rep in ("polar", "cart"):
+            g = torch.Generator().manual_seed(300 + D)
+            B, N = 3, 6
+            x = torch.randn(B, N, 3 * D, generator=g)
+            x[..., :D] *= 2.0
+            # degenerate rows: axis-aligned / opposite velocities (angle wraps), a tiny velocity
+            x[0, 0, D:2 * D] = torch.tensor([1.0, 0.0, 0.0][:D])
+            x[0, 1, D:2 * D] = torch.tensor([-1.0, 0.0, 0.0][:D])
+            x[0, 2, D:2 * D] = torch.tensor([-1.0, -1e-8, 0.0][:D])
+            x[1, 0, D:2 * D] = 1e-6 * x[1, 0, D:2 * D]
+            loc = AugmentedLocalizer(N, use_3d=use_3d, pos_representation=rep)
+            with torch.no_grad():
+                rel_feat, Rinv, edge_attr, edge_pos = loc(x)
+                r64 = [t.numpy() for t in AugmentedLocalizer(N, use_3d=use_3d, pos_representation=rep)(x.double())]
+            np.savez(os.path.join(out_dir, f"s2s_localizer_D{D}_{rep}.npz"), **{
+                "in.x": x.numpy(), "ref.rel_feat": rel_feat.numpy(), "ref.Rinv": Rinv.numpy(),
+                "ref.edge_attr": edge_attr.numpy(), "ref.edge_pos": edge_pos.numpy(),
+                "ref64.rel_feat": r64[0], "ref64.edge_attr": r64[2],
+                "send": loc.send_edges.numpy(), "recv": loc.recv_edges.numpy()})
+            print("wrote s2s_localizer_D%d_%s.npz" % (D, rep), tuple(rel_feat.shape), tuple(edge_attr.shape),
+                  tuple(edge_pos.shape))
+
+
 if __name__ == "__main__":
     main()
+    localizer_fixtures(os.path.join(REPO, "tests", "golden"))

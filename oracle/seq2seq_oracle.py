@@ -40,3 +40,110 @@ def predict_field(sd, x: torch.Tensor, num_dims: int) -> torch.Tensor:
     h = F.silu(F.linear(h, sd["field_net.0.weight"], sd["field_net.0.bias"]))
     h = F.silu(F.linear(h, sd["field_net.2.weight"], sd["field_net.2.bias"]))
     return F.linear(h, sd["field_net.4.weight"], sd["field_net.4.bias"])
+
+
+# ---------------------------------------------------------------------------------------------
+# Row A9: augmented local frames of the seq2seq model
+#   AugmentedLocalizer.forward            <- nn/utils/augmented_global_to_local.py:52-68
+#   canonicalize_augmented_inputs         <- nn/utils/canonicalization.py:33-56
+#   create_augmented_edge_attr_pos_vel    <- canonicalization.py:111-140 (2-D)
+#   create_augmented_3d_edge_attr_pos_vel <- canonicalization.py:143-172 (3-D)
+#   geometry helpers                      <- nn/utils/geometry.py:7-66,76-127
+# Parity status: PINNED by tests/golden/s2s_localizer_D{2,3}_{polar,cart}.npz (imported reference
+# AugmentedLocalizer, oracle/make_golden_seq2seq.py).
+# ---------------------------------------------------------------------------------------------
+_PI = math.pi
+
+
+def _rot2(theta):
+    c, s = torch.cos(theta), torch.sin(theta)                  # geometry.py:13-23; theta [..., 1]
+    return torch.stack([torch.cat([c, -s], -1), torch.cat([s, c], -1)], -2)
+
+
+def _rot3(theta, phi):
+    c, s, cp, sp = torch.cos(theta), torch.sin(theta), torch.cos(phi), torch.sin(phi)     # geometry.py:24-34
+    return torch.stack([torch.cat([cp * c, -s, sp * c], -1), torch.cat([cp * s, c, sp * s], -1),
+                        torch.cat([-sp, torch.zeros_like(c), cp], -1)], -2)
+
+
+def _spherical3(v):
+    """rho, theta in [0, 2pi), phi (geometry.py:37-66 with symmetric_theta=False)."""
+    rho = torch.norm(v, p=2, dim=-1, keepdim=True)
+    theta = torch.atan2(v[..., [1]], v[..., [0]])
+    theta = theta + (theta < 0).type_as(theta) * (2 * _PI)
+    phi = torch.acos(torch.clamp(v[..., 2:] / (rho + 1e-7), min=-1.0, max=1.0))
+    return rho, theta, phi
+
+
+def _mv(R, v):
+    return (R @ v.unsqueeze(-1)).squeeze(-1)
+
+
+def canonicalize_augmented(x, use_3d):
+    """canonicalization.py:33-56: ([0 | R^T v (2-D: |v| in slot 2) | R^T f], Rinv)."""
+    if use_3d:
+        vel, forces = x[..., 3:6], x[..., 6:9]
+        _, theta, phi = _spherical3(vel)
+        Rinv = _rot3(theta, phi)
+        r = Rinv.transpose(-1, -2)
+        return torch.cat([torch.zeros_like(x[..., :3]), _mv(r, vel), _mv(r, forces)], -1), Rinv
+    vel, forces = x[..., 2:4], x[..., 4:6]
+    Rinv = _rot2(torch.atan2(vel[..., [1]], vel[..., [0]]))
+    canon = torch.zeros_like(x)
+    canon[..., 2] = torch.norm(vel, dim=-1)
+    canon[..., 4:6] = _mv(Rinv.transpose(-1, -2), forces)
+    return canon, Rinv
+
+
+def augmented_edge_attr(x, send, recv, use_3d):
+    """Edge features of j -> i in i's frame; x [B, M, 3D], send / recv index the M axis."""
+    xj, xi = x[:, send], x[:, recv]
+    if not use_3d:                                              # canonicalization.py:111-140
+        yaw_i = torch.atan2(xi[..., [3]], xi[..., [2]])
+        r = _rot2(yaw_i).transpose(-1, -2)
+        dyaw = torch.atan2(xj[..., 3], xj[..., 2]) - torch.atan2(xi[..., 3], xi[..., 2])   # angle_diff, geometry.py:116-127
+        dyaw = torch.where(dyaw >= _PI, dyaw - 2 * _PI, dyaw)
+        dyaw = torch.where(dyaw < -_PI, dyaw + 2 * _PI, dyaw)
+        dyaw = (dyaw / _PI).unsqueeze(-1)
+        dp = xj[..., :2] - xi[..., :2]
+        dist = torch.norm(dp, dim=-1, keepdim=True)
+        dth = torch.atan2(dp[..., 1], dp[..., 0]).unsqueeze(-1) - yaw_i
+        dth = dth + (dth <= -_PI).type_as(dth) * (2 * _PI)      # wrap_angles(normalize=True), geometry.py:108-113
+        dth = dth - (dth > _PI).type_as(dth) * (2 * _PI)
+        dth = dth / _PI
+        return torch.cat([_mv(r, dp), dyaw, dist, dth, _mv(r, xj[..., 2:4]), _mv(r, xj[..., 4:6])], -1)
+    _, yaw_j, pitch_j = _spherical3(xj[..., 3:6])              # canonicalization.py:143-172
+    _, yaw_i, pitch_i = _spherical3(xi[..., 3:6])
+    r = _rot3(yaw_i, pitch_i).transpose(-1, -2)
+    dp = xj[..., :3] - xi[..., :3]
+    dist, _, _ = _spherical3(dp)
+    M = r @ _rot3(yaw_j, pitch_j).transpose(-1, -2)
+    euler = torch.stack([torch.atan2(M[..., 1, 0], M[..., 0, 0]), torch.asin(-M[..., 2, 0]),
+                         torch.atan2(M[..., 2, 1], M[..., 2, 2])], -1)             # ZYX, not normalised (:154)
+    rdp = _mv(r, dp)
+    _, dth, dph = _spherical3(rdp)
+    return torch.cat([rdp, euler, dist, dth, dph, _mv(r, xj[..., 3:6]), _mv(r, xj[..., 6:9])], -1)
+
+
+EDGE_POS_IDX = {(False, "cart"): [0, 1, 2], (False, "polar"): [2, 3, 4],
+                (True, "cart"): [0, 1, 2, 3, 4, 5], (True, "polar"): [3, 4, 5, 6, 7, 8]}    # :19-24
+
+
+def augmented_localizer(x, use_3d=False, pos_representation="polar"):
+    """augmented_global_to_local.py:52-68.  x [B, N, 3D] -> rel_feat [B, N, 7D+O], Rinv [B, N, D, D],
+    edge_attr [B, N(N-1), 2(4D+O)+3D], edge_pos [B, N(N-1), D+O] for the fully connected graph."""
+    B, N, F = x.shape
+    D = 3 if use_3d else 2
+    send, recv = torch.where(~torch.eye(N, dtype=bool))                               # :31-32
+    send_x, recv_x = torch.where(~torch.eye(N + 1, N, dtype=bool))                    # :33-34, origin = node N
+    canon, Rinv = canonicalize_augmented(x, use_3d)
+    origin = torch.zeros(3 * D, dtype=x.dtype)
+    origin[D] = 1.0                                                                    # pos 0, vel e1, force 0 (:41)
+    ext = torch.cat([x, origin.expand(B, 1, 3 * D)], 1)
+    ea = augmented_edge_attr(ext, send_x, recv_x, use_3d)
+    ne = recv.shape[0]
+    origin_ea, ea = ea[:, ne:], ea[:, :ne]                                             # :61-62
+    edge_pos = ea[..., EDGE_POS_IDX[(use_3d, pos_representation)]]
+    edge_attr = torch.cat([ea, canon[:, recv], origin_ea[:, recv]], -1)
+    rel_feat = torch.cat([canon, origin_ea], -1)
+    return rel_feat, Rinv, edge_attr, edge_pos

@@ -47,3 +47,41 @@ def test_field_query_fresh_inputs_and_ragged_sizes(D):
             assert scale_rel_err(field.cpu(), want) <= TOL, shape
     with pytest.raises(Exception):
         m(torch.zeros(3, 2 * D))                      # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("rep", ["polar", "cart"])
+@pytest.mark.parametrize("D", [2, 3])
+def test_augmented_localizer_matches_reference(D, rep):
+    """Row A9 vs the imported reference AugmentedLocalizer (incl. velocities on the angle branch cuts)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from aether_amd.nn.seq2seq.localizer import AugmentedLocalizer
+    d = np.load(os.path.join(GOLDEN, f"s2s_localizer_D{D}_{rep}.npz"))
+    x = torch.from_numpy(d["in.x"]).cuda()
+    loc = AugmentedLocalizer(x.shape[1], use_3d=D == 3, pos_representation=rep)
+    assert torch.equal(loc.send_edges, torch.from_numpy(d["send"])) and torch.equal(loc.recv_edges, torch.from_numpy(d["recv"]))
+    outs = loc(x)
+    for got, key in zip(outs, ("ref.rel_feat", "ref.Rinv", "ref.edge_attr", "ref.edge_pos")):
+        want = torch.from_numpy(d[key])
+        assert got.shape == want.shape, key
+        # angles sitting exactly on a branch cut (the fixture has such rows) may land on the other side by
+        # one rounding: compare modulo the wrap (2 in normalised units, 2 pi otherwise) column by column
+        diff = (got.cpu() - want).abs()
+        wrap = torch.minimum(diff, torch.minimum((diff - 2.0).abs(), (diff - 2 * 3.14159274).abs()))
+        assert float(wrap.max()) <= TOL * max(1.0, float(want.abs().max())), key
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_augmented_localizer_fresh_inputs(D):
+    from aether_amd.nn.seq2seq.localizer import AugmentedLocalizer
+    g = torch.Generator().manual_seed(11)
+    for (B, N, rep) in [(1, 2, "polar"), (7, 5, "cart"), (128, 20, "polar")]:
+        x = torch.randn(B, N, 3 * D, generator=g)
+        x[..., :D] *= 3.0
+        loc = AugmentedLocalizer(N, use_3d=D == 3, pos_representation=rep)
+        outs = loc(x.cuda())
+        wants = S.augmented_localizer(x, D == 3, rep)
+        for got, want in zip(outs, wants):
+            assert got.shape == want.shape
+            assert scale_rel_err(got.cpu(), want) <= TOL, (B, N, rep)

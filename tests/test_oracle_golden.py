@@ -5,7 +5,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CASES, GRAD_CASES, load_case, load_state_dict, scale_rel_err
+import os
+
+from conftest import CASES, GOLDEN, GRAD_CASES, load_case, load_state_dict, scale_rel_err
 from oracle import aether_oracle as O
 
 STAGES = ["field", "rel_feat", "R", "edge_attr_local", "x1", "e1", "x2", "e2", "x3", "e3",
@@ -156,3 +158,22 @@ def test_seq2seq_field(D):
     assert scale_rel_err(field, torch.from_numpy(d["ref.field"])) <= 1e-6
     sd64 = {k: v.double() for k, v in sd.items()}
     assert scale_rel_err(S.predict_field(sd64, x.double(), D), torch.from_numpy(d["ref64.field"])) <= 1e-12
+
+
+@pytest.mark.parametrize("rep", ["polar", "cart"])
+@pytest.mark.parametrize("D", [2, 3])
+def test_seq2seq_augmented_localizer(D, rep):
+    """Row A9: augmented local frames (virtual origin node) vs the imported reference AugmentedLocalizer,
+    including velocities on the angle branch cuts and a near-zero velocity."""
+    from oracle import seq2seq_oracle as S
+    d = np.load(os.path.join(GOLDEN, f"s2s_localizer_D{D}_{rep}.npz"))
+    x = torch.from_numpy(d["in.x"])
+    rel_feat, Rinv, edge_attr, edge_pos = S.augmented_localizer(x, D == 3, rep)
+    for got, key in ((rel_feat, "ref.rel_feat"), (Rinv, "ref.Rinv"), (edge_attr, "ref.edge_attr"),
+                     (edge_pos, "ref.edge_pos")):
+        want = torch.from_numpy(d[key])
+        assert got.shape == want.shape, key
+        assert scale_rel_err(got, want) <= 1e-6, key
+    r64 = S.augmented_localizer(x.double(), D == 3, rep)
+    assert scale_rel_err(r64[0], torch.from_numpy(d["ref64.rel_feat"])) <= 1e-12
+    assert scale_rel_err(r64[2], torch.from_numpy(d["ref64.edge_attr"])) <= 1e-12
