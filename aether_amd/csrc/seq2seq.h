@@ -241,27 +241,46 @@ k_s2s_aug_nodes(const float* __restrict__ x, float* __restrict__ rel_feat, float
         for (int b = 0; b < D; ++b) Rinv[n * D * D + a * D + b] = R[a][b];
 }
 
+// One workgroup = 256 consecutive edges.  Every thread builds its edge's row in LDS; the rows then leave
+// as fully coalesced stores (consecutive lanes write consecutive floats): a thread writing its own 96- or
+// 156-byte row scatters every store instruction over 64 rows (2.3 TB/s measured vs 4+ this way).
 template <int D>
 __global__ void __launch_bounds__(256)
 k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, const int64_t* __restrict__ recv,
                 const float* __restrict__ rel_feat, int polar, float* __restrict__ edge_attr,
                 float* __restrict__ edge_pos, int64_t n_edges) {
     using A = AugDims<D>;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_edges) return;
-    const int64_t j = send[e], i = recv[e];
-    float xj[3 * D], xi[3 * D], o[A::NF];
+    constexpr int LDR = A::EA + 1;                                   // odd row stride: conflict-free column writes
+    __shared__ float rows[256 * LDR];
+    __shared__ float prow[256 * (A::EP + 1)];
+    const int64_t e0 = (int64_t)blockIdx.x * 256;
+    const int64_t e = e0 + threadIdx.x;
+    if (e < n_edges) {
+        const int64_t j = send[e], i = recv[e];
+        float xj[3 * D], xi[3 * D], o[A::NF];
 #pragma unroll
-    for (int t = 0; t < 3 * D; ++t) { xj[t] = x[j * 3 * D + t]; xi[t] = x[i * 3 * D + t]; }
-    aug_edge<D>(xj, xi, o);
-    float* out = edge_attr + e * A::EA;
+        for (int t = 0; t < 3 * D; ++t) { xj[t] = x[j * 3 * D + t]; xi[t] = x[i * 3 * D + t]; }
+        aug_edge<D>(xj, xi, o);
+        float* out = rows + threadIdx.x * LDR;
 #pragma unroll
-    for (int t = 0; t < A::NF; ++t) out[t] = o[t];
+        for (int t = 0; t < A::NF; ++t) out[t] = o[t];
 #pragma unroll
-    for (int t = 0; t < A::RF; ++t) out[A::NF + t] = rel_feat[i * A::RF + t];
-    const int p0 = polar ? (D == 2 ? 2 : 3) : 0;                      // augmented_global_to_local.py:19-24
+        for (int t = 0; t < A::RF; ++t) out[A::NF + t] = rel_feat[i * A::RF + t];
+        const int p0 = polar ? (D == 2 ? 2 : 3) : 0;                  // augmented_global_to_local.py:19-24
 #pragma unroll
-    for (int t = 0; t < A::EP; ++t) edge_pos[e * A::EP + t] = o[p0 + t];
+        for (int t = 0; t < A::EP; ++t) prow[threadIdx.x * (A::EP + 1) + t] = o[p0 + t];
+    }
+    __syncthreads();
+    const int64_t left = n_edges - e0;
+    const int cnt = (int)(left < 256 ? left : 256);
+    for (int idx = threadIdx.x; idx < cnt * A::EA; idx += 256) {
+        const int r = idx / A::EA, c = idx - r * A::EA;
+        edge_attr[e0 * A::EA + idx] = rows[r * LDR + c];
+    }
+    for (int idx = threadIdx.x; idx < cnt * A::EP; idx += 256) {
+        const int r = idx / A::EP, c = idx - r * A::EP;
+        edge_pos[e0 * A::EP + idx] = prow[r * (A::EP + 1) + c];
+    }
 }
 
 }  // namespace
