@@ -623,10 +623,10 @@ int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, in
     if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     const dim3 gh((unsigned)((n_points + 63) / 64), (unsigned)((hidden + 127) / 128));
-    k_s2s_linear<true, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, n_points, hidden);
-    k_s2s_linear<true, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, n_points, hidden);
+    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0);
+    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0);
     const dim3 go((unsigned)((n_points + 63) / 64), 1);
-    k_s2s_linear<false, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, n_points, num_dims);
+    k_s2s_linear<0, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, hidden, n_points, num_dims, nullptr, 0, 0);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }
@@ -650,6 +650,126 @@ int aether_s2s_localize(int num_dims, int64_t n_nodes, int64_t n_edges, const fl
         if (n_edges > 0)
             k_s2s_aug_edges<3><<<dim3(eb), dim3(256), 0, st>>>(x, send, recv, rel_feat, polar, edge_attr, edge_pos, n_edges);
     }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+namespace {
+// Y[N][ldy] = act(X[N][K] W^T + b) [* scale] [+ Y]; act: 0 none, 2 ReLU, 3 tanh
+int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
+               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st) {
+    if (K % 16 != 0) return fail(AETHER_EINVAL, "s2s_linear: K must be a multiple of 16");
+    const bool big = M >= 128;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
+#define S2S_CASE(A)                                                                                          \
+    if (big) k_s2s_linear<A, 4><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate); \
+    else k_s2s_linear<A, 1><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate)
+    if (act == 0) { S2S_CASE(0); } else if (act == 2) { S2S_CASE(2); } else { S2S_CASE(3); }
+#undef S2S_CASE
+    return AETHER_OK;
+}
+
+struct S2SDecLayout {
+    size_t A[4], S[4], T1, M, agg_h, agg_p, ext, rel, relp, Rinv, ea, eap, epos, rp, ip, np_, hh, o1, o2, pred,
+        p1p[4], irp, iip, inp, total;
+    int RF, RFp, EA, EAp, EP;
+    S2SDecLayout(int D, int h, int64_t Nn, int64_t E) {
+        const int O = D * (D - 1) / 2, NF = 4 * D + O;
+        RF = 3 * D + NF; EA = NF + RF; EP = D + O;
+        RFp = (RF + 15) / 16 * 16; EAp = (EA + 15) / 16 * 16;
+        size_t off = 0;
+        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+        const size_t nn = (size_t)Nn, ee = (size_t)E, hh_ = (size_t)h;
+        for (auto& v : A) v = take(nn * hh_);
+        for (auto& v : S) v = take(nn * hh_);
+        T1 = take(ee * hh_); M = take(ee * hh_);
+        agg_h = take(nn * hh_); agg_p = take(nn * hh_);
+        ext = take(nn * 3 * D); rel = take(nn * RF); relp = take(nn * RFp); Rinv = take(nn * D * D);
+        ea = take(ee * EA); eap = take(ee * EAp); epos = take(ee * EP);
+        rp = take(nn * hh_); ip = take(nn * hh_); np_ = take(nn * hh_); hh = take(nn * hh_);
+        o1 = take(nn * hh_); o2 = take(nn * hh_); pred = take(nn * 2 * D);
+        for (auto& v : p1p) v = take(hh_ * EAp);
+        irp = take(hh_ * RFp); iip = take(hh_ * RFp); inp = take(hh_ * RFp);
+        total = off;
+    }
+};
+}  // namespace
+
+size_t aether_s2s_decoder_workspace_bytes(int num_dims, int hidden, int64_t n_nodes, int64_t n_edges) {
+    if ((num_dims != 2 && num_dims != 3) || hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
+    return S2SDecLayout(num_dims, hidden, n_nodes, n_edges).total;
+}
+
+int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int hidden, int num_edge_types,
+                            int skip_first, int64_t n_nodes, int64_t n_edges, const float* inputs,
+                            const float* hidden_in, const float* edge_w, const float* field, const int64_t* send,
+                            const int64_t* recv, const int64_t* order, const int64_t* rowptr, void* workspace,
+                            size_t workspace_bytes, float* outputs, float* hidden_out, void* stream) {
+    if (!p || !inputs || !hidden_in || !field || !workspace || !outputs || !hidden_out || !rowptr)
+        return fail(AETHER_EINVAL, "s2s_decoder: null pointer");
+    if (n_edges > 0 && (!edge_w || !send || !recv || !order)) return fail(AETHER_EINVAL, "s2s_decoder: null edge pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_decoder: num_dims must be 2 or 3");
+    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "s2s_decoder: hidden must be a multiple of 32");
+    if (num_edge_types < 1 || num_edge_types > 4) return fail(AETHER_EINVAL, "s2s_decoder: 1..4 edge types");
+    if (n_nodes <= 0 || n_edges < 0) return fail(AETHER_EINVAL, "s2s_decoder: bad sizes");
+    const int D = num_dims, h = hidden, K = num_edge_types, k0 = skip_first ? 1 : 0;
+    S2SDecLayout L(D, h, n_nodes, n_edges);
+    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "s2s_decoder: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int64_t Nn = n_nodes, E = n_edges;
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    // ---- messages from the hidden states (aether.py:596-617)
+    if (E > 0) {
+        bool first = true;
+        for (int k = k0; k < K; ++k) {
+            if (s2s_linear(0, p->msg_fc1_w[k], 2 * h, p->msg_fc1_b[k], hidden_in, wp(L.A[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+            if (s2s_linear(0, p->msg_fc1_w[k] + h, 2 * h, nullptr, hidden_in, wp(L.S[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+            k_s2s_pair_tanh<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.A[k]), wp(L.S[k]), send, recv, wp(L.T1), h, E);
+            if (s2s_linear(3, p->msg_fc2_w[k], h, p->msg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, first ? 0 : 1, st)) return AETHER_EINVAL;
+            first = false;
+        }
+        if (first) HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
+    }
+    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_h), h);
+    // ---- local frames of [inputs | field] (:620-622) and the messages from the present state (:624-635)
+    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
+    int rc = aether_s2s_localize(D, Nn, E, wp(L.ext), send, recv, 1, wp(L.rel), wp(L.Rinv), wp(L.ea), wp(L.epos), stream);
+    if (rc != AETHER_OK) return rc;
+    k_s2s_pad_rows<<<blocks(Nn * L.RFp), dim3(256), 0, st>>>(wp(L.rel), L.RF, L.RF, wp(L.relp), L.RFp, Nn);
+    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->input_r_w, L.RF, L.RF, wp(L.irp), L.RFp, h);
+    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->input_i_w, L.RF, L.RF, wp(L.iip), L.RFp, h);
+    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->input_n_w, L.RF, L.RF, wp(L.inp), L.RFp, h);
+    if (E > 0) {
+        k_s2s_pad_rows<<<blocks(E * L.EAp), dim3(256), 0, st>>>(wp(L.ea), L.EA, L.EA, wp(L.eap), L.EAp, E);
+        bool first = true;
+        for (int k = k0; k < K; ++k) {
+            k_s2s_pad_rows<<<blocks((int64_t)h * L.EAp), dim3(256), 0, st>>>(p->pmsg_fc1_w[k], L.EA, L.EA, wp(L.p1p[k]), L.EAp, h);
+            if (s2s_linear(2, wp(L.p1p[k]), L.EAp, p->pmsg_fc1_b[k], wp(L.eap), wp(L.T1), h, L.EAp, E, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+            if (s2s_linear(2, p->pmsg_fc2_w[k], h, p->pmsg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, first ? 0 : 1, st)) return AETHER_EINVAL;
+            first = false;
+        }
+    }
+    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_p), h);
+    // ---- GRU-style gate (:638-646)
+    struct Gate { const float *iw, *ib, *pw, *pb, *hw; float* y; };
+    const Gate gates[3] = {{wp(L.irp), p->input_r_b, p->present_r_w, p->present_r_b, p->hidden_r_w, wp(L.rp)},
+                           {wp(L.iip), p->input_i_b, p->present_i_w, p->present_i_b, p->hidden_i_w, wp(L.ip)},
+                           {wp(L.inp), p->input_n_b, p->present_n_w, p->present_n_b, nullptr, wp(L.np_)}};
+    for (const Gate& g : gates) {
+        if (s2s_linear(0, g.iw, L.RFp, g.ib, wp(L.relp), g.y, h, L.RFp, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+        if (s2s_linear(0, g.pw, h, g.pb, wp(L.agg_p), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
+        if (g.hw && s2s_linear(0, g.hw, h, nullptr, wp(L.agg_h), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
+    }
+    if (s2s_linear(0, p->hidden_h_w, h, nullptr, wp(L.agg_h), wp(L.hh), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    k_s2s_gate<<<blocks(Nn * h), dim3(256), 0, st>>>(wp(L.rp), wp(L.ip), wp(L.np_), wp(L.hh), hidden_in, hidden_out, Nn * h);
+    // ---- output MLP, globalise, residual (:649-654)
+    if (s2s_linear(2, p->out0_w, h, p->out0_b, hidden_out, wp(L.o1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(2, p->out3_w, h, p->out3_b, wp(L.o1), wp(L.o2), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->out6_w, h, p->out6_b, wp(L.o2), wp(L.pred), 2 * D, h, Nn, 2 * D, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (D == 2) k_s2s_globalize<2><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
+    else k_s2s_globalize<3><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }

@@ -30,15 +30,17 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
     gamma[n * 2 * half + half + k] = cosf(p);
 }
 
-// Y[n][m] = act(sum_k W[m][k] X[n][k] + b[m]); W [M][K] row-major (nn.Linear), X [N][K], Y [N][ldy].
+// Y[n][m] = act(sum_k W[m][k] X[n][k] + b[m]); W [M][K] rows at stride ldw (nn.Linear), X [N][K], Y [N][ldy].
 // K % 16 == 0.  grid = (ceil(N / 64), ceil(M / (32 MT))), 4 waves = 2 (m) x 2 (n); a wave owns
 // MT x 2 MFMA tiles (16 MT rows x 32 points) and keeps the fragments of the next PF k-groups in flight
 // (4 waves per SIMD at MT = 4: the kernel is bound by the latency of its L2 reads, occupancy matters
 // more than a deeper ring or whole-line fragment pairs -- both were measured slower).
-template <bool SILU, int MT>
+// Epilogue: v = act(acc + b) [* scale[n * sstride]] [+ Y]  (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh).
+template <int ACT, int MT>
 __global__ void __launch_bounds__(256)
 k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ X,
-             float* __restrict__ Y, int M, int K, int64_t N, int ldy) {
+             float* __restrict__ Y, int M, int K, int ldw, int64_t N, int ldy,
+             const float* __restrict__ scale, int sstride, int accumulate) {
     constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -51,7 +53,7 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = m0 + 16 * t + i;
-        wrow[t] = W + (size_t)(m < M ? m : M - 1) * K + 4 * q;
+        wrow[t] = W + (size_t)(m < M ? m : M - 1) * ldw + 4 * q;
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -63,7 +65,10 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
     for (int mb = 0; mb < MT; ++mb) {
         f32x4 b4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int m = m0 + 16 * mb + 4 * q + r; b4[r] = m < M ? bias[m] : 0.0f; }
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * mb + 4 * q + r;
+            b4[r] = (bias != nullptr && m < M) ? bias[m] : 0.0f;
+        }
         acc[mb][0] = b4; acc[mb][1] = b4;
     }
     const int steps = K >> 4;
@@ -107,12 +112,23 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
         for (int mb = 0; mb < MT; ++mb) {
             const int m = m0 + 16 * mb + 4 * q;
             f32x4 v = acc[mb][nb];
-            if (SILU) v = silu4(v);
+            if (ACT == 1) v = silu4(v);
+            if (ACT == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            }
+            if (ACT == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            }
+            if (scale != nullptr) v = v * scale[(size_t)n * sstride];
             if (m + 3 < M) {
+                if (accumulate) v += ld4(Y + (size_t)n * ldy + m);
                 st4(Y + (size_t)n * ldy + m, v);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (m + r < M) Y[(size_t)n * ldy + m + r] = v[r];
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < M) Y[(size_t)n * ldy + m + r] = v[r] + (accumulate ? Y[(size_t)n * ldy + m + r] : 0.0f);
             }
         }
     }
@@ -281,6 +297,97 @@ k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, c
         const int r = idx / A::EP, c = idx - r * A::EP;
         edge_pos[e0 * A::EP + idx] = prow[r * (A::EP + 1) + c];
     }
+}
+
+}  // namespace
+
+// =====================================================================================================
+// Row A10, decoder half: RecurrentDecoder.forward (nn/seq2seq/aether.py:590-654), SURVEY.md Appendix B.4.
+// The Linear layers run through k_s2s_linear; the first message Linear is split per node
+// (W1 [h][2h] = [W_recv | W_send], aether.py:597-601: receivers first), so the [E, 2h] concatenation is
+// never built: T1 = tanh(A[recv] + S[send]) with A = W_recv hid + b, S = W_send hid.
+namespace {
+
+// T[e][:] = tanh(A[recv[e]][:] + S[send[e]][:]); one thread per (edge, 4 columns)
+__global__ void __launch_bounds__(256)
+k_s2s_pair_tanh(const float* __restrict__ A, const float* __restrict__ S, const int64_t* __restrict__ send,
+                const int64_t* __restrict__ recv, float* __restrict__ T, int h, int64_t n_edges) {
+    const int q4 = h >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_edges * q4) return;
+    const int64_t e = idx / q4;
+    const int c = (int)(idx - e * q4) * 4;
+    const f32x4 v = ld4(A + (size_t)recv[e] * h + c) + ld4(S + (size_t)send[e] * h + c);
+    st4(T + (size_t)e * h + c, f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])});
+}
+
+// agg[n][:] = sum over the node's in-edges (order[rowptr[n] .. rowptr[n+1])) of M[edge][:] / max(count, 1):
+// torch_scatter mean (aether.py:617,635).  One workgroup per node, a thread per 4 columns, fixed order.
+__global__ void __launch_bounds__(128)
+k_s2s_segment_mean(const float* __restrict__ Mx, const int64_t* __restrict__ order, const int64_t* __restrict__ rowptr,
+                   float* __restrict__ agg, int h) {
+    const int64_t n = blockIdx.x;
+    const int64_t beg = rowptr[n], end = rowptr[n + 1];
+    for (int c = threadIdx.x * 4; c < h; c += 128 * 4) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t k = beg; k < end; ++k) s += ld4(Mx + (size_t)order[k] * h + c);
+        const float cnt = (float)(end - beg > 1 ? end - beg : 1);
+        st4(agg + (size_t)n * h + c, s / cnt);
+    }
+}
+
+// dst[r][0..cols_pad) = src[r][0..cols) zero padded (row strides ld_src / cols_pad)
+__global__ void __launch_bounds__(256)
+k_s2s_pad_rows(const float* __restrict__ src, int cols, int ld_src, float* __restrict__ dst, int cols_pad,
+               int64_t rows) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * cols_pad) return;
+    const int64_t r = idx / cols_pad;
+    const int c = (int)(idx - r * cols_pad);
+    dst[idx] = c < cols ? src[r * ld_src + c] : 0.0f;
+}
+
+// ext[n] = [inputs[n] (2D) | field[n] (D)]   (aether.py:620)
+__global__ void __launch_bounds__(256)
+k_s2s_extend(const float* __restrict__ inputs, const float* __restrict__ field, float* __restrict__ ext, int D,
+             int64_t n_nodes) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_nodes * 3 * D) return;
+    const int64_t n = idx / (3 * D);
+    const int c = (int)(idx - n * 3 * D);
+    ext[idx] = c < 2 * D ? inputs[n * 2 * D + c] : field[n * D + (c - 2 * D)];
+}
+
+// GRU-style gate (aether.py:643-646): r = sigmoid(rp), i = sigmoid(ip), n = tanh(np + r * hh),
+// hidden' = (1 - i) * n + i * hidden
+__global__ void __launch_bounds__(256)
+k_s2s_gate(const float* __restrict__ rp, const float* __restrict__ ip, const float* __restrict__ np_,
+           const float* __restrict__ hh, const float* __restrict__ hidden, float* __restrict__ hidden_out,
+           int64_t count) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= count) return;
+    const float r = 1.0f / (1.0f + expf(-rp[idx]));
+    const float i = 1.0f / (1.0f + expf(-ip[idx]));
+    const float n = tanhf(np_[idx] + r * hh[idx]);
+    hidden_out[idx] = (1.0f - i) * n + i * hidden[idx];
+}
+
+// outputs = inputs + [R y_pos | R y_vel]   (Globalizer, local_to_global.py:12-13; aether.py:651-652)
+template <int D>
+__global__ void __launch_bounds__(256)
+k_s2s_globalize(const float* __restrict__ inputs, const float* __restrict__ pred, const float* __restrict__ Rinv,
+                float* __restrict__ out, int64_t n_nodes) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_nodes) return;
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk)
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int b = 0; b < D; ++b) s += Rinv[n * D * D + a * D + b] * pred[n * 2 * D + chunk * D + b];
+            out[n * 2 * D + chunk * D + a] = inputs[n * 2 * D + chunk * D + a] + s;
+        }
 }
 
 }  // namespace

@@ -211,6 +211,45 @@ int aether_s2s_localize(int num_dims, int64_t n_nodes, int64_t n_edges, const fl
                         float* Rinv, float* edge_attr, float* edge_pos, void* stream);
 
 /*
+ * seq2seq Aether, one step of the recurrent decoder (decoder half): replaces
+ * RecurrentDecoder.forward (nn/seq2seq/aether.py:590-654) on a flattened batch -- messages from the
+ * hidden states and from the present local-frame features per edge type, mean by receiver, GRU-style gate,
+ * output MLP, rotate back (Globalizer, nn/utils/local_to_global.py:7-13), residual.
+ *   params     : pointers to the reference module's tensors (nn.Linear layout weight[out][in]);
+ *                index k of the arrays = edge type k (at most 4)
+ *   inputs     : float[n_nodes][2D]  pos | vel          hidden_in : float[n_nodes][h]
+ *   edge_w     : float[n_edges][K]   edge-type weights (one-hot or soft; `edges` of the reference)
+ *   field      : float[n_nodes][D]   predicted field (aether_s2s_field)
+ *   send, recv : int64[n_edges]      global node indices, messages j -> i
+ *   order, rowptr : int64[n_edges], int64[n_nodes + 1]  edges grouped by receiver (stable), CSR offsets
+ *   outputs    : float[n_nodes][2D]  hidden_out : float[n_nodes][h]  (may not alias hidden_in)
+ *   workspace  : aether_s2s_decoder_workspace_bytes(D, h, n_nodes, n_edges) bytes
+ * Dropout is 0 (the reference forces it to 0 outside training, aether.py:594).  Stream-ordered.
+ */
+typedef struct AetherS2SDecoderParams {
+    const float* msg_fc1_w[4]; const float* msg_fc1_b[4];    /* [h][2h] (receiver | sender halves), [h] */
+    const float* msg_fc2_w[4]; const float* msg_fc2_b[4];    /* [h][h], [h] */
+    const float* hidden_r_w; const float* hidden_i_w; const float* hidden_h_w;      /* [h][h], no bias */
+    const float* present_r_w; const float* present_r_b;
+    const float* present_i_w; const float* present_i_b;
+    const float* present_n_w; const float* present_n_b;      /* [h][h], [h] */
+    const float* out0_w; const float* out0_b; const float* out3_w; const float* out3_b;   /* [h][h], [h] */
+    const float* out6_w; const float* out6_b;                /* [2D][h], [2D] */
+    const float* pmsg_fc1_w[4]; const float* pmsg_fc1_b[4];  /* [h][2(4D+O)+3D], [h] */
+    const float* pmsg_fc2_w[4]; const float* pmsg_fc2_b[4];  /* [h][h], [h] */
+    const float* input_r_w; const float* input_r_b;
+    const float* input_i_w; const float* input_i_b;
+    const float* input_n_w; const float* input_n_b;          /* [h][7D+O], [h] */
+} AetherS2SDecoderParams;
+size_t aether_s2s_decoder_workspace_bytes(int num_dims, int hidden, int64_t n_nodes, int64_t n_edges);
+int aether_s2s_decoder_step(const AetherS2SDecoderParams* params, int num_dims, int hidden, int num_edge_types,
+                            int skip_first, int64_t n_nodes, int64_t n_edges, const float* inputs,
+                            const float* hidden_in, const float* edge_w, const float* field,
+                            const int64_t* send, const int64_t* recv, const int64_t* order,
+                            const int64_t* rowptr, void* workspace, size_t workspace_bytes, float* outputs,
+                            float* hidden_out, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

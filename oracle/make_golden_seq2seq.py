@@ -91,6 +91,59 @@ def localizer_fixtures(out_dir):
                   tuple(edge_pos.shape))
 
 
+def decoder_fixtures(out_dir):
+    """Row A10 (decoder half): the imported reference RecurrentDecoder, one step.  The class imports
+    torch_scatter (not installed: the same stand-in as oracle/make_golden.py is placed in sys.modules)
+    and calls ``.cuda()`` on its receiver index (aether.py:617,635): on this GPU-less box the method is
+    replaced by the identity for the duration of the call.  Parameters come from the class's own
+    constructor under ``torch.manual_seed(DEC_SEED)``; the tests recreate them with the drop-in module,
+    whose constructor creates the same tensors in the same order (checksums stored).  (No fp64 run: the
+    reference allocates fp32 accumulators inside forward.)"""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import contextlib, io
+    import make_golden as MG
+    MG._install_scatter_standin()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from nn.seq2seq.aether import RecurrentDecoder
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for use_3d in (False, True):
+            D = 3 if use_3d else 2
+            B, N, H = 2, 5, 512
+            params = {"num_vars": N, "input_size": 2 * D, "gpu": False, "decoder_hidden": H, "num_edge_types": 2,
+                      "skip_first": False, "decoder_dropout": 0.0, "use_3d": use_3d}
+            torch.manual_seed(DEC_SEED)
+            with contextlib.redirect_stdout(io.StringIO()):
+                dec = RecurrentDecoder(params).eval()
+            g = torch.Generator().manual_seed(500 + D)
+            inputs = torch.randn(B, N, 2 * D, generator=g)
+            hidden = torch.randn(B, N, H, generator=g) * 0.5
+            field = torch.randn(B, N, D, generator=g) * 0.3
+            E = N * (N - 1)
+            hard = torch.nn.functional.one_hot(torch.randint(0, 2, (B, E), generator=g), 2).float()
+            soft = torch.softmax(torch.randn(B, E, 2, generator=g), -1)
+            out = {"in.inputs": inputs.numpy(), "in.hidden": hidden.numpy(), "in.field": field.numpy(),
+                   "in.edges_hard": hard.numpy(), "in.edges_soft": soft.numpy(), "seed": np.int64(DEC_SEED),
+                   "hidden_size": np.int64(H), "num_vars": np.int64(N)}
+            with torch.no_grad():
+                for name, z in (("hard", hard), ("soft", soft)):
+                    o, h2 = dec(inputs, hidden, z, field)
+                    out[f"ref.{name}.outputs"], out[f"ref.{name}.hidden"] = o.numpy(), h2.numpy()
+            for k, v in dec.state_dict().items():
+                out["sum." + k] = np.float64(v.double().sum().item())
+                out["abs." + k] = np.float64(v.double().abs().sum().item())
+            out["keys"] = np.array(list(dec.state_dict().keys()))
+            np.savez(os.path.join(out_dir, f"s2s_decoder_D{D}.npz"), **out)
+            print("wrote s2s_decoder_D%d.npz" % D, len(dec.state_dict()), "tensors")
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
+DEC_SEED = 4321
+
 if __name__ == "__main__":
     main()
     localizer_fixtures(os.path.join(REPO, "tests", "golden"))
+    decoder_fixtures(os.path.join(REPO, "tests", "golden"))

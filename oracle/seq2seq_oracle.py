@@ -147,3 +147,56 @@ def augmented_localizer(x, use_3d=False, pos_representation="polar"):
     edge_attr = torch.cat([ea, canon[:, recv], origin_ea[:, recv]], -1)
     rel_feat = torch.cat([canon, origin_ea], -1)
     return rel_feat, Rinv, edge_attr, edge_pos
+
+
+# ---------------------------------------------------------------------------------------------
+# Row A10 (decoder half): one step of the recurrent decoder
+#   RecurrentDecoder.forward   <- nn/seq2seq/aether.py:590-654
+#   Globalizer.forward         <- nn/utils/local_to_global.py:7-13
+# Parity status: PINNED by tests/golden/s2s_decoder_D{2,3}.npz (imported reference RecurrentDecoder,
+# oracle/make_golden_seq2seq.py; torch_scatter stand-in and an identity `.cuda()` as documented there).
+# ---------------------------------------------------------------------------------------------
+def _scatter_mean_dim1(src, index, n):
+    """torch_scatter.scatter(src, index, dim=1, reduce='mean'): sum / max(count, 1) (aether.py:617,635)."""
+    out = torch.zeros(src.shape[0], n, src.shape[2], dtype=src.dtype)
+    out.index_add_(1, index, src)
+    cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+    return out / cnt.clamp(min=1).view(1, n, 1)
+
+
+def decoder_step(sd, inputs, hidden, edges, predicted_field, use_3d=False, skip_first=False, send=None,
+                 recv=None):
+    """``sd``: the reference RecurrentDecoder's state_dict.  inputs [B, N, 2D], hidden [B, N, h], edges
+    [B, N(N-1), K] (edge-type weights), predicted_field [B, N, D] -> (outputs [B, N, 2D], hidden')."""
+    B, N, _ = inputs.shape
+    D = 3 if use_3d else 2
+    if send is None:
+        send, recv = torch.where(~torch.eye(N, dtype=bool))
+    K = edges.shape[-1]
+    lin = lambda name, v: F.linear(v, sd[name + ".weight"], sd.get(name + ".bias"))
+    pre_msg = torch.cat([hidden[:, recv], hidden[:, send]], -1)                       # :597-601 (receivers first)
+    all_msgs = torch.zeros(B, recv.shape[0], hidden.shape[-1], dtype=inputs.dtype)
+    for k in range(1 if skip_first else 0, K):                                        # :606-614
+        msg = torch.tanh(lin(f"msg_fc1.{k}", pre_msg))
+        msg = torch.tanh(lin(f"msg_fc2.{k}", msg))
+        all_msgs = all_msgs + msg * edges[:, :, k:k + 1]
+    agg = _scatter_mean_dim1(all_msgs, recv, N)                                       # :617
+    ext = torch.cat([inputs, predicted_field], -1)                                    # :620
+    rel_feat, Rinv, edge_attr, _ = augmented_localizer(ext, use_3d, "polar") if recv.shape[0] == N * (N - 1) \
+        else (None, None, None, None)
+    present = torch.zeros_like(all_msgs)
+    for k in range(1 if skip_first else 0, K):                                        # :626-633
+        msg = torch.relu(lin(f"present_msg_fc1.{k}", edge_attr))
+        msg = torch.relu(lin(f"present_msg_fc2.{k}", msg))
+        present = present + msg * edges[:, :, k:k + 1]
+    pagg = _scatter_mean_dim1(present, recv, N)                                       # :635
+    inp_r = lin("input_r", rel_feat) + lin("present_r", pagg)                         # :639-641
+    inp_i = lin("input_i", rel_feat) + lin("present_i", pagg)
+    inp_n = lin("input_n", rel_feat) + lin("present_n", pagg)
+    r = torch.sigmoid(inp_r + lin("hidden_r", agg))                                   # :643-646
+    i = torch.sigmoid(inp_i + lin("hidden_i", agg))
+    n = torch.tanh(inp_n + r * lin("hidden_h", agg))
+    hidden = (1 - i) * n + i * hidden
+    pred = lin("out_mlp.6", torch.relu(lin("out_mlp.3", torch.relu(lin("out_mlp.0", hidden)))))   # :649
+    pred_global = torch.cat([torch.einsum("...ij,...j->...i", Rinv, c) for c in pred.split(D, dim=-1)], -1)
+    return inputs + pred_global, hidden                                               # :651-654

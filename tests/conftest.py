@@ -65,3 +65,22 @@ def load_s2s_field(D):
     for k, v in sd.items():
         assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
     return d, sd
+
+
+def load_s2s_decoder(D):
+    """Golden fixture of the seq2seq decoder step + the reference's parameters, recreated from the stored
+    seed through the drop-in module's constructor (same tensors, same order; checksums verified)."""
+    import numpy as _np
+    import torch as _torch
+    from aether_amd.nn.seq2seq.decoder import RecurrentDecoder
+    d = _np.load(os.path.join(GOLDEN, f"s2s_decoder_D{D}.npz"))
+    params = {"num_vars": int(d["num_vars"]), "input_size": 2 * D, "gpu": False,
+              "decoder_hidden": int(d["hidden_size"]), "num_edge_types": 2, "skip_first": False,
+              "decoder_dropout": 0.0, "use_3d": D == 3}
+    _torch.manual_seed(int(d["seed"]))
+    dec = RecurrentDecoder(params, device=None)
+    sd = {k: v.detach() for k, v in dec.state_dict().items()}
+    assert list(sd.keys()) == [str(k) for k in d["keys"]]
+    for k, v in sd.items():
+        assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
+    return d, sd, params

@@ -85,3 +85,42 @@ def test_augmented_localizer_fresh_inputs(D):
         for got, want in zip(outs, wants):
             assert got.shape == want.shape
             assert scale_rel_err(got.cpu(), want) <= TOL, (B, N, rep)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_decoder_step_matches_reference(D):
+    """Row A10 (decoder half): one RecurrentDecoder step vs the imported reference, h = 512, one-hot and soft
+    edge-type weights."""
+    from conftest import load_s2s_decoder
+    from aether_amd.nn.seq2seq.decoder import RecurrentDecoder
+    d, sd, params = load_s2s_decoder(D)
+    dec = RecurrentDecoder(params, device="cuda")
+    dec.load_state_dict(sd)
+    t = lambda k: torch.from_numpy(d[k]).cuda()
+    for name in ("hard", "soft"):
+        out, hid = dec(t("in.inputs"), t("in.hidden"), t("in.edges_" + name), t("in.field"))
+        assert scale_rel_err(hid.cpu(), torch.from_numpy(d[f"ref.{name}.hidden"])) <= TOL, name
+        assert scale_rel_err(out.cpu(), torch.from_numpy(d[f"ref.{name}.outputs"])) <= TOL, name
+    assert dec.get_initial_hidden(torch.zeros(3, 7, 5, 4, device="cuda")).shape == (3, 5, 512)
+
+
+def test_decoder_step_fresh_batch_vs_oracle():
+    """A full-size batch (B=16, N=20) against the oracle, three steps chained (hidden fed back)."""
+    from aether_amd.nn.seq2seq.decoder import RecurrentDecoder
+    D, N, B, H = 2, 20, 16, 512
+    params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": H, "num_edge_types": 2,
+              "skip_first": False, "decoder_dropout": 0.0, "use_3d": False}
+    torch.manual_seed(7)
+    dec = RecurrentDecoder(params, device="cuda")
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, N, 2 * D, generator=g)
+    hid = torch.zeros(B, N, H)
+    z = torch.nn.functional.one_hot(torch.randint(0, 2, (B, N * (N - 1)), generator=g), 2).float()
+    f = torch.randn(B, N, D, generator=g) * 0.3
+    xg, hg = x.cuda(), hid.cuda()
+    for step in range(3):
+        x, hid = S.decoder_step(sd, x, hid, z, f, False)
+        xg, hg = dec(xg, hg, z.cuda(), f.cuda())
+        assert scale_rel_err(hg.cpu(), hid) <= TOL, step
+        assert scale_rel_err(xg.cpu(), x) <= TOL, step

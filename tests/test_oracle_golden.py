@@ -177,3 +177,17 @@ def test_seq2seq_augmented_localizer(D, rep):
     r64 = S.augmented_localizer(x.double(), D == 3, rep)
     assert scale_rel_err(r64[0], torch.from_numpy(d["ref64.rel_feat"])) <= 1e-12
     assert scale_rel_err(r64[2], torch.from_numpy(d["ref64.edge_attr"])) <= 1e-12
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_seq2seq_decoder_step(D):
+    """Row A10 (decoder half): one RecurrentDecoder step vs the imported reference, hard (one-hot) and soft
+    edge-type weights."""
+    from conftest import load_s2s_decoder
+    from oracle import seq2seq_oracle as S
+    d, sd, _ = load_s2s_decoder(D)
+    t = lambda k: torch.from_numpy(d[k])
+    for name in ("hard", "soft"):
+        out, hid = S.decoder_step(sd, t("in.inputs"), t("in.hidden"), t("in.edges_" + name), t("in.field"), D == 3)
+        assert scale_rel_err(out, t(f"ref.{name}.outputs")) <= 2e-6, name
+        assert scale_rel_err(hid, t(f"ref.{name}.hidden")) <= 2e-6, name
