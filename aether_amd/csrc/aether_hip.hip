@@ -623,10 +623,10 @@ int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, in
     if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     const dim3 gh((unsigned)((n_points + 63) / 64), (unsigned)((hidden + 127) / 128));
-    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0);
-    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0);
+    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr);
+    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr);
     const dim3 go((unsigned)((n_points + 63) / 64), 1);
-    k_s2s_linear<0, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, hidden, n_points, num_dims, nullptr, 0, 0);
+    k_s2s_linear<0, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, hidden, n_points, num_dims, nullptr, 0, 0, nullptr, nullptr, nullptr);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }
@@ -657,13 +657,14 @@ int aether_s2s_localize(int num_dims, int64_t n_nodes, int64_t n_edges, const fl
 namespace {
 // Y[N][ldy] = act(X[N][K] W^T + b) [* scale] [+ Y]; act: 0 none, 2 ReLU, 3 tanh
 int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
-               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st) {
+               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st,
+               const int64_t* xidx = nullptr, const int64_t* yidx = nullptr, const int* n_dev = nullptr) {
     if (K % 16 != 0) return fail(AETHER_EINVAL, "s2s_linear: K must be a multiple of 16");
     const bool big = M >= 128;
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
 #define S2S_CASE(A)                                                                                          \
-    if (big) k_s2s_linear<A, 4><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate); \
-    else k_s2s_linear<A, 1><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate)
+    if (big) k_s2s_linear<A, 4><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev); \
+    else k_s2s_linear<A, 1><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev)
     if (act == 0) { S2S_CASE(0); } else if (act == 2) { S2S_CASE(2); } else { S2S_CASE(3); }
 #undef S2S_CASE
     return AETHER_OK;
@@ -671,7 +672,7 @@ int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X,
 
 struct S2SDecLayout {
     size_t A[4], S[4], T1, M, agg_h, agg_p, ext, rel, relp, Rinv, ea, eap, epos, rp, ip, np_, hh, o1, o2, pred,
-        p1p[4], irp, iip, inp, total;
+        p1p[4], irp, iip, inp, list[4], counts, total;
     int RF, RFp, EA, EAp, EP;
     S2SDecLayout(int D, int h, int64_t Nn, int64_t E) {
         const int O = D * (D - 1) / 2, NF = 4 * D + O;
@@ -690,6 +691,8 @@ struct S2SDecLayout {
         o1 = take(nn * hh_); o2 = take(nn * hh_); pred = take(nn * 2 * D);
         for (auto& v : p1p) v = take(hh_ * EAp);
         irp = take(hh_ * RFp); iip = take(hh_ * RFp); inp = take(hh_ * RFp);
+        for (auto& v : list) v = take(ee * 2);           // int64 edge ids of one type
+        counts = take(64);
         total = off;
     }
 };
@@ -720,17 +723,25 @@ int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int h
     auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int64_t Nn = n_nodes, E = n_edges;
     auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    // ---- edges per type: with one-hot types every edge is evaluated for its own type only (the other
+    // term of the reference's sum is multiplied by zero, aether.py:613,632)
+    int* counts = reinterpret_cast<int*>(ws + L.counts);
+    auto elist = [&](int k) { return reinterpret_cast<int64_t*>(ws + L.list[k]); };
+    if (E > 0) {
+        HIP_OK(hipMemsetAsync(counts, 0, 64 * sizeof(int), st));
+        for (int k = k0; k < K; ++k)
+            k_s2s_select<<<blocks(E), dim3(256), 0, st>>>(edge_w, K, k, E, elist(k), counts + k);
+    }
     // ---- messages from the hidden states (aether.py:596-617)
     if (E > 0) {
-        bool first = true;
+        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
         for (int k = k0; k < K; ++k) {
             if (s2s_linear(0, p->msg_fc1_w[k], 2 * h, p->msg_fc1_b[k], hidden_in, wp(L.A[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
             if (s2s_linear(0, p->msg_fc1_w[k] + h, 2 * h, nullptr, hidden_in, wp(L.S[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-            k_s2s_pair_tanh<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.A[k]), wp(L.S[k]), send, recv, wp(L.T1), h, E);
-            if (s2s_linear(3, p->msg_fc2_w[k], h, p->msg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, first ? 0 : 1, st)) return AETHER_EINVAL;
-            first = false;
+            k_s2s_pair_tanh<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.A[k]), wp(L.S[k]), send, recv, elist(k), counts + k, wp(L.T1), h);
+            if (s2s_linear(3, p->msg_fc2_w[k], h, p->msg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, 1, st,
+                           nullptr, elist(k), counts + k)) return AETHER_EINVAL;
         }
-        if (first) HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
     }
     k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_h), h);
     // ---- local frames of [inputs | field] (:620-622) and the messages from the present state (:624-635)
@@ -743,12 +754,13 @@ int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int h
     k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->input_n_w, L.RF, L.RF, wp(L.inp), L.RFp, h);
     if (E > 0) {
         k_s2s_pad_rows<<<blocks(E * L.EAp), dim3(256), 0, st>>>(wp(L.ea), L.EA, L.EA, wp(L.eap), L.EAp, E);
-        bool first = true;
+        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
         for (int k = k0; k < K; ++k) {
             k_s2s_pad_rows<<<blocks((int64_t)h * L.EAp), dim3(256), 0, st>>>(p->pmsg_fc1_w[k], L.EA, L.EA, wp(L.p1p[k]), L.EAp, h);
-            if (s2s_linear(2, wp(L.p1p[k]), L.EAp, p->pmsg_fc1_b[k], wp(L.eap), wp(L.T1), h, L.EAp, E, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-            if (s2s_linear(2, p->pmsg_fc2_w[k], h, p->pmsg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, first ? 0 : 1, st)) return AETHER_EINVAL;
-            first = false;
+            if (s2s_linear(2, wp(L.p1p[k]), L.EAp, p->pmsg_fc1_b[k], wp(L.eap), wp(L.T1), h, L.EAp, E, h, nullptr, 0, 0, st,
+                           elist(k), nullptr, counts + k)) return AETHER_EINVAL;
+            if (s2s_linear(2, p->pmsg_fc2_w[k], h, p->pmsg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, 1, st,
+                           nullptr, elist(k), counts + k)) return AETHER_EINVAL;
         }
     }
     k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_p), h);

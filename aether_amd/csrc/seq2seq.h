@@ -36,11 +36,16 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
 // (4 waves per SIMD at MT = 4: the kernel is bound by the latency of its L2 reads, occupancy matters
 // more than a deeper ring or whole-line fragment pairs -- both were measured slower).
 // Epilogue: v = act(acc + b) [* scale[n * sstride]] [+ Y]  (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh).
+// Optional row lists gather X rows / scatter Y rows (edges of one type, compacted on the device).
 template <int ACT, int MT>
 __global__ void __launch_bounds__(256)
 k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ X,
              float* __restrict__ Y, int M, int K, int ldw, int64_t N, int ldy,
-             const float* __restrict__ scale, int sstride, int accumulate) {
+             const float* __restrict__ scale, int sstride, int accumulate,
+             const int64_t* __restrict__ xidx /* row n of X is X[xidx[n]] */,
+             const int64_t* __restrict__ yidx /* row n of Y (and of scale) is yidx[n] */,
+             const int* __restrict__ n_dev /* non-null: N = *n_dev (compacted row lists) */) {
+    if (n_dev != nullptr) N = *n_dev;
     constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -57,8 +62,10 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int64_t n = n0 + 16 * t + i;
-        xrow[t] = X + (size_t)(n < N ? n : N - 1) * K + 4 * q;
+        int64_t n = n0 + 16 * t + i;
+        n = n < N ? n : N - 1;
+        if (xidx != nullptr) n = xidx[n];
+        xrow[t] = X + (size_t)n * K + 4 * q;
     }
     f32x4 acc[MT][2];
 #pragma unroll
@@ -106,8 +113,9 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        const int64_t n = n0 + 16 * nb + i;
+        int64_t n = n0 + 16 * nb + i;
         if (n >= N) continue;
+        if (yidx != nullptr) n = yidx[n];
 #pragma unroll
         for (int mb = 0; mb < MT; ++mb) {
             const int m = m0 + 16 * mb + 4 * q;
@@ -308,17 +316,35 @@ k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, c
 // never built: T1 = tanh(A[recv] + S[send]) with A = W_recv hid + b, S = W_send hid.
 namespace {
 
-// T[e][:] = tanh(A[recv[e]][:] + S[send[e]][:]); one thread per (edge, 4 columns)
+// T[j][:] = tanh(A[recv[e]][:] + S[send[e]][:]), e = list[j] (j < *count); one thread per (row, 4 columns)
 __global__ void __launch_bounds__(256)
 k_s2s_pair_tanh(const float* __restrict__ A, const float* __restrict__ S, const int64_t* __restrict__ send,
-                const int64_t* __restrict__ recv, float* __restrict__ T, int h, int64_t n_edges) {
+                const int64_t* __restrict__ recv, const int64_t* __restrict__ list, const int* __restrict__ count,
+                float* __restrict__ T, int h) {
     const int q4 = h >> 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_edges * q4) return;
-    const int64_t e = idx / q4;
-    const int c = (int)(idx - e * q4) * 4;
+    if (idx >= (int64_t)*count * q4) return;
+    const int64_t j = idx / q4;
+    const int c = (int)(idx - j * q4) * 4;
+    const int64_t e = list[j];
     const f32x4 v = ld4(A + (size_t)recv[e] * h + c) + ld4(S + (size_t)send[e] * h + c);
-    st4(T + (size_t)e * h + c, f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])});
+    st4(T + (size_t)j * h + c, f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])});
+}
+
+// list = the edges whose weight for type k is not zero (one-hot types: the edges of that type; soft
+// types: all of them).  One slot range per wave (ballot + one atomic); the order of the list does not
+// affect any result (every row is computed on its own and scattered back by edge id).
+__global__ void __launch_bounds__(256)
+k_s2s_select(const float* __restrict__ edge_w, int K, int k, int64_t n_edges, int64_t* __restrict__ list,
+             int* __restrict__ count) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = e < n_edges && edge_w[e * K + k] != 0.0f;
+    const unsigned long long mask = __ballot(on);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && mask) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, 0);
+    if (on) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
 }
 
 // agg[n][:] = sum over the node's in-edges (order[rowptr[n] .. rowptr[n+1])) of M[edge][:] / max(count, 1):
