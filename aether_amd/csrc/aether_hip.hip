@@ -623,10 +623,10 @@ int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, in
     if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     const dim3 gh((unsigned)((n_points + 63) / 64), (unsigned)((hidden + 127) / 128));
-    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr);
-    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr);
+    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
     const dim3 go((unsigned)((n_points + 63) / 64), 1);
-    k_s2s_linear<0, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, hidden, n_points, num_dims, nullptr, 0, 0, nullptr, nullptr, nullptr);
+    k_s2s_linear<0, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, hidden, n_points, num_dims, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }
@@ -658,14 +658,15 @@ namespace {
 // Y[N][ldy] = act(X[N][K] W^T + b) [* scale] [+ Y]; act: 0 none, 2 ReLU, 3 tanh
 int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
                int ldy, const float* scale, int sstride, int accumulate, hipStream_t st,
-               const int64_t* xidx = nullptr, const int64_t* yidx = nullptr, const int* n_dev = nullptr) {
+               const int64_t* xidx = nullptr, const int64_t* yidx = nullptr, const int* n_dev = nullptr,
+               const float* post_scale = nullptr, const float* post_shift = nullptr) {
     if (K % 16 != 0) return fail(AETHER_EINVAL, "s2s_linear: K must be a multiple of 16");
     const bool big = M >= 128;
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
 #define S2S_CASE(A)                                                                                          \
-    if (big) k_s2s_linear<A, 4><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev); \
-    else k_s2s_linear<A, 1><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev)
-    if (act == 0) { S2S_CASE(0); } else if (act == 2) { S2S_CASE(2); } else { S2S_CASE(3); }
+    if (big) k_s2s_linear<A, 4><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift); \
+    else k_s2s_linear<A, 1><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift)
+    if (act == 0) { S2S_CASE(0); } else if (act == 2) { S2S_CASE(2); } else if (act == 3) { S2S_CASE(3); } else { S2S_CASE(4); }
 #undef S2S_CASE
     return AETHER_OK;
 }
@@ -743,7 +744,7 @@ int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int h
                            nullptr, elist(k), counts + k)) return AETHER_EINVAL;
         }
     }
-    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_h), h);
+    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_h), h, 0.0f);
     // ---- local frames of [inputs | field] (:620-622) and the messages from the present state (:624-635)
     k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
     int rc = aether_s2s_localize(D, Nn, E, wp(L.ext), send, recv, 1, wp(L.rel), wp(L.Rinv), wp(L.ea), wp(L.epos), stream);
@@ -763,7 +764,7 @@ int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int h
                            nullptr, elist(k), counts + k)) return AETHER_EINVAL;
         }
     }
-    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_p), h);
+    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_p), h, 0.0f);
     // ---- GRU-style gate (:638-646)
     struct Gate { const float *iw, *ib, *pw, *pb, *hw; float* y; };
     const Gate gates[3] = {{wp(L.irp), p->input_r_b, p->present_r_w, p->present_r_b, p->hidden_r_w, wp(L.rp)},
@@ -782,6 +783,113 @@ int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int h
     if (s2s_linear(0, p->out6_w, h, p->out6_b, wp(L.o2), wp(L.pred), 2 * D, h, Nn, 2 * D, nullptr, 0, 0, st)) return AETHER_EINVAL;
     if (D == 2) k_s2s_globalize<2><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
     else k_s2s_globalize<3><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+namespace {
+struct S2SPriorLayout {
+    size_t ext, rel, relp, Rinv, ea, epos, hw, eaf, X0, X1, X3, Ps, Pr, T1, X4, G, Y1, Y2, bn, res1p, total;
+    int RF, RFp, EA, EP;
+    S2SPriorLayout(int D, int h, int R, int ph, int64_t Nn, int64_t E) {
+        const int O = D * (D - 1) / 2, NF = 4 * D + O;
+        RF = 3 * D + NF; EA = NF + RF; EP = D + O;
+        RFp = (RF + 15) / 16 * 16;
+        size_t off = 0;
+        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+        const size_t nn = (size_t)Nn, ee = (size_t)E, hh = (size_t)h;
+        ext = take(nn * 3 * D); rel = take(nn * RF); relp = take(nn * RFp); Rinv = take(nn * D * D);
+        ea = take(ee * EA); epos = take(ee * EP); hw = take(ee * hh); eaf = take(ee * hh);
+        X0 = take(nn * hh); X1 = take(nn * hh); X3 = take(nn * hh); Ps = take(nn * hh); Pr = take(nn * hh);
+        T1 = take(ee * hh); X4 = take(ee * hh); G = take(ee * 4 * (size_t)R);
+        Y1 = take(ee * (size_t)(ph > 0 ? ph : 1)); Y2 = take(ee * (size_t)(ph > 0 ? ph : 1));
+        bn = take(4 * hh); res1p = take(hh * RFp);
+        total = off;
+    }
+};
+}  // namespace
+
+size_t aether_s2s_prior_workspace_bytes(int num_dims, int hidden, int rnn_hidden, int prior_hidden,
+                                        int64_t n_nodes, int64_t n_edges) {
+    if ((num_dims != 2 && num_dims != 3) || hidden <= 0 || rnn_hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
+    return S2SPriorLayout(num_dims, hidden, rnn_hidden, prior_hidden, n_nodes, n_edges).total;
+}
+
+int aether_s2s_prior_step(const AetherS2SPriorParams* p, int num_dims, int hidden, int rnn_hidden, int prior_layers,
+                          int prior_hidden, int num_edge_types, int polar, int num_vars, int64_t n_nodes,
+                          int64_t n_edges, const float* inputs, const float* field, const float* h0, const float* c0,
+                          const int64_t* send, const int64_t* recv, const int64_t* order, const int64_t* rowptr,
+                          void* workspace, size_t workspace_bytes, float* logits, float* h1, float* c1, void* stream) {
+    if (!p || !inputs || !field || !h0 || !c0 || !send || !recv || !order || !rowptr || !workspace || !logits || !h1 || !c1)
+        return fail(AETHER_EINVAL, "s2s_prior: null pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_prior: num_dims must be 2 or 3");
+    if (hidden < 128 || hidden % 128 != 0) return fail(AETHER_EINVAL, "s2s_prior: hidden must be a multiple of 128");
+    if (rnn_hidden < 16 || rnn_hidden % 16 != 0) return fail(AETHER_EINVAL, "s2s_prior: rnn_hidden must be a multiple of 16");
+    if (prior_layers < 1 || prior_layers > 4) return fail(AETHER_EINVAL, "s2s_prior: 1..4 prior layers");
+    if (prior_layers > 1 && (prior_hidden < 16 || prior_hidden % 16 != 0))
+        return fail(AETHER_EINVAL, "s2s_prior: prior_hidden must be a multiple of 16");
+    if (num_edge_types < 1 || num_edge_types > 4 || num_vars < 2 || n_nodes <= 0 || n_edges <= 0)
+        return fail(AETHER_EINVAL, "s2s_prior: bad sizes");
+    const int D = num_dims, h = hidden, R = rnn_hidden, K = num_edge_types;
+    S2SPriorLayout L(D, h, R, prior_hidden, n_nodes, n_edges);
+    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "s2s_prior: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int64_t Nn = n_nodes, E = n_edges;
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    // ---- local frames (:385-388) and the anisotropic edge filter (:391)
+    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
+    int rc = aether_s2s_localize(D, Nn, E, wp(L.ext), send, recv, polar, wp(L.rel), wp(L.Rinv), wp(L.ea), wp(L.epos), stream);
+    if (rc != AETHER_OK) return rc;
+    k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0, p->filt_b0, wp(L.epos), L.EP, wp(L.hw), h, E);
+    {
+        const dim3 grid((unsigned)((E + 63) / 64), (unsigned)(h / 128));
+        if (D == 2) k_s2s_filter<24><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
+        else k_s2s_filter<39><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
+    }
+    // ---- x = edge2node(edge_attr) + res1(rel_feat) (:393-395): sum over in-edges / (num_vars - 1)
+    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.eaf), order, rowptr, wp(L.X0), h, (float)(num_vars - 1));
+    k_s2s_pad_rows<<<blocks(Nn * L.RFp), dim3(256), 0, st>>>(wp(L.rel), L.RF, L.RF, wp(L.relp), L.RFp, Nn);
+    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->res1_w, L.RF, L.RF, wp(L.res1p), L.RFp, h);
+    if (s2s_linear(0, wp(L.res1p), L.RFp, p->res1_b, wp(L.relp), wp(L.X0), h, L.RFp, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
+    // ---- mlp3 (RefNRIMLP, eval): Linear-ELU-Linear-ELU-BatchNorm
+    float *bn3s = wp(L.bn), *bn3b = wp(L.bn) + h, *bn4s = wp(L.bn) + 2 * h, *bn4b = wp(L.bn) + 3 * h;
+    k_s2s_bn_affine<<<blocks(h), dim3(256), 0, st>>>(p->mlp3_bn_w, p->mlp3_bn_b, p->mlp3_bn_mean, p->mlp3_bn_var, bn3s, bn3b, h);
+    k_s2s_bn_affine<<<blocks(h), dim3(256), 0, st>>>(p->mlp4_bn_w, p->mlp4_bn_b, p->mlp4_bn_mean, p->mlp4_bn_var, bn4s, bn4b, h);
+    if (s2s_linear(4, p->mlp3_w0, h, p->mlp3_b0, wp(L.X0), wp(L.X1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(4, p->mlp3_w3, h, p->mlp3_b3, wp(L.X1), wp(L.X3), h, h, Nn, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr, bn3s, bn3b)) return AETHER_EINVAL;
+    // ---- mlp4 on [x_send | x_recv | edge] (:396-398): the first Linear split per node / per edge
+    if (s2s_linear(0, p->mlp4_w0, 3 * h, p->mlp4_b0, wp(L.X3), wp(L.Ps), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->mlp4_w0 + h, 3 * h, nullptr, wp(L.X3), wp(L.Pr), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->mlp4_w0 + 2 * h, 3 * h, nullptr, wp(L.eaf), wp(L.T1), h, h, E, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    k_s2s_edge_sum_elu<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.T1), wp(L.Ps), wp(L.Pr), send, recv, h, E);
+    if (s2s_linear(4, p->mlp4_w3, h, p->mlp4_b3, wp(L.T1), wp(L.X4), h, h, E, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr, bn4s, bn4b)) return AETHER_EINVAL;
+    // ---- one LSTM step per edge (:400-407)
+    if (s2s_linear(0, p->lstm_w_ih, h, p->lstm_b_ih, wp(L.X4), wp(L.G), 4 * R, h, E, 4 * R, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->lstm_w_hh, R, p->lstm_b_hh, h0, wp(L.G), 4 * R, R, E, 4 * R, nullptr, 0, 1, st)) return AETHER_EINVAL;
+    k_s2s_lstm_cell<<<blocks(E * R), dim3(256), 0, st>>>(wp(L.G), c0, h1, c1, R, E);
+    // ---- prior_fc_out (:408)
+    const float* cur = h1;
+    int cur_k = R;
+    for (int l = 0; l < prior_layers; ++l) {
+        const bool last = l + 1 == prior_layers;
+        float* dst = last ? logits : wp(l % 2 == 0 ? L.Y1 : L.Y2);
+        const int M = last ? K : prior_hidden;
+        if (s2s_linear(last ? 0 : 4, p->prior_w[l], cur_k, p->prior_b[l], cur, dst, M, cur_k, E, M, nullptr, 0, 0, st)) return AETHER_EINVAL;
+        cur = dst;
+        cur_k = M;
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+int aether_s2s_gumbel_hard(const float* logits, const float* uniform, float tau, int num_edge_types, int64_t n_edges,
+                           float* edges, void* stream) {
+    if (!logits || !uniform || !edges) return fail(AETHER_EINVAL, "s2s_gumbel: null pointer");
+    if (num_edge_types < 1 || num_edge_types > 4 || n_edges <= 0 || !(tau > 0.0f)) return fail(AETHER_EINVAL, "s2s_gumbel: bad sizes");
+    k_s2s_gumbel_hard<<<dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        logits, uniform, tau, num_edge_types, edges, n_edges);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }

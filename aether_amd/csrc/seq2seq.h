@@ -35,7 +35,8 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
 // MT x 2 MFMA tiles (16 MT rows x 32 points) and keeps the fragments of the next PF k-groups in flight
 // (4 waves per SIMD at MT = 4: the kernel is bound by the latency of its L2 reads, occupancy matters
 // more than a deeper ring or whole-line fragment pairs -- both were measured slower).
-// Epilogue: v = act(acc + b) [* scale[n * sstride]] [+ Y]  (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh).
+// Epilogue: v = act(acc + b) [affine per channel] [* scale[n * sstride]] [+ Y]
+// (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU).
 // Optional row lists gather X rows / scatter Y rows (edges of one type, compacted on the device).
 template <int ACT, int MT>
 __global__ void __launch_bounds__(256)
@@ -44,7 +45,9 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
              const float* __restrict__ scale, int sstride, int accumulate,
              const int64_t* __restrict__ xidx /* row n of X is X[xidx[n]] */,
              const int64_t* __restrict__ yidx /* row n of Y (and of scale) is yidx[n] */,
-             const int* __restrict__ n_dev /* non-null: N = *n_dev (compacted row lists) */) {
+             const int* __restrict__ n_dev /* non-null: N = *n_dev (compacted row lists) */,
+             const float* __restrict__ post_scale /* non-null: v = v * post_scale[m] + post_shift[m] (BatchNorm, eval) */,
+             const float* __restrict__ post_shift) {
     if (n_dev != nullptr) N = *n_dev;
     constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -128,6 +131,15 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
             if (ACT == 3) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            }
+            if (ACT == 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);     // ELU, alpha = 1
+            }
+            if (post_scale != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < M) v[r] = v[r] * post_scale[m + r] + post_shift[m + r];
             }
             if (scale != nullptr) v = v * scale[(size_t)n * sstride];
             if (m + 3 < M) {
@@ -351,13 +363,13 @@ k_s2s_select(const float* __restrict__ edge_w, int K, int k, int64_t n_edges, in
 // torch_scatter mean (aether.py:617,635).  One workgroup per node, a thread per 4 columns, fixed order.
 __global__ void __launch_bounds__(128)
 k_s2s_segment_mean(const float* __restrict__ Mx, const int64_t* __restrict__ order, const int64_t* __restrict__ rowptr,
-                   float* __restrict__ agg, int h) {
+                   float* __restrict__ agg, int h, float fixed_div /* > 0: sum / fixed_div (Encoder.edge2node) */) {
     const int64_t n = blockIdx.x;
     const int64_t beg = rowptr[n], end = rowptr[n + 1];
     for (int c = threadIdx.x * 4; c < h; c += 128 * 4) {
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int64_t k = beg; k < end; ++k) s += ld4(Mx + (size_t)order[k] * h + c);
-        const float cnt = (float)(end - beg > 1 ? end - beg : 1);
+        const float cnt = fixed_div > 0.0f ? fixed_div : (float)(end - beg > 1 ? end - beg : 1);
         st4(agg + (size_t)n * h + c, s / cnt);
     }
 }
@@ -414,6 +426,157 @@ k_s2s_globalize(const float* __restrict__ inputs, const float* __restrict__ pred
             for (int b = 0; b < D; ++b) s += Rinv[n * D * D + a * D + b] * pred[n * 2 * D + chunk * D + b];
             out[n * 2 * D + chunk * D + a] = inputs[n * 2 * D + chunk * D + a] + s;
         }
+}
+
+}  // namespace
+
+// =====================================================================================================
+// Row A10, prior half: Encoder.single_step_forward (nn/seq2seq/aether.py:384-410), SURVEY.md Appendix B.5.
+namespace {
+
+// hw[e][c] = ELU(sum_p W1[c][p] pos[e][p] + b1[c]): the first layer of the hyper-network (pos_size = 3 | 6)
+__global__ void __launch_bounds__(256)
+k_s2s_pos_hidden(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ pos, int P,
+                 float* __restrict__ hw, int h, int64_t n_edges) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_edges * h) return;
+    const int64_t e = idx / h;
+    const int c = (int)(idx - e * h);
+    float s = b1[c];
+    for (int p = 0; p < P; ++p) s = fmaf(W1[c * P + p], pos[e * P + p], s);
+    hw[idx] = s > 0.0f ? s : expm1f(s);
+}
+
+// Anisotropic edge filter (nn/nn/anisotropic_filter.py:34-40):
+//   out[e][c] = sum_r ea[e][r] * (b2[r h + c] + sum_k L2[r h + c][k] hw[e][k]),   r < R (24 | 39), c, k < h.
+// The [E, R h] filter bank of the reference is never materialised: the contraction runs as one GEMM over
+// K' = R h with the B operand formed on the fly, x[(r, k)] = ea[e][r] * hw[e][k] (one hw fragment per
+// k-group, scaled by the edge's R feature values held in registers).  grid = (ceil(E / 64), h / 128),
+// 4 waves = 2 (c) x 2 (e); a wave owns 64 outputs x 32 edges; the L2 fragments of the next r are in flight.
+template <int R>
+__global__ void __launch_bounds__(256)
+k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const float* __restrict__ ea,
+             const float* __restrict__ hw, float* __restrict__ out, int h, int64_t n_edges) {
+    constexpr int MT = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = (int)blockIdx.y * 128 + 64 * (wave >> 1);
+    const int64_t n0 = (int64_t)blockIdx.x * 64 + 32 * (wave & 1);
+    if (n0 >= n_edges) return;
+    float ev[2][R];
+    const float* hrow[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int64_t n = n0 + 16 * nb + i;
+        n = n < n_edges ? n : n_edges - 1;
+        hrow[nb] = hw + (size_t)n * h + 4 * q;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ev[nb][r] = ea[(size_t)n * R + r];
+    }
+    // bias term: sum_r ea[e][r] * b2[r h + m]
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) {
+        acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) {
+            const f32x4 bv = ld4(b2 + (size_t)r * h + m0 + 16 * mb + 4 * q);
+            acc[mb][0] += bv * ev[0][r];
+            acc[mb][1] += bv * ev[1][r];
+        }
+    }
+    const float* wbase = L2w + (size_t)(m0 + i) * h + 4 * q;          // row (r h + m0 + 16 mb + i), k-group a
+    const int steps = h >> 4;
+    for (int a = 0; a < steps; ++a) {
+        const f32x4 hf0 = ld4(hrow[0] + 16 * a), hf1 = ld4(hrow[1] + 16 * a);
+        f32x4 wv[MT], wn[MT];
+#pragma unroll
+        for (int mb = 0; mb < MT; ++mb) wv[mb] = ld4(wbase + (size_t)(16 * mb) * h + 16 * a);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int rn = r + 1 < R ? r + 1 : r;
+#pragma unroll
+            for (int mb = 0; mb < MT; ++mb) wn[mb] = ld4(wbase + ((size_t)rn * h + 16 * mb) * h + 16 * a);
+            const f32x4 x0 = hf0 * ev[0][r], x1 = hf1 * ev[1][r];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int mb = 0; mb < MT; ++mb) {
+                    acc[mb][0] = mfma16(wv[mb][b], x0[b], acc[mb][0]);
+                    acc[mb][1] = mfma16(wv[mb][b], x1[b], acc[mb][1]);
+                }
+#pragma unroll
+            for (int mb = 0; mb < MT; ++mb) wv[mb] = wn[mb];
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int64_t n = n0 + 16 * nb + i;
+        if (n >= n_edges) continue;
+#pragma unroll
+        for (int mb = 0; mb < MT; ++mb) st4(out + (size_t)n * h + m0 + 16 * mb + 4 * q, acc[mb][nb]);
+    }
+}
+
+// T[e][:] = ELU(T[e][:] + Ps[send[e]][:] + Pr[recv[e]][:])   (first Linear of mlp4 on [x_send | x_recv | edge])
+__global__ void __launch_bounds__(256)
+k_s2s_edge_sum_elu(float* __restrict__ T, const float* __restrict__ Ps, const float* __restrict__ Pr,
+                   const int64_t* __restrict__ send, const int64_t* __restrict__ recv, int h, int64_t n_edges) {
+    const int q4 = h >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_edges * q4) return;
+    const int64_t e = idx / q4;
+    const int c = (int)(idx - e * q4) * 4;
+    f32x4 v = ld4(T + (size_t)e * h + c) + ld4(Ps + (size_t)send[e] * h + c) + ld4(Pr + (size_t)recv[e] * h + c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);
+    st4(T + (size_t)e * h + c, v);
+}
+
+// BatchNorm1d in eval mode as a per-channel affine: scale = w / sqrt(var + eps), shift = b - mean * scale
+__global__ void __launch_bounds__(256)
+k_s2s_bn_affine(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift, int n) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const float sc = w[c] / sqrtf(var[c] + 1e-5f);
+    scale[c] = sc;
+    shift[c] = b[c] - mean[c] * sc;
+}
+
+// One LSTM step (torch.nn.LSTM gate order i, f, g, o): gates [E][4R] -> h1, c1
+__global__ void __launch_bounds__(256)
+k_s2s_lstm_cell(const float* __restrict__ gates, const float* __restrict__ c0, float* __restrict__ h1,
+                float* __restrict__ c1, int R, int64_t n_edges) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_edges * R) return;
+    const int64_t e = idx / R;
+    const int c = (int)(idx - e * R);
+    const float* g = gates + (size_t)e * 4 * R;
+    const float ig = 1.0f / (1.0f + expf(-g[c])), fg = 1.0f / (1.0f + expf(-g[R + c]));
+    const float gg = tanhf(g[2 * R + c]), og = 1.0f / (1.0f + expf(-g[3 * R + c]));
+    const float cn = fg * c0[idx] + ig * gg;
+    c1[idx] = cn;
+    h1[idx] = og * tanhf(cn);
+}
+
+// gumbel_softmax(hard=True) with the uniform draw supplied (nn/utils/model_utils.py:58-118)
+__global__ void __launch_bounds__(256)
+k_s2s_gumbel_hard(const float* __restrict__ logits, const float* __restrict__ uniform, float tau, int K,
+                  float* __restrict__ edges, int64_t n_edges) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    float y[4], mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const float g = -logf(1e-10f - logf(uniform[e * K + k] + 1e-10f));
+        y[k] = (logits[e * K + k] + g) / tau;
+        mx = fmaxf(mx, y[k]);
+    }
+    float sum = 0.0f;
+    for (int k = 0; k < K; ++k) { y[k] = expf(y[k] - mx); sum += y[k]; }
+    int best = 0;
+    for (int k = 0; k < K; ++k) { y[k] = y[k] / sum; if (y[k] > y[best]) best = k; }
+    for (int k = 0; k < K; ++k) edges[e * K + k] = ((k == best ? 1.0f : 0.0f) - y[k]) + y[k];
 }
 
 }  // namespace

@@ -250,6 +250,43 @@ int aether_s2s_decoder_step(const AetherS2SDecoderParams* params, int num_dims, 
                             float* hidden_out, void* stream);
 
 /*
+ * seq2seq Aether, one step of the encoder's prior (prior half): replaces
+ * Encoder.single_step_forward (nn/seq2seq/aether.py:384-410) on a flattened batch -- local frames,
+ * anisotropic edge filter (nn/nn/anisotropic_filter.py:34-40; the [E, R h] filter bank is never
+ * materialised), edge2node / res1, mlp3, node2edge + skip, mlp4 (RefNRIMLP in eval mode: BatchNorm with
+ * running statistics, nn/utils/model_utils.py:15-55), one LSTM step per edge, prior_fc_out.
+ *   params  : the reference Encoder's tensors (nn.Linear / nn.LSTM layouts; gate order i, f, g, o)
+ *   inputs  : float[n_nodes][2D]   field : float[n_nodes][D]   h0, c0 : float[n_edges][rnn_hidden]
+ *   send, recv, order, rowptr : as for aether_s2s_decoder_step;  num_vars = objects per graph (edge2node
+ *                               divides by num_vars - 1, aether.py:348)
+ *   logits  : float[n_edges][K]    h1, c1 : float[n_edges][rnn_hidden]
+ *   workspace : aether_s2s_prior_workspace_bytes(...) bytes
+ * aether_s2s_gumbel_hard: gumbel_softmax(hard=True) of nn/utils/model_utils.py:58-118 with the uniform
+ * draw U[n_edges][K] supplied by the caller (the reference draws it with torch.rand on the host).
+ */
+typedef struct AetherS2SPriorParams {
+    const float* mlp3_w0; const float* mlp3_b0; const float* mlp3_w3; const float* mlp3_b3;       /* [h][h] */
+    const float* mlp3_bn_w; const float* mlp3_bn_b; const float* mlp3_bn_mean; const float* mlp3_bn_var;
+    const float* mlp4_w0; const float* mlp4_b0; const float* mlp4_w3; const float* mlp4_b3;       /* [h][3h], [h][h] */
+    const float* mlp4_bn_w; const float* mlp4_bn_b; const float* mlp4_bn_mean; const float* mlp4_bn_var;
+    const float* lstm_w_ih; const float* lstm_w_hh; const float* lstm_b_ih; const float* lstm_b_hh; /* [4R][h], [4R][R] */
+    const float* prior_w[4]; const float* prior_b[4];                                            /* prior_fc_out */
+    const float* res1_w; const float* res1_b;                                                    /* [h][7D+O] */
+    const float* filt_w0; const float* filt_b0;                                                  /* [h][D+O] */
+    const float* filt_w2; const float* filt_b2;                                                  /* [R h][h], R = 2(4D+O)+3D */
+} AetherS2SPriorParams;
+size_t aether_s2s_prior_workspace_bytes(int num_dims, int hidden, int rnn_hidden, int prior_hidden,
+                                        int64_t n_nodes, int64_t n_edges);
+int aether_s2s_prior_step(const AetherS2SPriorParams* params, int num_dims, int hidden, int rnn_hidden,
+                          int prior_layers, int prior_hidden, int num_edge_types, int polar, int num_vars,
+                          int64_t n_nodes, int64_t n_edges, const float* inputs, const float* field,
+                          const float* h0, const float* c0, const int64_t* send, const int64_t* recv,
+                          const int64_t* order, const int64_t* rowptr, void* workspace, size_t workspace_bytes,
+                          float* logits, float* h1, float* c1, void* stream);
+int aether_s2s_gumbel_hard(const float* logits, const float* uniform, float tau, int num_edge_types,
+                           int64_t n_edges, float* edges, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

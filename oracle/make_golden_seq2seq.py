@@ -141,9 +141,70 @@ def decoder_fixtures(out_dir):
         torch.Tensor.cuda = orig_cuda
 
 
+def prior_fixtures(out_dir):
+    """Row A10 (prior half): the imported reference Encoder.single_step_forward (eval mode; BatchNorm
+    running statistics set to non-trivial values) + gumbel_softmax(hard) with the uniform noise captured."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import contextlib, io
+    import make_golden as MG
+    MG._install_scatter_standin()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from nn.seq2seq.aether import Encoder
+        from nn.utils import model_utils
+    for use_3d in (False, True):
+        D = 3 if use_3d else 2
+        B, N, H, R = 2, 5, 512, 128
+        params = enc_params(N, D, H, R)
+        torch.manual_seed(ENC_SEED)
+        with contextlib.redirect_stdout(io.StringIO()):
+            enc = Encoder(params).eval()
+        g = torch.Generator().manual_seed(700 + D)
+        with torch.no_grad():
+            for bn in (enc.mlp3.bn, enc.mlp4.bn):                  # as after training: non-trivial statistics
+                bn.running_mean.copy_(torch.randn(H, generator=g) * 0.2)
+                bn.running_var.copy_(torch.rand(H, generator=g) + 0.5)
+                bn.weight.copy_(1.0 + 0.1 * torch.randn(H, generator=g))
+                bn.bias.copy_(0.1 * torch.randn(H, generator=g))
+        E = N * (N - 1)
+        inputs = torch.randn(B, N, 2 * D, generator=g)
+        field = torch.randn(B, N, D, generator=g) * 0.3
+        h0, c0 = torch.randn(B, E, R, generator=g) * 0.3, torch.randn(B, E, R, generator=g) * 0.3
+        with torch.no_grad():
+            logits, (h1, c1) = enc.single_step_forward(inputs, (h0, c0), field)
+            # gumbel_softmax draws torch.rand on the CPU (model_utils.py:66): capture the draw
+            torch.manual_seed(99)
+            U = torch.rand(B * E, 2)
+            torch.manual_seed(99)
+            edges = model_utils.gumbel_softmax(logits.reshape(-1, 2), tau=0.5, hard=True).view(B, E, 2)
+        out = {"in.inputs": inputs.numpy(), "in.field": field.numpy(), "in.h0": h0.numpy(), "in.c0": c0.numpy(),
+               "in.uniform": U.numpy(), "ref.logits": logits.numpy(), "ref.h1": h1.numpy(), "ref.c1": c1.numpy(),
+               "ref.edges": edges.numpy(), "tau": np.float64(0.5), "seed": np.int64(ENC_SEED),
+               "hidden_size": np.int64(H), "rnn_hidden": np.int64(R), "num_vars": np.int64(N)}
+        for k in ("mlp3.bn", "mlp4.bn"):
+            for t in ("running_mean", "running_var", "weight", "bias"):
+                out[f"bn.{k}.{t}"] = enc.state_dict()[f"{k}.{t}"].numpy()
+        for k, v in enc.state_dict().items():
+            if v.dtype.is_floating_point and ".bn." not in k:
+                out["sum." + k] = np.float64(v.double().sum().item())
+                out["abs." + k] = np.float64(v.double().abs().sum().item())
+        out["keys"] = np.array(list(enc.state_dict().keys()))
+        np.savez(os.path.join(out_dir, f"s2s_prior_D{D}.npz"), **out)
+        print("wrote s2s_prior_D%d.npz" % D, len(enc.state_dict()), "tensors")
+
+
+def enc_params(N, D, H, R):
+    return {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
+            "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "input_size": 2 * D,
+            "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 256, "prior_num_layers": 3,
+            "prior_hidden_size": 256, "use_3d": D == 3, "pos_representation": "polar"}
+
+
 DEC_SEED = 4321
+ENC_SEED = 2468
 
 if __name__ == "__main__":
     main()
     localizer_fixtures(os.path.join(REPO, "tests", "golden"))
     decoder_fixtures(os.path.join(REPO, "tests", "golden"))
+    prior_fixtures(os.path.join(REPO, "tests", "golden"))

@@ -200,3 +200,62 @@ def decoder_step(sd, inputs, hidden, edges, predicted_field, use_3d=False, skip_
     pred = lin("out_mlp.6", torch.relu(lin("out_mlp.3", torch.relu(lin("out_mlp.0", hidden)))))   # :649
     pred_global = torch.cat([torch.einsum("...ij,...j->...i", Rinv, c) for c in pred.split(D, dim=-1)], -1)
     return inputs + pred_global, hidden                                               # :651-654
+
+
+# ---------------------------------------------------------------------------------------------
+# Row A10 (prior half): one step of the encoder's prior
+#   Encoder.single_step_forward   <- nn/seq2seq/aether.py:384-410
+#   AnisotropicEdgeFilter.forward <- nn/nn/anisotropic_filter.py:34-40
+#   RefNRIMLP (eval)              <- nn/utils/model_utils.py:15-55
+#   gumbel_softmax(hard)          <- nn/utils/model_utils.py:58-118 (noise passed in)
+# Parity status: PINNED by tests/golden/s2s_prior_D{2,3}.npz (imported reference Encoder).
+# ---------------------------------------------------------------------------------------------
+def _refnri_mlp(sd, prefix, x):
+    """Linear-ELU-Linear-ELU-BatchNorm1d in eval mode (running statistics), model_utils.py:18-55."""
+    x = F.elu(F.linear(x, sd[prefix + ".model.0.weight"], sd[prefix + ".model.0.bias"]))
+    x = F.elu(F.linear(x, sd[prefix + ".model.3.weight"], sd[prefix + ".model.3.bias"]))
+    return (x - sd[prefix + ".bn.running_mean"]) / torch.sqrt(sd[prefix + ".bn.running_var"] + 1e-5) \
+        * sd[prefix + ".bn.weight"] + sd[prefix + ".bn.bias"]
+
+
+def prior_step(sd, inputs, prior_state, predicted_field, use_3d=False, pos_representation="cart",
+               prior_layers=3):
+    """``sd``: the reference Encoder's state_dict.  inputs [B, N, 2D], prior_state (h, c) each
+    [B, E, rnn], predicted_field [B, N, D] -> (logits [B, E, K], (h', c'))."""
+    B, N, _ = inputs.shape
+    send, recv = torch.where(~torch.eye(N, dtype=bool))          # np.where(ones - eye): the same order (:251-253)
+    ext = torch.cat([inputs, predicted_field], -1)                                     # :385
+    rel_feat, _, edge_attr, edge_pos = augmented_localizer(ext, use_3d, pos_representation)
+    hw = F.elu(F.linear(edge_pos, sd["edge_filter.edge_filter.0.weight"], sd["edge_filter.edge_filter.0.bias"]))
+    ew = F.linear(hw, sd["edge_filter.edge_filter.2.weight"], sd["edge_filter.edge_filter.2.bias"])
+    nrf = edge_attr.shape[-1]
+    ew = ew.reshape(ew.shape[:-1] + (nrf, ew.shape[-1] // nrf))                        # anisotropic_filter.py:36-38
+    ea = (edge_attr.unsqueeze(-2) @ ew).squeeze(-2)                                    # :39
+    res_x = F.linear(rel_feat, sd["res1.weight"], sd["res1.bias"])                     # :393
+    incoming = torch.zeros(B, N, ea.shape[-1], dtype=ea.dtype).index_add_(1, recv, ea) # edge2node, :340-348
+    x = incoming / (N - 1) + res_x
+    x = _refnri_mlp(sd, "mlp3", x)
+    x = torch.cat([x[:, send], x[:, recv], ea], -1)                                    # node2edge + skip, :333-338,397
+    x = _refnri_mlp(sd, "mlp4", x)
+    h0, c0 = prior_state
+    gates = F.linear(x, sd["forward_rnn.weight_ih_l0"], sd["forward_rnn.bias_ih_l0"]) + \
+        F.linear(h0, sd["forward_rnn.weight_hh_l0"], sd["forward_rnn.bias_hh_l0"])   # nn.LSTM, one step (:405)
+    i, f, g, o = gates.chunk(4, -1)
+    c1 = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(g)
+    h1 = torch.sigmoid(o) * torch.tanh(c1)
+    y = h1
+    for layer in range(prior_layers):                                                  # prior_fc_out, :293-303
+        y = F.linear(y, sd[f"prior_fc_out.{2 * layer}.weight"], sd[f"prior_fc_out.{2 * layer}.bias"])
+        if layer + 1 < prior_layers:
+            y = F.elu(y)
+    return y, (h1, c1)
+
+
+def gumbel_hard(logits, uniform, tau):
+    """gumbel_softmax(hard=True) with the uniform noise U supplied (model_utils.py:58-118):
+    g = -log(eps - log(U + eps)); y_soft = softmax((logits + g) / tau); y = onehot(argmax) - y_soft + y_soft."""
+    eps = 1e-10
+    g = -torch.log(eps - torch.log(uniform + eps))
+    y_soft = F.softmax((logits + g) / tau, dim=-1)
+    y_hard = torch.zeros_like(y_soft).scatter_(-1, y_soft.argmax(-1, keepdim=True), 1.0)
+    return y_hard - y_soft + y_soft

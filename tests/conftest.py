@@ -84,3 +84,29 @@ def load_s2s_decoder(D):
     for k, v in sd.items():
         assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
     return d, sd, params
+
+
+def load_s2s_prior(D):
+    """Golden fixture of the seq2seq prior step + the reference Encoder's parameters, recreated from the
+    stored seed through the drop-in module's constructor (checksums verified) with the fixture's
+    BatchNorm statistics."""
+    import numpy as _np
+    import torch as _torch
+    from aether_amd.nn.seq2seq.encoder import Encoder
+    d = _np.load(os.path.join(GOLDEN, f"s2s_prior_D{D}.npz"))
+    params = {"num_vars": int(d["num_vars"]), "num_edge_types": 2, "encoder_dropout": 0.0,
+              "encoder_hidden": int(d["hidden_size"]), "encoder_rnn_hidden": int(d["rnn_hidden"]),
+              "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 3,
+              "encoder_mlp_hidden": 256, "prior_num_layers": 3, "prior_hidden_size": 256, "use_3d": D == 3,
+              "pos_representation": "polar"}
+    _torch.manual_seed(int(d["seed"]))
+    enc = Encoder(params, device=None)
+    sd = enc.state_dict()
+    assert list(sd.keys()) == [str(k) for k in d["keys"]]
+    for k in ("mlp3.bn", "mlp4.bn"):
+        for t in ("running_mean", "running_var", "weight", "bias"):
+            sd[f"{k}.{t}"].copy_(_torch.from_numpy(d[f"bn.{k}.{t}"]))
+    for k, v in sd.items():
+        if "sum." + k in d:
+            assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
+    return d, {k: v.detach() for k, v in sd.items()}, params

@@ -124,3 +124,24 @@ def test_decoder_step_fresh_batch_vs_oracle():
         xg, hg = dec(xg, hg, z.cuda(), f.cuda())
         assert scale_rel_err(hg.cpu(), hid) <= TOL, step
         assert scale_rel_err(xg.cpu(), x) <= TOL, step
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_prior_step_matches_reference(D):
+    """Row A10 (prior half): Encoder.single_step_forward and the hard Gumbel sample vs the imported reference."""
+    from conftest import load_s2s_prior
+    from aether_amd.nn.seq2seq.encoder import Encoder, gumbel_softmax_hard
+    d, sd, params = load_s2s_prior(D)
+    enc = Encoder(params, device="cuda").eval()
+    enc.load_state_dict(sd)
+    t = lambda k: torch.from_numpy(d[k]).cuda()
+    logits, (h1, c1) = enc.single_step_forward(t("in.inputs"), (t("in.h0"), t("in.c0")), t("in.field"))
+    for got, key in ((h1, "ref.h1"), (c1, "ref.c1"), (logits, "ref.logits")):
+        assert scale_rel_err(got.cpu(), torch.from_numpy(d[key])) <= TOL, key
+    # the sample is a discontinuous function of the logits: feed the reference's own logits
+    edges = gumbel_softmax_hard(t("ref.logits"), t("in.uniform").view(t("ref.logits").shape), float(d["tau"]))
+    ref_edges = torch.from_numpy(d["ref.edges"])
+    assert torch.equal(edges.cpu().argmax(-1), ref_edges.argmax(-1))
+    assert scale_rel_err(edges.cpu(), ref_edges) <= 1e-6
+    with pytest.raises(Exception):
+        enc.train().single_step_forward(t("in.inputs"), (t("in.h0"), t("in.c0")), t("in.field"))

@@ -191,3 +191,19 @@ def test_seq2seq_decoder_step(D):
         out, hid = S.decoder_step(sd, t("in.inputs"), t("in.hidden"), t("in.edges_" + name), t("in.field"), D == 3)
         assert scale_rel_err(out, t(f"ref.{name}.outputs")) <= 2e-6, name
         assert scale_rel_err(hid, t(f"ref.{name}.hidden")) <= 2e-6, name
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_seq2seq_prior_step(D):
+    """Row A10 (prior half): Encoder.single_step_forward + hard Gumbel sample vs the imported reference."""
+    from conftest import load_s2s_prior
+    from oracle import seq2seq_oracle as S
+    d, sd, params = load_s2s_prior(D)
+    t = lambda k: torch.from_numpy(d[k])
+    logits, (h1, c1) = S.prior_step(sd, t("in.inputs"), (t("in.h0"), t("in.c0")), t("in.field"), D == 3,
+                                    params["pos_representation"], params["prior_num_layers"])
+    assert scale_rel_err(logits, t("ref.logits")) <= 5e-6
+    assert scale_rel_err(h1, t("ref.h1")) <= 5e-6 and scale_rel_err(c1, t("ref.c1")) <= 5e-6
+    edges = S.gumbel_hard(t("ref.logits").reshape(-1, 2), t("in.uniform"), float(d["tau"])).view_as(t("ref.edges"))
+    assert torch.equal(edges.argmax(-1), t("ref.edges").argmax(-1))
+    assert scale_rel_err(edges, t("ref.edges")) <= 1e-6
