@@ -4,8 +4,8 @@ Mirrors the parts of ``nn.seq2seq.aether.Aether`` (aether.py:14-191) that run on
 ``predict_field`` (:86-90), ``single_step_forward`` (:92-101) and the prediction loop of
 ``predict_future`` (:175-185).  Sub-modules carry the reference's names -- ``encoder``, ``decoder``,
 ``field_net``, ``coordinate_embedding`` -- so ``load_state_dict(reference_model.state_dict())`` works.
-The burn-in half of ``predict_future`` (the bidirectional sequence encoder, aether.py:161-174) and the
-training loss are not part of this path.
+``predict_future`` runs its burn-in half with the same step (the prior path of the encoder is causal);
+the posterior encoder (reverse LSTM, ``encoder_fc_out``) and the training loss are not part of this path.
 """
 from __future__ import annotations
 
@@ -50,6 +50,26 @@ class Aether(nn.Module):
         edges = gumbel_softmax_hard(edge_logits, uniform, self.gumbel_temp)
         predictions, decoder_hidden = self.decoder(inputs, decoder_hidden, edges, predicted_field)
         return predictions, decoder_hidden, edges
+
+    @torch.no_grad()
+    def predict_future(self, inputs, prediction_steps, return_edges=False, uniform=None):
+        """aether.py:155-191.  inputs [B, T, N, 2D] (burn-in observations).  The burn-in half runs the prior
+        step by step: the encoder's prior path is causal (forward LSTM from the zero state, BatchNorm in eval
+        mode), so the chained ``single_step_forward`` equals ``Encoder.forward``'s prior logits and state
+        (pinned against the reference's own ``predict_future``).  ``uniform`` [T - 1 + steps, B, E, K]."""
+        B, T, N, _ = inputs.shape
+        E = N * (N - 1)
+        decoder_hidden = self.decoder.get_initial_hidden(inputs)
+        R = self.encoder.rnn_hidden_size
+        prior_hidden = (torch.zeros(B, E, R, device=inputs.device), torch.zeros(B, E, R, device=inputs.device))
+        for step in range(T - 1):
+            current_inputs = inputs[:, step]
+            field, _ = self.predict_field(current_inputs)
+            logits, prior_hidden = self.encoder.single_step_forward(current_inputs, prior_hidden, field)
+            _, decoder_hidden, _ = self.single_step_forward(current_inputs, decoder_hidden, logits, True, field,
+                                                            None if uniform is None else uniform[step])
+        return self.predict_from_state(inputs[:, T - 1], decoder_hidden, prior_hidden, prediction_steps,
+                                       None if uniform is None else uniform[T - 1:], return_edges)
 
     @torch.no_grad()
     def predict_from_state(self, predictions, decoder_hidden, prior_hidden, prediction_steps, uniform=None,

@@ -193,6 +193,62 @@ def prior_fixtures(out_dir):
         print("wrote s2s_prior_D%d.npz" % D, len(enc.state_dict()), "tensors")
 
 
+def future_fixture(out_dir):
+    """End to end: the imported reference seq2seq ``Aether.predict_future`` (burn-in + prediction loop).
+    gumbel_softmax draws torch.rand on the host: the global generator is seeded before the call and the
+    same draws are regenerated afterwards for the fixture.  The seed is accepted only if every sampled
+    edge type wins its Gumbel race by a clear margin, so that fp32 reordering cannot flip a sample."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import contextlib, io
+    import make_golden as MG
+    import seq2seq_oracle as S
+    MG._install_scatter_standin()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from nn.seq2seq.aether import Aether
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        D, B, N, T, steps, H, R = 2, 2, 5, 4, 3, 128, 64
+        params = dict(enc_params(N, D, H, R))
+        params.update({"gpu": False, "decoder_hidden": H, "skip_first": False, "decoder_dropout": 0.0,
+                       "gumbel_temp": 0.5, "encoder_mlp_hidden": 64, "prior_hidden_size": 64, "rff_std": 1.0})
+        torch.manual_seed(FUT_SEED)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = Aether(params).eval()
+        g = torch.Generator().manual_seed(900)
+        inputs = torch.randn(B, T, N, 2 * D, generator=g)
+        E = N * (N - 1)
+        for noise_seed in range(50):
+            torch.manual_seed(1000 + noise_seed)
+            with torch.no_grad():
+                preds, edges = model.predict_future(inputs, steps, return_edges=True)
+            torch.manual_seed(1000 + noise_seed)
+            U = torch.stack([torch.rand(B * E, 2) for _ in range(T - 1 + steps)])
+            sd = {k: v.detach() for k, v in model.state_dict().items()}
+            o_preds, o_edges = S.predict_future(sd, inputs, steps, U, 0.5, False, "polar", 3, return_edges=True)
+            if torch.equal(o_edges.argmax(-1), edges.argmax(-1)):
+                break
+        else:
+            raise RuntimeError("no noise seed with unambiguous samples")
+        out = {"in.inputs": inputs.numpy(), "in.uniform": U.numpy(), "ref.predictions": preds.numpy(),
+               "ref.edges": edges.numpy(), "seed": np.int64(FUT_SEED), "steps": np.int64(steps),
+               "hidden_size": np.int64(H), "rnn_hidden": np.int64(R), "num_vars": np.int64(N)}
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point:
+                out["sum." + k] = np.float64(v.double().sum().item())
+                out["abs." + k] = np.float64(v.double().abs().sum().item())
+        out["keys"] = np.array(list(model.state_dict().keys()))
+        np.savez(os.path.join(out_dir, "s2s_future_D2.npz"), **out)
+        print("wrote s2s_future_D2.npz", tuple(preds.shape), "noise seed", 1000 + noise_seed,
+              "oracle err", float((o_preds - preds).abs().max() / preds.abs().max()))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
+FUT_SEED = 1357
+
+
 def enc_params(N, D, H, R):
     return {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
             "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "input_size": 2 * D,
@@ -208,3 +264,4 @@ if __name__ == "__main__":
     localizer_fixtures(os.path.join(REPO, "tests", "golden"))
     decoder_fixtures(os.path.join(REPO, "tests", "golden"))
     prior_fixtures(os.path.join(REPO, "tests", "golden"))
+    future_fixture(os.path.join(REPO, "tests", "golden"))

@@ -259,3 +259,46 @@ def gumbel_hard(logits, uniform, tau):
     y_soft = F.softmax((logits + g) / tau, dim=-1)
     y_hard = torch.zeros_like(y_soft).scatter_(-1, y_soft.argmax(-1, keepdim=True), 1.0)
     return y_hard - y_soft + y_soft
+
+
+# ---------------------------------------------------------------------------------------------
+# predict_future (nn/seq2seq/aether.py:155-191) restated with the step functions above.  The burn-in half
+# runs the encoder step by step: its prior path is causal (forward LSTM from the zero state, per-feature
+# BatchNorm in eval mode), so Encoder.forward's prior logits / state (:350-382) equal the chained
+# single_step_forward; the reverse LSTM and encoder_fc_out only feed the training posterior.
+# Parity status: PINNED by tests/golden/s2s_future_D2.npz (the imported reference Aether.predict_future).
+# ---------------------------------------------------------------------------------------------
+def predict_future(sd, inputs, prediction_steps, uniform, tau, use_3d=False, pos_representation="cart",
+                   prior_layers=3, rnn_hidden=None, return_edges=False):
+    """``sd``: the reference seq2seq Aether's state_dict.  inputs [B, T, N, 2D]; ``uniform``
+    [T - 1 + prediction_steps, B * E, K]: the U(0,1) draws of gumbel_softmax in call order."""
+    D = 3 if use_3d else 2
+    B, T, N, _ = inputs.shape
+    E = N * (N - 1)
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    dec = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    h = dec["hidden_r.weight"].shape[0]
+    R = enc["forward_rnn.weight_hh_l0"].shape[1]
+    hidden = torch.zeros(B, N, h, dtype=inputs.dtype)
+    state = (torch.zeros(B, E, R, dtype=inputs.dtype), torch.zeros(B, E, R, dtype=inputs.dtype))
+    draw = 0
+    preds, edges_all = [], []
+
+    def step(x, hidden, state, draw):
+        field = predict_field(sd, x, D)
+        logits, state = prior_step(enc, x, state, field, use_3d, pos_representation, prior_layers)
+        z = gumbel_hard(logits.reshape(-1, logits.shape[-1]), uniform[draw], tau).view(logits.shape)
+        out, hidden = decoder_step(dec, x, hidden, z, field, use_3d)
+        return out, hidden, state, z
+
+    for t in range(T - 1):                                            # burn-in, :165-173
+        _, hidden, state, _ = step(inputs[:, t], hidden, state, draw)
+        draw += 1
+    x = inputs[:, T - 1]                                              # :174
+    for _ in range(prediction_steps):                                 # :175-185
+        x, hidden, state, z = step(x, hidden, state, draw)
+        draw += 1
+        preds.append(x)
+        edges_all.append(z)
+    preds = torch.stack(preds, 1)
+    return (preds, torch.stack(edges_all, 1)) if return_edges else preds

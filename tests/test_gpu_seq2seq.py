@@ -188,3 +188,17 @@ def test_autoregressive_prediction_loop_vs_oracle():
         x, hid, ps = x_n, hid_n, ps_n
     traj, edges = model.predict_from_state(xg, hg, pg, T, uniform=U.cuda(), return_edges=True)
     assert traj.shape == (B, T, N, 2 * D) and edges.shape == (B, T, E, 2) and torch.isfinite(traj).all()
+
+
+def test_predict_future_matches_reference():
+    """The reference's own seq2seq Aether.predict_future (burn-in through the full-sequence encoder +
+    prediction loop) vs the drop-in, with the reference's Gumbel draws."""
+    from conftest import load_s2s_future
+    d, model, params = load_s2s_future()
+    model = model.cuda()
+    x = torch.from_numpy(d["in.inputs"]).cuda()
+    B, T, N, _ = x.shape
+    U = torch.from_numpy(d["in.uniform"]).cuda().view(-1, B, N * (N - 1), 2)
+    preds, edges = model.predict_future(x, int(d["steps"]), return_edges=True, uniform=U)
+    assert torch.equal(edges.cpu().argmax(-1), torch.from_numpy(d["ref.edges"]).argmax(-1))
+    assert scale_rel_err(preds.cpu(), torch.from_numpy(d["ref.predictions"])) <= TOL

@@ -207,3 +207,16 @@ def test_seq2seq_prior_step(D):
     edges = S.gumbel_hard(t("ref.logits").reshape(-1, 2), t("in.uniform"), float(d["tau"])).view_as(t("ref.edges"))
     assert torch.equal(edges.argmax(-1), t("ref.edges").argmax(-1))
     assert scale_rel_err(edges, t("ref.edges")) <= 1e-6
+
+
+def test_seq2seq_predict_future():
+    """End to end: burn-in + prediction loop vs the imported reference's own Aether.predict_future."""
+    from conftest import load_s2s_future
+    from oracle import seq2seq_oracle as S
+    d, model, params = load_s2s_future()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    t = lambda k: torch.from_numpy(d[k])
+    preds, edges = S.predict_future(sd, t("in.inputs"), int(d["steps"]), t("in.uniform"), 0.5, False, "polar", 3,
+                                    return_edges=True)
+    assert torch.equal(edges.argmax(-1), t("ref.edges").argmax(-1))
+    assert scale_rel_err(preds, t("ref.predictions")) <= 2e-6
