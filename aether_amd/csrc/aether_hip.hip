@@ -844,9 +844,10 @@ int aether_s2s_prior_step(const AetherS2SPriorParams* p, int num_dims, int hidde
     if (rc != AETHER_OK) return rc;
     k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0, p->filt_b0, wp(L.epos), L.EP, wp(L.hw), h, E);
     {
-        const dim3 grid((unsigned)((E + 63) / 64), (unsigned)(h / 128));
-        if (D == 2) k_s2s_filter<24><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
-        else k_s2s_filter<39><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
+        constexpr int NB = 4;
+        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128));
+        if (D == 2) k_s2s_filter<24, NB><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
+        else k_s2s_filter<39, NB><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
     }
     // ---- x = edge2node(edge_attr) + res1(rel_feat) (:393-395): sum over in-edges / (num_vars - 1)
     k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.eaf), order, rowptr, wp(L.X0), h, (float)(num_vars - 1));

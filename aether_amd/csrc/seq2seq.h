@@ -451,9 +451,9 @@ k_s2s_pos_hidden(const float* __restrict__ W1, const float* __restrict__ b1, con
 //   out[e][c] = sum_r ea[e][r] * (b2[r h + c] + sum_k L2[r h + c][k] hw[e][k]),   r < R (24 | 39), c, k < h.
 // The [E, R h] filter bank of the reference is never materialised: the contraction runs as one GEMM over
 // K' = R h with the B operand formed on the fly, x[(r, k)] = ea[e][r] * hw[e][k] (one hw fragment per
-// k-group, scaled by the edge's R feature values held in registers).  grid = (ceil(E / 64), h / 128),
-// 4 waves = 2 (c) x 2 (e); a wave owns 64 outputs x 32 edges; the L2 fragments of the next r are in flight.
-template <int R>
+// k-group, scaled by the edge's R feature values).  grid = (ceil(E / (32 NB)), h / 128), 4 waves =
+// 2 (c) x 2 (e); a wave owns 64 outputs x 16 NB edges (every L2 fragment feeds 4 NB MFMAs).
+template <int R, int NB>
 __global__ void __launch_bounds__(256)
 k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const float* __restrict__ ea,
              const float* __restrict__ hw, float* __restrict__ out, int h, int64_t n_edges) {
@@ -461,12 +461,12 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m0 = (int)blockIdx.y * 128 + 64 * (wave >> 1);
-    const int64_t n0 = (int64_t)blockIdx.x * 64 + 32 * (wave & 1);
+    const int64_t n0 = (int64_t)blockIdx.x * (32 * NB) + 16 * NB * (wave & 1);
     if (n0 >= n_edges) return;
-    float ev[2][R];
-    const float* hrow[2];
+    float ev[NB][R];
+    const float* hrow[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         int64_t n = n0 + 16 * nb + i;
         n = n < n_edges ? n : n_edges - 1;
         hrow[nb] = hw + (size_t)n * h + 4 * q;
@@ -474,15 +474,15 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
         for (int r = 0; r < R; ++r) ev[nb][r] = ea[(size_t)n * R + r];
     }
     // bias term: sum_r ea[e][r] * b2[r h + m]
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][NB];
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb) {
-        acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < R; ++r) {
             const f32x4 bv = ld4(b2 + (size_t)r * h + m0 + 16 * mb + 4 * q);
-            acc[mb][0] += bv * ev[0][r];
-            acc[mb][1] += bv * ev[1][r];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += bv * ev[nb][r];
         }
     }
     const float* wbase = L2w + (size_t)(m0 + i) * h + 4 * q;          // row (r h + m0 + 16 mb + i), k-group a
@@ -500,31 +500,36 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p) wfetch(ring[p], p < total ? p : total - 1);
-    f32x4 hf0 = f32x4{0.f, 0.f, 0.f, 0.f}, hf1 = hf0;
+    f32x4 hf[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) hf[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s0 = 0; s0 < total; s0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int sidx = s0 + p;
             if (sidx < total) {
                 const int a = sidx / R, r = sidx - a * R;
-                if (r == 0) { hf0 = ld4(hrow[0] + 16 * a); hf1 = ld4(hrow[1] + 16 * a); }
-                f32x4 wv[MT];
+                if (r == 0) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) hf[nb] = ld4(hrow[nb] + 16 * a);
+                }
+                f32x4 wv[MT], xf[NB];
 #pragma unroll
                 for (int mb = 0; mb < MT; ++mb) wv[mb] = ring[p][mb];
                 wfetch(ring[p], sidx + PF < total ? sidx + PF : total - 1);
-                const f32x4 x0 = hf0 * ev[0][r], x1 = hf1 * ev[1][r];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) xf[nb] = hf[nb] * ev[nb][r];
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
-                    for (int mb = 0; mb < MT; ++mb) {
-                        acc[mb][0] = mfma16(wv[mb][b], x0[b], acc[mb][0]);
-                        acc[mb][1] = mfma16(wv[mb][b], x1[b], acc[mb][1]);
-                    }
+                    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma16(wv[mb][b], xf[nb][b], acc[mb][nb]);
             }
         }
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const int64_t n = n0 + 16 * nb + i;
         if (n >= n_edges) continue;
 #pragma unroll
