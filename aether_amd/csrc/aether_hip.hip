@@ -599,6 +599,13 @@ extern "C" {
 const char* aether_version(void) { return "aether_hip 0.2 (gfx950, fp32 MFMA 16x16x4, fused + streamed)"; }
 const char* aether_last_error(void) { return g_err; }
 
+namespace {
+int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
+               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st,
+               const int64_t* xidx = nullptr, const int64_t* yidx = nullptr, const int* n_dev = nullptr,
+               const float* post_scale = nullptr, const float* post_shift = nullptr);
+}  // namespace
+
 size_t aether_s2s_field_workspace_bytes(int64_t n_points, int hidden) {
     if (n_points <= 0 || hidden <= 0) return 0;
     return (size_t)3 * (size_t)n_points * (size_t)hidden * sizeof(float) + 768;
@@ -622,11 +629,9 @@ int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, in
     const unsigned rb = (unsigned)((n_points * half + 255) / 256);
     if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
     else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
-    const dim3 gh((unsigned)((n_points + 63) / 64), (unsigned)((hidden + 127) / 128));
-    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w0, p->b0, gamma, h1, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
-    k_s2s_linear<1, 4><<<gh, dim3(256), 0, st>>>(p->w2, p->b2, h1, h2, hidden, hidden, hidden, n_points, hidden, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
-    const dim3 go((unsigned)((n_points + 63) / 64), 1);
-    k_s2s_linear<0, 1><<<go, dim3(256), 0, st>>>(p->w4, p->b4, h2, field, num_dims, hidden, hidden, n_points, num_dims, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (s2s_linear(1, p->w0, hidden, p->b0, gamma, h1, hidden, hidden, n_points, hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(1, p->w2, hidden, p->b2, h1, h2, hidden, hidden, n_points, hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->w4, hidden, p->b4, h2, field, num_dims, hidden, n_points, num_dims, nullptr, 0, 0, st)) return AETHER_EINVAL;
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }
@@ -655,18 +660,23 @@ int aether_s2s_localize(int num_dims, int64_t n_nodes, int64_t n_edges, const fl
 }
 
 namespace {
-// Y[N][ldy] = act(X[N][K] W^T + b) [* scale] [+ Y]; act: 0 none, 2 ReLU, 3 tanh
+// Y[N][ldy] = act(X[N][K] W^T + b) [* scale] [+ Y]; act: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU
 int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
-               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st,
-               const int64_t* xidx = nullptr, const int64_t* yidx = nullptr, const int* n_dev = nullptr,
-               const float* post_scale = nullptr, const float* post_shift = nullptr) {
+               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st, const int64_t* xidx,
+               const int64_t* yidx, const int* n_dev, const float* post_scale, const float* post_shift) {
     if (K % 16 != 0) return fail(AETHER_EINVAL, "s2s_linear: K must be a multiple of 16");
     const bool big = M >= 128;
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
-#define S2S_CASE(A)                                                                                          \
-    if (big) k_s2s_linear<A, 4><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift); \
-    else k_s2s_linear<A, 1><<<grid, dim3(256), 0, st>>>(W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift)
-    if (act == 0) { S2S_CASE(0); } else if (act == 2) { S2S_CASE(2); } else if (act == 3) { S2S_CASE(3); } else { S2S_CASE(4); }
+    const bool wide = big && N >= 16384;             // 64 points per wave once there are enough workgroups
+    const int nt = wide ? 4 : 2;
+    const dim3 grid((unsigned)((N + 32 * nt - 1) / (32 * nt)), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
+#define S2S_ARGS W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift
+#define S2S_CASE(A)                                                                     \
+    if (wide) k_s2s_linear<A, 4, 4><<<grid, dim3(256), 0, st>>>(S2S_ARGS);              \
+    else if (big) k_s2s_linear<A, 4, 2><<<grid, dim3(256), 0, st>>>(S2S_ARGS);          \
+    else k_s2s_linear<A, 1, 2><<<grid, dim3(256), 0, st>>>(S2S_ARGS)
+    if (act == 0) { S2S_CASE(0); } else if (act == 1) { S2S_CASE(1); } else if (act == 2) { S2S_CASE(2); }
+    else if (act == 3) { S2S_CASE(3); } else { S2S_CASE(4); }
+#undef S2S_ARGS
 #undef S2S_CASE
     return AETHER_OK;
 }

@@ -31,14 +31,14 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
 }
 
 // Y[n][m] = act(sum_k W[m][k] X[n][k] + b[m]); W [M][K] rows at stride ldw (nn.Linear), X [N][K], Y [N][ldy].
-// K % 16 == 0.  grid = (ceil(N / 64), ceil(M / (32 MT))), 4 waves = 2 (m) x 2 (n); a wave owns
-// MT x 2 MFMA tiles (16 MT rows x 32 points) and keeps the fragments of the next PF k-groups in flight
+// K % 16 == 0.  grid = (ceil(N / (32 NT)), ceil(M / (32 MT))), 4 waves = 2 (m) x 2 (n); a wave owns
+// MT x NT MFMA tiles (16 MT rows x 16 NT points) and keeps the fragments of the next PF k-groups in flight
 // (4 waves per SIMD at MT = 4: the kernel is bound by the latency of its L2 reads, occupancy matters
 // more than a deeper ring or whole-line fragment pairs -- both were measured slower).
 // Epilogue: v = act(acc + b) [affine per channel] [* scale[n * sstride]] [+ Y]
 // (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU).
 // Optional row lists gather X rows / scatter Y rows (edges of one type, compacted on the device).
-template <int ACT, int MT>
+template <int ACT, int MT, int NT>
 __global__ void __launch_bounds__(256)
 k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ X,
              float* __restrict__ Y, int M, int K, int ldw, int64_t N, int ldy,
@@ -53,24 +53,24 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m0 = (int)blockIdx.y * (32 * MT) + 16 * MT * (wave >> 1);
-    const int64_t n0 = (int64_t)blockIdx.x * 64 + 32 * (wave & 1);
+    const int64_t n0 = (int64_t)blockIdx.x * (32 * NT) + 16 * NT * (wave & 1);
     if (m0 >= M || n0 >= N) return;
     // rows / points past the end are clamped for the loads and masked at the store
     const float* wrow[MT];
-    const float* xrow[2];
+    const float* xrow[NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = m0 + 16 * t + i;
         wrow[t] = W + (size_t)(m < M ? m : M - 1) * ldw + 4 * q;
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
         int64_t n = n0 + 16 * t + i;
         n = n < N ? n : N - 1;
         if (xidx != nullptr) n = xidx[n];
         xrow[t] = X + (size_t)n * K + 4 * q;
     }
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb) {
         f32x4 b4;
@@ -79,43 +79,44 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
             const int m = m0 + 16 * mb + 4 * q + r;
             b4[r] = (bias != nullptr && m < M) ? bias[m] : 0.0f;
         }
-        acc[mb][0] = b4; acc[mb][1] = b4;
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = b4;
     }
     const int steps = K >> 4;
-    f32x4 wq[PF][MT], xq[PF][2];                      // ring of prefetched fragments
+    f32x4 wq[PF][MT], xq[PF][NT];                      // ring of prefetched fragments
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         const int a = p < steps ? p : steps - 1;
 #pragma unroll
         for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * a);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) xq[p][t] = ld4(xrow[t] + 16 * a);
+        for (int t = 0; t < NT; ++t) xq[p][t] = ld4(xrow[t] + 16 * a);
     }
     for (int a0 = 0; a0 < steps; a0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             if (a0 + p < steps) {
-                f32x4 wv[MT], xv[2];
+                f32x4 wv[MT], xv[NT];
 #pragma unroll
                 for (int t = 0; t < MT; ++t) wv[t] = wq[p][t];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) xv[t] = xq[p][t];
+                for (int t = 0; t < NT; ++t) xv[t] = xq[p][t];
                 const int an = a0 + p + PF < steps ? a0 + p + PF : steps - 1;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * an);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) xq[p][t] = ld4(xrow[t] + 16 * an);
+                for (int t = 0; t < NT; ++t) xq[p][t] = ld4(xrow[t] + 16 * an);
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
                     for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma16(wv[mb][b], xv[nb][b], acc[mb][nb]);
+                        for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = mfma16(wv[mb][b], xv[nb][b], acc[mb][nb]);
             }
         }
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NT; ++nb) {
         int64_t n = n0 + 16 * nb + i;
         if (n >= N) continue;
         if (yidx != nullptr) n = yidx[n];
