@@ -101,6 +101,72 @@ def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0):
     }
 
 
+def _seq2seq_line(args):
+    """One autoregressive step of the seq2seq model (field query -> prior step -> hard Gumbel sample ->
+    decoder step; nn/seq2seq/aether.py:175-185) on one GPU, B x N from --batch / --nodes, h = 512.  A
+    separate line: the headline metric of BASELINE.json is the state2state step (default mode)."""
+    import contextlib, io
+    from aether_amd.nn.seq2seq.aether import Aether as S2S
+    B, N, D, H, R = args.batch, args.nodes, args.dims, 512, 128
+    params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": H, "num_edge_types": 2,
+              "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3, "encoder_dropout": 0.0,
+              "encoder_hidden": H, "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 3,
+              "encoder_mlp_hidden": 256, "prior_num_layers": 3, "prior_hidden_size": 256,
+              "pos_representation": "polar", "gumbel_temp": 0.5}
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = S2S(params, device="cuda").eval()
+    E = N * (N - 1)
+    x = torch.randn(B, N, 2 * D, device="cuda")
+    hid = torch.zeros(B, N, H, device="cuda")
+    ps = (torch.zeros(B, E, R, device="cuda"), torch.zeros(B, E, R, device="cuda"))
+    U = torch.rand(B, E, 2, device="cuda")
+
+    def step():
+        f, _ = m.predict_field(x)
+        lg, s2 = m.encoder.single_step_forward(x, ps, f)
+        return m.single_step_forward(x, hid, lg, True, f, U)
+
+    for _ in range(max(1, min(args.warmup, 5))):
+        step()
+    torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 50))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # dominant kernel: the anisotropic-filter GEMM of the prior step, timed with events on the launch stream
+    f, _ = m.predict_field(x)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    reps = 10
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        m.encoder.single_step_forward(x, ps, f)
+    ev[1].record()
+    torch.cuda.synchronize()
+    prior_ms = ev[0].elapsed_time(ev[1]) / reps
+    nrf = 4 * D + D * (D - 1) // 2
+    r_feat = 2 * nrf + 3 * D
+    filt_flop = float(B * E) * r_feat * H * H * 2
+    line = {"metric": "seq2seq autoregressive edge-steps/sec (field + prior + sample + decoder step, h=512)",
+            "value": B * E / dt, "unit": "edge-steps/s", "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 5),
+            "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"seq2seq-{D}d-N{N}-B{B}-h{H}", "num_dims": D, "nodes_per_graph": N,
+                       "graphs_per_gpu": B, "edges_per_gpu": B * E, "hidden": H, "launch": "eager"},
+            "roofline": {"bound": "mfma", "kernel": "prior step (k_s2s_filter dominates)", "unit": "TFLOP/s",
+                         "achieved": filt_flop / (prior_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "frac": filt_flop / (prior_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_us": prior_ms * 1e3,
+                         "algorithmic_flop_per_launch": filt_flop,
+                         "note": "algorithmic = the filter contraction alone (R h^2 MACs per edge); the time is the "
+                                 "whole prior step, so the fraction is a lower bound for the filter GEMM"},
+            "cpu_baseline": None}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,7 +186,11 @@ def main():
     ap.add_argument("--dims", type=int, default=WORKLOAD["D"], help="2 (headline) or 3 (cfg3)")
     ap.add_argument("--batch", type=int, default=WORKLOAD["B"])
     ap.add_argument("--nodes", type=int, default=WORKLOAD["N"])
+    ap.add_argument("--seq2seq", action="store_true",
+                    help="time the seq2seq model's autoregressive step (SURVEY 8a rows A8-A10) instead: its own JSON line")
     args = ap.parse_args()
+    if args.seq2seq:
+        return _seq2seq_line(args)
 
     rank, world, local = _dist_env()
     if world != args.gpus:
