@@ -244,8 +244,9 @@ def prior_step(sd, inputs, prior_state, predicted_field, use_3d=False, pos_repre
     c1 = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(g)
     h1 = torch.sigmoid(o) * torch.tanh(c1)
     y = h1
-    for layer in range(prior_layers):                                                  # prior_fc_out, :293-303
-        y = F.linear(y, sd[f"prior_fc_out.{2 * layer}.weight"], sd[f"prior_fc_out.{2 * layer}.bias"])
+    for layer in range(prior_layers):                                                  # prior_fc_out, :291-303
+        name = "prior_fc_out" if prior_layers == 1 else f"prior_fc_out.{2 * layer}"   # a bare Linear when 1 layer
+        y = F.linear(y, sd[name + ".weight"], sd[name + ".bias"])
         if layer + 1 < prior_layers:
             y = F.elu(y)
     return y, (h1, c1)

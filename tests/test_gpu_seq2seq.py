@@ -202,3 +202,50 @@ def test_predict_future_matches_reference():
     preds, edges = model.predict_future(x, int(d["steps"]), return_edges=True, uniform=U)
     assert torch.equal(edges.cpu().argmax(-1), torch.from_numpy(d["ref.edges"]).argmax(-1))
     assert scale_rel_err(preds.cpu(), torch.from_numpy(d["ref.predictions"])) <= TOL
+
+
+@pytest.mark.parametrize("D,K,skip_first", [(3, 2, False), (2, 3, True), (2, 1, False)])
+def test_decoder_step_variants_vs_oracle(D, K, skip_first):
+    """3-D frames, three edge types with the first one skipped (aether.py:606), a single edge type; soft weights."""
+    from aether_amd.nn.seq2seq.decoder import RecurrentDecoder
+    N, B, H = 7, 5, 64
+    params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": H, "num_edge_types": K,
+              "skip_first": skip_first, "decoder_dropout": 0.0, "use_3d": D == 3}
+    torch.manual_seed(31)
+    dec = RecurrentDecoder(params, device="cuda")
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(B, N, 2 * D, generator=g)
+    hid = torch.randn(B, N, H, generator=g) * 0.3
+    z = torch.softmax(torch.randn(B, N * (N - 1), K, generator=g), -1)
+    f = torch.randn(B, N, D, generator=g) * 0.3
+    want_x, want_h = S.decoder_step(sd, x, hid, z, f, D == 3, skip_first)
+    got_x, got_h = dec(x.cuda(), hid.cuda(), z.cuda(), f.cuda())
+    assert scale_rel_err(got_h.cpu(), want_h) <= TOL and scale_rel_err(got_x.cpu(), want_x) <= TOL
+
+
+@pytest.mark.parametrize("D,layers,rep", [(3, 3, "cart"), (2, 1, "polar"), (2, 2, "cart")])
+def test_prior_step_variants_vs_oracle(D, layers, rep):
+    """3-D frames, 'cart' edge positions, one- and two-layer prior_fc_out; BatchNorm statistics away from (0, 1)."""
+    from aether_amd.nn.seq2seq.encoder import Encoder
+    N, B, H, R = 6, 4, 128, 32
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
+              "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 1,
+              "encoder_mlp_hidden": 32, "prior_num_layers": layers, "prior_hidden_size": 48, "use_3d": D == 3,
+              "pos_representation": rep}
+    torch.manual_seed(41)
+    enc = Encoder(params, device="cuda").eval()
+    g = torch.Generator().manual_seed(42)
+    with torch.no_grad():
+        for bn in (enc.mlp3.bn, enc.mlp4.bn):
+            bn.running_mean.copy_((torch.randn(H, generator=g) * 0.2).cuda())
+            bn.running_var.copy_((torch.rand(H, generator=g) + 0.5).cuda())
+    sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    E = N * (N - 1)
+    x = torch.randn(B, N, 2 * D, generator=g)
+    f = torch.randn(B, N, D, generator=g) * 0.3
+    st = (torch.randn(B, E, R, generator=g) * 0.3, torch.randn(B, E, R, generator=g) * 0.3)
+    want_l, (want_h, want_c) = S.prior_step(sd, x, st, f, D == 3, rep, layers)
+    got_l, (got_h, got_c) = enc.single_step_forward(x.cuda(), (st[0].cuda(), st[1].cuda()), f.cuda())
+    for got, want in ((got_l, want_l), (got_h, want_h), (got_c, want_c)):
+        assert scale_rel_err(got.cpu(), want) <= TOL
