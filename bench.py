@@ -164,6 +164,48 @@ def _seq2seq_line(args):
                          "note": "algorithmic = the filter contraction alone (R h^2 MACs per edge); the time is the "
                                  "whole prior step, so the fraction is a lower bound for the filter GEMM"},
             "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        # the oracle's step on the host cores (bounded sample), which also checks the HIP step on this batch
+        from oracle import seq2seq_oracle as SO
+        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+        dec_sd = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+        xc, hc, Uc = x.cpu(), hid.cpu(), U.cpu()
+        psc = (ps[0].cpu(), ps[1].cpu())
+
+        def cpu_step():
+            f = SO.predict_field(sd, xc, D)
+            lg, st2 = SO.prior_step(enc_sd, xc, psc, f, D == 3, "polar", 3)
+            z = SO.gumbel_hard(lg.reshape(-1, 2), Uc.reshape(-1, 2), 0.5).view(lg.shape)
+            out, h2 = SO.decoder_step(dec_sd, xc, hc, z, f, D == 3)
+            return f, lg, z, out, h2
+
+        with torch.no_grad():
+            want = cpu_step()
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                cpu_step()
+                n += 1
+                el = time.perf_counter() - t0
+                if el > 12.0 or n >= 20:
+                    break
+            f_g, _ = m.predict_field(x)
+            lg_g, _ = m.encoder.single_step_forward(x, ps, f_g)
+            out_g, h_g, z_g = m.single_step_forward(x, hid, want[1].cuda(), True, want[0].cuda(), U)
+        rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+        line["cpu_baseline"] = {
+            "value": B * E * n / el, "unit": "edge-steps/s", "cores": cores, "kind": "port",
+            "ms_per_step": 1e3 * el / n,
+            "sample": f"{n} steps of the same B={B} N={N} batch in {el:.1f} s, torch CPU fp32, {cores} threads",
+            "parity": {"field_max_rel_err": rel(f_g, want[0]), "prior_logits_max_rel_err": rel(lg_g, want[1]),
+                       "sampled_types_equal": bool(torch.equal(z_g.cpu().argmax(-1), want[2].argmax(-1))),
+                       "decoder_outputs_max_rel_err": rel(out_g, want[3]),
+                       "decoder_hidden_max_rel_err": rel(h_g, want[4]), "tolerance": 1e-5,
+                       "checker": "oracle/seq2seq_oracle.py (pinned to the reference's golden vectors)"}}
+        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
     print(json.dumps(line), flush=True)
 
 
