@@ -94,6 +94,11 @@ SIGNATURES = {
                               [C.c_size_t] + [C.c_void_p] * 4),
     "aether_s2s_gumbel_hard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
+    "aether_dynamic_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "aether_forward_field": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo),
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "aether_debug_fetch": (C.c_int64, [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "aether_set_option": (C.c_int, [C.c_char_p, C.c_int]),

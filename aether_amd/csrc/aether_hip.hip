@@ -32,6 +32,7 @@
 #include "fused.h"
 #include "backward.h"
 #include "seq2seq.h"
+#include "dynfield.h"
 
 #include <mutex>
 #include <utility>
@@ -337,7 +338,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     {
         ProfScope ps(K_NODE_PREP, st);
         k_node_prep<D><<<dim3((unsigned)((Nn + 15) / 16)), dim3(64), 0, st>>>(P, x, vel, charges,
-                                                                              nodeinfo, wp(W.x[0]), Nn);
+                                                                              nodeinfo, wp(W.x[0]), step.ext_field, Nn);
     }
     const int64_t n_chunks = (E + 255) / 256;
     const int64_t n_tiles = (E + 15) / 16;
@@ -1113,10 +1114,11 @@ size_t aether_workspace_bytes(int64_t n_nodes, int64_t n_edges, int num_dims, in
     return WsLayout(n_nodes, n_edges, num_dims, keep_for_backward != 0).total;
 }
 
-int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
-                   const float* x, const float* vel, const float* charges,
-                   const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
-                   void* workspace, size_t workspace_bytes, float* out, int flags, void* stream) {
+static int forward_common(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
+                          const float* x, const float* vel, const float* charges,
+                          const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
+                          void* workspace, size_t workspace_bytes, float* out, int flags, void* stream,
+                          const float* field) {
     if (!params || !x || !vel || !charges || !graph || !info || !workspace || !out)
         return fail(AETHER_EINVAL, "forward: null pointer");
     if (info->n_nodes != n_nodes || info->n_edges != n_edges)
@@ -1133,7 +1135,7 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
         return fail(AETHER_EINVAL, "forward: fused path requested but the graph has no groups");
     const bool keep = (flags & AETHER_FLAG_KEEP_INTERMEDIATES) != 0;
     const bool reused = (flags & AETHER_FLAG_WORKSPACE_REUSED) != 0;
-    const StepExtras no_extras{nullptr, nullptr, 1.0f};
+    const StepExtras no_extras{nullptr, nullptr, 1.0f, field};
     if (fused) {
         if (num_dims == 2)
             return fused_impl<2>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,
@@ -1146,6 +1148,39 @@ int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, in
                                 (const char*)graph, (char*)workspace, out, keep, no_extras, st);
     return streamed_impl<3>(*params, n_nodes, n_edges, x, vel, charges, edge_attr_orig,
                             (const char*)graph, (char*)workspace, out, keep, no_extras, st);
+}
+
+int aether_forward(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
+                   const float* x, const float* vel, const float* charges,
+                   const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
+                   void* workspace, size_t workspace_bytes, float* out, int flags, void* stream) {
+    return forward_common(params, num_dims, n_nodes, n_edges, x, vel, charges, edge_attr_orig, graph, info, workspace,
+                          workspace_bytes, out, flags, stream, nullptr);
+}
+
+int aether_forward_field(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
+                         const float* x, const float* vel, const float* charges, const float* field,
+                         const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
+                         void* workspace, size_t workspace_bytes, float* out, int flags, void* stream) {
+    if (!field) return fail(AETHER_EINVAL, "forward_field: null field");
+    if (flags & AETHER_FLAG_KEEP_INTERMEDIATES)
+        return fail(AETHER_EINVAL, "forward_field: inference only (aether_backward differentiates the built-in field net)");
+    return forward_common(params, num_dims, n_nodes, n_edges, x, vel, charges, edge_attr_orig, graph, info, workspace,
+                          workspace_bytes, out, flags, stream, field);
+}
+
+int aether_dynamic_field(const AetherDynFieldParams* p, int num_dims, int64_t n_graphs, int nodes_per_graph,
+                         const float* x, const float* vel, const float* charges, float* field, void* stream) {
+    if (!p || !x || !vel || !charges || !field) return fail(AETHER_EINVAL, "dynamic_field: null pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "dynamic_field: num_dims must be 2 or 3");
+    if (n_graphs <= 0 || nodes_per_graph <= 0 || nodes_per_graph > DYNFIELD_MAX_NODES)
+        return fail(AETHER_EINVAL, "dynamic_field: 1..2048 nodes per graph");
+    if (n_graphs >= ((int64_t)1 << 31)) return fail(AETHER_EINVAL, "dynamic_field: too many graphs");
+    hipStream_t st = (hipStream_t)stream;
+    if (num_dims == 2) k_dynfield<2><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, field, nodes_per_graph);
+    else k_dynfield<3><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, field, nodes_per_graph);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
 }
 
 int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x0,
@@ -1173,7 +1208,7 @@ int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, in
         const float* x = t == 0 ? x0 : trajectory + (size_t)(t - 1) * stride;
         const float* v = t == 0 ? vel0 : reinterpret_cast<const float*>(ws + W.velbuf[(t - 1) & 1]);
         float* out = trajectory + (size_t)t * stride;
-        StepExtras ex{charges, reinterpret_cast<float*>(ws + W.velbuf[t & 1]), dt};
+        StepExtras ex{charges, reinterpret_cast<float*>(ws + W.velbuf[t & 1]), dt, nullptr};
         const bool reused = t > 0 || (flags & AETHER_FLAG_WORKSPACE_REUSED);   // the step before re-armed the flags
         int rc;
         if (fused)

@@ -325,7 +325,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             if (q == 0 && live) {
                 float f[D], R[D][D], cv[D], cf[D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) f[d] = acc3[d];
+                for (int d = 0; d < D; ++d)
+                    f[d] = dbg.step.ext_field ? dbg.step.ext_field[(int64_t)(vb + node) * D + d] : acc3[d];
                 node_frame<D>(vz, f, R, cv, cf);
                 float* ni = ninfo + node * 24;
 #pragma unroll

@@ -15,7 +15,7 @@ template <int D>
 __global__ void __launch_bounds__(64)
 k_node_prep(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
             const float* __restrict__ charges, float* __restrict__ nodeinfo,
-            float* __restrict__ x0, int64_t n_nodes) {
+            float* __restrict__ x0, const float* __restrict__ ext_field, int64_t n_nodes) {
     using NI = NodeInfo<D>;
     constexpr int FIN = 2 * D + 16;
     __shared__ float rel[16 * 8];                              // [node][cv | cf] for the x0 operand
@@ -90,7 +90,7 @@ k_node_prep(AetherParams P, const float* __restrict__ x, const float* __restrict
     if (q == 0) {
         float f[D], R[D][D], cv[D], cf[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) f[d] = acc3[d];
+        for (int d = 0; d < D; ++d) f[d] = ext_field ? ext_field[g * D + d] : acc3[d];
         node_frame<D>(vz, f, R, cv, cf);
 #pragma unroll
         for (int d = 0; d < D; ++d) { rel[i * 8 + d] = cv[d]; rel[i * 8 + D + d] = cf[d]; }

@@ -1,0 +1,162 @@
+"""MI355X drop-in for the reference's ``nn.state2state.dynamic_field_aether.DynamicFieldAether``
+(the model experiments/lorentz/main.py:148-149 builds for ``--model dynamic_field_aether``).
+
+Same constructor, ``forward(h, x, edges, vel, edge_attr_orig, charges, num_nodes)`` and ``state_dict`` keys
+(dynamic_field_aether.py:51-100).  The field comes from ``aether_dynamic_field`` (attention-pooled graph
+summary + FiLM field net, :11-48), everything after it from the same kernels as ``Aether``
+(``aether_forward_field``).  Inference only; no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from .aether import GraphCache, _GNN
+
+
+class _AttentionalAggregation(nn.Module):
+    """Parameter holder with torch_geometric's sub-module names (``gate_nn``, ``nn``)."""
+
+    def __init__(self, gate_nn, nn_):
+        super().__init__()
+        self.gate_nn = gate_nn
+        self.nn = nn_
+
+
+class _GraphSummary(nn.Module):
+    def __init__(self, input_size, hidden_size):                       # graph_pool.py:8-23
+        super().__init__()
+        self.summary_net = _AttentionalAggregation(
+            nn.Sequential(nn.Linear(input_size, hidden_size), nn.SiLU(), nn.Linear(hidden_size, 1)),
+            nn.Sequential(nn.Linear(input_size, hidden_size), nn.SiLU(), nn.Linear(hidden_size, hidden_size)))
+
+
+class _FiLM(nn.Module):
+    def __init__(self, x_size, z_size, hidden_size):                   # film.py:48-55
+        super().__init__()
+        self.modulator = nn.Sequential(nn.Linear(z_size, hidden_size), nn.SiLU(), nn.Linear(hidden_size, hidden_size),
+                                       nn.SiLU(), nn.Linear(hidden_size, 2 * x_size))
+
+
+class _FilmedNetwork(nn.Module):
+    def __init__(self, x_size, z_size, hidden_size, out_size):         # film.py:12-24
+        super().__init__()
+        self.linear_1 = nn.Linear(x_size, hidden_size)
+        self.linear_2 = nn.Linear(hidden_size, hidden_size)
+        self.linear_3 = nn.Linear(hidden_size, out_size)
+        self.film_1 = _FiLM(hidden_size, z_size, hidden_size)
+        self.film_2 = _FiLM(hidden_size, z_size, hidden_size)
+
+
+class _LatentFieldNetwork(nn.Module):
+    def __init__(self, num_dims, hidden_size, class_embedding_dim):    # dynamic_field_aether.py:12-26
+        super().__init__()
+        self.summary_net = _GraphSummary(2 * num_dims, hidden_size)
+        self.wrapper = _FilmedNetwork(2 * num_dims + class_embedding_dim, hidden_size, hidden_size, num_dims)
+        self.class_embedding = nn.Embedding(3, class_embedding_dim)
+
+
+class _DynFieldParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "gate_w0", "gate_b0", "gate_w2", "gate_b2", "nn_w0", "nn_b0", "nn_w2", "nn_b2",
+        "lin1_w", "lin1_b", "lin2_w", "lin2_b", "lin3_w", "lin3_b",
+        "film1_w0", "film1_b0", "film1_w2", "film1_b2", "film1_w4", "film1_b4",
+        "film2_w0", "film2_b0", "film2_w2", "film2_b2", "film2_w4", "film2_b4", "emb")]
+
+
+class DynamicFieldAether(nn.Module):
+    """Drop-in for nn/state2state/dynamic_field_aether.py:51-100."""
+
+    def __init__(self, input_size, hidden_size, dropout_prob, num_dims, device="cuda"):
+        super().__init__()
+        if hidden_size != 64:
+            raise ValueError("the HIP kernels are built for hidden_size=64 (experiments/lorentz/main.py:42-43)")
+        if num_dims not in (2, 3) or input_size != 2 * num_dims:
+            raise ValueError("num_dims must be 2 or 3 and input_size == 2*num_dims")
+        if dropout_prob != 0.0:
+            raise ValueError("dropout_prob must be 0.0 (the runner's value, main.py:149)")
+        self.gnn = _GNN(input_size, hidden_size, dropout_prob, num_dims, additional_features=num_dims)
+        self.num_dims = num_dims
+        self.field_net = _LatentFieldNetwork(num_dims, 32, 16)
+        self._graphs = GraphCache()
+        self.flags = 0
+        self._ws = None
+        self._ws_key = None
+        self.to(device)
+        self.params = self.__str__()
+
+    def __str__(self):
+        params = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
+        print("Network Size", params)
+        return str(params)
+
+    def _structs(self, device):
+        sd = dict(self.named_parameters())
+        D = self.num_dims
+        # the built-in field net is bypassed; its slots of AetherParams point at readable scratch of the right size
+        dummy = {"field_net.net.0.weight": (32, 2 * D + 16), "field_net.net.0.bias": (32,), "field_net.net.2.weight": (32, 32),
+                 "field_net.net.2.bias": (32,), "field_net.net.4.weight": (D, 32), "field_net.net.4.bias": (D,)}
+        if getattr(self, "_dummy", None) is None or next(iter(self._dummy.values())).device != device:
+            self._dummy = {k: torch.zeros(*shape, device=device) for k, shape in dummy.items()}
+        tensors = {k: v for k, v in sd.items()}
+        tensors.update(self._dummy)
+        ps = _lib.params_struct(tensors)
+        f = "field_net."
+        w = f + "wrapper."
+        names = [f + "summary_net.summary_net.gate_nn.0", f + "summary_net.summary_net.gate_nn.2",
+                 f + "summary_net.summary_net.nn.0", f + "summary_net.summary_net.nn.2",
+                 w + "linear_1", w + "linear_2", w + "linear_3",
+                 w + "film_1.modulator.0", w + "film_1.modulator.2", w + "film_1.modulator.4",
+                 w + "film_2.modulator.0", w + "film_2.modulator.2", w + "film_2.modulator.4"]
+        ptrs = []
+        for n in names:
+            ptrs += [sd[n + ".weight"].data_ptr(), sd[n + ".bias"].data_ptr()]
+        ptrs.append(sd[f + "class_embedding.weight"].data_ptr())
+        return ps, _DynFieldParams(*ptrs)
+
+    @torch.no_grad()
+    def forward(self, h, x, edges, vel, edge_attr_orig, charges, num_nodes):
+        """``h`` is ignored, as in the reference (dynamic_field_aether.py:79-100)."""
+        if not x.is_cuda:
+            raise _lib.AetherHipError("aether_amd.DynamicFieldAether runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        lib = _lib.load()
+        send, recv = edges
+        if send.dtype != torch.int64 or recv.dtype != torch.int64:
+            raise TypeError("edges must be int64 (torch.LongTensor), as in the reference")
+        n_nodes, D = x.shape
+        E = send.numel()
+        if D != self.num_dims or vel.shape != x.shape or n_nodes % int(num_nodes) != 0:
+            raise ValueError("x/vel must be [B * num_nodes, num_dims]")
+        if recv.numel() != E or edge_attr_orig.shape != (E, 2) or charges.numel() != n_nodes:
+            raise ValueError("edge index / edge_attr / charges shapes do not match")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        x, vel, ea, charges = f32(x), f32(vel), f32(edge_attr_orig), f32(charges)
+        graph, ginfo = self._graphs.get(send.contiguous(), recv.contiguous(), n_nodes)
+        ps, fps = self._structs(x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
+        _lib.check(lib.aether_dynamic_field(C.byref(fps), D, n_nodes // int(num_nodes), int(num_nodes), x.data_ptr(),
+                                            vel.data_ptr(), charges.data_ptr(), field.data_ptr(), stream),
+                   "aether_dynamic_field")
+        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 0)
+        if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
+            self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        flags = self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES
+        fused = ginfo.n_groups > 0 and E > 0 and not (flags & _lib.FLAG_FORCE_STREAMED)
+        ws_key = (self._ws.data_ptr(), n_nodes, E, D, graph.data_ptr()) if fused else None
+        if ws_key is not None and self._ws_key == ws_key:
+            flags |= _lib.FLAG_WORKSPACE_REUSED
+        self._ws_key = None
+        out = torch.empty_like(x)
+        _lib.check(lib.aether_forward_field(C.byref(ps), D, n_nodes, E, x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
+                                            field.data_ptr(), ea.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                            self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), flags, stream),
+                   "aether_forward_field")
+        self._ws_key = ws_key
+        self.last_field = field
+        return out

@@ -171,6 +171,33 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
                            const void* workspace, float* dst, void* stream);
 
 /*
+ * Dynamic-field variant of the state2state model: DynamicFieldAether.forward
+ * (nn/state2state/dynamic_field_aether.py:79-100) = aether_dynamic_field (LatentFieldNetwork, :31-48:
+ * attention-pooled graph summary + FiLM field net, hidden 32) followed by aether_forward_field, i.e.
+ * aether_forward with the per-node field supplied instead of the built-in field net (params->field_* are
+ * not read for the result but must point to readable memory of the documented sizes).  Inference only.
+ *   graphs are consecutive blocks of nodes_per_graph nodes (x.reshape(-1, num_nodes, .), :38);
+ *   field : float[n_nodes][D]
+ */
+typedef struct AetherDynFieldParams {
+    const float* gate_w0; const float* gate_b0; const float* gate_w2; const float* gate_b2;   /* [32][2D],[32],[1][32],[1] */
+    const float* nn_w0; const float* nn_b0; const float* nn_w2; const float* nn_b2;           /* [32][2D],[32],[32][32],[32] */
+    const float* lin1_w; const float* lin1_b; const float* lin2_w; const float* lin2_b;       /* [32][2D+16],[32],[32][32],[32] */
+    const float* lin3_w; const float* lin3_b;                                                 /* [D][32],[D] */
+    const float* film1_w0; const float* film1_b0; const float* film1_w2; const float* film1_b2;
+    const float* film1_w4; const float* film1_b4;                                             /* [32][32] x2, [64][32] */
+    const float* film2_w0; const float* film2_b0; const float* film2_w2; const float* film2_b2;
+    const float* film2_w4; const float* film2_b4;
+    const float* emb;                                                                         /* [3][16] */
+} AetherDynFieldParams;
+int aether_dynamic_field(const AetherDynFieldParams* params, int num_dims, int64_t n_graphs, int nodes_per_graph,
+                         const float* x, const float* vel, const float* charges, float* field, void* stream);
+int aether_forward_field(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
+                         const float* x, const float* vel, const float* charges, const float* field,
+                         const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
+                         void* workspace, size_t workspace_bytes, float* out, int flags, void* stream);
+
+/*
  * seq2seq Aether, field query: replaces Aether.predict_field
  * (nn/seq2seq/aether.py:86-90) = FourierFeatureMapper (nn/nn/fourier_feature_mapper.py:7-21) followed by
  * field_net (aether.py:72-78).  Unlike the state2state field it sees positions only.

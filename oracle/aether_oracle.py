@@ -164,12 +164,15 @@ def out_mlp(sd, x):
 
 
 # --------------------------------------------------------------------- whole
-def aether_forward(sd, x, vel, edges, edge_attr_orig, charges, return_all=False):
-    """aether.py:169-186.  ``sd`` maps reference state_dict keys to tensors."""
+def aether_forward(sd, x, vel, edges, edge_attr_orig, charges, return_all=False, field=None):
+    """aether.py:169-186.  ``sd`` maps reference state_dict keys to tensors.  ``field``: a precomputed
+    per-node field replaces the built-in field net (the dynamic-field variant, dynamic_field_aether.py:84-97,
+    is this function with ``dynamic_field`` below)."""
     D = x.shape[-1]
     send, recv = edges
     inputs = torch.cat([x, vel], dim=-1)
-    field = field_net(sd, x, vel, charges)
+    if field is None:
+        field = field_net(sd, x, vel, charges)
     ext = torch.cat([inputs, field], dim=-1)
     rel_feat, R = canonical_nodes(ext, D)
     ea = edge_features(ext, send, recv, D)
@@ -187,6 +190,44 @@ def aether_forward(sd, x, vel, edges, edge_attr_orig, charges, return_all=False)
     out = x + pred
     res["out"] = out
     return res if return_all else out
+
+
+# --------------------------------------------------------------------- dynamic-field variant
+def dynamic_field(sd, x, vel, charges, num_nodes):
+    """LatentFieldNetwork.forward (nn/state2state/dynamic_field_aether.py:31-48): per-graph attention-pooled
+    summary of [pos | vel] (GraphSummary, graph_pool.py:7-29, with PyG's AttentionalAggregation semantics:
+    softmax of gate_nn over the nodes of a graph -- exp(g - max) / (sum + 1e-16) -- weighting nn(x)), then a
+    FiLM-modulated MLP on [pos | vel | class embedding] (film.py:5-60).  Graphs are consecutive blocks of
+    ``num_nodes`` nodes.  Parity: pinned by tests/golden/dynfield_D*.npz (imported reference with the
+    documented stand-in for the uninstalled torch_geometric op, oracle/make_golden_dynfield.py)."""
+    pre = "field_net."
+    lin = lambda name, v: F.linear(v, sd[pre + name + ".weight"], sd[pre + name + ".bias"])
+    inputs = torch.cat([x, vel], -1)
+    Bn = inputs.shape[0] // num_nodes
+    xs = inputs.reshape(Bn, num_nodes, -1)
+    gate = lin("summary_net.summary_net.gate_nn.2", F.silu(lin("summary_net.summary_net.gate_nn.0", xs)))
+    val = lin("summary_net.summary_net.nn.2", F.silu(lin("summary_net.summary_net.nn.0", xs)))
+    w = (gate - gate.max(dim=1, keepdim=True).values).exp()
+    w = w / (w.sum(dim=1, keepdim=True) + 1e-16)
+    summary = (w * val).sum(dim=1)                                             # [B, hidden]
+    z = summary.repeat_interleave(num_nodes, dim=0)                            # graph_summary[batch], :41-44
+    emb = sd[pre + "class_embedding.weight"][(charges + 1).long()].squeeze(1)  # :28-34
+    y = lin("wrapper.linear_1", torch.cat([inputs, emb], -1))
+
+    def film(name, y):                                                         # film.py:41-60
+        m = lin(name + ".modulator.4", F.silu(lin(name + ".modulator.2", F.silu(lin(name + ".modulator.0", z)))))
+        gamma, beta = torch.chunk(m, 2, dim=-1)
+        return (1.0 + gamma) * y + beta
+
+    y = F.silu(film("wrapper.film_1", y))
+    y = F.silu(film("wrapper.film_2", lin("wrapper.linear_2", y)))
+    return lin("wrapper.linear_3", y)
+
+
+def dynamic_field_aether_forward(sd, x, vel, edges, edge_attr_orig, charges, num_nodes):
+    """DynamicFieldAether.forward (dynamic_field_aether.py:79-100)."""
+    return aether_forward(sd, x, vel, edges, edge_attr_orig, charges,
+                          field=dynamic_field(sd, x, vel, charges, num_nodes))
 
 
 def rollout(sd, x, vel, edges, charges, steps, dt=1.0):

@@ -220,3 +220,22 @@ def test_seq2seq_predict_future():
                                     return_edges=True)
     assert torch.equal(edges.argmax(-1), t("ref.edges").argmax(-1))
     assert scale_rel_err(preds, t("ref.predictions")) <= 2e-6
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_dynamic_field_variant(D):
+    """DynamicFieldAether (attention-pooled graph summary + FiLM field net) vs the imported
+    reference (torch_geometric's AttentionalAggregation replaced by a stand-in with its published semantics)."""
+    from aether_amd.edges import get_edges
+    d = np.load(os.path.join(GOLDEN, f"dynfield_D{D}.npz"))
+    sd = {str(k): torch.from_numpy(d["sd." + str(k)]) for k in d["keys"]}
+    for name in ("small", "cfg"):
+        B, N = int(d[f"{name}.B"]), int(d[f"{name}.N"])
+        t = lambda k: torch.from_numpy(d[f"{name}.in.{k}"])
+        field = O.dynamic_field(sd, t("x"), t("vel"), t("charges"), N)
+        assert scale_rel_err(field, torch.from_numpy(d[f"{name}.ref.field"])) <= 1e-6
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        f64 = O.dynamic_field(sd64, t("x").double(), t("vel").double(), t("charges").double(), N)
+        assert scale_rel_err(f64, torch.from_numpy(d[f"{name}.ref64.field"])) <= 1e-12
+        out = O.dynamic_field_aether_forward(sd, t("x"), t("vel"), get_edges(B, N), t("edge_attr"), t("charges"), N)
+        assert scale_rel_err(out, torch.from_numpy(d[f"{name}.ref.out"])) <= 1e-6
