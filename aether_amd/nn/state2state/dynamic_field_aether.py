@@ -86,6 +86,9 @@ class DynamicFieldAether(nn.Module):
         self.flags = 0
         self._ws = None
         self._ws_key = None
+        self._plist = None
+        self._struct_cache = None
+        self._dummy = None
         self.to(device)
         self.params = self.__str__()
 
@@ -94,13 +97,33 @@ class DynamicFieldAether(nn.Module):
         print("Network Size", params)
         return str(params)
 
+    def _apply(self, fn, *a, **k):
+        self._plist = None                # parameter storage may move (.to / .cuda / .float)
+        self._struct_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plist = None
+        self._struct_cache = None
+        return super().load_state_dict(*a, **k)
+
     def _structs(self, device):
+        if self._plist is None:
+            self._plist = [p for _, p in self.named_parameters()]
+        key = (str(device),) + tuple([p.data_ptr() for p in self._plist])
+        if self._struct_cache is not None and self._struct_cache[0] == key:
+            return self._struct_cache[1], self._struct_cache[2]
+        ps, fps = self._build_structs(device)
+        self._struct_cache = (key, ps, fps)
+        return ps, fps
+
+    def _build_structs(self, device):
         sd = dict(self.named_parameters())
         D = self.num_dims
         # the built-in field net is bypassed; its slots of AetherParams point at readable scratch of the right size
         dummy = {"field_net.net.0.weight": (32, 2 * D + 16), "field_net.net.0.bias": (32,), "field_net.net.2.weight": (32, 32),
                  "field_net.net.2.bias": (32,), "field_net.net.4.weight": (D, 32), "field_net.net.4.bias": (D,)}
-        if getattr(self, "_dummy", None) is None or next(iter(self._dummy.values())).device != device:
+        if self._dummy is None or next(iter(self._dummy.values())).device != device:
             self._dummy = {k: torch.zeros(*shape, device=device) for k, shape in dummy.items()}
         tensors = {k: v for k, v in sd.items()}
         tensors.update(self._dummy)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Time the dynamic-field variant on the GPU box: field kernel alone and the whole step (B=128, N=20)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aether_amd.nn.state2state.aether import Aether
+from aether_amd.nn.state2state.dynamic_field_aether import DynamicFieldAether
+from aether_amd.synthetic import make_batch
+for D in (3, 2):
+    B, N = 128, 20
+    m = DynamicFieldAether(2 * D, 64, 0.0, D, device="cuda")
+    a = Aether(2 * D, 64, 0.0, D, device="cuda")
+    inp = make_batch(B, N, D, seed=0, device="cuda")
+    def timed(fn, reps=200):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    with torch.no_grad():
+        t_dyn = timed(lambda: m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"], N))
+        t_std = timed(lambda: a(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]))
+    print("D=%d B=%d N=%d: dynamic-field step %.3f ms (built-in field net: %.3f ms), %.2f G edge-messages/s"
+          % (D, B, N, t_dyn, t_std, 4 * B * N * (N - 1) / t_dyn / 1e6))
