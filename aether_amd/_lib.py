@@ -92,6 +92,16 @@ SIGNATURES = {
     "aether_s2s_prior_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "aether_s2s_prior_step": (C.c_int, [C.c_void_p] + [C.c_int] * 8 + [C.c_int64, C.c_int64] + [C.c_void_p] * 9 +
                               [C.c_size_t] + [C.c_void_p] * 4),
+    "aether_s2s_graph_summary_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "aether_s2s_graph_summary": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "aether_s2s_film_modulation_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "aether_s2s_film_modulation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p]),
+    "aether_s2s_film_field_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "aether_s2s_film_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_void_p]),
     "aether_s2s_gumbel_hard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "aether_dynamic_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

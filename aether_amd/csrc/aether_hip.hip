@@ -33,6 +33,7 @@
 #include "backward.h"
 #include "seq2seq.h"
 #include "dynfield.h"
+#include "s2s_dynfield.h"
 
 #include <mutex>
 #include <utility>
@@ -604,7 +605,8 @@ namespace {
 int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
                int ldy, const float* scale, int sstride, int accumulate, hipStream_t st,
                const int64_t* xidx = nullptr, const int64_t* yidx = nullptr, const int* n_dev = nullptr,
-               const float* post_scale = nullptr, const float* post_shift = nullptr);
+               const float* post_scale = nullptr, const float* post_shift = nullptr,
+               const float* film_gamma = nullptr, const float* film_beta = nullptr, int film_rows = 1);
 }  // namespace
 
 size_t aether_s2s_field_workspace_bytes(int64_t n_points, int hidden) {
@@ -664,13 +666,15 @@ namespace {
 // Y[N][ldy] = act(X[N][K] W^T + b) [* scale] [+ Y]; act: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU
 int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
                int ldy, const float* scale, int sstride, int accumulate, hipStream_t st, const int64_t* xidx,
-               const int64_t* yidx, const int* n_dev, const float* post_scale, const float* post_shift) {
+               const int64_t* yidx, const int* n_dev, const float* post_scale, const float* post_shift,
+               const float* film_gamma, const float* film_beta, int film_rows) {
     if (K % 16 != 0) return fail(AETHER_EINVAL, "s2s_linear: K must be a multiple of 16");
     const bool big = M >= 128;
     const bool wide = big && N >= 16384;             // 64 points per wave once there are enough workgroups
     const int nt = wide ? 4 : 2;
     const dim3 grid((unsigned)((N + 32 * nt - 1) / (32 * nt)), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
-#define S2S_ARGS W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift
+#define S2S_ARGS W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift, \
+                 film_gamma, film_beta, film_rows
 #define S2S_CASE(A)                                                                     \
     if (wide) k_s2s_linear<A, 4, 4><<<grid, dim3(256), 0, st>>>(S2S_ARGS);              \
     else if (big) k_s2s_linear<A, 4, 2><<<grid, dim3(256), 0, st>>>(S2S_ARGS);          \
@@ -892,6 +896,147 @@ int aether_s2s_prior_step(const AetherS2SPriorParams* p, int num_dims, int hidde
         cur = dst;
         cur_k = M;
     }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+// ------------------------------------------------------------------ seq2seq dynamic-field variant (N3)
+namespace {
+struct S2SSummaryLayout {
+    size_t xp, wep, emb, gi, gh, h, aug, g0p, n0p, gate, total;
+    int inp, Kp;
+    S2SSummaryLayout(int64_t B, int N, int T, int in, int H) {
+        inp = (in + 15) / 16 * 16; Kp = (in + H + 15) / 16 * 16;
+        const size_t S = (size_t)B * N, R = S * T, hh = (size_t)H;
+        size_t off = 0;
+        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+        xp = take(R * inp); wep = take(hh * inp); emb = take(R * hh);
+        gi = take(R * 3 * hh);                  // after the GRU: T1 | T2 | V of the attention nets
+        gh = take(S * 3 * hh); h = take(S * hh);
+        aug = take(R * Kp); g0p = take(hh * Kp); n0p = take(hh * Kp); gate = take(R);
+        total = off;
+    }
+};
+}  // namespace
+
+size_t aether_s2s_graph_summary_workspace_bytes(int64_t batch, int num_objects, int timesteps, int input_size,
+                                                int hidden) {
+    if (batch <= 0 || num_objects <= 0 || timesteps <= 0 || input_size <= 0 || hidden <= 0) return 0;
+    return S2SSummaryLayout(batch, num_objects, timesteps, input_size, hidden).total + 256;
+}
+
+int aether_s2s_graph_summary(const AetherS2SGraphSummaryParams* p, int64_t batch, int num_objects, int timesteps,
+                             int input_size, int hidden, int pe_len, const float* x, void* workspace,
+                             size_t workspace_bytes, float* summary, void* stream) {
+    if (!p || !x || !workspace || !summary || !p->emb_w || !p->emb_b || !p->gru_w_ih || !p->gru_w_hh || !p->gru_b_ih ||
+        !p->gru_b_hh || !p->pe || !p->gate_w0 || !p->gate_b0 || !p->gate_w2 || !p->gate_b2 || !p->nn_w0 || !p->nn_b0 ||
+        !p->nn_w2 || !p->nn_b2)
+        return fail(AETHER_EINVAL, "s2s_graph_summary: null pointer");
+    if (batch <= 0 || num_objects <= 0 || timesteps <= 0 || input_size <= 0)
+        return fail(AETHER_EINVAL, "s2s_graph_summary: bad sizes");
+    if (hidden < 16 || hidden % 16 != 0) return fail(AETHER_EINVAL, "s2s_graph_summary: hidden must be a multiple of 16");
+    if (timesteps > pe_len)
+        return fail(AETHER_EINVAL, "s2s_graph_summary: more time steps than rows of the positional encoding");
+    const S2SSummaryLayout L(batch, num_objects, timesteps, input_size, hidden);
+    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "s2s_graph_summary: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
+    auto wp = [&](size_t o) { return reinterpret_cast<float*>(ws + o); };
+    const int in = input_size, H = hidden, T = timesteps;
+    const int64_t S = batch * num_objects, R = S * T;
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    // particle embedding and the input half of the GRU for every time step at once (graph_pool.py:62-63)
+    k_s2s_pad_rows<<<blocks(R * L.inp), dim3(256), 0, st>>>(x, in, in, wp(L.xp), L.inp, R);
+    k_s2s_pad_rows<<<blocks((int64_t)H * L.inp), dim3(256), 0, st>>>(p->emb_w, in, in, wp(L.wep), L.inp, H);
+    if (s2s_linear(0, wp(L.wep), L.inp, p->emb_b, wp(L.xp), wp(L.emb), H, L.inp, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->gru_w_ih, H, p->gru_b_ih, wp(L.emb), wp(L.gi), 3 * H, H, R, 3 * H, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    HIP_OK(hipMemsetAsync(wp(L.h), 0, (size_t)S * H * sizeof(float), st));
+    for (int t = 0; t < T; ++t) {
+        if (s2s_linear(0, p->gru_w_hh, H, p->gru_b_hh, wp(L.h), wp(L.gh), 3 * H, H, S, 3 * H, nullptr, 0, 0, st)) return AETHER_EINVAL;
+        k_s2s_gru_gate<<<blocks(S * H), dim3(256), 0, st>>>(wp(L.gi) + (size_t)t * 3 * H, (int64_t)T * 3 * H, wp(L.gh),
+                                                            wp(L.h), H, S);
+    }
+    // [x | last hidden] + pe, then the two nets of the attention pooling (:66-70)
+    k_s2s_augment<<<blocks(R * L.Kp), dim3(256), 0, st>>>(x, wp(L.h), p->pe, wp(L.aug), in, H, L.Kp, T, R);
+    k_s2s_pad_rows<<<blocks((int64_t)H * L.Kp), dim3(256), 0, st>>>(p->gate_w0, in + H, in + H, wp(L.g0p), L.Kp, H);
+    k_s2s_pad_rows<<<blocks((int64_t)H * L.Kp), dim3(256), 0, st>>>(p->nn_w0, in + H, in + H, wp(L.n0p), L.Kp, H);
+    float* T1 = wp(L.gi);
+    float* T2 = T1 + (size_t)R * H;
+    float* V = T2 + (size_t)R * H;
+    if (s2s_linear(1, wp(L.g0p), L.Kp, p->gate_b0, wp(L.aug), T1, H, L.Kp, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->gate_w2, H, p->gate_b2, T1, wp(L.gate), 1, H, R, 1, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(1, wp(L.n0p), L.Kp, p->nn_b0, wp(L.aug), T2, H, L.Kp, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->nn_w2, H, p->nn_b2, T2, V, H, H, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    k_s2s_attn_pool<<<dim3((unsigned)batch, (unsigned)((H + 255) / 256)), dim3(256), 0, st>>>(
+        wp(L.gate), V, summary, num_objects * T, H);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+size_t aether_s2s_film_modulation_bytes(int64_t batch, int mlp_hidden) {
+    if (batch <= 0 || mlp_hidden <= 0) return 0;
+    return (size_t)5 * (size_t)batch * (size_t)mlp_hidden * sizeof(float);
+}
+
+int aether_s2s_film_modulation(const AetherS2SFilmParams* p, int graph_hidden, int mlp_hidden, int64_t batch,
+                               const float* summary, float* mod, size_t mod_bytes, void* stream) {
+    if (!p || !summary || !mod) return fail(AETHER_EINVAL, "s2s_film_modulation: null pointer");
+    for (int k = 0; k < 4; ++k)
+        if (!p->mod_w0[k] || !p->mod_b0[k] || !p->mod_w2[k] || !p->mod_b2[k])
+            return fail(AETHER_EINVAL, "s2s_film_modulation: null pointer");
+    if (batch <= 0 || graph_hidden < 16 || graph_hidden % 16 != 0 || mlp_hidden < 16 || mlp_hidden % 16 != 0)
+        return fail(AETHER_EINVAL, "s2s_film_modulation: graph_hidden and mlp_hidden must be multiples of 16");
+    if (mod_bytes < aether_s2s_film_modulation_bytes(batch, mlp_hidden))
+        return fail(AETHER_ESPACE, "s2s_film_modulation: mod buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plane = (size_t)batch * mlp_hidden;
+    float* tmp = mod + 4 * plane;
+    for (int k = 0; k < 4; ++k) {
+        if (s2s_linear(1, p->mod_w0[k], graph_hidden, p->mod_b0[k], summary, tmp, mlp_hidden, graph_hidden, batch,
+                       mlp_hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
+        if (s2s_linear(0, p->mod_w2[k], mlp_hidden, p->mod_b2[k], tmp, mod + k * plane, mlp_hidden, mlp_hidden, batch,
+                       mlp_hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+size_t aether_s2s_film_field_workspace_bytes(int64_t n_points, int hidden, int mlp_hidden) {
+    if (n_points <= 0 || hidden <= 0 || mlp_hidden <= 0) return 0;
+    return align_up((size_t)n_points * hidden * 4, 256) + 2 * align_up((size_t)n_points * mlp_hidden * 4, 256) + 256;
+}
+
+int aether_s2s_film_field(const AetherS2SFilmParams* p, int num_dims, int hidden, int mlp_hidden, int64_t n_points,
+                          int64_t rows_per_graph, const float* x, int x_stride, const float* mod, int64_t batch,
+                          void* workspace, size_t workspace_bytes, float* field, void* stream) {
+    if (!p || !x || !mod || !workspace || !field || !p->B || !p->lin1_w || !p->lin1_b || !p->lin2_w || !p->lin2_b ||
+        !p->lin3_w || !p->lin3_b)
+        return fail(AETHER_EINVAL, "s2s_film_field: null pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_film_field: num_dims must be 2 or 3");
+    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "s2s_film_field: hidden must be a multiple of 32");
+    if (mlp_hidden < 16 || mlp_hidden % 16 != 0) return fail(AETHER_EINVAL, "s2s_film_field: mlp_hidden must be a multiple of 16");
+    if (n_points <= 0 || x_stride < num_dims || rows_per_graph <= 0 || batch <= 0 ||
+        (n_points + rows_per_graph - 1) / rows_per_graph > batch || rows_per_graph > INT32_MAX)
+        return fail(AETHER_EINVAL, "s2s_film_field: bad sizes (n_points must fit batch * rows_per_graph)");
+    if (workspace_bytes < aether_s2s_film_field_workspace_bytes(n_points, hidden, mlp_hidden))
+        return fail(AETHER_ESPACE, "s2s_film_field: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
+    const size_t gplane = align_up((size_t)n_points * hidden * 4, 256), hplane = align_up((size_t)n_points * mlp_hidden * 4, 256);
+    float* gamma = reinterpret_cast<float*>(ws);
+    float* h1 = reinterpret_cast<float*>(ws + gplane);
+    float* h2 = reinterpret_cast<float*>(ws + gplane + hplane);
+    const size_t plane = (size_t)batch * mlp_hidden;
+    const int half = hidden / 2, rows = (int)rows_per_graph;
+    const unsigned rb = (unsigned)((n_points * half + 255) / 256);
+    if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
+    else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
+    if (s2s_linear(1, p->lin1_w, hidden, p->lin1_b, gamma, h1, mlp_hidden, hidden, n_points, mlp_hidden, nullptr, 0, 0, st,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, mod, mod + plane, rows)) return AETHER_EINVAL;
+    if (s2s_linear(1, p->lin2_w, mlp_hidden, p->lin2_b, h1, h2, mlp_hidden, mlp_hidden, n_points, mlp_hidden, nullptr, 0, 0, st,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, mod + 2 * plane, mod + 3 * plane, rows)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->lin3_w, mlp_hidden, p->lin3_b, h2, field, num_dims, mlp_hidden, n_points, num_dims, nullptr, 0, 0, st))
+        return AETHER_EINVAL;
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }

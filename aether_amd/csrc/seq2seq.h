@@ -35,7 +35,7 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
 // MT x NT MFMA tiles (16 MT rows x 16 NT points) and keeps the fragments of the next PF k-groups in flight
 // (4 waves per SIMD at MT = 4: the kernel is bound by the latency of its L2 reads, occupancy matters
 // more than a deeper ring or whole-line fragment pairs -- both were measured slower).
-// Epilogue: v = act(acc + b) [affine per channel] [* scale[n * sstride]] [+ Y]
+// Epilogue: v = act([FiLM per graph](acc + b)) [affine per channel] [* scale[n * sstride]] [+ Y]
 // (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU).
 // Optional row lists gather X rows / scatter Y rows (edges of one type, compacted on the device).
 template <int ACT, int MT, int NT>
@@ -47,7 +47,10 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
              const int64_t* __restrict__ yidx /* row n of Y (and of scale) is yidx[n] */,
              const int* __restrict__ n_dev /* non-null: N = *n_dev (compacted row lists) */,
              const float* __restrict__ post_scale /* non-null: v = v * post_scale[m] + post_shift[m] (BatchNorm, eval) */,
-             const float* __restrict__ post_shift) {
+             const float* __restrict__ post_shift,
+             const float* __restrict__ film_gamma /* non-null: v = (1 + gamma[g][m]) v + beta[g][m] before act, */,
+             const float* __restrict__ film_beta  /* g = n / film_rows (FiLM per graph, nn/nn/film.py:58-60)   */,
+             int film_rows) {
     if (n_dev != nullptr) N = *n_dev;
     constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,10 +123,16 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
         int64_t n = n0 + 16 * nb + i;
         if (n >= N) continue;
         if (yidx != nullptr) n = yidx[n];
+        const size_t g = film_gamma != nullptr ? (size_t)(n / film_rows) * M : 0;
 #pragma unroll
         for (int mb = 0; mb < MT; ++mb) {
             const int m = m0 + 16 * mb + 4 * q;
             f32x4 v = acc[mb][nb];
+            if (film_gamma != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < M) v[r] = (1.0f + film_gamma[g + m + r]) * v[r] + film_beta[g + m + r];
+            }
             if (ACT == 1) v = silu4(v);
             if (ACT == 2) {
 #pragma unroll

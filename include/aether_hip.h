@@ -314,6 +314,56 @@ int aether_s2s_gumbel_hard(const float* logits, const float* uniform, float tau,
                            int64_t n_edges, float* edges, void* stream);
 
 /*
+ * seq2seq dynamic-field variant: nn/seq2seq/dynamic_field_aether.py, the model
+ * scripts/gravitational_field_3d_aether.sh trains (use_charges is never set by a runner: False).
+ *
+ * aether_s2s_graph_summary replaces GraphSummary.forward (nn/nn/graph_pool.py:50-71), run once per
+ * sequence on the burn-in trajectories (dynamic_field_aether.py:214-218): particle embedding, a GRU over
+ * time per object, [x | last hidden] + sinusoidal positional encoding (:10-28, eval mode: no dropout), and
+ * torch_geometric's AttentionalAggregation over all (object, time) items of a graph
+ * (softmax = exp(g - max) / (sum + 1e-16)).
+ *   x       : float[batch][num_objects][timesteps][input_size]
+ *   params  : nn.Linear / nn.GRU layouts (gates r, z, n); pe = buffer `pe.pe` [pe_len][input_size + hidden]
+ *   summary : float[batch][hidden]
+ * aether_s2s_film_modulation: the four FiLM modulators of FilmedNetwork (nn/nn/film.py:43-60) applied to the
+ * summary: mod = gamma_1 | beta_1 | gamma_2 | beta_2, each [batch][mlp_hidden] (+ one scratch plane);
+ * the summary is fixed for a sequence, so this also runs once.
+ * aether_s2s_film_field replaces predict_field (dynamic_field_aether.py:117-134): Fourier features, then
+ * linear_1 - FiLM - SiLU - linear_2 - FiLM - SiLU - linear_3 (nn/nn/filmed_network.py:27-35); point n belongs
+ * to graph n / rows_per_graph.
+ */
+typedef struct AetherS2SGraphSummaryParams {
+    const float* emb_w; const float* emb_b;                     /* particle_embedding [H][in], [H] */
+    const float* gru_w_ih; const float* gru_w_hh;               /* rnn.weight_{ih,hh}_l0 [3H][H] */
+    const float* gru_b_ih; const float* gru_b_hh;               /* [3H] */
+    const float* pe;                                            /* [pe_len][in + H] */
+    const float* gate_w0; const float* gate_b0; const float* gate_w2; const float* gate_b2;  /* [H][in+H], [H], [1][H], [1] */
+    const float* nn_w0; const float* nn_b0; const float* nn_w2; const float* nn_b2;          /* [H][in+H], [H], [H][H], [H] */
+} AetherS2SGraphSummaryParams;
+size_t aether_s2s_graph_summary_workspace_bytes(int64_t batch, int num_objects, int timesteps, int input_size,
+                                                int hidden);
+int aether_s2s_graph_summary(const AetherS2SGraphSummaryParams* params, int64_t batch, int num_objects,
+                             int timesteps, int input_size, int hidden, int pe_len, const float* x,
+                             void* workspace, size_t workspace_bytes, float* summary, void* stream);
+
+typedef struct AetherS2SFilmParams {
+    const float* B;                                             /* coordinate_embedding.B [D][h/2] */
+    const float* lin1_w; const float* lin1_b;                   /* [mh][h] */
+    const float* lin2_w; const float* lin2_b;                   /* [mh][mh] */
+    const float* lin3_w; const float* lin3_b;                   /* [D][mh] */
+    /* film_{1,2}.{gamma,beta}.{0,2}: [mh][gh], [mh], [mh][mh], [mh]; index = 2 * (film - 1) + (beta ? 1 : 0) */
+    const float* mod_w0[4]; const float* mod_b0[4]; const float* mod_w2[4]; const float* mod_b2[4];
+} AetherS2SFilmParams;
+size_t aether_s2s_film_modulation_bytes(int64_t batch, int mlp_hidden);
+int aether_s2s_film_modulation(const AetherS2SFilmParams* params, int graph_hidden, int mlp_hidden, int64_t batch,
+                               const float* summary, float* mod, size_t mod_bytes, void* stream);
+size_t aether_s2s_film_field_workspace_bytes(int64_t n_points, int hidden, int mlp_hidden);
+int aether_s2s_film_field(const AetherS2SFilmParams* params, int num_dims, int hidden, int mlp_hidden,
+                          int64_t n_points, int64_t rows_per_graph, const float* x, int x_stride,
+                          const float* mod, int64_t batch, void* workspace, size_t workspace_bytes,
+                          float* field, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

@@ -246,6 +246,81 @@ def future_fixture(out_dir):
         torch.Tensor.cuda = orig_cuda
 
 
+def dynfield_future_fixture(out_dir):
+    """SURVEY 8f N3, seq2seq half: the imported reference ``nn.seq2seq.dynamic_field_aether.DynamicFieldAether``
+    (3-D, the gravitational model): ``graph_pooler`` (GraphSummary), ``predict_field`` (FilmedNetwork) and
+    ``predict_future``.  Stand-ins as in oracle/make_golden_dynfield.py (torch_scatter,
+    torch_geometric AttentionalAggregation) and the identity ``.cuda()``; ``params['field']`` (a data-side
+    object used only to draw visualisation grids, dynamic_field_aether.py:88-95) is None."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import contextlib, io
+    import make_golden as MG
+    import make_golden_dynfield as MGD
+    import seq2seq_oracle as S
+    MG._install_scatter_standin()
+    MGD.install_pyg_standin()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from nn.seq2seq.dynamic_field_aether import DynamicFieldAether
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        D, B, N, T, steps, H, R, GH, MH = 3, 2, 5, 5, 3, 128, 64, 64, 96
+        params = dict(enc_params(N, D, H, R))
+        params.update({"gpu": False, "decoder_hidden": H, "skip_first": False, "decoder_dropout": 0.0,
+                       "gumbel_temp": 0.5, "encoder_mlp_hidden": 64, "prior_hidden_size": 64, "rff_std": 1.0,
+                       "pos_representation": "cart", "graph_hidden": GH, "mlp_hidden": MH, "field": None})
+        torch.manual_seed(DYN_SEED)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = DynamicFieldAether(params).eval()
+        g = torch.Generator().manual_seed(901)
+        inputs = torch.randn(B, T, N, 2 * D, generator=g)
+        E = N * (N - 1)
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            x = inputs[:, :-1].transpose(2, 1).contiguous()                  # dynamic_field_aether.py:214
+            summary = model.graph_pooler(x)                                   # :218
+            field0, _ = model.predict_field(x, summary, None)                 # :219
+            m64 = model.double()
+            summary64 = m64.graph_pooler(x.double())
+            field64, _ = m64.predict_field(x.double(), summary64, None)
+            model.float()
+        for noise_seed in range(50):
+            torch.manual_seed(2000 + noise_seed)
+            with torch.no_grad():
+                preds, edges = model.predict_future(inputs, steps, return_edges=True)
+            torch.manual_seed(2000 + noise_seed)
+            U = torch.stack([torch.rand(B * E, 2) for _ in range(T - 1 + steps)])
+            o_preds, o_edges = S.predict_future_dynamic_field(sd, inputs, steps, U, 0.5, True, "cart", 3,
+                                                              return_edges=True)
+            if torch.equal(o_edges.argmax(-1), edges.argmax(-1)):
+                break
+        else:
+            raise RuntimeError("no noise seed with unambiguous samples")
+        out = {"in.inputs": inputs.numpy(), "in.uniform": U.numpy(), "ref.predictions": preds.numpy(),
+               "ref.edges": edges.numpy(), "ref.summary": summary.numpy(), "ref.field": field0.numpy(),
+               "ref64.summary": summary64.numpy(), "ref64.field": field64.numpy(),
+               "seed": np.int64(DYN_SEED), "steps": np.int64(steps), "hidden_size": np.int64(H),
+               "rnn_hidden": np.int64(R), "num_vars": np.int64(N), "graph_hidden": np.int64(GH),
+               "mlp_hidden": np.int64(MH)}
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point:
+                out["sum." + k] = np.float64(v.double().sum().item())
+                out["abs." + k] = np.float64(v.double().abs().sum().item())
+        out["keys"] = np.array(list(model.state_dict().keys()))
+        np.savez(os.path.join(out_dir, "s2s_dynfield_D3.npz"), **out)
+        gp = {k[len("graph_pooler."):]: v for k, v in sd.items() if k.startswith("graph_pooler.")}
+        o_sum = S.graph_summary(gp, x)
+        print("wrote s2s_dynfield_D3.npz", tuple(preds.shape), "noise seed", 2000 + noise_seed,
+              "oracle err: summary", float((o_sum - summary).abs().max() / summary.abs().max()),
+              "field", float((S.film_field(sd, x, summary, D) - field0).abs().max() / field0.abs().max()),
+              "future", float((o_preds - preds).abs().max() / preds.abs().max()))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
+DYN_SEED = 9753
+
 FUT_SEED = 1357
 
 
@@ -265,3 +340,4 @@ if __name__ == "__main__":
     decoder_fixtures(os.path.join(REPO, "tests", "golden"))
     prior_fixtures(os.path.join(REPO, "tests", "golden"))
     future_fixture(os.path.join(REPO, "tests", "golden"))
+    dynfield_future_fixture(os.path.join(REPO, "tests", "golden"))

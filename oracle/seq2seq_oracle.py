@@ -270,7 +270,7 @@ def gumbel_hard(logits, uniform, tau):
 # Parity status: PINNED by tests/golden/s2s_future_D2.npz (the imported reference Aether.predict_future).
 # ---------------------------------------------------------------------------------------------
 def predict_future(sd, inputs, prediction_steps, uniform, tau, use_3d=False, pos_representation="cart",
-                   prior_layers=3, rnn_hidden=None, return_edges=False):
+                   prior_layers=3, rnn_hidden=None, return_edges=False, field_fn=None):
     """``sd``: the reference seq2seq Aether's state_dict.  inputs [B, T, N, 2D]; ``uniform``
     [T - 1 + prediction_steps, B * E, K]: the U(0,1) draws of gumbel_softmax in call order."""
     D = 3 if use_3d else 2
@@ -285,8 +285,11 @@ def predict_future(sd, inputs, prediction_steps, uniform, tau, use_3d=False, pos
     draw = 0
     preds, edges_all = [], []
 
+    if field_fn is None:
+        field_fn = lambda x: predict_field(sd, x, D)
+
     def step(x, hidden, state, draw):
-        field = predict_field(sd, x, D)
+        field = field_fn(x)
         logits, state = prior_step(enc, x, state, field, use_3d, pos_representation, prior_layers)
         z = gumbel_hard(logits.reshape(-1, logits.shape[-1]), uniform[draw], tau).view(logits.shape)
         out, hidden = decoder_step(dec, x, hidden, z, field, use_3d)
@@ -303,3 +306,91 @@ def predict_future(sd, inputs, prediction_steps, uniform, tau, use_3d=False, pos
         edges_all.append(z)
     preds = torch.stack(preds, 1)
     return (preds, torch.stack(edges_all, 1)) if return_edges else preds
+
+
+# ---------------------------------------------------------------------------------------------
+# seq2seq dynamic-field variant (nn/seq2seq/dynamic_field_aether.py, the model
+# scripts/gravitational_field_3d_aether.sh trains).  With use_charges False (no runner sets it) it is the
+# seq2seq Aether whose field query is FiLM-conditioned on a summary of the burn-in trajectories:
+#   GraphSummary.forward   <- nn/nn/graph_pool.py:50-71  (particle embedding, GRU over time, sinusoidal
+#                             positional encoding :10-28, attention pooling over all (object, time) items)
+#   FilmedNetwork / FiLM   <- nn/nn/filmed_network.py:27-35, nn/nn/film.py:53-60
+#   predict_field          <- dynamic_field_aether.py:117-134
+#   predict_future         <- dynamic_field_aether.py:207-246 (summary from inputs[:, :-1], fixed afterwards)
+# torch_geometric's AttentionalAggregation (not installed) is restated from its published definition:
+# out_b = sum_i softmax_b(gate_nn(x))_i * nn(x)_i with softmax = exp(g - max_b) / (sum_b exp(g - max_b) + 1e-16).
+# Parity status: PINNED by tests/golden/s2s_dynfield_D3.npz (the imported reference GraphSummary /
+# DynamicFieldAether with the same documented stand-in for AttentionalAggregation as
+# oracle/make_golden_dynfield.py).
+# ---------------------------------------------------------------------------------------------
+def positional_encoding(d_model: int, length: int, dtype=torch.float32) -> torch.Tensor:
+    """graph_pool.py:15-20: pe[t, 0::2] = sin(t * div), pe[t, 1::2] = cos(t * div)."""
+    position = torch.arange(length).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(length, d_model)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.to(dtype)
+
+
+def _gru_last(sd, prefix, y):
+    """Final hidden state of nn.GRU(batch_first=True) from the zero state; y [S, T, H]."""
+    w_ih, w_hh = sd[prefix + "weight_ih_l0"], sd[prefix + "weight_hh_l0"]
+    b_ih, b_hh = sd[prefix + "bias_ih_l0"], sd[prefix + "bias_hh_l0"]
+    H = w_hh.shape[1]
+    h = torch.zeros(y.shape[0], H, dtype=y.dtype)
+    for t in range(y.shape[1]):
+        gi = F.linear(y[:, t], w_ih, b_ih)
+        gh = F.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+    return h
+
+
+def graph_summary(sd, x):
+    """``sd``: the 'graph_pooler.' keys with the prefix removed.  x [B, N, T, input_size] -> [B, H]."""
+    Bt, N, T, _ = x.shape
+    y = F.linear(x, sd["particle_embedding.weight"], sd["particle_embedding.bias"]).flatten(0, 1)
+    emb = _gru_last(sd, "rnn.", y).reshape(Bt, N, 1, -1).expand(Bt, N, T, -1)
+    a = torch.cat([x, emb], -1)                                            # graph_pool.py:66-67
+    a = a + positional_encoding(a.shape[-1], T, x.dtype)                   # :68 (dropout: eval mode)
+    a = a.reshape(Bt, N * T, -1)                                           # items of graph b: all (object, time)
+    g = F.linear(F.silu(F.linear(a, sd["summary_net.gate_nn.0.weight"], sd["summary_net.gate_nn.0.bias"])),
+                 sd["summary_net.gate_nn.2.weight"], sd["summary_net.gate_nn.2.bias"])
+    v = F.linear(F.silu(F.linear(a, sd["summary_net.nn.0.weight"], sd["summary_net.nn.0.bias"])),
+                 sd["summary_net.nn.2.weight"], sd["summary_net.nn.2.bias"])
+    e = torch.exp(g - g.max(dim=1, keepdim=True).values)
+    w = e / (e.sum(dim=1, keepdim=True) + 1e-16)
+    return (w * v).sum(dim=1)
+
+
+def _film(sd, prefix, y, z):
+    def mlp(name):
+        return F.linear(F.silu(F.linear(z, sd[f"{prefix}{name}.0.weight"], sd[f"{prefix}{name}.0.bias"])),
+                        sd[f"{prefix}{name}.2.weight"], sd[f"{prefix}{name}.2.bias"])
+    return (1.0 + mlp("gamma")) * y + mlp("beta")                          # film.py:58-60
+
+
+def film_field(sd, x, summary, num_dims):
+    """dynamic_field_aether.py:117-134 with use_charges False.  ``sd``: 'coordinate_embedding.B' and the
+    'film_net.' keys; x [B, ..., >= D]; summary [B, Hg], broadcast over the middle axes."""
+    coords = x[..., :num_dims]
+    h = fourier_features(coords, sd["coordinate_embedding.B"])
+    z = summary.reshape(summary.shape[0], *([1] * (x.ndim - 2)), summary.shape[-1])
+    y = F.linear(h, sd["film_net.linear_1.weight"], sd["film_net.linear_1.bias"])
+    y = F.silu(_film(sd, "film_net.film_1.", y, z))
+    y = F.linear(y, sd["film_net.linear_2.weight"], sd["film_net.linear_2.bias"])
+    y = F.silu(_film(sd, "film_net.film_2.", y, z))
+    return F.linear(y, sd["film_net.linear_3.weight"], sd["film_net.linear_3.bias"])
+
+
+def predict_future_dynamic_field(sd, inputs, prediction_steps, uniform, tau, use_3d=True, pos_representation="cart",
+                                 prior_layers=3, return_edges=False):
+    """dynamic_field_aether.py:207-246: the summary of inputs[:, :-1] conditions every field query."""
+    D = 3 if use_3d else 2
+    gp = {k[len("graph_pooler."):]: v for k, v in sd.items() if k.startswith("graph_pooler.")}
+    summary = graph_summary(gp, inputs[:, :-1].transpose(2, 1).contiguous())
+    return predict_future(sd, inputs, prediction_steps, uniform, tau, use_3d, pos_representation, prior_layers,
+                          return_edges=return_edges, field_fn=lambda x: film_field(sd, x, summary, D))

@@ -133,3 +133,28 @@ def load_s2s_future():
         if "sum." + k in d:
             assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
     return d, model, params
+
+
+def load_s2s_dynfield():
+    """Golden fixture of the reference's seq2seq ``DynamicFieldAether`` (graph summary, FiLM field query,
+    ``predict_future``) + the model's parameters recreated from the stored seed through the drop-in constructor
+    (key order and checksums verified)."""
+    import numpy as _np
+    import torch as _torch
+    from aether_amd.nn.seq2seq.dynamic_field_aether import DynamicFieldAether
+    d = _np.load(os.path.join(GOLDEN, "s2s_dynfield_D3.npz"))
+    N, H, R = int(d["num_vars"]), int(d["hidden_size"]), int(d["rnn_hidden"])
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
+              "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "input_size": 6, "encoder_mlp_num_layers": 3,
+              "encoder_mlp_hidden": 64, "prior_num_layers": 3, "prior_hidden_size": 64, "use_3d": True,
+              "pos_representation": "cart", "gpu": False, "decoder_hidden": H, "skip_first": False,
+              "decoder_dropout": 0.0, "gumbel_temp": 0.5, "rff_std": 1.0, "graph_hidden": int(d["graph_hidden"]),
+              "mlp_hidden": int(d["mlp_hidden"]), "field": None}
+    _torch.manual_seed(int(d["seed"]))
+    model = DynamicFieldAether(params, device=None).eval()
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in d["keys"]]
+    for k, v in sd.items():
+        if "sum." + k in d:
+            assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
+    return d, model, params

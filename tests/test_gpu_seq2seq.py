@@ -249,3 +249,70 @@ def test_prior_step_variants_vs_oracle(D, layers, rep):
     got_l, (got_h, got_c) = enc.single_step_forward(x.cuda(), (st[0].cuda(), st[1].cuda()), f.cuda())
     for got, want in ((got_l, want_l), (got_h, want_h), (got_c, want_c)):
         assert scale_rel_err(got.cpu(), want) <= TOL
+
+
+# ---------------------------------------------------------------- dynamic-field variant
+def test_dynamic_field_variant_matches_reference():
+    """nn/seq2seq/dynamic_field_aether.py: graph summary (GRU + attention pooling), FiLM field query and the whole
+    predict_future vs the imported reference's outputs, with the reference's Gumbel draws."""
+    from conftest import load_s2s_dynfield
+    d, model, params = load_s2s_dynfield()
+    model = model.cuda()
+    t = lambda k: torch.from_numpy(d[k])
+    inputs = t("in.inputs").cuda()
+    B, T, N, _ = inputs.shape
+    x = inputs[:, :-1].transpose(2, 1).contiguous()
+    summary = model.graph_pooler(x)
+    assert scale_rel_err(summary.cpu(), t("ref.summary")) <= TOL
+    assert scale_rel_err(summary.cpu(), t("ref64.summary").float()) <= TOL
+    field, coords = model.predict_field(x, t("ref.summary").cuda())
+    assert torch.equal(coords, x[..., :3])
+    assert scale_rel_err(field.cpu(), t("ref.field")) <= TOL and scale_rel_err(field.cpu(), t("ref64.field").float()) <= TOL
+    U = t("in.uniform").cuda().view(-1, B, N * (N - 1), 2)
+    preds, edges = model.predict_future(inputs, int(d["steps"]), return_edges=True, uniform=U)
+    assert torch.equal(edges.cpu().argmax(-1), t("ref.edges").argmax(-1))
+    assert scale_rel_err(preds.cpu(), t("ref.predictions")) <= TOL
+
+
+@pytest.mark.parametrize("D,B,N,T,H,GH,MH", [(3, 4, 5, 49, 128, 64, 96), (2, 3, 7, 10, 64, 32, 48), (3, 2, 3, 100, 64, 48, 64)])
+def test_dynamic_field_variant_vs_oracle(D, B, N, T, H, GH, MH):
+    """Fresh inputs at other shapes: the gravitational runner's 49 burn-in steps, 2-D, the positional encoding's
+    full length; rows of a graph that straddle MFMA tiles; modulation cache across calls."""
+    from aether_amd.nn.seq2seq.dynamic_field_aether import DynamicFieldAether
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H, "encoder_rnn_hidden": 32,
+              "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 32,
+              "prior_num_layers": 3, "prior_hidden_size": 32, "use_3d": D == 3, "pos_representation": "cart",
+              "gpu": True, "decoder_hidden": H, "skip_first": False, "decoder_dropout": 0.0, "gumbel_temp": 0.5,
+              "graph_hidden": GH, "mlp_hidden": MH, "field": None}
+    torch.manual_seed(70 + D)
+    model = DynamicFieldAether(params, device="cuda").eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    gp = {k[len("graph_pooler."):]: v for k, v in sd.items() if k.startswith("graph_pooler.")}
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(B, N, T, 2 * D, generator=g)
+    want = S.graph_summary(gp, x)
+    got = model.graph_pooler(x.cuda())
+    assert scale_rel_err(got.cpu(), want) <= TOL
+    f_want = S.film_field(sd, x, want, D)
+    f_got, _ = model.predict_field(x.cuda(), got)
+    assert scale_rel_err(f_got.cpu(), f_want) <= 2 * TOL
+    x1 = torch.randn(B, N, 2 * D, generator=g)                         # per-step query, same summary (cached modulation)
+    f1, _ = model.predict_field(x1.cuda(), got)
+    assert scale_rel_err(f1.cpu(), S.film_field(sd, x1, want, D)) <= 2 * TOL
+    other = torch.randn(B, GH, generator=g)                            # a different summary must not hit the cache
+    f2, _ = model.predict_field(x1.cuda(), other.cuda())
+    assert scale_rel_err(f2.cpu(), S.film_field(sd, x1, other, D)) <= 2 * TOL
+
+
+def test_dynamic_field_variant_errors():
+    from aether_amd.nn.seq2seq.dynamic_field_aether import DynamicFieldAether, GraphSummary
+    from aether_amd import _lib
+    with pytest.raises(ValueError):
+        GraphSummary(6, 40)
+    gs = GraphSummary(6, 32).cuda()
+    with pytest.raises(_lib.AetherHipError):
+        gs(torch.zeros(2, 3, 4, 6))                                    # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        gs(torch.zeros(2, 3, 101, 6, device="cuda"))                   # longer than the positional encoding
+    with pytest.raises(ValueError):
+        gs(torch.zeros(2, 3, 4, 5, device="cuda"))

@@ -222,6 +222,27 @@ def test_seq2seq_predict_future():
     assert scale_rel_err(preds, t("ref.predictions")) <= 2e-6
 
 
+def test_seq2seq_dynamic_field_variant():
+    """SURVEY 8f N3, seq2seq half: GraphSummary, the FiLM field query and predict_future of the imported
+    reference nn.seq2seq.dynamic_field_aether.DynamicFieldAether (3-D)."""
+    from conftest import load_s2s_dynfield
+    from oracle import seq2seq_oracle as S
+    d, model, params = load_s2s_dynfield()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    t = lambda k: torch.from_numpy(d[k])
+    x = t("in.inputs")[:, :-1].transpose(2, 1).contiguous()
+    gp = {k[len("graph_pooler."):]: v for k, v in sd.items() if k.startswith("graph_pooler.")}
+    summary = S.graph_summary(gp, x)
+    assert scale_rel_err(summary, t("ref.summary")) <= 2e-6
+    assert scale_rel_err(S.graph_summary({k: v.double() for k, v in gp.items()}, x.double()), t("ref64.summary")) <= 1e-12
+    field = S.film_field(sd, x, t("ref.summary"), 3)
+    assert field.shape == x.shape[:-1] + (3,) and scale_rel_err(field, t("ref.field")) <= 2e-6
+    preds, edges = S.predict_future_dynamic_field(sd, t("in.inputs"), int(d["steps"]), t("in.uniform"), 0.5, True,
+                                                  "cart", 3, return_edges=True)
+    assert torch.equal(edges.argmax(-1), t("ref.edges").argmax(-1))
+    assert scale_rel_err(preds, t("ref.predictions")) <= 2e-6
+
+
 @pytest.mark.parametrize("D", [2, 3])
 def test_dynamic_field_variant(D):
     """DynamicFieldAether (attention-pooled graph summary + FiLM field net) vs the imported
