@@ -34,6 +34,7 @@
 #include "seq2seq.h"
 #include "dynfield.h"
 #include "s2s_dynfield.h"
+#include "knn.h"
 
 #include <mutex>
 #include <utility>
@@ -1037,6 +1038,53 @@ int aether_s2s_film_field(const AetherS2SFilmParams* p, int num_dims, int hidden
                    nullptr, nullptr, nullptr, nullptr, nullptr, mod + 2 * plane, mod + 3 * plane, rows)) return AETHER_EINVAL;
     if (s2s_linear(0, p->lin3_w, mlp_hidden, p->lin3_b, h2, field, num_dims, mlp_hidden, n_points, num_dims, nullptr, 0, 0, st))
         return AETHER_EINVAL;
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+// ------------------------------------------------------------------ kNN edge builder (N2)
+namespace {
+struct KnnLayout {
+    size_t nbr, cnt, node_off, edge_off, total;
+    KnnLayout(int64_t S, int N, int k) {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+        nbr = take((size_t)S * N * k * 4); cnt = take((size_t)S * N * 4);
+        node_off = take((size_t)S * 8); edge_off = take((size_t)S * 8);
+        total = off;
+    }
+};
+}  // namespace
+
+size_t aether_knn_workspace_bytes(int64_t n_scenes, int n_objects, int k) {
+    if (n_scenes <= 0 || n_objects <= 0 || k <= 0) return 0;
+    return KnnLayout(n_scenes, n_objects, k).total + 256;
+}
+
+int aether_knn_edges(const float* x, int x_stride, const float* masks, int64_t n_scenes, int n_objects, int k,
+                     int64_t* send, int64_t* recv, int64_t* scene_edges, int64_t* scene_nodes, int64_t* totals,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !masks || !send || !recv || !scene_edges || !scene_nodes || !totals || !workspace)
+        return fail(AETHER_EINVAL, "knn_edges: null pointer");
+    if (n_scenes <= 0 || n_scenes > INT32_MAX || n_objects <= 0 || n_objects > KNN_MAX_OBJECTS || x_stride < 2)
+        return fail(AETHER_EINVAL, "knn_edges: bad sizes (at most 8192 objects per scene, x_stride >= 2)");
+    if (k < 1 || k > KNN_MAX_K) return fail(AETHER_EINVAL, "knn_edges: k must be in 1..16");
+    const KnnLayout L(n_scenes, n_objects, k);
+    if (workspace_bytes < L.total + 256) return fail(AETHER_ESPACE, "knn_edges: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
+    int* nbr = reinterpret_cast<int*>(ws + L.nbr);
+    int* cnt = reinterpret_cast<int*>(ws + L.cnt);
+    int64_t* node_off = reinterpret_cast<int64_t*>(ws + L.node_off);
+    int64_t* edge_off = reinterpret_cast<int64_t*>(ws + L.edge_off);
+    const int N = n_objects;
+    const size_t lds_sel = (size_t)3 * N * 4 + 257 * 4, lds_wr = (size_t)2 * N * 4 + 257 * 4;
+    if (ensure_dynamic_lds((const void*)k_knn_select, lds_sel) || ensure_dynamic_lds((const void*)k_knn_write, lds_wr))
+        return AETHER_EHIP;
+    k_knn_select<<<dim3((unsigned)n_scenes), dim3(256), lds_sel, st>>>(x, x_stride, masks, N, k, nbr, cnt, scene_nodes,
+                                                                      scene_edges);
+    k_knn_scan<<<dim3(1), dim3(1024), 0, st>>>(scene_nodes, scene_edges, n_scenes, node_off, edge_off, totals);
+    k_knn_write<<<dim3((unsigned)n_scenes), dim3(256), lds_wr, st>>>(masks, nbr, cnt, N, k, node_off, edge_off, send, recv);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }

@@ -364,6 +364,27 @@ int aether_s2s_film_field(const AetherS2SFilmParams* params, int num_dims, int h
                           float* field, void* stream);
 
 /*
+ * k-nearest-neighbour edge builder for variable-N scenes: replaces Encoder.knn_edges
+ * (nn/dynamicvars/aether_dynamicvars.py:559-586; the same method in the other *_dynamicvars.py) and the send /
+ * recv half of get_knn_graph_info (experiments/ind/single_ind_data.py:186-217).
+ *   x        : float[n_scenes][n_objects][x_stride]   the first two columns are the 2-D position
+ *   masks    : float[n_scenes][n_objects]             != 0: the object is present in the scene
+ *   k        : neighbours per object (the reference: min(10, n_objects - 1)); 1 <= k <= 16
+ *   send, recv : int64[capacity], capacity >= n_scenes * n_objects * k; the first totals[0] entries are
+ *              written: scene by scene, object by object, nearest neighbour first, in the compacted
+ *              numbering (present objects of all scenes counted consecutively).  As in the reference,
+ *              `send` is the querying object and `recv` its neighbour.
+ *   scene_edges, scene_nodes : int64[n_scenes]  edges / present objects per scene
+ *   totals   : int64[2] = {edges, present objects}
+ * Equal distances keep index order (torch.topk leaves that order unspecified).  Stream-ordered, no host
+ * synchronisation; read totals[0] after the stream to size the result.
+ */
+size_t aether_knn_workspace_bytes(int64_t n_scenes, int n_objects, int k);
+int aether_knn_edges(const float* x, int x_stride, const float* masks, int64_t n_scenes, int n_objects, int k,
+                     int64_t* send, int64_t* recv, int64_t* scene_edges, int64_t* scene_nodes, int64_t* totals,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

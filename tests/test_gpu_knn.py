@@ -1,0 +1,69 @@
+"""kNN edge builder: the HIP path vs the reference's own outputs (bit-exact indices) and vs the
+oracle on fresh scenes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from aether_amd import _lib
+from aether_amd.knn import csr_by_receiver, get_knn_graph_info, knn_edges
+from oracle import knn_oracle as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["small", "scenes", "few", "wide", "flat"])
+def test_knn_edges_match_reference(name):
+    d = np.load(os.path.join(GOLDEN, "knn_edges.npz"))
+    x, m = torch.from_numpy(d[name + ".x"]).cuda(), torch.from_numpy(d[name + ".masks"]).cuda()
+    send, recv, num = knn_edges(x, m, k=int(d[name + ".k"]))
+    assert send.dtype == torch.int64 and recv.dtype == torch.int64
+    assert np.array_equal(send.cpu().numpy(), d[name + ".send"])
+    assert np.array_equal(recv.cpu().numpy(), d[name + ".recv"])
+    assert np.array_equal(num.cpu().numpy(), d[name + ".num"])
+
+
+def test_knn_graph_info_matches_reference():
+    d = np.load(os.path.join(GOLDEN, "knn_edges.npz"))
+    x, m = torch.from_numpy(d["info.x"]).cuda(), torch.from_numpy(d["info.masks"]).cuda()
+    send, recv = get_knn_graph_info(x, m, int(d["info.masks"].sum()))
+    assert np.array_equal(send.cpu().numpy(), d["info.send"]) and np.array_equal(recv.cpu().numpy(), d["info.recv"])
+    order, rowptr = csr_by_receiver(recv, int(d["info.masks"].sum()))
+    r = recv[order].cpu().numpy()
+    assert (np.diff(r) >= 0).all() and int(rowptr[-1]) == recv.numel()
+
+
+@pytest.mark.parametrize("S,N,k,p", [(64, 40, 10, 0.6), (3, 300, 10, 0.9), (500, 7, 10, 0.5), (2, 17, 16, 1.0),
+                                     (5, 12, 1, 0.8)])
+def test_knn_edges_vs_oracle(S, N, k, p):
+    """cfg4-like batches (64 scenes of up to 40 agents), a large scene (several passes per thread), many tiny
+    scenes, the maximum k, k = 1; lattice positions with many exactly equal distances (index order decides)."""
+    g = torch.Generator().manual_seed(S * 1000 + N)
+    x = torch.randn(S, N, 4, generator=g) * 20.0
+    m = (torch.rand(S, N, generator=g) < p).float()
+    for xx in (x, torch.round(x / 8.0)):                      # random, then a coarse integer lattice (ties)
+        send, recv, num = knn_edges(xx.cuda(), m.cuda(), k=k)
+        ws, wr, wn = K.knn_edges(xx.numpy(), m.numpy(), k)
+        assert np.array_equal(send.cpu().numpy(), ws) and np.array_equal(recv.cpu().numpy(), wr)
+        assert int(num) == int(wn)
+    # structure: sources ascending, k (or fewer) neighbours each, no self edges, scenes do not mix
+    s, r = send.cpu().numpy(), recv.cpu().numpy()
+    assert (np.diff(s) >= 0).all() and (s != r).all()
+    assert np.bincount(s).max() <= min(k, N - 1)
+
+
+def test_knn_edges_empty_and_errors():
+    x = torch.randn(2, 3, 5, 4, device="cuda")
+    send, recv, num = knn_edges(x, torch.zeros(2, 3, 5, device="cuda"))
+    assert send.numel() == 0 and recv.numel() == 0 and num.tolist() == [0, 0]
+    one = torch.zeros(2, 3, 5, device="cuda"); one[..., 2] = 1.0      # single objects: no edges
+    assert knn_edges(x, one)[0].numel() == 0
+    with pytest.raises(_lib.AetherHipError):
+        knn_edges(x.cpu(), one.cpu())
+    with pytest.raises(ValueError):
+        knn_edges(x, one[..., :4])
+    with pytest.raises(ValueError):
+        knn_edges(torch.randn(2, 30, 4, device="cuda"), torch.ones(2, 30, device="cuda"), k=17)
+    assert get_knn_graph_info(x[0, 0], one[0, 0], 1) == (None, None)

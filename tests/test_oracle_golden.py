@@ -260,3 +260,16 @@ def test_dynamic_field_variant(D):
         assert scale_rel_err(f64, torch.from_numpy(d[f"{name}.ref64.field"])) <= 1e-12
         out = O.dynamic_field_aether_forward(sd, t("x"), t("vel"), get_edges(B, N), t("edge_attr"), t("charges"), N)
         assert scale_rel_err(out, torch.from_numpy(d[f"{name}.ref.out"])) <= 1e-6
+
+
+def test_knn_edge_builder():
+    """the kNN edge builder vs the imported reference Encoder.knn_edges / get_knn_graph_info
+    (bit-exact indices; fixtures hold scenes whose neighbour distances are separated, see make_golden_knn.py)."""
+    from oracle import knn_oracle as K
+    d = np.load(os.path.join(GOLDEN, "knn_edges.npz"))
+    for name in ("small", "scenes", "few", "wide", "flat"):
+        s, r, n = K.knn_edges(d[name + ".x"], d[name + ".masks"], int(d[name + ".k"]))
+        assert np.array_equal(s, d[name + ".send"]) and np.array_equal(r, d[name + ".recv"]), name
+        assert np.array_equal(n, d[name + ".num"]), name
+    s, r = K.knn_graph_info(d["info.x"], d["info.masks"])
+    assert np.array_equal(s, d["info.send"]) and np.array_equal(r, d["info.recv"])
