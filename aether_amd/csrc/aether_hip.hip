@@ -35,6 +35,7 @@
 #include "dynfield.h"
 #include "s2s_dynfield.h"
 #include "knn.h"
+#include "sim.h"
 
 #include <mutex>
 #include <utility>
@@ -1085,6 +1086,56 @@ int aether_knn_edges(const float* x, int x_stride, const float* masks, int64_t n
                                                                       scene_edges);
     k_knn_scan<<<dim3(1), dim3(1024), 0, st>>>(scene_nodes, scene_edges, n_scenes, node_off, edge_off, totals);
     k_knn_write<<<dim3((unsigned)n_scenes), dim3(256), lds_wr, st>>>(masks, nbr, cnt, N, k, node_off, edge_off, send, recv);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+// ------------------------------------------------------------------ simulators (N4)
+namespace {
+int sim_check(int64_t n_sims, int n_balls, int total_balls, int dim, int T, int sample_freq) {
+    if (n_sims <= 0 || n_balls < 0 || total_balls <= 0 || n_balls > total_balls || total_balls > SIM_MAX_BALLS)
+        return fail(AETHER_EINVAL, "simulator: bad sizes (at most 64 balls per simulation)");
+    if (dim != 2 && dim != 3) return fail(AETHER_EINVAL, "simulator: dim must be 2 or 3");
+    if (T <= 0 || sample_freq <= 0 || T % sample_freq != 0)
+        return fail(AETHER_EINVAL, "simulator: T must be a positive multiple of sample_freq");
+    return AETHER_OK;
+}
+}  // namespace
+
+int aether_sim_electrostatic(const double* loc0, const double* vel0, const double* charges, int64_t n_sims, int n_balls,
+                             int total_balls, int dim, int T, int sample_freq, double interaction_strength,
+                             double delta_T, double max_F, double* loc, double* vel, int64_t* maxed_out, void* stream) {
+    if (!loc0 || !vel0 || !charges || !maxed_out || (T / (sample_freq > 0 ? sample_freq : 1) > 1 && (!loc || !vel)))
+        return fail(AETHER_EINVAL, "sim_electrostatic: null pointer");
+    if (int rc = sim_check(n_sims, n_balls, total_balls, dim, T, sample_freq)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemsetAsync(maxed_out, 0, (size_t)n_sims * sizeof(int64_t), st));
+    const int spw = 64 / total_balls;
+    const dim3 grid((unsigned)((n_sims + spw - 1) / spw));
+    if (dim == 2)
+        k_sim_electrostatic<2><<<grid, dim3(64), 0, st>>>(loc0, vel0, charges, n_sims, n_balls, total_balls, T, sample_freq,
+                                                          interaction_strength, delta_T, max_F, loc, vel, maxed_out);
+    else
+        k_sim_electrostatic<3><<<grid, dim3(64), 0, st>>>(loc0, vel0, charges, n_sims, n_balls, total_balls, T, sample_freq,
+                                                          interaction_strength, delta_T, max_F, loc, vel, maxed_out);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+int aether_sim_gravitational(const double* pos0, const double* vel0, const double* mass, int64_t n_sims, int n_balls,
+                             int total_balls, int dim, int T, int sample_freq, double interaction_strength, double dt,
+                             double softening, double* pos, double* vel, double* force, void* stream) {
+    if (!pos0 || !vel0 || !mass || !pos || !vel || !force) return fail(AETHER_EINVAL, "sim_gravitational: null pointer");
+    if (int rc = sim_check(n_sims, n_balls, total_balls, dim, T, sample_freq)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int spw = 64 / total_balls;
+    const dim3 grid((unsigned)((n_sims + spw - 1) / spw));
+    if (dim == 2)
+        k_sim_gravitational<2><<<grid, dim3(64), 0, st>>>(pos0, vel0, mass, n_sims, n_balls, total_balls, T, sample_freq,
+                                                          interaction_strength, dt, softening, pos, vel, force);
+    else
+        k_sim_gravitational<3><<<grid, dim3(64), 0, st>>>(pos0, vel0, mass, n_sims, n_balls, total_balls, T, sample_freq,
+                                                          interaction_strength, dt, softening, pos, vel, force);
     HIP_OK(hipGetLastError());
     return AETHER_OK;
 }

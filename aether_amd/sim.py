@@ -1,0 +1,203 @@
+"""The reference's dataset simulators with the integration on the MI355X.
+
+``ElectrostaticFieldSim`` and ``GravitationalFieldSim`` keep the constructors, attributes, random-number protocol
+and ``sample_trajectory`` results of experiments/electrostatic/dataset/electrostatic_field_sim.py and
+experiments/gravitational/dataset/gravitational_field_sim.py: every random draw (charges, initial state, field
+sources, observation noise) is made on the host with the same numpy generators in the same order, so a dataset
+comes out draw for draw; the T-step integration -- the part that takes the reference hours for 70 000
+simulations -- runs in ``aether_sim_electrostatic`` / ``aether_sim_gravitational`` (fp64).
+``sample_trajectories(num_sims, ...)`` batches the loop of experiments/electrostatic/dataset/generate_dataset.py
+:15-60 into one launch.  ``as_tensor=True`` leaves the frames on the device for the model.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _device(device):
+    if not torch.cuda.is_available():
+        raise _lib.AetherHipError("aether_amd.sim integrates on an MI355X only (there is no CPU fallback)")
+    return torch.device(device)
+
+
+class ElectrostaticFieldSim(object):
+    def __init__(self, n_balls=5, box_size=5., loc_std=1., vel_norm=0.5, interaction_strength=1., noise_var=0., dim=2,
+                 static_balls=0, static_charge_strength=1.0, device="cuda"):
+        self.n_balls, self.box_size, self.loc_std, self.vel_norm = n_balls, box_size, loc_std, vel_norm
+        self.interaction_strength, self.noise_var, self.dim, self.static_balls = interaction_strength, noise_var, dim, static_balls
+        self._charge_types = np.array([-1., 0., 1.])
+        self._static_charge_strength = static_charge_strength
+        self._delta_T = 0.001
+        self._max_F = 0.1 / self._delta_T
+        self._particle_seed = 0
+        self.reset_particle_rng()
+        self._field_seed = 1
+        self.reset_field_rng()
+        self.sampler = self.sample_location_inside_box
+        self.device = device
+        self.last_maxed_out = None
+        if n_balls + static_balls > 64 or dim not in (2, 3):
+            raise ValueError("at most 64 balls per simulation, dim 2 or 3")
+
+    def reset_particle_rng(self):
+        self.particle_rng = np.random.default_rng(self._particle_seed)
+
+    def reset_field_rng(self):
+        self.field_rng = np.random.default_rng(self._field_seed)
+
+    def sample_location_inside_box(self):
+        return self.field_rng.uniform(-self.box_size, self.box_size, (self.static_balls, self.dim))
+
+    # -- host side: the random draws of sample_trajectory, in its order --------------------------------------
+    def _draw_initial(self, charge_prob, field_charge_prob):
+        n = self.n_balls
+        if self.static_balls > 0:                                          # electrostatic_field_sim.py:79-92
+            field_charge_prob = charge_prob if field_charge_prob is None else field_charge_prob
+            charges = np.concatenate([
+                self.particle_rng.choice(self._charge_types, size=(n, 1), p=charge_prob),
+                self.field_rng.choice(self._charge_types, size=(self.static_balls, 1), p=field_charge_prob)
+                * self._static_charge_strength])
+        else:
+            charges = self.particle_rng.choice(self._charge_types, size=(n, 1), p=charge_prob)
+        loc0 = np.concatenate([self.particle_rng.normal(size=(n, self.dim)) * self.loc_std, self.sampler()], 0)   # :99-101
+        vel0 = self.particle_rng.normal(size=(n, self.dim))                                                         # :102-104
+        vel0 = vel0 * self.vel_norm / np.sqrt((vel0 ** 2).sum(axis=1, keepdims=True))
+        vel0 = np.concatenate([vel0, np.zeros((self.static_balls, self.dim))], 0)
+        # the reference asserts that no pair starts without interaction (:121)
+        total = n + self.static_balls
+        diff = loc0[:, None, :] - loc0[None, :, :]
+        with np.errstate(divide="ignore"):
+            fs = self.interaction_strength * (charges @ charges.T) / np.power((diff ** 2).sum(-1), 1.5)
+        assert np.abs(fs[~np.eye(total, dtype=bool)]).min() > 1e-10
+        return charges, loc0, vel0
+
+    def _draw_noise(self, T_save):
+        n = self.n_balls                                                    # :164-166
+        return (self.particle_rng.normal(size=(T_save, n, self.dim)) * self.noise_var,
+                self.particle_rng.normal(size=(T_save, n, self.dim)) * self.noise_var)
+
+    # -- device side ----------------------------------------------------------------------------------------------
+    def _integrate(self, loc0, vel0, charges, T, sample_freq):
+        """loc0, vel0 [S, M, D], charges [S, M] (numpy fp64) -> loc, vel [S, T_save, M, D] (CUDA fp64), capped [S]."""
+        lib = _lib.load()
+        dev = _device(self.device)
+        S, M, D = loc0.shape
+        T_save = T // sample_freq - 1
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        l0, v0, q = up(loc0), up(vel0), up(charges)
+        loc = torch.empty(S, max(T_save, 0), M, D, dtype=torch.float64, device=dev)
+        vel = torch.empty_like(loc)
+        maxed = torch.empty(S, dtype=torch.int64, device=dev)
+        st = lib.aether_sim_electrostatic(l0.data_ptr(), v0.data_ptr(), q.data_ptr(), S, self.n_balls, M, D, T, sample_freq,
+                                          float(self.interaction_strength), float(self._delta_T), float(self._max_F),
+                                          loc.data_ptr(), vel.data_ptr(), maxed.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_sim_electrostatic")
+        return loc, vel, maxed
+
+    def sample_trajectories(self, num_sims, T=10000, sample_freq=10, charge_prob=[0.5, 0.0, 0.5], field_charge_prob=None,
+                            field_seeds=None, reset_field_rng=False, as_tensor=False):
+        """``num_sims`` consecutive ``sample_trajectory`` calls in one launch.  ``field_seeds`` (an iterator) and
+        ``reset_field_rng`` reproduce generate_dataset.py:31-34 (a new field seed per simulation / the same
+        field for all).  Returns loc, vel [S, T_save, M, D], edges [S, M, M], charges [S, M, 1]."""
+        assert T % sample_freq == 0
+        T_save = int(T / sample_freq - 1)
+        n = self.n_balls
+        draws = []
+        for _ in range(num_sims):
+            if field_seeds is not None:
+                self._field_seed = next(field_seeds)
+            if reset_field_rng or field_seeds is not None:
+                self.reset_field_rng()
+            draws.append(self._draw_initial(charge_prob, field_charge_prob) + self._draw_noise(T_save))
+        charges = np.stack([d[0] for d in draws])
+        loc, vel, maxed = self._integrate(np.stack([d[1] for d in draws]), np.stack([d[2] for d in draws]),
+                                          charges[..., 0], T, sample_freq)
+        self.last_maxed_out = maxed
+        if self.noise_var != 0:
+            loc[:, :, :n] += torch.from_numpy(np.stack([d[3] for d in draws])).to(loc.device)
+            vel[:, :, :n] += torch.from_numpy(np.stack([d[4] for d in draws])).to(loc.device)
+        edges = charges @ charges.transpose(0, 2, 1)
+        if as_tensor:
+            return loc, vel, torch.from_numpy(edges).to(loc.device), torch.from_numpy(charges).to(loc.device)
+        return loc.cpu().numpy(), vel.cpu().numpy(), edges, charges
+
+    def sample_trajectory(self, T=10000, sample_freq=10, charge_prob=[0.5, 0.0, 0.5], field_charge_prob=None):
+        """electrostatic_field_sim.py:63-170: (loc, vel [T_save, M, D], edges [M, M], charges [M, 1])."""
+        loc, vel, edges, charges = self.sample_trajectories(1, T, sample_freq, charge_prob, field_charge_prob)
+        print(int(self.last_maxed_out[0]))                                  # :168
+        return loc[0], vel[0], edges[0], charges[0]
+
+
+class GravitationalFieldSim(object):
+    def __init__(self, n_balls=100, box_size=1.0, loc_std=1, vel_norm=0.5, interaction_strength=1, noise_var=0, dt=0.001,
+                 softening=0.1, dim=3, static_balls=0, static_mass=1.0, device="cuda", **kwargs):
+        self.n_balls, self.loc_std, self.vel_norm, self.interaction_strength = n_balls, loc_std, vel_norm, interaction_strength
+        self.noise_var, self.dt, self.softening = noise_var, dt, softening
+        self.position_variance = 1.0
+        self.dim, self.static_balls, self.static_mass = dim, static_balls, static_mass
+        self._field_seed = 1
+        self.reset_field_rng()
+        self.box_size = box_size
+        self.device = device
+        if n_balls + static_balls > 64 or dim not in (2, 3):
+            raise ValueError("at most 64 balls per simulation, dim 2 or 3")
+
+    def reset_field_rng(self):
+        self.field_rng = np.random.default_rng(self._field_seed)
+
+    def sample_location_inside_box(self):
+        return self.field_rng.uniform(-self.box_size, self.box_size, (self.static_balls, self.dim))
+
+    def _draw_initial(self):
+        N, total = self.n_balls, self.n_balls + self.static_balls           # gravitational_field_sim.py:87-96
+        mass = np.concatenate([np.ones((N, 1)), self.static_mass * np.ones((self.static_balls, 1))], 0)
+        pos = self.position_variance * np.random.randn(total, self.dim)
+        vel = np.concatenate([np.random.randn(N, self.dim), np.zeros((self.static_balls, self.dim))], 0)
+        vel -= np.mean(mass * vel, 0) / np.mean(mass)
+        return mass, pos, vel
+
+    def _draw_noise(self, T_save):
+        N = self.n_balls                                                    # :128-130
+        return tuple(np.random.randn(T_save, N, self.dim) * self.noise_var for _ in range(3))
+
+    def _integrate(self, pos0, vel0, mass, T, sample_freq):
+        lib = _lib.load()
+        dev = _device(self.device)
+        S, M, D = pos0.shape
+        T_save = T // sample_freq
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        p0, v0, m = up(pos0), up(vel0), up(mass)
+        pos = torch.empty(S, T_save, M, D, dtype=torch.float64, device=dev)
+        vel, force = torch.empty_like(pos), torch.empty_like(pos)
+        st = lib.aether_sim_gravitational(p0.data_ptr(), v0.data_ptr(), m.data_ptr(), S, self.n_balls, M, D, T, sample_freq,
+                                          float(self.interaction_strength), float(self.dt), float(self.softening),
+                                          pos.data_ptr(), vel.data_ptr(), force.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_sim_gravitational")
+        return pos, vel, force
+
+    def sample_trajectories(self, num_sims, T=10000, sample_freq=10, as_tensor=False):
+        """``num_sims`` consecutive ``sample_trajectory`` calls (global numpy generator, as the reference) in one
+        launch: pos, vel, force [S, T_save, M, D], mass [S, M, 1]."""
+        assert T % sample_freq == 0
+        T_save = int(T / sample_freq)
+        N = self.n_balls
+        draws = [self._draw_initial() + self._draw_noise(T_save) for _ in range(num_sims)]
+        mass = np.stack([d[0] for d in draws])
+        pos, vel, force = self._integrate(np.stack([d[1] for d in draws]), np.stack([d[2] for d in draws]), mass[..., 0],
+                                          T, sample_freq)
+        if self.noise_var != 0:
+            for out, k in ((pos, 3), (vel, 4), (force, 5)):
+                out[:, :, :N] += torch.from_numpy(np.stack([d[k] for d in draws])).to(out.device)
+        if as_tensor:
+            return pos, vel, force, torch.from_numpy(mass).to(pos.device)
+        return pos.cpu().numpy(), vel.cpu().numpy(), force.cpu().numpy(), mass
+
+    def sample_trajectory(self, T=10000, sample_freq=10):
+        """gravitational_field_sim.py:75-131: (pos, vel, force [T_save, M, D], mass [M, 1])."""
+        pos, vel, force, mass = self.sample_trajectories(1, T, sample_freq)
+        return pos[0], vel[0], force[0], mass[0]

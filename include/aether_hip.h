@@ -385,6 +385,32 @@ int aether_knn_edges(const float* x, int x_stride, const float* masks, int64_t n
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * On-device data side: the simulators that generate the reference's datasets, batched over
+ * simulations (fp64, as numpy).  The random draws (charges, initial state, field sources, observation noise)
+ * stay with the caller's numpy generators, so a dataset is reproduced draw for draw.
+ *
+ * aether_sim_electrostatic replaces the integration of ElectrostaticFieldSim.sample_trajectory
+ * (experiments/electrostatic/dataset/electrostatic_field_sim.py:108-163): Coulomb forces between all balls
+ * (n_balls moving, then total_balls - n_balls static field sources), force capped at max_F, leap-frog.
+ *   loc0, vel0 : double[n_sims][total_balls][dim]   initial state (:96-104; static velocities 0)
+ *   charges    : double[n_sims][total_balls]        (:79-92)
+ *   loc, vel   : double[n_sims][T/sample_freq - 1][total_balls][dim]   saved frames (:139-142; static rows constant)
+ *   maxed_out  : int64[n_sims]   number of capped forces (the count the reference prints, :168)
+ * aether_sim_gravitational replaces GravitationalFieldSim.sample_trajectory's loop
+ * (experiments/gravitational/dataset/gravitational_field_sim.py:99-125): softened gravity, kick-drift-kick.
+ *   pos0, vel0 : double[n_sims][total_balls][dim] (velocities in the centre-of-mass frame, :96); mass [n_sims][total_balls]
+ *   pos, vel, force : double[n_sims][T/sample_freq][total_balls][dim]
+ * total_balls <= 64, dim 2 or 3.  Stream-ordered.
+ */
+int aether_sim_electrostatic(const double* loc0, const double* vel0, const double* charges, int64_t n_sims,
+                             int n_balls, int total_balls, int dim, int T, int sample_freq,
+                             double interaction_strength, double delta_T, double max_F, double* loc, double* vel,
+                             int64_t* maxed_out, void* stream);
+int aether_sim_gravitational(const double* pos0, const double* vel0, const double* mass, int64_t n_sims, int n_balls,
+                             int total_balls, int dim, int T, int sample_freq, double interaction_strength,
+                             double dt, double softening, double* pos, double* vel, double* force, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

@@ -1,0 +1,138 @@
+"""Dataset simulators: host-side random-draw protocol + oracle vs the imported reference's outputs
+(CPU), and the HIP integration vs the same outputs (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from aether_amd.sim import ElectrostaticFieldSim, GravitationalFieldSim
+from oracle import sim_oracle as SO
+from oracle.make_golden_sim import ELECTRO_CASES, GRAV_CASES
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _electro_replay(name):
+    """The drop-in's host side replays the reference's draws; yields per simulation (charges, loc0, vel0, noise)."""
+    kw, T, sf, S, seed0 = ELECTRO_CASES[name]
+    sim = ElectrostaticFieldSim(**kw)
+    T_save = T // sf - 1
+    for i in range(S):
+        if seed0 is not None:
+            sim._field_seed = seed0 + i
+            sim.reset_field_rng()
+        yield sim, sim._draw_initial([0.5, 0.0, 0.5], None) + sim._draw_noise(T_save)
+
+
+@pytest.mark.parametrize("name", list(ELECTRO_CASES))
+def test_electrostatic_oracle_and_host_protocol(name):
+    d = np.load(os.path.join(GOLDEN, "sim_electrostatic.npz"))
+    kw, T, sf, S, _ = ELECTRO_CASES[name]
+    for i, (sim, (charges, loc0, vel0, nl, nv)) in enumerate(_electro_replay(name)):
+        assert np.array_equal(charges, d[name + ".charges"][i])                      # same draws as the reference
+        n = sim.n_balls
+        assert np.array_equal(loc0[n:], d[name + ".loc"][i, 0, n:])                  # field sources
+        loc, vel, count = SO.electrostatic_trajectory(loc0, vel0, charges[:, 0], n, T, sf, sim.interaction_strength,
+                                                      sim._delta_T, sim._max_F)
+        loc[:, :n] += nl
+        vel[:, :n] += nv
+        assert _rel(loc, d[name + ".loc"][i]) <= 1e-11 and _rel(vel, d[name + ".vel"][i]) <= 1e-11
+        assert count == int(d[name + ".maxed"][i])
+        assert np.array_equal(charges @ charges.T, d[name + ".edges"][i])
+
+
+@pytest.mark.parametrize("name", list(GRAV_CASES))
+def test_gravitational_oracle_and_host_protocol(name):
+    d = np.load(os.path.join(GOLDEN, "sim_gravitational.npz"))
+    kw, T, sf, S, seed = GRAV_CASES[name]
+    np.random.seed(seed)
+    sim = GravitationalFieldSim(**kw)
+    for i in range(S):
+        mass, pos0, vel0 = sim._draw_initial()
+        noise = sim._draw_noise(T // sf)
+        assert np.array_equal(mass, d[name + ".mass"][i])
+        pos, vel, force = SO.gravitational_trajectory(pos0, vel0, mass, sim.n_balls, T, sf, sim.interaction_strength,
+                                                      sim.dt, sim.softening)
+        for out, nz, key in ((pos, noise[0], "pos"), (vel, noise[1], "vel"), (force, noise[2], "force")):
+            out[:, :sim.n_balls] += nz
+            assert _rel(out, d[f"{name}.{key}"][i]) <= 1e-11, key
+
+
+# ----------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ELECTRO_CASES))
+def test_electrostatic_sim_matches_reference(name, capsys):
+    d = np.load(os.path.join(GOLDEN, "sim_electrostatic.npz"))
+    kw, T, sf, S, seed0 = ELECTRO_CASES[name]
+    # one batched launch, with the generator script's field-seed protocol
+    sim = ElectrostaticFieldSim(**kw)
+    seeds = None if seed0 is None else iter(range(seed0, seed0 + S))
+    loc, vel, edges, charges = sim.sample_trajectories(S, T, sf, field_seeds=seeds)
+    assert loc.dtype == np.float64 and loc.shape == d[name + ".loc"].shape
+    assert np.array_equal(charges, d[name + ".charges"]) and np.array_equal(edges, d[name + ".edges"])
+    assert _rel(loc, d[name + ".loc"]) <= 1e-9 and _rel(vel, d[name + ".vel"]) <= 1e-9
+    assert sim.last_maxed_out.tolist() == d[name + ".maxed"].tolist()
+    # the reference's own call sequence, one simulation at a time
+    sim = ElectrostaticFieldSim(**kw)
+    for i in range(S):
+        if seed0 is not None:
+            sim._field_seed = seed0 + i
+            sim.reset_field_rng()
+        l1, v1, e1, c1 = sim.sample_trajectory(T=T, sample_freq=sf)
+        assert capsys.readouterr().out.split()[-1] == str(int(d[name + ".maxed"][i]))      # prints the capped count
+        assert np.array_equal(l1, loc[i]) and np.array_equal(v1, vel[i]) and np.array_equal(c1, charges[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(GRAV_CASES))
+def test_gravitational_sim_matches_reference(name):
+    d = np.load(os.path.join(GOLDEN, "sim_gravitational.npz"))
+    kw, T, sf, S, seed = GRAV_CASES[name]
+    np.random.seed(seed)
+    sim = GravitationalFieldSim(**kw)
+    for i in range(S):                                             # sequential calls share the global generator
+        pos, vel, force, mass = sim.sample_trajectory(T=T, sample_freq=sf)
+        assert np.array_equal(mass, d[name + ".mass"][i])
+        for got, key in ((pos, "pos"), (vel, "vel"), (force, "force")):
+            assert _rel(got, d[f"{name}.{key}"][i]) <= 1e-9, key
+
+
+@pytest.mark.gpu
+def test_sim_batches_vs_oracle_and_errors():
+    """Many simulations per launch (several share a wavefront; the last wavefront is ragged), tensors left on the
+    device, 64 balls, and the argument checks."""
+    from aether_amd import _lib
+    sim = ElectrostaticFieldSim(n_balls=4, static_balls=5, dim=2, box_size=3.0)
+    sim._particle_seed = 9
+    sim.reset_particle_rng()
+    loc, vel, edges, charges = sim.sample_trajectories(37, T=120, sample_freq=10, as_tensor=True)
+    assert loc.is_cuda and loc.shape == (37, 11, 9, 2)
+    ref = ElectrostaticFieldSim(n_balls=4, static_balls=5, dim=2, box_size=3.0)
+    ref._particle_seed = 9
+    ref.reset_particle_rng()
+    for i in range(37):
+        c, l0, v0 = ref._draw_initial([0.5, 0.0, 0.5], None)
+        ref._draw_noise(11)
+        want_l, want_v, cnt = SO.electrostatic_trajectory(l0, v0, c[:, 0], 4, 120, 10)
+        assert _rel(loc[i].cpu().numpy(), want_l) <= 1e-9 and _rel(vel[i].cpu().numpy(), want_v) <= 1e-9
+        assert int(sim.last_maxed_out[i]) == cnt
+    np.random.seed(3)
+    g = GravitationalFieldSim(n_balls=40, static_balls=24, dim=3, static_mass=0.5)
+    pos, vel, force, mass = g.sample_trajectories(3, T=40, sample_freq=10)
+    np.random.seed(3)
+    g2 = GravitationalFieldSim(n_balls=40, static_balls=24, dim=3, static_mass=0.5)
+    for i in range(3):
+        m, p0, v0 = g2._draw_initial()
+        g2._draw_noise(4)
+        wp, wv, wf = SO.gravitational_trajectory(p0, v0, m, 40, 40, 10)
+        assert _rel(pos[i], wp) <= 1e-9 and _rel(vel[i], wv) <= 1e-9 and _rel(force[i], wf) <= 1e-9
+    with pytest.raises(ValueError):
+        ElectrostaticFieldSim(n_balls=60, static_balls=10)
+    with pytest.raises(AssertionError):
+        sim.sample_trajectories(1, T=105, sample_freq=10)
+    lib = _lib.load()
+    assert lib.aether_sim_electrostatic(None, None, None, 1, 1, 1, 2, 10, 10, 1.0, 0.001, 100.0, None, None, None, None) != 0
