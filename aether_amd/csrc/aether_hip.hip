@@ -806,8 +806,15 @@ int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int h
 
 namespace {
 struct S2SPriorLayout {
-    size_t ext, rel, relp, Rinv, ea, epos, hw, eaf, X0, X1, X3, Ps, Pr, T1, X4, G, Y1, Y2, bn, res1p, total;
-    int RF, RFp, EA, EP;
+    size_t ext, rel, relp, Rinv, ea, epos, hw, eaf, X0, X1, X3, Ps, Pr, T1, X4, G, Y1, Y2, bn, res1p, fpart, total;
+    int RF, RFp, EA, EP, splits;
+    // k-splits of the filter GEMM: with few edges its (E / 128) x (h / 128) workgroups do not fill 256 CUs
+    static int filter_splits(int h, int64_t E) {
+        const int64_t base = ((E + 127) / 128) * (h / 128);
+        int s = 1;
+        while (s < 16 && base * s < 768 && (h / 16) % (2 * s) == 0) s *= 2;
+        return s;
+    }
     S2SPriorLayout(int D, int h, int R, int ph, int64_t Nn, int64_t E) {
         const int O = D * (D - 1) / 2, NF = 4 * D + O;
         RF = 3 * D + NF; EA = NF + RF; EP = D + O;
@@ -821,6 +828,8 @@ struct S2SPriorLayout {
         T1 = take(ee * hh); X4 = take(ee * hh); G = take(ee * 4 * (size_t)R);
         Y1 = take(ee * (size_t)(ph > 0 ? ph : 1)); Y2 = take(ee * (size_t)(ph > 0 ? ph : 1));
         bn = take(4 * hh); res1p = take(hh * RFp);
+        splits = filter_splits(h, E);
+        fpart = take(splits > 1 ? ee * hh * splits : 0);
         total = off;
     }
 };
@@ -862,9 +871,16 @@ int aether_s2s_prior_step(const AetherS2SPriorParams* p, int num_dims, int hidde
     k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0, p->filt_b0, wp(L.epos), L.EP, wp(L.hw), h, E);
     {
         constexpr int NB = 4;
-        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128));
-        if (D == 2) k_s2s_filter<24, NB><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
-        else k_s2s_filter<39, NB><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), wp(L.eaf), h, E);
+        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128), (unsigned)L.splits);
+        float* dst = L.splits > 1 ? wp(L.fpart) : wp(L.eaf);
+        if (L.splits > 1) {
+            if (D == 2) k_s2s_filter<24, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
+            else k_s2s_filter<39, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
+        } else {
+            if (D == 2) k_s2s_filter<24, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
+            else k_s2s_filter<39, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
+        }
+        if (L.splits > 1) k_s2s_sum_planes<<<blocks(E * h / 4), dim3(256), 0, st>>>(dst, L.splits, E * (int64_t)h, wp(L.eaf));
     }
     // ---- x = edge2node(edge_attr) + res1(rel_feat) (:393-395): sum over in-edges / (num_vars - 1)
     k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.eaf), order, rowptr, wp(L.X0), h, (float)(num_vars - 1));

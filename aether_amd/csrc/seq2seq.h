@@ -461,9 +461,12 @@ k_s2s_pos_hidden(const float* __restrict__ W1, const float* __restrict__ b1, con
 //   out[e][c] = sum_r ea[e][r] * (b2[r h + c] + sum_k L2[r h + c][k] hw[e][k]),   r < R (24 | 39), c, k < h.
 // The [E, R h] filter bank of the reference is never materialised: the contraction runs as one GEMM over
 // K' = R h with the B operand formed on the fly, x[(r, k)] = ea[e][r] * hw[e][k] (one hw fragment per
-// k-group, scaled by the edge's R feature values).  grid = (ceil(E / (32 NB)), h / 128), 4 waves =
+// k-group, scaled by the edge's R feature values).  grid = (ceil(E / (32 NB)), h / 128, splits), 4 waves =
 // 2 (c) x 2 (e); a wave owns 64 outputs x 16 NB edges (every L2 fragment feeds 4 NB MFMAs).
-template <int R, int NB>
+// With few edges (the reference's 5-object graphs: 2,560 edges = 80 workgroups on 256 CUs) the k-groups are
+// split over gridDim.z; split z writes its partial sums to plane z of `out` (bias in plane 0) and
+// k_s2s_sum_planes adds the planes in order.
+template <int R, int NB, bool SPLIT>
 __global__ void __launch_bounds__(256)
 k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const float* __restrict__ ea,
              const float* __restrict__ hw, float* __restrict__ out, int h, int64_t n_edges) {
@@ -472,16 +475,28 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
     const int i = lane & 15, q = lane >> 4;
     const int m0 = (int)blockIdx.y * 128 + 64 * (wave >> 1);
     const int64_t n0 = (int64_t)blockIdx.x * (32 * NB) + 16 * NB * (wave & 1);
+    // the edges' R feature values, staged once: evs[r][half][i][nb] (a lane's NB values are one 16-byte read;
+    // indexing a per-thread array with the runtime r put it in scratch memory)
+    __shared__ float evs[R * 32 * NB];
+    for (int idx = threadIdx.x; idx < R * 32 * NB; idx += 256) {
+        const int r = idx / (32 * NB), rem = idx - r * (32 * NB);
+        const int half = rem / (16 * NB), ii = (rem - half * 16 * NB) / NB, nb = rem % NB;
+        int64_t n = (int64_t)blockIdx.x * (32 * NB) + 16 * NB * half + 16 * nb + ii;
+        n = n < n_edges ? n : n_edges - 1;
+        evs[idx] = ea[(size_t)n * R + r];
+    }
+    __syncthreads();
     if (n0 >= n_edges) return;
-    float ev[NB][R];
+    const int splits = SPLIT ? (int)gridDim.z : 1, z = SPLIT ? (int)blockIdx.z : 0;
+    if (SPLIT) out += (size_t)z * n_edges * h;
+    static_assert(NB == 4, "one 16-byte LDS read per step holds the NB feature values of a lane");
+    const float* evl = evs + 16 * NB * (wave & 1) + NB * i;
     const float* hrow[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         int64_t n = n0 + 16 * nb + i;
         n = n < n_edges ? n : n_edges - 1;
         hrow[nb] = hw + (size_t)n * h + 4 * q;
-#pragma unroll
-        for (int r = 0; r < R; ++r) ev[nb][r] = ea[(size_t)n * R + r];
     }
     // bias term: sum_r ea[e][r] * b2[r h + m]
     f32x4 acc[MT][NB];
@@ -489,19 +504,22 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
     for (int mb = 0; mb < MT; ++mb) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < R; ++r) {
+#pragma nounroll
+        for (int r = 0; r < (SPLIT && z != 0 ? 0 : R); ++r) {
             const f32x4 bv = ld4(b2 + (size_t)r * h + m0 + 16 * mb + 4 * q);
+            const f32x4 e4 = *reinterpret_cast<const f32x4*>(evl + r * (32 * NB));
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += bv * ev[nb][r];
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += bv * e4[nb];
         }
     }
     const float* wbase = L2w + (size_t)(m0 + i) * h + 4 * q;          // row (r h + m0 + 16 mb + i), k-group a
     const int steps = h >> 4;
+    const int first = SPLIT ? (steps / splits) * z * R : 0;           // this split's k-groups: steps / splits of them
     // flat step s = a * R + r; the fragments of the next PF steps are in flight (L2 latency ~ 3 steps of
     // MFMAs: 14.0 -> 7.7 ms per prior step at 48,640 edges).  The loop stays rolled: fully unrolling r made
     // the compiler hoist every load (290 - 506 VGPRs, one wave per SIMD, 11.6 ms).
     constexpr int PF = 3;
-    const int total = steps * R;
+    const int total = SPLIT ? first + (steps / splits) * R : steps * R;
     f32x4 ring[PF][MT];
     auto wfetch = [&](f32x4 (&dst)[MT], int sidx) {
         const int a = sidx / R, r = sidx - a * R;
@@ -509,11 +527,11 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
         for (int mb = 0; mb < MT; ++mb) dst[mb] = ld4(wbase + ((size_t)r * h + 16 * mb) * h + 16 * a);
     };
 #pragma unroll
-    for (int p = 0; p < PF; ++p) wfetch(ring[p], p < total ? p : total - 1);
+    for (int p = 0; p < PF; ++p) wfetch(ring[p], first + p < total ? first + p : total - 1);
     f32x4 hf[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) hf[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < total; s0 += PF) {
+    for (int s0 = first; s0 < total; s0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int sidx = s0 + p;
@@ -527,8 +545,9 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
 #pragma unroll
                 for (int mb = 0; mb < MT; ++mb) wv[mb] = ring[p][mb];
                 wfetch(ring[p], sidx + PF < total ? sidx + PF : total - 1);
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(evl + r * (32 * NB));
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) xf[nb] = hf[nb] * ev[nb][r];
+                for (int nb = 0; nb < NB; ++nb) xf[nb] = hf[nb] * e4[nb];
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -545,6 +564,16 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
 #pragma unroll
         for (int mb = 0; mb < MT; ++mb) st4(out + (size_t)n * h + m0 + 16 * mb + 4 * q, acc[mb][nb]);
     }
+}
+
+// out[i] = planes[0][i] + planes[1][i] + ... (fixed order); count % 4 == 0
+__global__ void __launch_bounds__(256)
+k_s2s_sum_planes(const float* __restrict__ planes, int n_planes, int64_t count, float* __restrict__ out) {
+    const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (idx >= count) return;
+    f32x4 v = ld4(planes + idx);
+    for (int z = 1; z < n_planes; ++z) v += ld4(planes + (size_t)z * count + idx);
+    st4(out + idx, v);
 }
 
 // T[e][:] = ELU(T[e][:] + Ps[send[e]][:] + Pr[recv[e]][:])   (first Linear of mlp4 on [x_send | x_recv | edge])

@@ -18,7 +18,111 @@ from .encoder import Encoder, gumbel_softmax_hard
 from .field import FieldQuery
 
 
-class Aether(nn.Module):
+def _tensors_key(module):
+    return tuple(t.data_ptr() for t in list(module.parameters()) + list(module.buffers()))
+
+
+class _StepRunner:
+    """One autoregressive step -- field query -> prior step -> hard Gumbel sample -> decoder step -- captured once in
+    a hipGraph (``torch.cuda.CUDAGraph``: every launch of the step is stream-ordered and free of host
+    synchronisation) and replayed per time step on static state buffers.  The reference's configurations have
+    5 objects per graph: the step is ~80 short kernels; a replay issues them with one launch.  Results are
+    bit-identical to the eager step (same kernels).  Opt-in (``graph=True``): on the MI355X box the step is bound
+    by the fixed latencies of those kernels, not by the host (1.52 ms eager vs 1.59 ms replayed at B=128, N=5,
+    tools/s2s_dynfield_time.py), so it only pays where the host is slower than the GPU.
+    """
+
+    def __init__(self, model, field_fn, B, N, device):
+        D, E, K = model.num_dims, N * (N - 1), model.num_edge_types
+        R, h = model.encoder.rnn_hidden_size, model.decoder.msg_out_shape
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
+        self.x, self.dh, self.ph, self.pc = z(B, N, 2 * D), z(B, N, h), z(B, E, R), z(B, E, R)
+        self.u = torch.full((B, E, K), 0.5, dtype=torch.float32, device=device)
+        self.model, self.field_fn = model, field_fn
+        self.edges = None
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):                              # warm-up: lazy initialisation, workspaces, caches
+            self._step()
+            self._step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        self.field_fn = None                                       # only needed for the capture
+        self.keep = model._graph_keepalive()                       # buffers whose addresses the graph holds
+
+    def _step(self):
+        m = self.model
+        field = self.field_fn(self.x)
+        logits, (h1, c1) = m.encoder.single_step_forward(self.x, (self.ph, self.pc), field)
+        edges = gumbel_softmax_hard(logits, self.u, m.gumbel_temp)
+        pred, dh = m.decoder(self.x, self.dh, edges, field)
+        self.x.copy_(pred); self.dh.copy_(dh); self.ph.copy_(h1); self.pc.copy_(c1)
+        self.edges = edges
+
+    def load(self, x=None, decoder_hidden=None, prior_hidden=None):
+        if x is not None:
+            self.x.copy_(x)
+        if decoder_hidden is not None:
+            self.dh.copy_(decoder_hidden)
+        if prior_hidden is not None:
+            self.ph.copy_(prior_hidden[0]); self.pc.copy_(prior_hidden[1])
+
+    def step(self, uniform):
+        self.u.copy_(uniform)
+        self.graph.replay()
+
+
+class _StepLoop:
+    """Mixin of the two seq2seq models: the burn-in / prediction loops on a cached ``_StepRunner``."""
+
+    def _graph_keepalive(self):
+        """Workspaces and index tensors the captured launches point at (a module may later replace its cached
+        workspace by a larger one; the graph must keep the one it was captured with alive)."""
+        keep = [list(m._cache.values()) for m in (self.encoder, self.decoder)]
+        fq = getattr(self, "_fq", None)
+        if fq is not None:
+            keep.append(fq[0]._ws)
+        return keep
+
+    def _runner(self, field_fn, B, N, device, extra_key=()):
+        key = (B, N, str(device), _tensors_key(self)) + tuple(extra_key)
+        hit = self.__dict__.setdefault("_runners", {})
+        if key not in hit:
+            hit.clear()                                            # parameters moved or shapes changed: drop old graphs
+            hit[key] = _StepRunner(self, field_fn, B, N, device)
+        return hit[key]
+
+    def _graphed(self, field_fn, burn_in, x_last, decoder_hidden, prior_hidden, steps, uniform, return_edges,
+                 extra_key=()):
+        """burn_in: [B, T0, N, 2D] observations stepped through with teacher forcing (may be None), then ``steps``
+        autoregressive steps from x_last.  uniform [T0 + steps, B, E, K] or None (drawn on the device)."""
+        B, N = x_last.shape[0], x_last.shape[1]
+        dev = x_last.device
+        T0 = 0 if burn_in is None else burn_in.shape[1]
+        E, K = N * (N - 1), self.num_edge_types
+        if uniform is None:
+            uniform = torch.rand(T0 + steps, B, E, K, device=dev)
+        uniform = uniform.reshape(T0 + steps, B, E, K)
+        run = self._runner(field_fn, B, N, dev, extra_key)
+        run.load(decoder_hidden=decoder_hidden, prior_hidden=prior_hidden)
+        for t in range(T0):
+            run.load(x=burn_in[:, t])
+            run.step(uniform[t])
+        run.load(x=x_last)
+        preds = torch.empty(B, steps, N, x_last.shape[-1], dtype=torch.float32, device=dev)
+        edges = torch.empty(B, steps, E, K, dtype=torch.float32, device=dev) if return_edges else None
+        for t in range(steps):
+            run.step(uniform[T0 + t])
+            preds[:, t].copy_(run.x)
+            if return_edges:
+                edges[:, t].copy_(run.edges)
+        state = (run.dh.clone(), (run.ph.clone(), run.pc.clone()))
+        return preds, edges, state
+
+
+class Aether(_StepLoop, nn.Module):
     def __init__(self, params, device="cuda"):
         super().__init__()
         self.num_vars = params["num_vars"]
@@ -52,16 +156,22 @@ class Aether(nn.Module):
         return predictions, decoder_hidden, edges
 
     @torch.no_grad()
-    def predict_future(self, inputs, prediction_steps, return_edges=False, uniform=None):
+    def predict_future(self, inputs, prediction_steps, return_edges=False, uniform=None, graph=False):
         """aether.py:155-191.  inputs [B, T, N, 2D] (burn-in observations).  The burn-in half runs the prior
         step by step: the encoder's prior path is causal (forward LSTM from the zero state, BatchNorm in eval
         mode), so the chained ``single_step_forward`` equals ``Encoder.forward``'s prior logits and state
-        (pinned against the reference's own ``predict_future``).  ``uniform`` [T - 1 + steps, B, E, K]."""
+        (pinned against the reference's own ``predict_future``).  ``uniform`` [T - 1 + steps, B, E, K].
+        ``graph``: replay the step from a captured hipGraph (``_StepRunner``) instead of launching it kernel by kernel."""
         B, T, N, _ = inputs.shape
         E = N * (N - 1)
         decoder_hidden = self.decoder.get_initial_hidden(inputs)
         R = self.encoder.rnn_hidden_size
         prior_hidden = (torch.zeros(B, E, R, device=inputs.device), torch.zeros(B, E, R, device=inputs.device))
+        if graph:
+            preds, edges, _ = self._graphed(lambda x: self.predict_field(x)[0], inputs[:, :T - 1].float(),
+                                            inputs[:, T - 1].float(), decoder_hidden, prior_hidden,
+                                            int(prediction_steps), uniform, return_edges)
+            return (preds, edges) if return_edges else preds
         for step in range(T - 1):
             current_inputs = inputs[:, step]
             field, _ = self.predict_field(current_inputs)
@@ -69,14 +179,18 @@ class Aether(nn.Module):
             _, decoder_hidden, _ = self.single_step_forward(current_inputs, decoder_hidden, logits, True, field,
                                                             None if uniform is None else uniform[step])
         return self.predict_from_state(inputs[:, T - 1], decoder_hidden, prior_hidden, prediction_steps,
-                                       None if uniform is None else uniform[T - 1:], return_edges)
+                                       None if uniform is None else uniform[T - 1:], return_edges, graph=False)
 
     @torch.no_grad()
     def predict_from_state(self, predictions, decoder_hidden, prior_hidden, prediction_steps, uniform=None,
-                           return_edges=False):
+                           return_edges=False, graph=False):
         """The prediction loop of ``predict_future`` (aether.py:175-185), starting from the state the burn-in
         leaves behind: last observed state ``predictions`` [B, N, 2D], ``decoder_hidden`` [B, N, h],
         ``prior_hidden`` = (h, c) each [B, E, rnn].  ``uniform`` [steps, B, E, K] fixes the Gumbel draws."""
+        if graph:
+            preds, edges, _ = self._graphed(lambda x: self.predict_field(x)[0], None, predictions.float(),
+                                            decoder_hidden, prior_hidden, int(prediction_steps), uniform, return_edges)
+            return (preds, edges) if return_edges else preds
         all_predictions, all_edges = [], []
         for step in range(int(prediction_steps)):
             current_field, _ = self.predict_field(predictions)

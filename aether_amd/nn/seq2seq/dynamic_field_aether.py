@@ -21,6 +21,7 @@ import torch.nn as nn
 from ... import _lib
 from ..state2state.dynamic_field_aether import _AttentionalAggregation
 from .decoder import RecurrentDecoder
+from .aether import _StepLoop
 from .encoder import Encoder, gumbel_softmax_hard
 from .field import _CoordinateEmbedding
 
@@ -121,7 +122,7 @@ class _FilmedNetwork(nn.Module):
         self.film_2 = _FiLM(hidden_size, z_size, hidden_size)
 
 
-class DynamicFieldAether(nn.Module):
+class DynamicFieldAether(_StepLoop, nn.Module):
     def __init__(self, params, device="cuda"):
         super().__init__()
         if params.get("use_charges", False):
@@ -143,7 +144,7 @@ class DynamicFieldAether(nn.Module):
         self.graph_pooler = GraphSummary(params["input_size"], self.graph_hidden)
         self.film_net = _FilmedNetwork(hidden_size, self.graph_hidden, self.mlp_hidden, self.num_dims)
         self.field = params.get("field")                                  # data-side grid helper (:88-95), unused here
-        self._mod, self._ws = None, None
+        self._mod, self._ws, self._mod_buf = None, None, {}
         if device is not None:
             self.to(device)
 
@@ -169,7 +170,10 @@ class DynamicFieldAether(nn.Module):
             return hit[3]
         B = summary.shape[0]
         nbytes = lib.aether_s2s_film_modulation_bytes(B, self.mlp_hidden)
-        mod = torch.empty(nbytes // 4, dtype=torch.float32, device=summary.device)
+        mod = self._mod_buf.get((B, str(summary.device)))          # one buffer per batch size, rewritten in place:
+        if mod is None:                                            # a captured step graph keeps reading it
+            mod = self._mod_buf[(B, str(summary.device))] = torch.empty(nbytes // 4, dtype=torch.float32,
+                                                                        device=summary.device)
         st = lib.aether_s2s_film_modulation(C.byref(ps), self.graph_hidden, self.mlp_hidden, B, summary.data_ptr(),
                                             mod.data_ptr(), nbytes, torch.cuda.current_stream(summary.device).cuda_stream)
         _lib.check(st, "aether_s2s_film_modulation")
@@ -226,12 +230,16 @@ class DynamicFieldAether(nn.Module):
         predictions, decoder_hidden = self.decoder(inputs, decoder_hidden, edges, predicted_field)
         return predictions, decoder_hidden, edges
 
+    def _graph_keepalive(self):
+        return super()._graph_keepalive() + [self._ws, list(self._mod_buf.values())]
+
     @torch.no_grad()
     def predict_future(self, inputs, prediction_steps, return_edges=False, return_everything=False, charges=None,
-                       uniform=None):
+                       uniform=None, graph=False):
         """dynamic_field_aether.py:207-246.  inputs [B, T, N, 2D].  The summary of ``inputs[:, :-1]`` conditions every
         field query; the burn-in half runs the (causal) prior step by step, as in ``Aether.predict_future``.
-        ``uniform`` [T - 1 + steps, B, E, K] fixes the Gumbel draws."""
+        ``uniform`` [T - 1 + steps, B, E, K] fixes the Gumbel draws.  ``graph``: replay the step from a captured
+        hipGraph (not with ``return_everything``, which also collects the burn-in predictions)."""
         if charges is not None:
             raise _lib.AetherHipError("charges (use_charges) are not part of this path")
         B, T, N, _ = inputs.shape
@@ -242,6 +250,12 @@ class DynamicFieldAether(nn.Module):
         x = inputs[:, :-1].transpose(2, 1).contiguous()                    # :214
         gr_summary = self.graph_pooler(x)                                  # :218
         predicted_field, _ = self.predict_field(x, gr_summary)             # :219, [B, N, T - 1, D]
+        if graph and not return_everything:
+            mod = self._mod_buf[(B, str(inputs.device))]
+            preds, edges, _ = self._graphed(lambda xx: self.predict_field(xx, gr_summary)[0], inputs[:, :T - 1].float(),
+                                            inputs[:, T - 1].float(), decoder_hidden, prior_hidden,
+                                            int(prediction_steps), uniform, return_edges, extra_key=(mod.data_ptr(),))
+            return (preds, edges) if return_edges else preds
         all_predictions, all_edges = [], []
         for step in range(T - 1):
             current_inputs = inputs[:, step]

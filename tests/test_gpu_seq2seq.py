@@ -316,3 +316,33 @@ def test_dynamic_field_variant_errors():
         gs(torch.zeros(2, 3, 101, 6, device="cuda"))                   # longer than the positional encoding
     with pytest.raises(ValueError):
         gs(torch.zeros(2, 3, 4, 5, device="cuda"))
+
+
+# ---------------------------------------------------------------- captured step graph
+@pytest.mark.parametrize("variant", ["aether", "dynamic_field"])
+def test_step_graph_equals_eager(variant):
+    """predict_future replays the step from a captured hipGraph by default: bit-identical to launching the step
+    kernel by kernel, also on a second sequence (graph reused; the dynamic-field modulation is rewritten in place)
+    and from predict_from_state; without given noise the draws come from the device."""
+    from conftest import load_s2s_dynfield, load_s2s_future
+    d, model, params = load_s2s_future() if variant == "aether" else load_s2s_dynfield()
+    model = model.cuda()
+    x = torch.from_numpy(d["in.inputs"]).cuda()
+    B, T, N, _ = x.shape
+    steps = 6
+    g = torch.Generator().manual_seed(5)
+    U = torch.rand(T - 1 + steps, B, N * (N - 1), 2, generator=g).cuda()
+    for k, inputs in enumerate((x, x.flip(0) * 0.9 + 0.05)):
+        pg, eg = model.predict_future(inputs, steps, return_edges=True, uniform=U, graph=True)
+        pe, ee = model.predict_future(inputs, steps, return_edges=True, uniform=U, graph=False)
+        assert torch.equal(pg, pe) and torch.equal(eg, ee), k
+    assert len(model._runners) == 1
+    if variant == "aether":
+        hid = torch.randn(B, N, model.decoder.msg_out_shape, device="cuda") * 0.2
+        R = model.encoder.rnn_hidden_size
+        prior = (torch.randn(B, N * (N - 1), R, device="cuda") * 0.2, torch.randn(B, N * (N - 1), R, device="cuda") * 0.2)
+        a = model.predict_from_state(x[:, -1], hid, prior, steps, uniform=U[:steps], graph=True)
+        b = model.predict_from_state(x[:, -1], hid, prior, steps, uniform=U[:steps], graph=False)
+        assert torch.equal(a, b)
+    free = model.predict_future(x, steps)
+    assert free.shape == (B, steps, N, x.shape[-1]) and torch.isfinite(free).all()

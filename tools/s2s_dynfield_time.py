@@ -53,5 +53,7 @@ dt = timed(fresh_mod, 30)
 print("FiLM modulation + one-step query (cache miss)          : %.3f ms" % (dt * 1e3))
 U = torch.rand(T + 20, B, N * (N - 1), 2, device="cuda")
 inputs = torch.randn(B, T + 1, N, 2 * D, device="cuda")
-dt = timed(lambda: model.predict_future(inputs, 20, uniform=U), 2)
-print("predict_future  %d burn-in + 20 prediction steps        : %.1f ms  (%.2f ms per step)" % (T, dt * 1e3, dt * 1e3 / (T + 20)))
+for name, graph in (("step by step", False), ("captured step graph", True)):
+    dt = timed(lambda: model.predict_future(inputs, 20, uniform=U, graph=graph), 3)
+    print("predict_future  %d burn-in + 20 prediction steps, %-20s: %.1f ms  (%.2f ms per step)" %
+          (T, name, dt * 1e3, dt * 1e3 / (T + 20)))

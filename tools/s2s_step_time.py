@@ -7,18 +7,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aether_amd.nn.seq2seq.decoder import RecurrentDecoder
 from aether_amd.nn.seq2seq.encoder import Encoder, gumbel_softmax_hard
 from aether_amd.nn.seq2seq.field import FieldQuery
-D, N, B, H, R = 2, 20, 128, 512, 128
-dparams = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": H, "num_edge_types": 2,
-           "skip_first": False, "decoder_dropout": 0.0, "use_3d": False}
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--dims", type=int, default=2)
+ap.add_argument("--nodes", type=int, default=20)
+ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--decoder-hidden", type=int, default=512)
+a = ap.parse_args()
+D, N, B, H, R = a.dims, a.nodes, a.batch, 512, 128
+dparams = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": a.decoder_hidden, "num_edge_types": 2,
+           "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3}
 eparams = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H, "encoder_rnn_hidden": R,
            "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 256,
-           "prior_num_layers": 3, "prior_hidden_size": 256, "use_3d": False, "pos_representation": "polar"}
+           "prior_num_layers": 3, "prior_hidden_size": 256, "use_3d": D == 3,
+           "pos_representation": "polar" if D == 2 else "cart"}
 dec = RecurrentDecoder(dparams, device="cuda")
 enc = Encoder(eparams, device="cuda").eval()
 fq = FieldQuery(D, H, device="cuda")
 E = N * (N - 1)
 x = torch.randn(B, N, 2 * D, device="cuda")
-hid = torch.zeros(B, N, H, device="cuda")
+hid = torch.zeros(B, N, a.decoder_hidden, device="cuda")
 ps = (torch.zeros(B, E, R, device="cuda"), torch.zeros(B, E, R, device="cuda"))
 U = torch.rand(B, E, 2, device="cuda")
 def timed(fn, reps=10):
