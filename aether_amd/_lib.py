@@ -109,6 +109,11 @@ SIGNATURES = {
                                  [C.c_double] * 3 + [C.c_void_p] * 4),
     "aether_sim_gravitational": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 5 +
                                  [C.c_double] * 3 + [C.c_void_p] * 4),
+    "aether_backward_field": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 6 +
+                              [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aether_dynamic_field_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
+    "aether_dynamic_field_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 5 +
+                                      [C.c_size_t, C.c_void_p]),
     "aether_s2s_gumbel_hard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "aether_dynamic_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

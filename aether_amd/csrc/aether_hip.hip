@@ -456,7 +456,7 @@ int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st) 
 template <int D>
 int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int64_t E, const float* x,
                   const float* vel, const float* charges, const char* graph, char* ws, const float* g_out,
-                  hipStream_t st) {
+                  hipStream_t st, float* grad_field = nullptr) {
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
     constexpr int FIN = 2 * D + 16;
     GraphLayout G(E, Nn, false);
@@ -579,15 +579,23 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         } else {
             // ---- res + field net
             { ProfScope ps(KB_FIELD, st);
-            kb_field<D><<<dim3((unsigned)((Nn + 7) / 8)), dim3(256), 0, st>>>(
-                P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
-                wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
-                wp(W.ONEHOT), Nn); }
+            if (grad_field != nullptr)
+                kb_field<D, true><<<dim3((unsigned)((Nn + 7) / 8)), dim3(256), 0, st>>>(
+                    P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
+                    wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
+                    wp(W.ONEHOT), grad_field, Nn);
+            else
+                kb_field<D, false><<<dim3((unsigned)((Nn + 7) / 8)), dim3(256), 0, st>>>(
+                    P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
+                    wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
+                    wp(W.ONEHOT), nullptr, Nn); }
             L.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
-            L.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
-            L.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
-            L.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
-            L.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
+            if (grad_field == nullptr) {
+                L.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
+                L.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
+                L.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
+                L.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
+            }
         }
     }
     if (run_outer(L, partial, W.partial_cap, st)) return AETHER_EHIP;
@@ -1423,8 +1431,6 @@ int aether_forward_field(const AetherParams* params, int num_dims, int64_t n_nod
                          const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
                          void* workspace, size_t workspace_bytes, float* out, int flags, void* stream) {
     if (!field) return fail(AETHER_EINVAL, "forward_field: null field");
-    if (flags & AETHER_FLAG_KEEP_INTERMEDIATES)
-        return fail(AETHER_EINVAL, "forward_field: inference only (aether_backward differentiates the built-in field net)");
     return forward_common(params, num_dims, n_nodes, n_edges, x, vel, charges, edge_attr_orig, graph, info, workspace,
                           workspace_bytes, out, flags, stream, field);
 }
@@ -1503,6 +1509,61 @@ int aether_backward(const AetherParams* params, const AetherParams* grads, int n
                                 (char*)workspace, grad_out, st);
     return backward_impl<3>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
                             (char*)workspace, grad_out, st);
+}
+
+int aether_backward_field(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,
+                          int64_t n_edges, const float* x, const float* vel, const float* charges,
+                          const void* graph, const AetherGraphInfo* info, void* workspace, size_t workspace_bytes,
+                          const float* grad_out, float* grad_field, void* stream) {
+    if (!params || !grads || !x || !vel || !charges || !graph || !info || !workspace || !grad_out || !grad_field)
+        return fail(AETHER_EINVAL, "backward_field: null pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "backward_field: num_dims must be 2 or 3");
+    if (n_nodes <= 0 || n_edges < 0 || info->n_nodes != n_nodes || info->n_edges != n_edges)
+        return fail(AETHER_EINVAL, "backward_field: bad sizes");
+    if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 1))
+        return fail(AETHER_ESPACE, "backward_field: workspace too small (forward must run with KEEP_INTERMEDIATES)");
+    hipStream_t st = (hipStream_t)stream;
+    if (num_dims == 2)
+        return backward_impl<2>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
+                                (char*)workspace, grad_out, st, grad_field);
+    return backward_impl<3>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
+                            (char*)workspace, grad_out, st, grad_field);
+}
+
+size_t aether_dynamic_field_backward_workspace_bytes(int num_dims, int64_t n_graphs) {
+    if ((num_dims != 2 && num_dims != 3) || n_graphs <= 0) return 0;
+    const size_t total = num_dims == 2 ? DynOff<2>::total : DynOff<3>::total;
+    return (size_t)n_graphs * total * sizeof(float) + 256;
+}
+
+int aether_dynamic_field_backward(const AetherDynFieldParams* p, const AetherDynFieldParams* grads, int num_dims,
+                                  int64_t n_graphs, int nodes_per_graph, const float* x, const float* vel,
+                                  const float* charges, const float* grad_field, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!p || !grads || !x || !vel || !charges || !grad_field || !workspace)
+        return fail(AETHER_EINVAL, "dynamic_field_backward: null pointer");
+    {
+        const float* const* gp = reinterpret_cast<const float* const*>(grads);
+        for (size_t k = 0; k < sizeof(AetherDynFieldParams) / sizeof(const float*); ++k)
+            if (!gp[k]) return fail(AETHER_EINVAL, "dynamic_field_backward: null gradient pointer");
+    }
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "dynamic_field_backward: num_dims must be 2 or 3");
+    if (n_graphs <= 0 || nodes_per_graph <= 0 || nodes_per_graph > DYNFIELD_MAX_NODES)
+        return fail(AETHER_EINVAL, "dynamic_field_backward: 1..2048 nodes per graph");
+    if (n_graphs >= ((int64_t)1 << 31)) return fail(AETHER_EINVAL, "dynamic_field_backward: too many graphs");
+    if (workspace_bytes < aether_dynamic_field_backward_workspace_bytes(num_dims, n_graphs))
+        return fail(AETHER_ESPACE, "dynamic_field_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
+    if (num_dims == 2) {
+        kb_dynfield<2><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph);
+        k_dynfield_reduce<2><<<dim3((DynOff<2>::total + 255) / 256), dim3(256), 0, st>>>(partial, n_graphs, *grads);
+    } else {
+        kb_dynfield<3><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph);
+        k_dynfield_reduce<3><<<dim3((DynOff<3>::total + 255) / 256), dim3(256), 0, st>>>(partial, n_graphs, *grads);
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
 }
 
 int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int64_t n_edges,

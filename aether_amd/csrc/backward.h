@@ -654,7 +654,8 @@ __device__ __forceinline__ float sum32(float v) {       // all-reduce over the 3
     return v;
 }
 
-template <int D>
+// EXT: the field was supplied from outside (aether_forward_field): only dL/df is produced (grad_field [n][D]).
+template <int D, bool EXT>
 __global__ void __launch_bounds__(256)
 kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
          const float* __restrict__ charges, const float* __restrict__ nodeinfo,
@@ -663,7 +664,8 @@ kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ 
          const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm,
          float* __restrict__ RELF, float* __restrict__ Z, float* __restrict__ H1f,
          float* __restrict__ H2f, float* __restrict__ DPH1, float* __restrict__ DPH2,
-         float* __restrict__ DF, float* __restrict__ DZE, float* __restrict__ ONEHOT, int64_t n_nodes) {
+         float* __restrict__ DF, float* __restrict__ DZE, float* __restrict__ ONEHOT, float* __restrict__ grad_field,
+         int64_t n_nodes) {
     using NI = NodeInfo<D>;
     constexpr int FIN = 2 * D + 16;
     constexpr int O = D * (D - 1) / 2;
@@ -710,6 +712,17 @@ kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * dcf[b];
         df[a] = s;
+    }
+    if (EXT) {
+        if (ok && t < 16) {
+            float rv = 0.f;                                       // rel_feat row for dW_res
+            if (t >= D && t < 2 * D) rv = ni[NI::CV + t - D];
+            if (t >= 2 * D && t < 3 * D) rv = ni[NI::CF + t - 2 * D];
+            RELF[n * 16 + t] = rv;
+#pragma unroll
+            for (int d = 0; d < D; ++d) if (t == d) grad_field[n * D + d] = df[d];
+        }
+        return;
     }
     // ---- recompute the field MLP: thread t owns hidden unit t
     long ci = (long)(charges[nc] + 1.0f);

@@ -4,7 +4,9 @@
 Same constructor, ``forward(h, x, edges, vel, edge_attr_orig, charges, num_nodes)`` and ``state_dict`` keys
 (dynamic_field_aether.py:51-100).  The field comes from ``aether_dynamic_field`` (attention-pooled graph
 summary + FiLM field net, :11-48), everything after it from the same kernels as ``Aether``
-(``aether_forward_field``).  Inference only; no CPU fallback.
+(``aether_forward_field``).  With gradients enabled the step goes through ``_DynStep``: ``aether_backward_field``
+(GNN gradients + dL/dfield) and ``aether_dynamic_field_backward`` (FiLM field net, modulators, attention pooling),
+so the training loop of experiments/lorentz/main.py:200-260 works unchanged.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -68,6 +70,50 @@ class _DynFieldParams(C.Structure):
         "film2_w0", "film2_b0", "film2_w2", "film2_b2", "film2_w4", "film2_b4", "emb")]
 
 
+class _DynStep(torch.autograd.Function):
+    """aether_dynamic_field + aether_forward_field / their backward halves behind torch.autograd (parameters only
+    get gradients: the runner detaches positions and edge attributes, experiments/lorentz/main.py:243-247)."""
+
+    N_FIXED = 8
+
+    @staticmethod
+    def forward(ctx, module, x, vel, ea, charges, graph, n_edges, num_nodes, *params):
+        out, field, ws = module._launch(x, vel, ea, charges, graph, n_edges, num_nodes, train=True)
+        ctx.module, ctx.saved = module, (x, vel, charges, graph, ws, n_edges, num_nodes)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        module = ctx.module
+        x, vel, charges, (graph, ginfo), ws, n_edges, num_nodes = ctx.saved
+        D, n_nodes = module.num_dims, x.shape[0]
+        ps, fps = module._structs(x.device)
+        names = [n for n, _ in module.named_parameters()]
+        grads = {n: torch.zeros_like(p) for n, p in module.named_parameters()}
+        gtensors = dict(grads)
+        gtensors.update(module._dummy)                               # field_net.net.* slots: not written in this mode
+        gs = _lib.params_struct(gtensors)
+        gfs = module._dyn_struct(grads)
+        g = grad_out.to(torch.float32).contiguous()
+        grad_field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.aether_backward_field(C.byref(ps), C.byref(gs), D, n_nodes, n_edges, x.data_ptr(), vel.data_ptr(),
+                                             charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                             ws.numel(), g.data_ptr(), grad_field.data_ptr(), stream),
+                   "aether_backward_field")
+        n_graphs = n_nodes // num_nodes
+        need = lib.aether_dynamic_field_backward_workspace_bytes(D, n_graphs)
+        dws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.aether_dynamic_field_backward(C.byref(fps), C.byref(gfs), D, n_graphs, num_nodes, x.data_ptr(),
+                                                     vel.data_ptr(), charges.data_ptr(), grad_field.data_ptr(),
+                                                     dws.data_ptr(), dws.numel(), stream),
+                   "aether_dynamic_field_backward")
+        module.last_grad_field = grad_field
+        need_g = ctx.needs_input_grad[_DynStep.N_FIXED:]
+        return (None,) * _DynStep.N_FIXED + tuple(grads[n] if k else None for n, k in zip(names, need_g))
+
+
 class DynamicFieldAether(nn.Module):
     """Drop-in for nn/state2state/dynamic_field_aether.py:51-100."""
 
@@ -128,26 +174,60 @@ class DynamicFieldAether(nn.Module):
         tensors = {k: v for k, v in sd.items()}
         tensors.update(self._dummy)
         ps = _lib.params_struct(tensors)
-        f = "field_net."
-        w = f + "wrapper."
-        names = [f + "summary_net.summary_net.gate_nn.0", f + "summary_net.summary_net.gate_nn.2",
-                 f + "summary_net.summary_net.nn.0", f + "summary_net.summary_net.nn.2",
-                 w + "linear_1", w + "linear_2", w + "linear_3",
-                 w + "film_1.modulator.0", w + "film_1.modulator.2", w + "film_1.modulator.4",
-                 w + "film_2.modulator.0", w + "film_2.modulator.2", w + "film_2.modulator.4"]
-        ptrs = []
-        for n in names:
-            ptrs += [sd[n + ".weight"].data_ptr(), sd[n + ".bias"].data_ptr()]
-        ptrs.append(sd[f + "class_embedding.weight"].data_ptr())
-        return ps, _DynFieldParams(*ptrs)
+        return ps, self._dyn_struct(sd)
 
-    @torch.no_grad()
+    _DYN_NAMES = ["summary_net.summary_net.gate_nn.0", "summary_net.summary_net.gate_nn.2", "summary_net.summary_net.nn.0",
+                  "summary_net.summary_net.nn.2", "wrapper.linear_1", "wrapper.linear_2", "wrapper.linear_3",
+                  "wrapper.film_1.modulator.0", "wrapper.film_1.modulator.2", "wrapper.film_1.modulator.4",
+                  "wrapper.film_2.modulator.0", "wrapper.film_2.modulator.2", "wrapper.film_2.modulator.4"]
+
+    def _dyn_struct(self, tensors):
+        """AetherDynFieldParams from {parameter name: tensor} (the parameters themselves or their gradients)."""
+        ptrs = []
+        for n in self._DYN_NAMES:
+            ptrs += [tensors["field_net." + n + ".weight"].data_ptr(), tensors["field_net." + n + ".bias"].data_ptr()]
+        ptrs.append(tensors["field_net.class_embedding.weight"].data_ptr())
+        return _DynFieldParams(*ptrs)
+
+    def _launch(self, x, vel, ea, charges, graph, n_edges, num_nodes, train):
+        lib = _lib.load()
+        graph, ginfo = graph
+        n_nodes, D, E = x.shape[0], self.num_dims, n_edges
+        ps, fps = self._structs(x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
+        _lib.check(lib.aether_dynamic_field(C.byref(fps), D, n_nodes // int(num_nodes), int(num_nodes), x.data_ptr(),
+                                            vel.data_ptr(), charges.data_ptr(), field.data_ptr(), stream),
+                   "aether_dynamic_field")
+        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 1 if train else 0)
+        flags = self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES
+        ws_key = None
+        if train:                           # the backward reads this forward's intermediates: one workspace per call
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            flags |= _lib.FLAG_KEEP_INTERMEDIATES
+        else:
+            if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
+                self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            ws = self._ws
+            fused = ginfo.n_groups > 0 and E > 0 and not (flags & _lib.FLAG_FORCE_STREAMED)
+            ws_key = (ws.data_ptr(), n_nodes, E, D, graph.data_ptr()) if fused else None
+            if ws_key is not None and self._ws_key == ws_key:
+                flags |= _lib.FLAG_WORKSPACE_REUSED
+        self._ws_key = None
+        out = torch.empty_like(x)
+        _lib.check(lib.aether_forward_field(C.byref(ps), D, n_nodes, E, x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
+                                            field.data_ptr(), ea.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                            ws.data_ptr(), ws.numel(), out.data_ptr(), flags, stream),
+                   "aether_forward_field")
+        self._ws_key = ws_key
+        self.last_field = field
+        return out, field, ws
+
     def forward(self, h, x, edges, vel, edge_attr_orig, charges, num_nodes):
         """``h`` is ignored, as in the reference (dynamic_field_aether.py:79-100)."""
         if not x.is_cuda:
             raise _lib.AetherHipError("aether_amd.DynamicFieldAether runs on an MI355X only; got a CPU tensor "
                                       "(there is no CPU fallback)")
-        lib = _lib.load()
         send, recv = edges
         if send.dtype != torch.int64 or recv.dtype != torch.int64:
             raise TypeError("edges must be int64 (torch.LongTensor), as in the reference")
@@ -159,27 +239,8 @@ class DynamicFieldAether(nn.Module):
             raise ValueError("edge index / edge_attr / charges shapes do not match")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         x, vel, ea, charges = f32(x), f32(vel), f32(edge_attr_orig), f32(charges)
-        graph, ginfo = self._graphs.get(send.contiguous(), recv.contiguous(), n_nodes)
-        ps, fps = self._structs(x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
-        _lib.check(lib.aether_dynamic_field(C.byref(fps), D, n_nodes // int(num_nodes), int(num_nodes), x.data_ptr(),
-                                            vel.data_ptr(), charges.data_ptr(), field.data_ptr(), stream),
-                   "aether_dynamic_field")
-        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 0)
-        if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
-            self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-        flags = self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES
-        fused = ginfo.n_groups > 0 and E > 0 and not (flags & _lib.FLAG_FORCE_STREAMED)
-        ws_key = (self._ws.data_ptr(), n_nodes, E, D, graph.data_ptr()) if fused else None
-        if ws_key is not None and self._ws_key == ws_key:
-            flags |= _lib.FLAG_WORKSPACE_REUSED
-        self._ws_key = None
-        out = torch.empty_like(x)
-        _lib.check(lib.aether_forward_field(C.byref(ps), D, n_nodes, E, x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
-                                            field.data_ptr(), ea.data_ptr(), graph.data_ptr(), C.byref(ginfo),
-                                            self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), flags, stream),
-                   "aether_forward_field")
-        self._ws_key = ws_key
-        self.last_field = field
-        return out
+        graph = self._graphs.get(send.contiguous(), recv.contiguous(), n_nodes)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _DynStep.apply(self, x, vel, ea, charges, graph, E, int(num_nodes), *self.parameters())
+        with torch.no_grad():
+            return self._launch(x, vel, ea, charges, graph, E, int(num_nodes), train=False)[0]

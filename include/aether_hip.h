@@ -175,7 +175,7 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
  * (nn/state2state/dynamic_field_aether.py:79-100) = aether_dynamic_field (LatentFieldNetwork, :31-48:
  * attention-pooled graph summary + FiLM field net, hidden 32) followed by aether_forward_field, i.e.
  * aether_forward with the per-node field supplied instead of the built-in field net (params->field_* are
- * not read for the result but must point to readable memory of the documented sizes).  Inference only.
+ * not read for the result but must point to readable memory of the documented sizes).
  *   graphs are consecutive blocks of nodes_per_graph nodes (x.reshape(-1, num_nodes, .), :38);
  *   field : float[n_nodes][D]
  */
@@ -196,6 +196,24 @@ int aether_forward_field(const AetherParams* params, int num_dims, int64_t n_nod
                          const float* x, const float* vel, const float* charges, const float* field,
                          const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
                          void* workspace, size_t workspace_bytes, float* out, int flags, void* stream);
+/*
+ * Training of the dynamic-field variant.  aether_backward_field = aether_backward for a step that ran through
+ * aether_forward_field with AETHER_FLAG_KEEP_INTERMEDIATES: gradients of the GNN / res / out-MLP tensors into
+ * `grads` (grads->field_* are not written) and dL/dfield into grad_field [n_nodes][D].
+ * aether_dynamic_field_backward then differentiates LatentFieldNetwork (dynamic_field_aether.py:31-48: FiLM field
+ * net, FiLM modulators, attention pooling): `grads` holds one output pointer per tensor of `params`;
+ * workspace: aether_dynamic_field_backward_workspace_bytes(num_dims, n_graphs) bytes (one partial gradient row per
+ * graph, added over the graphs in order: no atomics).  Positions / velocities are data: no gradient w.r.t. them.
+ */
+int aether_backward_field(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,
+                          int64_t n_edges, const float* x, const float* vel, const float* charges,
+                          const void* graph, const AetherGraphInfo* info, void* workspace, size_t workspace_bytes,
+                          const float* grad_out, float* grad_field, void* stream);
+size_t aether_dynamic_field_backward_workspace_bytes(int num_dims, int64_t n_graphs);
+int aether_dynamic_field_backward(const AetherDynFieldParams* params, const AetherDynFieldParams* grads, int num_dims,
+                                  int64_t n_graphs, int nodes_per_graph, const float* x, const float* vel,
+                                  const float* charges, const float* grad_field, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /*
  * seq2seq Aether, field query: replaces Aether.predict_field

@@ -102,6 +102,37 @@ def test_variable_n_knn_scenes(D):
     assert info.n_groups == 0 or info.max_group_nodes <= 32
 
 
+def test_cfg4_device_built_knn_graph():
+    """cfg4 end to end on the device: 64 padded scenes with presence masks -> aether_knn_edges (compacted
+    numbering) -> Aether.forward on the compacted agents, vs the oracle on the oracle's own kNN graph."""
+    from aether_amd.knn import knn_edges
+    from oracle import knn_oracle as K
+    D, S, N = 2, 64, 40
+    sd = load_state_dict(D)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(S, N, D, generator=g) * 3.0
+    v = torch.randn(S, N, D, generator=g)
+    v = 0.5 * v / v.norm(dim=-1, keepdim=True)
+    q = torch.randint(0, 2, (S, N, 1), generator=g).float() * 2 - 1
+    masks = (torch.rand(S, N, generator=g) < 0.6).float()
+    keep = masks.bool().reshape(-1)
+    xc, vc, qc = x.reshape(-1, D)[keep], v.reshape(-1, D)[keep], q.reshape(-1, 1)[keep]      # compacted agents
+    ws, wr, _ = K.knn_edges(x.numpy(), masks.numpy(), 10)
+    # the reference lists (query, neighbour); messages flow neighbour -> query
+    o_edges = [torch.from_numpy(wr), torch.from_numpy(ws)]
+    want = O.aether_forward(sd, xc, vc, o_edges, prepare_edge_attr(xc, o_edges, qc[o_edges[0]] * qc[o_edges[1]]), qc)
+    dev = "cuda"
+    send, recv, num = knn_edges(x.to(dev), masks.to(dev), k=10)
+    assert torch.equal(send.cpu(), torch.from_numpy(ws)) and torch.equal(recv.cpu(), torch.from_numpy(wr))
+    edges = [recv, send]
+    xd, vd, qd = xc.to(dev), vc.to(dev), qc.to(dev)
+    ea = prepare_edge_attr(xd, edges, qd[edges[0]] * qd[edges[1]])
+    m = _model(D)
+    with torch.no_grad():
+        out = m(vd.norm(dim=-1, keepdim=True), xd, edges, vd, ea, qd)
+    assert int(num) == send.numel() and scale_rel_err(out.cpu(), want) <= TOL
+
+
 def test_large_dense_graph_cfg5_shape():
     """One fully connected graph, N=512 (261,632 edges): cfg5's shape at a size the oracle finishes."""
     D = 2

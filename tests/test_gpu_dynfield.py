@@ -35,7 +35,8 @@ def test_dynamic_field_matches_reference(D, flags):
         B, N = int(d[f"{name}.B"]), int(d[f"{name}.N"])
         t = lambda k: torch.from_numpy(d[f"{name}.in.{k}"]).cuda()
         edges = get_edges(B, N, device="cuda")
-        out = m(None, t("x"), edges, t("vel"), t("edge_attr"), t("charges"), N)
+        with torch.no_grad():
+            out = m(None, t("x"), edges, t("vel"), t("edge_attr"), t("charges"), N)
         assert scale_rel_err(m.last_field.cpu(), torch.from_numpy(d[f"{name}.ref.field"])) <= TOL, name
         assert scale_rel_err(out.cpu(), torch.from_numpy(d[f"{name}.ref.out"])) <= TOL, name
 
@@ -46,9 +47,77 @@ def test_dynamic_field_fresh_batches_vs_oracle(D):
     for (B, N, seed) in [(1, 2, 1), (128, 20, 2), (3, 300, 3)]:          # 300 nodes: streamed path, several passes per thread
         inp = make_batch(B, N, D, seed=seed)
         want = O.dynamic_field_aether_forward(sd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"], N)
+        with torch.no_grad():
+            out = m(None, inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(), inp["edge_attr"].cuda(),
+                    inp["charges"].cuda(), N)
+        assert scale_rel_err(out.cpu(), want) <= TOL, (B, N)
+        with torch.no_grad():
+            out2 = m(None, inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(), inp["edge_attr"].cuda(),
+                     inp["charges"].cuda(), N)
+        assert torch.equal(out, out2)                                   # deterministic, workspace reuse
+
+
+# ---------------------------------------------------------------- training (backward)
+GTOL = 5e-5
+
+
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_FORCE_STREAMED])
+@pytest.mark.parametrize("D", [2, 3])
+def test_dynamic_field_gradients_vs_oracle_autograd(D, flags):
+    """Every parameter gradient of the HIP backward (aether_backward_field + aether_dynamic_field_backward) vs
+    torch autograd through the oracle; also dL/dfield itself.  40 nodes: two LDS chunks per graph in the
+    field-net backward; 130 graphs: more graphs than CUs / 2."""
+    d, sd, m = _load(D)
+    m.flags = flags
+    for (B, N, seed) in [(4, 5, 11), (130, 20, 12), (3, 40, 13)]:
+        inp = make_batch(B, N, D, seed=seed)
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        field = O.dynamic_field(sdg, inp["x"], inp["vel"], inp["charges"], N)
+        field.retain_grad()
+        want = O.aether_forward(sdg, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"], field=field)
+        torch.nn.functional.mse_loss(want, inp["target"]).backward()
+        m.zero_grad(set_to_none=True)
         out = m(None, inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(), inp["edge_attr"].cuda(),
                 inp["charges"].cuda(), N)
-        assert scale_rel_err(out.cpu(), want) <= TOL, (B, N)
-        out2 = m(None, inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(), inp["edge_attr"].cuda(),
-                 inp["charges"].cuda(), N)
-        assert torch.equal(out, out2)                                   # deterministic, workspace reuse
+        assert out.requires_grad and scale_rel_err(out.detach().cpu(), want.detach()) <= TOL
+        torch.nn.functional.mse_loss(out, inp["target"].cuda()).backward()
+        assert scale_rel_err(m.last_grad_field.cpu(), field.grad) <= GTOL, (B, N)
+        for k, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            if k.endswith("gate_nn.2.bias"):          # softmax is shift invariant: this gradient is exactly zero
+                assert float(p.grad.abs().max()) <= 1e-9 and float(sdg[k].grad.abs().max()) <= 1e-9
+                continue
+            assert scale_rel_err(p.grad.cpu(), sdg[k].grad) <= GTOL, (B, N, k)
+
+
+def test_dynamic_field_training_step_reduces_loss():
+    """A few optimizer steps through the drop-in module, as the runner's loop does (main.py:200-260); gradients
+    accumulate like autograd's; a second backward through the same graph is refused by autograd itself."""
+    D = 2
+    d, sd, m = _load(D)
+    inp = make_batch(16, 20, D, seed=31)
+    args = (None, inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(), inp["edge_attr"].cuda(),
+            inp["charges"].cuda(), 20)
+    target = inp["target"].cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(m(*args), target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+    m.zero_grad(set_to_none=True)
+    torch.nn.functional.mse_loss(m(*args), target).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    torch.nn.functional.mse_loss(m(*args), target).backward()           # accumulates
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-6, atol=1e-12), k
+    frozen = [p for n, p in m.named_parameters() if n.startswith("gnn.")]
+    for p in frozen:
+        p.requires_grad_(False)
+    m.zero_grad(set_to_none=True)
+    torch.nn.functional.mse_loss(m(*args), target).backward()
+    assert all(p.grad is None for p in frozen)
+    assert all(p.grad is not None for n, p in m.named_parameters() if n.startswith("field_net."))
