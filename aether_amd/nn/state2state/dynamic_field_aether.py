@@ -89,8 +89,9 @@ class _DynStep(torch.autograd.Function):
         x, vel, charges, (graph, ginfo), ws, n_edges, num_nodes = ctx.saved
         D, n_nodes = module.num_dims, x.shape[0]
         ps, fps = module._structs(x.device)
-        names = [n for n, _ in module.named_parameters()]
-        grads = {n: torch.zeros_like(p) for n, p in module.named_parameters()}
+        names, offsets, total = module._grad_layout()
+        flat = torch.zeros(total, dtype=torch.float32, device=x.device)        # one buffer, one memset
+        grads = {n: flat[o:o + p.numel()].view_as(p) for (n, p), o in zip(module.named_parameters(), offsets)}
         gtensors = dict(grads)
         gtensors.update(module._dummy)                               # field_net.net.* slots: not written in this mode
         gs = _lib.params_struct(gtensors)
@@ -144,6 +145,7 @@ class DynamicFieldAether(nn.Module):
         return str(params)
 
     def _apply(self, fn, *a, **k):
+        self._glayout = None
         self._plist = None                # parameter storage may move (.to / .cuda / .float)
         self._struct_cache = None
         return super()._apply(fn, *a, **k)
@@ -180,6 +182,17 @@ class DynamicFieldAether(nn.Module):
                   "summary_net.summary_net.nn.2", "wrapper.linear_1", "wrapper.linear_2", "wrapper.linear_3",
                   "wrapper.film_1.modulator.0", "wrapper.film_1.modulator.2", "wrapper.film_1.modulator.4",
                   "wrapper.film_2.modulator.0", "wrapper.film_2.modulator.2", "wrapper.film_2.modulator.4"]
+
+    def _grad_layout(self):
+        """(parameter names, offsets into one flat gradient buffer (64-float aligned), total floats)."""
+        if getattr(self, "_glayout", None) is None:
+            names, offsets, total = [], [], 0
+            for n, p in self.named_parameters():
+                names.append(n)
+                offsets.append(total)
+                total += (p.numel() + 63) // 64 * 64
+            self._glayout = (names, offsets, total)
+        return self._glayout
 
     def _dyn_struct(self, tensors):
         """AetherDynFieldParams from {parameter name: tensor} (the parameters themselves or their gradients)."""

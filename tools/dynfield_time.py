@@ -25,3 +25,14 @@ for D in (3, 2):
         t_std = timed(lambda: a(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]))
     print("D=%d B=%d N=%d: dynamic-field step %.3f ms (built-in field net: %.3f ms), %.2f G edge-messages/s"
           % (D, B, N, t_dyn, t_std, 4 * B * N * (N - 1) / t_dyn / 1e6))
+    # training step (forward with kept intermediates + HIP backward of the GNN and of the field network + Adam)
+    def train_step(model, args, opt, target):
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.mse_loss(model(*args), target).backward()
+        opt.step()
+    tgt = inp["target"]
+    for name, model, args in (("dynamic field", m, (inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"], N)),
+                              ("built-in field", a, (inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]))):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        t = timed(lambda: train_step(model, args, opt, tgt), reps=50)
+        print("   eager training step, %-14s: %.3f ms" % (name, t))
