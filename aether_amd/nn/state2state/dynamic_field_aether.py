@@ -111,6 +111,10 @@ class _DynStep(torch.autograd.Function):
                                                      dws.data_ptr(), dws.numel(), stream),
                    "aether_dynamic_field_backward")
         module.last_grad_field = grad_field
+        if module.dp_group is not None:            # one all-reduce of the flat gradient buffer (RCCL), then the mean
+            import torch.distributed as dist
+            dist.all_reduce(flat, group=module.dp_group)
+            flat.div_(dist.get_world_size(module.dp_group))
         need_g = ctx.needs_input_grad[_DynStep.N_FIXED:]
         return (None,) * _DynStep.N_FIXED + tuple(grads[n] if k else None for n, k in zip(names, need_g))
 
@@ -131,6 +135,7 @@ class DynamicFieldAether(nn.Module):
         self.field_net = _LatentFieldNetwork(num_dims, 32, 16)
         self._graphs = GraphCache()
         self.flags = 0
+        self.dp_group = None               # set by aether_amd.parallel.attach_data_parallel
         self._ws = None
         self._ws_key = None
         self._plist = None

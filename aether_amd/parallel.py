@@ -39,7 +39,7 @@ def allreduce_mean_(flat: torch.Tensor, group=None):
 
 
 def attach_data_parallel(module, group=None, broadcast=True):
-    """Mark `module` (aether_amd Aether) as data-parallel over `group` (default: WORLD)."""
+    """Mark `module` (aether_amd Aether or DynamicFieldAether) as data-parallel over `group` (default: WORLD)."""
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     module.dp_group = group if group is not None else dist.group.WORLD

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, variant):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,9 +36,14 @@ def _worker(rank, world, port, q):
     D, B, N = 2, 8, 20
     dev = torch.device("cuda", 0)
     torch.manual_seed(100 + rank)                        # ranks start from different weights
-    m = Aether(2 * D, 64, 0.0, D, device=dev)
-    if rank == 0:
-        m.load_state_dict(load_state_dict(D))
+    if variant == "dynamic_field":
+        from aether_amd.nn.state2state.dynamic_field_aether import DynamicFieldAether
+        torch.manual_seed(100 + 7 * rank)
+        m = DynamicFieldAether(2 * D, 64, 0.0, D, device=dev)
+    else:
+        m = Aether(2 * D, 64, 0.0, D, device=dev)
+        if rank == 0:
+            m.load_state_dict(load_state_dict(D))
     attach_data_parallel(m)                              # broadcast from rank 0
     full = make_batch(B, N, D, seed=9)
     lo, hi = shard_graphs(B, rank, world)
@@ -47,26 +52,29 @@ def _worker(rank, world, port, q):
     x, v, q_, tgt = (full[k][sl].to(dev) for k in ("x", "vel", "charges", "target"))
     ea = prepare_edge_attr(x, edges, q_[edges[0]] * q_[edges[1]])
     opt = torch.optim.SGD(m.parameters(), lr=0.1)
-    out = m(v.norm(dim=-1, keepdim=True), x, edges, v, ea, q_)
+    extra = (N,) if variant == "dynamic_field" else ()
+    start = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}     # after the broadcast
+    out = m(v.norm(dim=-1, keepdim=True), x, edges, v, ea, q_, *extra)
     torch.nn.functional.mse_loss(out, tgt).backward()    # all-reduce + mean happen inside the backward
     grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
     opt.step()
     torch.cuda.synchronize()
     params = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
-    q.put((rank, grads, params, out.detach().cpu().numpy().copy(), (lo, hi)))      # numpy: pickled by value
+    q.put((rank, grads, params, out.detach().cpu().numpy().copy(), (lo, hi), start))      # numpy: pickled by value
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_on_one_gpu_match_single_process_gradients():
+@pytest.mark.parametrize("variant", ["aether", "dynamic_field"])
+def test_two_ranks_on_one_gpu_match_single_process_gradients(variant):
     from aether_amd.nn.state2state.aether import Aether
     from aether_amd.synthetic import make_batch
     from conftest import scale_rel_err
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, variant)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
@@ -74,14 +82,25 @@ def test_two_ranks_on_one_gpu_match_single_process_gradients():
         p.join(60)
         assert p.exitcode == 0
     D, B, N = 2, 8, 20
-    m = Aether(2 * D, 64, 0.0, D, device="cuda")
-    m.load_state_dict(load_state_dict(D))
+    if variant == "dynamic_field":
+        from aether_amd.nn.state2state.dynamic_field_aether import DynamicFieldAether
+        m = DynamicFieldAether(2 * D, 64, 0.0, D, device="cuda")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in res[0][5].items()})      # rank 0's broadcast weights
+        assert all((res[0][5][k] == res[1][5][k]).all() for k in res[0][5])
+        extra = (N,)
+    else:
+        m = Aether(2 * D, 64, 0.0, D, device="cuda")
+        m.load_state_dict(load_state_dict(D))
+        extra = ()
     full = make_batch(B, N, D, seed=9, device="cuda")
-    out = m(full["h"], full["x"], full["edges"], full["vel"], full["edge_attr"], full["charges"])
+    out = m(full["h"], full["x"], full["edges"], full["vel"], full["edge_attr"], full["charges"], *extra)
     torch.nn.functional.mse_loss(out, full["target"]).backward()
-    for rank, grads, params, out_r, (lo, hi) in res:
+    for rank, grads, params, out_r, (lo, hi), _ in res:
         assert torch.allclose(torch.from_numpy(out_r), out.detach().cpu()[lo * N:hi * N], atol=2e-6)   # no forward collective
         for k, p in m.named_parameters():
+            if k.endswith("gate_nn.2.bias"):            # exactly zero (softmax shift invariance): rounding noise
+                assert abs(float(grads[k][0])) <= 1e-9
+                continue
             assert scale_rel_err(torch.from_numpy(grads[k]), p.grad.cpu()) <= 5e-5, (rank, k)
     for k in res[0][2]:
         assert (res[0][2][k] == res[1][2][k]).all(), k                                      # replicas stay in sync
