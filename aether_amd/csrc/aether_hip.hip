@@ -926,6 +926,132 @@ int aether_s2s_prior_step(const AetherS2SPriorParams* p, int num_dims, int hidde
     return AETHER_OK;
 }
 
+// ------------------------------------------------------------------ variable-N decoder step (N2)
+namespace {
+struct DynDecLayout {
+    size_t A[4], S[4], T1, M, agg_h, agg_p, ext, rel, relp, Rinv, ea, ea15, epos, hw, fout, fpart, ewn, rp, ip, np_, hh, o1,
+        o2, pred, irp, iip, inp, list[4], counts, total;
+    int splits;
+    DynDecLayout(int h, int64_t Nn, int64_t E) {
+        size_t off = 0;
+        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+        const size_t nn = (size_t)Nn, ee = (size_t)E, hh_ = (size_t)h;
+        for (auto& v : A) v = take(nn * hh_);
+        for (auto& v : S) v = take(nn * hh_);
+        T1 = take(ee * hh_); M = take(ee * hh_);
+        agg_h = take(nn * hh_); agg_p = take(nn * hh_);
+        ext = take(nn * 6); rel = take(nn * 15); relp = take(nn * 16); Rinv = take(nn * 4);
+        ea = take(ee * 24); ea15 = take(ee * 15); epos = take(ee * 3); hw = take(ee * hh_); fout = take(ee * hh_);
+        splits = S2SPriorLayout::filter_splits(h, E);
+        fpart = take(splits > 1 ? ee * hh_ * splits : 0);
+        ewn = take(ee * 4);
+        rp = take(nn * hh_); ip = take(nn * hh_); np_ = take(nn * hh_); hh = take(nn * hh_);
+        o1 = take(nn * hh_); o2 = take(nn * hh_); pred = take(nn * 4);
+        irp = take(hh_ * 16); iip = take(hh_ * 16); inp = take(hh_ * 16);
+        for (auto& v : list) v = take(ee * 2);
+        counts = take(64);
+        total = off;
+    }
+};
+}  // namespace
+
+size_t aether_dyn_decoder_workspace_bytes(int hidden, int64_t n_nodes, int64_t n_edges) {
+    if (hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
+    return DynDecLayout(hidden, n_nodes, n_edges).total;
+}
+
+int aether_dyn_decoder_step(const AetherDynDecoderParams* p, int hidden, int num_edge_types, int skip_first, int polar,
+                            int64_t n_nodes, int64_t n_edges, const float* inputs, const float* hidden_in,
+                            const float* edge_w, const float* field, const float* edge_state, const int64_t* send,
+                            const int64_t* recv, const int64_t* agg_order, const int64_t* agg_rowptr, float agg_div,
+                            void* workspace, size_t workspace_bytes, float* outputs, float* hidden_out, void* stream) {
+    if (!p || !inputs || !hidden_in || !field || !workspace || !outputs || !hidden_out)
+        return fail(AETHER_EINVAL, "dyn_decoder: null pointer");
+    if (n_edges > 0 && (!edge_w || !send || !recv || !agg_order || !agg_rowptr))
+        return fail(AETHER_EINVAL, "dyn_decoder: null edge pointer");
+    if (hidden < 128 || hidden % 128 != 0) return fail(AETHER_EINVAL, "dyn_decoder: hidden must be a multiple of 128");
+    if (num_edge_types < 1 || num_edge_types > 4) return fail(AETHER_EINVAL, "dyn_decoder: 1..4 edge types");
+    if (skip_first && num_edge_types < 2) return fail(AETHER_EINVAL, "dyn_decoder: skip_first needs two edge types");
+    if (n_nodes <= 0 || n_edges < 0) return fail(AETHER_EINVAL, "dyn_decoder: bad sizes");
+    if (n_edges > 0 && !(agg_div > 0.0f)) return fail(AETHER_EINVAL, "dyn_decoder: agg_div must be positive");
+    constexpr int D = 2;
+    const int h = hidden, K = num_edge_types, k0 = skip_first ? 1 : 0;
+    DynDecLayout L(h, n_nodes, n_edges);
+    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "dyn_decoder: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int64_t Nn = n_nodes, E = n_edges;
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    int* counts = reinterpret_cast<int*>(ws + L.counts);
+    auto elist = [&](int k) { return reinterpret_cast<int64_t*>(ws + L.list[k]); };
+    // ---- canonical state and frames of the present objects (:790)
+    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
+    k_s2s_aug_nodes<2><<<blocks(Nn), dim3(256), 0, st>>>(wp(L.ext), wp(L.rel), wp(L.Rinv), Nn);
+    if (E > 0) {
+        HIP_OK(hipMemsetAsync(counts, 0, 64 * sizeof(int), st));
+        for (int k = k0; k < K; ++k)
+            k_s2s_select<<<blocks(E), dim3(256), 0, st>>>(edge_w, K, k, E, elist(k), counts + k);
+        // ---- messages from the hidden states, each type / norm (:797-814)
+        k_s2s_scale<<<blocks(E * K), dim3(256), 0, st>>>(edge_w, 1.0f / (float)(K - k0), wp(L.ewn), E * K);
+        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
+        for (int k = k0; k < K; ++k) {
+            if (s2s_linear(0, p->msg_fc1_w[k], 2 * h, p->msg_fc1_b[k], hidden_in, wp(L.A[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+            if (s2s_linear(0, p->msg_fc1_w[k] + h, 2 * h, nullptr, hidden_in, wp(L.S[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+            k_s2s_pair_tanh<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.A[k]), wp(L.S[k]), send, recv, elist(k), counts + k, wp(L.T1), h);
+            if (s2s_linear(3, p->msg_fc2_w[k], h, p->msg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, wp(L.ewn) + k, K, 1, st,
+                           nullptr, elist(k), counts + k)) return AETHER_EINVAL;
+        }
+        k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), agg_order, agg_rowptr, wp(L.agg_h), h, agg_div);
+        // ---- edge features [9 | canonical state of the receiver 6] and positions (:821-825): the first 15 of the
+        // 24 columns aether_s2s_localize's edge kernel writes (edge | canonical | origin-edge features)
+        k_s2s_aug_edges<2><<<blocks(E), dim3(256), 0, st>>>(edge_state ? edge_state : wp(L.ext), send, recv, wp(L.rel), polar,
+                                                           wp(L.ea), wp(L.epos), E);
+        k_s2s_pad_rows<<<blocks(E * 15), dim3(256), 0, st>>>(wp(L.ea), 15, 24, wp(L.ea15), 15, E);
+        // ---- messages from the present state: one anisotropic filter per edge type, ReLU (:827-835)
+        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
+        constexpr int NB = 4;
+        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128), (unsigned)L.splits);
+        for (int k = k0; k < K; ++k) {
+            k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0[k], p->filt_b0[k], wp(L.epos), 3, wp(L.hw), h, E, 1);
+            if (L.splits > 1) {
+                k_s2s_filter<15, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2[k], p->filt_b2[k], wp(L.ea15), wp(L.hw), wp(L.fpart), h, E);
+                k_s2s_sum_planes<<<blocks(E * h / 4), dim3(256), 0, st>>>(wp(L.fpart), L.splits, E * (int64_t)h, wp(L.fout));
+            } else {
+                k_s2s_filter<15, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2[k], p->filt_b2[k], wp(L.ea15), wp(L.hw), wp(L.fout), h, E);
+            }
+            k_s2s_relu_scale_acc<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.fout), edge_w + k, K, wp(L.M), h, E);
+        }
+        k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), agg_order, agg_rowptr, wp(L.agg_p), h, agg_div);
+    } else {
+        HIP_OK(hipMemsetAsync(wp(L.agg_h), 0, (size_t)Nn * h * 4, st));
+        HIP_OK(hipMemsetAsync(wp(L.agg_p), 0, (size_t)Nn * h * 4, st));
+    }
+    // ---- GRU-style gate (:845-852): input_* see the canonical state (6 columns of rel_feat)
+    k_s2s_pad_rows<<<blocks(Nn * 16), dim3(256), 0, st>>>(wp(L.rel), 6, 15, wp(L.relp), 16, Nn);
+    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->input_r_w, 6, 6, wp(L.irp), 16, h);
+    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->input_i_w, 6, 6, wp(L.iip), 16, h);
+    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->input_n_w, 6, 6, wp(L.inp), 16, h);
+    struct Gate { const float *iw, *ib, *pw, *pb, *hw; float* y; };
+    const Gate gates[3] = {{wp(L.irp), p->input_r_b, p->present_r_w, p->present_r_b, p->hidden_r_w, wp(L.rp)},
+                           {wp(L.iip), p->input_i_b, p->present_i_w, p->present_i_b, p->hidden_i_w, wp(L.ip)},
+                           {wp(L.inp), p->input_n_b, p->present_n_w, p->present_n_b, nullptr, wp(L.np_)}};
+    for (const Gate& g : gates) {
+        if (s2s_linear(0, g.iw, 16, g.ib, wp(L.relp), g.y, h, 16, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+        if (s2s_linear(0, g.pw, h, g.pb, wp(L.agg_p), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
+        if (g.hw && s2s_linear(0, g.hw, h, nullptr, wp(L.agg_h), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
+    }
+    if (s2s_linear(0, p->hidden_h_w, h, nullptr, wp(L.agg_h), wp(L.hh), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    k_s2s_gate<<<blocks(Nn * h), dim3(256), 0, st>>>(wp(L.rp), wp(L.ip), wp(L.np_), wp(L.hh), hidden_in, hidden_out, Nn * h);
+    // ---- output MLP, rotate back, residual (:855-861)
+    if (s2s_linear(2, p->out1_w, h, p->out1_b, hidden_out, wp(L.o1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(2, p->out2_w, h, p->out2_b, wp(L.o1), wp(L.o2), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->out3_w, h, p->out3_b, wp(L.o2), wp(L.pred), 2 * D, h, Nn, 2 * D, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    k_s2s_globalize<2><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
 // ------------------------------------------------------------------ seq2seq dynamic-field variant (N3)
 namespace {
 struct S2SSummaryLayout {

@@ -447,14 +447,37 @@ namespace {
 // hw[e][c] = ELU(sum_p W1[c][p] pos[e][p] + b1[c]): the first layer of the hyper-network (pos_size = 3 | 6)
 __global__ void __launch_bounds__(256)
 k_s2s_pos_hidden(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ pos, int P,
-                 float* __restrict__ hw, int h, int64_t n_edges) {
+                 float* __restrict__ hw, int h, int64_t n_edges, int relu = 0) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_edges * h) return;
     const int64_t e = idx / h;
     const int c = (int)(idx - e * h);
     float s = b1[c];
     for (int p = 0; p < P; ++p) s = fmaf(W1[c * P + p], pos[e * P + p], s);
-    hw[idx] = s > 0.0f ? s : expm1f(s);
+    hw[idx] = s > 0.0f ? s : (relu ? 0.0f : expm1f(s));
+}
+
+// M[e][:] += relu(F[e][:]) * w[e * K]   (present messages of the variable-N decoder, aether_dynamicvars.py:831-835)
+__global__ void __launch_bounds__(256)
+k_s2s_relu_scale_acc(const float* __restrict__ Fm, const float* __restrict__ w, int K, float* __restrict__ Mx, int h,
+                     int64_t n_edges) {
+    const int q4 = h >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_edges * q4) return;
+    const int64_t e = idx / q4;
+    const int c = (int)(idx - e * q4) * 4;
+    const float we = w[e * K];
+    f32x4 v = ld4(Fm + (size_t)e * h + c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f) * we;
+    st4(Mx + (size_t)e * h + c, ld4(Mx + (size_t)e * h + c) + v);
+}
+
+// dst[i] = src[i] * s
+__global__ void __launch_bounds__(256)
+k_s2s_scale(const float* __restrict__ src, float s, float* __restrict__ dst, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) dst[idx] = src[idx] * s;
 }
 
 // Anisotropic edge filter (nn/nn/anisotropic_filter.py:34-40):

@@ -1,0 +1,142 @@
+"""MI355X drop-in for the decoder of the reference's variable-N model (second half):
+``nn.dynamicvars.aether_dynamicvars.Decoder`` (aether_dynamicvars.py:703-870), the step the inD runner calls once
+per time step for the objects present in the scene.
+
+Same constructor dictionary, parameter names, creation order (so a seeded construction gives the reference's
+initial weights) and ``forward(inputs, hidden, edges, node_masks, graph_info, predicted_field)``.  The present
+objects are compacted on the device and the whole step runs in ``aether_dyn_decoder_step``; there is no CPU
+fallback.  Two properties of the reference are kept (see oracle/dynamicvars_oracle.py): the edge features read the
+un-compacted state with compacted indices, and a scene with a single present object raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ..seq2seq.encoder import _AnisotropicEdgeFilter
+
+
+class _DynDecoderParams(C.Structure):
+    _fields_ = ([(n, C.c_void_p * 4) for n in ("msg_fc1_w", "msg_fc1_b", "msg_fc2_w", "msg_fc2_b")] +
+                [(n, C.c_void_p) for n in ("hidden_r_w", "hidden_i_w", "hidden_h_w", "input_r_w", "input_r_b", "input_i_w",
+                                           "input_i_b", "input_n_w", "input_n_b", "present_r_w", "present_r_b",
+                                           "present_i_w", "present_i_b", "present_n_w", "present_n_b", "out1_w", "out1_b",
+                                           "out2_w", "out2_b", "out3_w", "out3_b")] +
+                [(n, C.c_void_p * 4) for n in ("filt_w0", "filt_b0", "filt_w2", "filt_b2")])
+
+
+class Decoder(nn.Module):
+    def __init__(self, params, device="cuda"):
+        super().__init__()
+        input_size = params["input_size"]
+        n_hid = params["decoder_hidden"]
+        edge_types = params["num_edge_types"]
+        if params.get("use_3d", False) or input_size != 4:
+            raise ValueError("the variable-N decoder is 2-D (the reference rotates back with Globalizer(num_dims=2))")
+        if n_hid % 128 != 0:
+            raise ValueError("decoder_hidden must be a multiple of 128")
+        if not 1 <= edge_types <= 4:
+            raise ValueError("num_edge_types must be 1..4")
+        if params["decoder_dropout"] != 0.0:
+            raise ValueError("decoder_dropout must be 0.0 (inference path)")
+        self.num_dims, self.msg_out_shape, self.edge_types = 2, n_hid, edge_types
+        self.skip_first_edge_type = params["skip_first"]
+        # creation order of aether_dynamicvars.py:716-770
+        self.msg_fc1 = nn.ModuleList([nn.Linear(2 * n_hid, n_hid) for _ in range(edge_types)])
+        self.msg_fc2 = nn.ModuleList([nn.Linear(n_hid, n_hid) for _ in range(edge_types)])
+        self.hidden_r = nn.Linear(n_hid, n_hid, bias=False)
+        self.hidden_i = nn.Linear(n_hid, n_hid, bias=False)
+        self.hidden_h = nn.Linear(n_hid, n_hid, bias=False)
+        self.input_r = nn.Linear(input_size + 2, n_hid, bias=True)
+        self.input_i = nn.Linear(input_size + 2, n_hid, bias=True)
+        self.input_n = nn.Linear(input_size + 2, n_hid, bias=True)
+        self.out_fc1 = nn.Linear(n_hid, n_hid)
+        self.out_fc2 = nn.Linear(n_hid, n_hid)
+        self.out_fc3 = nn.Linear(n_hid, input_size)
+        self.pos_representation = params["pos_representation"]
+        if self.pos_representation not in ("cart", "polar"):
+            raise ValueError
+        self.edge_filter = nn.ModuleList([_AnisotropicEdgeFilter(9 + input_size + 2, 3, n_hid, n_hid)
+                                          for _ in range(edge_types)])
+        self.present_r = nn.Linear(n_hid, n_hid, bias=True)
+        self.present_i = nn.Linear(n_hid, n_hid, bias=True)
+        self.present_n = nn.Linear(n_hid, n_hid, bias=True)
+        self._ws = None
+        if device is not None:
+            self.to(device)
+
+    def get_initial_hidden(self, inputs):
+        return torch.zeros(inputs.size(0), inputs.size(2), self.msg_out_shape, device=inputs.device)
+
+    def _param_struct(self):
+        ps = _DynDecoderParams()
+        ptr = lambda t: t.data_ptr()
+        for k in range(self.edge_types):
+            ps.msg_fc1_w[k], ps.msg_fc1_b[k] = ptr(self.msg_fc1[k].weight), ptr(self.msg_fc1[k].bias)
+            ps.msg_fc2_w[k], ps.msg_fc2_b[k] = ptr(self.msg_fc2[k].weight), ptr(self.msg_fc2[k].bias)
+            f = self.edge_filter[k].edge_filter
+            ps.filt_w0[k], ps.filt_b0[k], ps.filt_w2[k], ps.filt_b2[k] = ptr(f[0].weight), ptr(f[0].bias), ptr(f[2].weight), ptr(f[2].bias)
+        ps.hidden_r_w, ps.hidden_i_w, ps.hidden_h_w = ptr(self.hidden_r.weight), ptr(self.hidden_i.weight), ptr(self.hidden_h.weight)
+        for g in ("r", "i", "n"):
+            for kind in ("input", "present"):
+                lin = getattr(self, f"{kind}_{g}")
+                setattr(ps, f"{kind}_{g}_w", ptr(lin.weight)); setattr(ps, f"{kind}_{g}_b", ptr(lin.bias))
+        for j, lin in enumerate((self.out_fc1, self.out_fc2, self.out_fc3), 1):
+            setattr(ps, f"out{j}_w", ptr(lin.weight)); setattr(ps, f"out{j}_b", ptr(lin.bias))
+        for p in self.parameters():
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise _lib.AetherHipError("Decoder parameters must be contiguous fp32 CUDA tensors")
+        return ps
+
+    @torch.no_grad()
+    def forward(self, inputs, hidden, edges, node_masks, graph_info, predicted_field):
+        """aether_dynamicvars.py:775-870.  inputs [1, Nmax, 4], hidden [1, Nmax, h], edges [1, E, K], node_masks
+        [1, Nmax] (or [Nmax]), graph_info = (send_edges, recv_edges, edge2node_inds) in the numbering of the present
+        objects, predicted_field [1, Nmax, 2] -> (pred_all [1, Nmax, 4], hidden [1, Nmax, h])."""
+        if not inputs.is_cuda:
+            raise _lib.AetherHipError("aether_amd Decoder runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        if inputs.size(0) != 1:
+            raise ValueError("Batching during forward not currently supported")       # as the reference's models
+        lib = _lib.load()
+        dev = inputs.device
+        h, K = self.msg_out_shape, self.edge_types
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        inputs, hidden, field = f32(inputs), f32(hidden), f32(predicted_field)
+        node_inds = node_masks.reshape(-1).to(dev).nonzero()[:, -1]
+        nv = int(node_inds.numel())
+        if nv == 0:                                                                    # :841-843
+            return torch.zeros_like(inputs), hidden
+        if nv == 1:
+            raise _lib.AetherHipError("a scene with one present object: the reference fails here as well "
+                                      "(present_agg_msgs is never assigned, aether_dynamicvars.py:843-851)")
+        send, recv, e2n = (t.to(device=dev, dtype=torch.int64).contiguous() for t in graph_info)
+        E = send.numel()
+        if recv.numel() != E or edges.shape != (1, E, K) or e2n.ndim != 2 or e2n.shape[0] != nv:
+            raise ValueError("graph_info / edges do not match the present objects")
+        cur_in, cur_h, cur_f = inputs[0, node_inds].contiguous(), hidden[0, node_inds].contiguous(), field[0, node_inds].contiguous()
+        ext_full = torch.cat([inputs[0], field[0]], -1).contiguous()                  # indexed with compacted ids (:823)
+        rowptr = torch.arange(nv + 1, device=dev, dtype=torch.int64) * e2n.shape[1]
+        order = e2n.reshape(-1).contiguous()
+        ew = f32(edges)[0]
+        need = lib.aether_dyn_decoder_workspace_bytes(h, nv, E)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(nv, 4, dtype=torch.float32, device=dev)
+        new_h = torch.empty(nv, h, dtype=torch.float32, device=dev)
+        ps = self._param_struct()
+        st = lib.aether_dyn_decoder_step(C.byref(ps), h, K, 1 if self.skip_first_edge_type else 0,
+                                         1 if self.pos_representation == "polar" else 0, nv, E, cur_in.data_ptr(),
+                                         cur_h.data_ptr(), ew.data_ptr(), cur_f.data_ptr(), ext_full.data_ptr(),
+                                         send.data_ptr(), recv.data_ptr(), order.data_ptr(), rowptr.data_ptr(),
+                                         float(nv - 1), self._ws.data_ptr(), self._ws.numel(), out.data_ptr(),
+                                         new_h.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_dyn_decoder_step")
+        hidden = hidden.clone()
+        hidden[0, node_inds] = new_h
+        pred_all = torch.zeros_like(inputs)
+        pred_all[0, node_inds] = out
+        return pred_all, hidden

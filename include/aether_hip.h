@@ -429,6 +429,44 @@ int aether_sim_gravitational(const double* pos0, const double* vel0, const doubl
                              double dt, double softening, double* pos, double* vel, double* force, void* stream);
 
 /*
+ * Variable-N models, one step of the decoder (second half): replaces Decoder.forward of
+ * nn/dynamicvars/aether_dynamicvars.py:775-870 (2-D, one scene) on the objects present in the scene.
+ * Differences from aether_s2s_decoder_step: rel_feat = the canonical state only (canonicalize_augmented_inputs,
+ * 6 columns), messages from the present state through one AnisotropicEdgeFilter per edge type
+ * (nn/nn/anisotropic_filter.py:34-40 with a ReLU hidden layer, in_size 15 = 9 edge features + 6 receiver columns)
+ * followed by ReLU, hidden messages divided by the number of used edge types (:801-814), both aggregations are
+ * sums over the caller's lists divided by agg_div (the reference: edge2node_inds rows, / (num_vars - 1), :816-819).
+ *   inputs [n][4], field [n][2], hidden_in [n][h]: the present objects, compacted; edge_w [e][K]
+ *   edge_state : float[m][6] rows [pos | vel | field] indexed by send / recv for the edge features; NULL = the
+ *                compacted [inputs | field].  (The reference indexes the un-compacted array with compacted
+ *                indices, :823 -- pass that array to reproduce it when objects are missing.)
+ *   send, recv : int64[e] compacted object indices; agg_order int64[*], agg_rowptr int64[n + 1]: the edges summed
+ *                into each object (the reference's edge2node_inds, flattened, with rowptr[i] = i * k)
+ *   outputs [n][4], hidden_out [n][h];  h % 128 == 0
+ */
+typedef struct AetherDynDecoderParams {
+    const float* msg_fc1_w[4]; const float* msg_fc1_b[4];    /* [h][2h] (receiver | sender halves), [h] */
+    const float* msg_fc2_w[4]; const float* msg_fc2_b[4];    /* [h][h], [h] */
+    const float* hidden_r_w; const float* hidden_i_w; const float* hidden_h_w;      /* [h][h], no bias */
+    const float* input_r_w; const float* input_r_b;
+    const float* input_i_w; const float* input_i_b;
+    const float* input_n_w; const float* input_n_b;          /* [h][6], [h] */
+    const float* present_r_w; const float* present_r_b;
+    const float* present_i_w; const float* present_i_b;
+    const float* present_n_w; const float* present_n_b;      /* [h][h], [h] */
+    const float* out1_w; const float* out1_b; const float* out2_w; const float* out2_b;   /* out_fc1, out_fc2: [h][h] */
+    const float* out3_w; const float* out3_b;                /* out_fc3: [4][h] */
+    const float* filt_w0[4]; const float* filt_b0[4];        /* edge_filter.k.edge_filter.0: [h][3], [h] */
+    const float* filt_w2[4]; const float* filt_b2[4];        /* edge_filter.k.edge_filter.2: [15 h][h], [15 h] */
+} AetherDynDecoderParams;
+size_t aether_dyn_decoder_workspace_bytes(int hidden, int64_t n_nodes, int64_t n_edges);
+int aether_dyn_decoder_step(const AetherDynDecoderParams* params, int hidden, int num_edge_types, int skip_first,
+                            int polar, int64_t n_nodes, int64_t n_edges, const float* inputs, const float* hidden_in,
+                            const float* edge_w, const float* field, const float* edge_state, const int64_t* send,
+                            const int64_t* recv, const int64_t* agg_order, const int64_t* agg_rowptr, float agg_div,
+                            void* workspace, size_t workspace_bytes, float* outputs, float* hidden_out, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

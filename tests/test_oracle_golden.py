@@ -273,3 +273,18 @@ def test_knn_edge_builder():
         assert np.array_equal(n, d[name + ".num"]), name
     s, r = K.knn_graph_info(d["info.x"], d["info.masks"])
     assert np.array_equal(s, d["info.send"]) and np.array_equal(r, d["info.recv"])
+
+
+@pytest.mark.parametrize("name", ["full8", "tail6", "gaps", "knn20", "empty"])
+def test_dynamicvars_decoder_step(name):
+    """SURVEY 8f N2, second half: the variable-N decoder step vs the imported reference Decoder (graphs from the
+    reference's get_knn_graph_info): all present, trailing / interior objects missing, a 19-object kNN scene whose
+    edge2node_inds rows are not per-receiver groups, an empty scene."""
+    from conftest import load_dyn_decoder
+    from oracle import dynamicvars_oracle as DO
+    c, dec, params = load_dyn_decoder(name)
+    sd = {k: v.detach() for k, v in dec.state_dict().items()}
+    gi = (c["send"], c["recv"], c["e2n"]) if "send" in c else None
+    pred, hid = DO.decoder_step(sd, c["inputs"], c["hidden"], c["edges"], c["masks"], gi, c["field"],
+                                params["skip_first"], params["pos_representation"])
+    assert scale_rel_err(pred, c["ref.pred"]) <= 2e-6 and scale_rel_err(hid, c["ref.hidden"]) <= 2e-6
