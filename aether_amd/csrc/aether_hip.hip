@@ -1232,8 +1232,13 @@ int aether_knn_edges(const float* x, int x_stride, const float* masks, int64_t n
     const size_t lds_sel = (size_t)3 * N * 4 + 257 * 4, lds_wr = (size_t)2 * N * 4 + 257 * 4;
     if (ensure_dynamic_lds((const void*)k_knn_select, lds_sel) || ensure_dynamic_lds((const void*)k_knn_write, lds_wr))
         return AETHER_EHIP;
-    k_knn_select<<<dim3((unsigned)n_scenes), dim3(256), lds_sel, st>>>(x, x_stride, masks, N, k, nbr, cnt, scene_nodes,
-                                                                      scene_edges);
+    HIP_OK(hipMemsetAsync(scene_nodes, 0, (size_t)n_scenes * sizeof(int64_t), st));
+    HIP_OK(hipMemsetAsync(scene_edges, 0, (size_t)n_scenes * sizeof(int64_t), st));
+    // few large scenes: several workgroups per scene (each stages the scene and takes a slice of its objects)
+    int per_scene = 1;
+    while (per_scene * 256 < N && n_scenes * per_scene < 512) per_scene *= 2;
+    k_knn_select<<<dim3((unsigned)n_scenes, (unsigned)per_scene), dim3(256), lds_sel, st>>>(x, x_stride, masks, N, k, nbr, cnt,
+                                                                                           scene_nodes, scene_edges);
     k_knn_scan<<<dim3(1), dim3(1024), 0, st>>>(scene_nodes, scene_edges, n_scenes, node_off, edge_off, totals);
     k_knn_write<<<dim3((unsigned)n_scenes), dim3(256), lds_wr, st>>>(masks, nbr, cnt, N, k, node_off, edge_off, send, recv);
     HIP_OK(hipGetLastError());

@@ -40,7 +40,7 @@ __device__ inline int block_exclusive_scan(int* val, int n, int* part) {
 }
 
 // nbr[s][i][0..k): neighbours of object i, nearest first (local object ids); cnt[s][i]: how many are real.
-// scene_nodes[s], scene_edges[s]: present objects and edges of the scene.
+// scene_nodes[s], scene_edges[s] (zeroed by the host): present objects and edges of the scene.
 __global__ void __launch_bounds__(256)
 k_knn_select(const float* __restrict__ x, int x_stride, const float* __restrict__ masks, int N, int k,
              int* __restrict__ nbr, int* __restrict__ cnt, int64_t* __restrict__ scene_nodes,
@@ -59,7 +59,8 @@ k_knn_select(const float* __restrict__ x, int x_stride, const float* __restrict_
     }
     __syncthreads();
     int my_nodes = 0, my_edges = 0;
-    for (int i = tid; i < N; i += 256) {
+    // gridDim.y workgroups share a scene: each takes the objects i = blockIdx.y * 256 + tid (+ 256 gridDim.y ...)
+    for (int i = (int)blockIdx.y * 256 + tid; i < N; i += 256 * (int)gridDim.y) {
         int c = 0;
         if (pm[i] != 0.0f) {
             ++my_nodes;
@@ -101,7 +102,10 @@ k_knn_select(const float* __restrict__ x, int x_stride, const float* __restrict_
     red[tid] = my_edges;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
-    if (tid == 0) { scene_nodes[s] = nodes; scene_edges[s] = red[0]; }
+    if (tid == 0) {                                              // integer sums: the order of the atomics does not matter
+        atomicAdd(reinterpret_cast<unsigned long long*>(scene_nodes + s), (unsigned long long)nodes);
+        atomicAdd(reinterpret_cast<unsigned long long*>(scene_edges + s), (unsigned long long)red[0]);
+    }
 }
 
 // node_off[s], edge_off[s] = exclusive prefix sums over scenes; totals = {edges, nodes}.  One workgroup.
