@@ -143,6 +143,14 @@ class Aether(_StepLoop, nn.Module):
     def predict_field(self, x):
         return self._fq[0](x)
 
+    def calculate_loss(self, inputs, is_train=False, teacher_forcing=True, return_edges=False, return_logits=False,
+                       use_prior_logits=False):
+        """aether.py:103-153 (ELBO of the full-sequence posterior): not part of the prediction path.  The signature is
+        kept because experiments/electrostatic/evaluate.py:42-45 inspects it to decide which keyword arguments
+        ``predict_future`` takes."""
+        raise _lib.AetherHipError("calculate_loss (posterior encoder + training loss) is not part of this path; "
+                                  "predict_future / predict_from_state are")
+
     @torch.no_grad()
     def single_step_forward(self, inputs, decoder_hidden, edge_logits, hard_sample, predicted_field, uniform=None):
         """aether.py:92-101.  ``uniform``: the U(0,1) draw of ``gumbel_softmax`` ([B, E, K]); the reference draws it

@@ -148,6 +148,33 @@ class DynamicFieldAether(_StepLoop, nn.Module):
         if device is not None:
             self.to(device)
 
+    def calculate_loss(self, inputs, is_train=False, teacher_forcing=True, return_edges=False, return_logits=False,
+                       use_prior_logits=False, charges=None):
+        """dynamic_field_aether.py:151-205: not part of the prediction path; the signature is kept because
+        experiments/electrostatic/evaluate.py:42-45 inspects it (``charges`` is then passed to ``predict_future``)."""
+        raise _lib.AetherHipError("calculate_loss (posterior encoder + training loss) is not part of this path; "
+                                  "predict_future is")
+
+    def create_grid_points(self, box_size=5.0, grid_size=21, normalize=True):
+        """dynamic_field_aether.py:89-95: the grid of the data-side ``field`` object (``params['field']``)."""
+        test_positions = self.field._make_grid(box_size=box_size, grid_size=grid_size, ndim=self.num_dims)
+        if normalize:
+            test_positions = self.field._normalize(test_positions)
+        return test_positions
+
+    @torch.no_grad()
+    def predict_field_at_grid(self, inputs, box_size=5.0, grid_size=21, charges=None, oracle=None):
+        """dynamic_field_aether.py:103-115 (experiments/gravitational/evaluate.py:38-41): the field the summary of
+        ``inputs[:, :-1]`` induces at the grid points, [B, grid points, D]."""
+        if charges is not None:
+            raise _lib.AetherHipError("charges (use_charges) are not part of this path")
+        test_positions = self.create_grid_points(box_size=box_size, grid_size=grid_size, normalize=True).to(inputs.device)
+        test_positions = test_positions.unsqueeze(0).repeat(inputs.size(0), 1, 1)
+        x = inputs[:, :-1].transpose(2, 1).contiguous()
+        gr_summary = self.graph_pooler(x)
+        predicted_field, _ = self.predict_field(test_positions.contiguous(), gr_summary)
+        return predicted_field
+
     # -- field query ---------------------------------------------------------------------
     def _film_struct(self):
         f = self.film_net

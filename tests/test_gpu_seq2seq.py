@@ -346,3 +346,40 @@ def test_step_graph_equals_eager(variant):
         assert torch.equal(a, b)
     free = model.predict_future(x, steps)
     assert free.shape == (B, steps, N, x.shape[-1]) and torch.isfinite(free).all()
+
+
+def test_evaluation_runner_surface():
+    """What experiments/electrostatic/evaluate.py and experiments/gravitational/evaluate.py touch besides
+    predict_future: the calculate_loss signature (inspected for 'charges' / 'field') and predict_field_at_grid with
+    the data-side field object's grid helpers."""
+    import inspect
+    from conftest import load_s2s_dynfield, load_s2s_future
+    from aether_amd import _lib
+    _, base, _ = load_s2s_future()
+    args = inspect.getfullargspec(base.calculate_loss).args
+    assert "charges" not in args and "field" not in args
+    with pytest.raises(_lib.AetherHipError):
+        base.calculate_loss(None)
+    d, model, params = load_s2s_dynfield()
+    assert "charges" in inspect.getfullargspec(model.calculate_loss).args
+
+    class FieldStub:                                    # experiments/electrostatic/electrostatic_field.py:21-34,96-102
+        @staticmethod
+        def _make_grid(box_size=5.0, grid_size=21, ndim=2):
+            lin = [torch.linspace(-box_size, box_size, grid_size) for _ in range(ndim)]
+            return torch.reshape(torch.stack(torch.meshgrid(*lin, indexing="ij")), (ndim, -1)).flip(0).T
+
+        @staticmethod
+        def _normalize(data):
+            return data / 5.0
+
+    model.field = FieldStub()
+    model = model.cuda()
+    inputs = torch.from_numpy(d["in.inputs"]).cuda()
+    got = model.predict_field_at_grid(inputs, box_size=2.0, grid_size=5)
+    grid = model.create_grid_points(box_size=2.0, grid_size=5)
+    assert grid.shape == (125, 3) and got.shape == (inputs.shape[0], 125, 3)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    summary = torch.from_numpy(d["ref.summary"])
+    want = S.film_field(sd, grid.unsqueeze(0).repeat(inputs.shape[0], 1, 1), summary, 3)
+    assert scale_rel_err(got.cpu(), want) <= 2 * TOL
