@@ -117,6 +117,11 @@ SIGNATURES = {
     "aether_dyn_decoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64]),
     "aether_dyn_decoder_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64] +
                                 [C.c_void_p] * 9 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aether_dyn_prior_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]),
+    "aether_dyn_prior_step": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_int64, C.c_int64] + [C.c_void_p] * 9 +
+                              [C.c_size_t] + [C.c_void_p] * 4),
+    "aether_dyn_field_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "aether_dyn_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "aether_s2s_gumbel_hard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "aether_dynamic_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

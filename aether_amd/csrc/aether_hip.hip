@@ -1052,6 +1052,155 @@ int aether_dyn_decoder_step(const AetherDynDecoderParams* p, int hidden, int num
     return AETHER_OK;
 }
 
+// ------------------------------------------------------------------ variable-N encoder prior step and field (N2)
+namespace {
+struct DynPriorLayout {
+    size_t ext, rel, relp, Rinv, ea, ea15, epos, hw, eaf, fpart, X0, X1, X3, Ps, Pr, T1, X4, G, Y1, Y2, bn, w0p, total;
+    int splits;
+    DynPriorLayout(int h, int R, int ph, int64_t Nn, int64_t E) {
+        size_t off = 0;
+        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+        const size_t nn = (size_t)Nn, ee = (size_t)E, hh = (size_t)h;
+        ext = take(nn * 6); rel = take(nn * 15); relp = take(nn * 16); Rinv = take(nn * 4);
+        ea = take(ee * 24); ea15 = take(ee * 15); epos = take(ee * 3); hw = take(ee * hh); eaf = take(ee * hh);
+        splits = S2SPriorLayout::filter_splits(h, E);
+        fpart = take(splits > 1 ? ee * hh * splits : 0);
+        X0 = take(nn * hh); X1 = take(nn * hh); X3 = take(nn * hh); Ps = take(nn * hh); Pr = take(nn * hh);
+        T1 = take(ee * hh); X4 = take(ee * hh); G = take(ee * 4 * (size_t)R);
+        Y1 = take(ee * (size_t)(ph > 0 ? ph : 1)); Y2 = take(ee * (size_t)(ph > 0 ? ph : 1));
+        bn = take(6 * hh); w0p = take(hh * 16);
+        total = off;
+    }
+};
+}  // namespace
+
+size_t aether_dyn_prior_workspace_bytes(int hidden, int rnn_hidden, int prior_hidden, int64_t n_nodes, int64_t n_edges) {
+    if (hidden <= 0 || rnn_hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
+    return DynPriorLayout(hidden, rnn_hidden, prior_hidden, n_nodes, n_edges).total;
+}
+
+int aether_dyn_prior_step(const AetherDynPriorParams* p, int hidden, int rnn_hidden, int prior_layers, int prior_hidden,
+                          int num_edge_types, int polar, int64_t n_nodes, int64_t n_edges, const float* inputs,
+                          const float* field, const float* h0, const float* c0, const int64_t* send, const int64_t* recv,
+                          const int64_t* order, const int64_t* rowptr, void* workspace, size_t workspace_bytes,
+                          float* logits, float* h1, float* c1, void* stream) {
+    if (!p || !inputs || !field || !h0 || !c0 || !send || !recv || !order || !rowptr || !workspace || !logits || !h1 || !c1)
+        return fail(AETHER_EINVAL, "dyn_prior: null pointer");
+    if (hidden < 128 || hidden % 128 != 0) return fail(AETHER_EINVAL, "dyn_prior: hidden must be a multiple of 128");
+    if (rnn_hidden < 16 || rnn_hidden % 16 != 0) return fail(AETHER_EINVAL, "dyn_prior: rnn_hidden must be a multiple of 16");
+    if (prior_layers < 1 || prior_layers > 4) return fail(AETHER_EINVAL, "dyn_prior: 1..4 prior layers");
+    if (prior_layers > 1 && (prior_hidden < 16 || prior_hidden % 16 != 0))
+        return fail(AETHER_EINVAL, "dyn_prior: prior_hidden must be a multiple of 16");
+    if (num_edge_types < 1 || num_edge_types > 4 || n_nodes <= 0 || n_edges <= 0)
+        return fail(AETHER_EINVAL, "dyn_prior: bad sizes");
+    constexpr int D = 2;
+    const int h = hidden, R = rnn_hidden, K = num_edge_types;
+    DynPriorLayout L(h, R, prior_hidden, n_nodes, n_edges);
+    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "dyn_prior: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int64_t Nn = n_nodes, E = n_edges;
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    // ---- canonical states, edge features, anisotropic filter (:531-539)
+    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
+    k_s2s_aug_nodes<2><<<blocks(Nn), dim3(256), 0, st>>>(wp(L.ext), wp(L.rel), wp(L.Rinv), Nn);
+    k_s2s_aug_edges<2><<<blocks(E), dim3(256), 0, st>>>(wp(L.ext), send, recv, wp(L.rel), polar, wp(L.ea), wp(L.epos), E);
+    k_s2s_pad_rows<<<blocks(E * 15), dim3(256), 0, st>>>(wp(L.ea), 15, 24, wp(L.ea15), 15, E);
+    k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0, p->filt_b0, wp(L.epos), 3, wp(L.hw), h, E, 1);
+    {
+        constexpr int NB = 4;
+        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128), (unsigned)L.splits);
+        if (L.splits > 1) {
+            k_s2s_filter<15, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea15), wp(L.hw), wp(L.fpart), h, E);
+            k_s2s_sum_planes<<<blocks(E * h / 4), dim3(256), 0, st>>>(wp(L.fpart), L.splits, E * (int64_t)h, wp(L.eaf));
+        } else {
+            k_s2s_filter<15, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea15), wp(L.hw), wp(L.eaf), h, E);
+        }
+    }
+    // ---- x = sum over in-edges + mlp1(canonical state) (:541-542); RefNRIMLP (eval): Linear-ELU-Linear-ELU-BatchNorm
+    float* bns[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    const float* bnp[3][4] = {{p->mlp1_bn_w, p->mlp1_bn_b, p->mlp1_bn_mean, p->mlp1_bn_var},
+                              {p->mlp3_bn_w, p->mlp3_bn_b, p->mlp3_bn_mean, p->mlp3_bn_var},
+                              {p->mlp4_bn_w, p->mlp4_bn_b, p->mlp4_bn_mean, p->mlp4_bn_var}};
+    for (int j = 0; j < 3; ++j) {
+        if (!bnp[j][0]) continue;
+        if (!bnp[j][1] || !bnp[j][2] || !bnp[j][3]) return fail(AETHER_EINVAL, "dyn_prior: incomplete BatchNorm pointers");
+        bns[j][0] = wp(L.bn) + 2 * j * h; bns[j][1] = wp(L.bn) + (2 * j + 1) * h;
+        k_s2s_bn_affine<<<blocks(h), dim3(256), 0, st>>>(bnp[j][0], bnp[j][1], bnp[j][2], bnp[j][3], bns[j][0], bns[j][1], h);
+    }
+    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.eaf), order, rowptr, wp(L.X0), h, 1.0f);
+    k_s2s_pad_rows<<<blocks(Nn * 16), dim3(256), 0, st>>>(wp(L.rel), 6, 15, wp(L.relp), 16, Nn);
+    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->mlp1_w0, 6, 6, wp(L.w0p), 16, h);
+    if (s2s_linear(4, wp(L.w0p), 16, p->mlp1_b0, wp(L.relp), wp(L.X1), h, 16, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(4, p->mlp1_w3, h, p->mlp1_b3, wp(L.X1), wp(L.X0), h, h, Nn, h, nullptr, 0, 1, st, nullptr, nullptr, nullptr,
+                   bns[0][0], bns[0][1])) return AETHER_EINVAL;
+    if (s2s_linear(4, p->mlp3_w0, h, p->mlp3_b0, wp(L.X0), wp(L.X1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(4, p->mlp3_w3, h, p->mlp3_b3, wp(L.X1), wp(L.X3), h, h, Nn, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr,
+                   bns[1][0], bns[1][1])) return AETHER_EINVAL;
+    // ---- mlp4 on [x_send | x_recv | edge] (:545-547)
+    if (s2s_linear(0, p->mlp4_w0, 3 * h, p->mlp4_b0, wp(L.X3), wp(L.Ps), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->mlp4_w0 + h, 3 * h, nullptr, wp(L.X3), wp(L.Pr), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->mlp4_w0 + 2 * h, 3 * h, nullptr, wp(L.eaf), wp(L.T1), h, h, E, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    k_s2s_edge_sum_elu<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.T1), wp(L.Ps), wp(L.Pr), send, recv, h, E);
+    if (s2s_linear(4, p->mlp4_w3, h, p->mlp4_b3, wp(L.T1), wp(L.X4), h, h, E, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr,
+                   bns[2][0], bns[2][1])) return AETHER_EINVAL;
+    // ---- one LSTM step per edge, prior_fc_out (:688-696)
+    if (s2s_linear(0, p->lstm_w_ih, h, p->lstm_b_ih, wp(L.X4), wp(L.G), 4 * R, h, E, 4 * R, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->lstm_w_hh, R, p->lstm_b_hh, h0, wp(L.G), 4 * R, R, E, 4 * R, nullptr, 0, 1, st)) return AETHER_EINVAL;
+    k_s2s_lstm_cell<<<blocks(E * R), dim3(256), 0, st>>>(wp(L.G), c0, h1, c1, R, E);
+    const float* cur = h1;
+    int cur_k = R;
+    for (int l = 0; l < prior_layers; ++l) {
+        const bool last = l + 1 == prior_layers;
+        float* dst = last ? logits : wp(l % 2 == 0 ? L.Y1 : L.Y2);
+        const int M = last ? K : prior_hidden;
+        if (s2s_linear(last ? 0 : 4, p->prior_w[l], cur_k, p->prior_b[l], cur, dst, M, cur_k, E, M, nullptr, 0, 0, st)) return AETHER_EINVAL;
+        cur = dst;
+        cur_k = M;
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
+size_t aether_dyn_field_workspace_bytes(int64_t n_points, int hidden) {
+    if (n_points <= 0 || hidden <= 0) return 0;
+    const size_t n = (size_t)n_points, h = (size_t)hidden;
+    return align_up(n * 16 * 4, 256) + align_up(h * 16 * 4, 256) + align_up(n * 2 * h * 4, 256) + 2 * align_up(n * h * 4, 256) + 256;
+}
+
+int aether_dyn_field(const AetherDynFieldQueryParams* p, int hidden, int64_t n_points, const float* x, void* workspace,
+                     size_t workspace_bytes, float* field, void* stream) {
+    if (!p || !x || !workspace || !field || !p->B || !p->ang_w || !p->ang_b || !p->w0 || !p->b0 || !p->w2 || !p->b2 ||
+        !p->w4 || !p->b4)
+        return fail(AETHER_EINVAL, "dyn_field: null pointer");
+    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "dyn_field: hidden must be a multiple of 32");
+    if (n_points <= 0) return fail(AETHER_EINVAL, "dyn_field: bad sizes");
+    if (workspace_bytes < aether_dyn_field_workspace_bytes(n_points, hidden))
+        return fail(AETHER_ESPACE, "dyn_field: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int h = hidden, half = hidden / 2;
+    const size_t n = (size_t)n_points;
+    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* q = ws + off; off += align_up(bytes, 256); return reinterpret_cast<float*>(q); };
+    float* dir = take(n * 16 * 4);
+    float* awp = take((size_t)h * 16 * 4);
+    float* cat = take(n * 2 * h * 4);                               // [rff (h) | angular embedding (h)]
+    float* h1 = take(n * h * 4);
+    float* h2 = take(n * h * 4);
+    auto blocks = [](int64_t c) { return dim3((unsigned)((c + 255) / 256)); };
+    k_s2s_rff<2><<<blocks(n_points * half), dim3(256), 0, st>>>(x, 4, p->B, half, cat, n_points, 2 * h);
+    k_s2s_unit_velocity<<<blocks(n_points), dim3(256), 0, st>>>(x, dir, n_points);
+    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->ang_w, 2, 2, awp, 16, h);
+    if (s2s_linear(0, awp, 16, p->ang_b, dir, cat + h, h, 16, n_points, 2 * h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(1, p->w0, 2 * h, p->b0, cat, h1, h, 2 * h, n_points, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(1, p->w2, h, p->b2, h1, h2, h, h, n_points, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    if (s2s_linear(0, p->w4, h, p->b4, h2, field, 2, h, n_points, 2, nullptr, 0, 0, st)) return AETHER_EINVAL;
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
 // ------------------------------------------------------------------ seq2seq dynamic-field variant (N3)
 namespace {
 struct S2SSummaryLayout {

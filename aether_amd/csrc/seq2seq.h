@@ -18,7 +18,8 @@ constexpr float TWO_PI_S2S = 6.28318530717958647692f;
 template <int D>
 __global__ void __launch_bounds__(256)
 k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ Bm, int half,
-          float* __restrict__ gamma, int64_t n_points) {
+          float* __restrict__ gamma, int64_t n_points, int ld = 0 /* row stride of gamma; 0: 2 half */) {
+    if (ld == 0) ld = 2 * half;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_points * half) return;
     const int64_t n = idx / half;
@@ -26,8 +27,8 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
     float p = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) p = fmaf(TWO_PI_S2S * x[n * x_stride + d], Bm[d * half + k], p);
-    gamma[n * 2 * half + k] = sinf(p);
-    gamma[n * 2 * half + half + k] = cosf(p);
+    gamma[n * ld + k] = sinf(p);
+    gamma[n * ld + half + k] = cosf(p);
 }
 
 // Y[n][m] = act(sum_k W[m][k] X[n][k] + b[m]); W [M][K] rows at stride ldw (nn.Linear), X [N][K], Y [N][ldy].
@@ -471,6 +472,19 @@ k_s2s_relu_scale_acc(const float* __restrict__ Fm, const float* __restrict__ w, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f) * we;
     st4(Mx + (size_t)e * h + c, ld4(Mx + (size_t)e * h + c) + v);
+}
+
+// dst[n][0..16) = [v / max(|v|, 1e-12) (2) | 0 ...], v = x[n][2..4)   (F.normalize of the velocity, padded to a k-group)
+__global__ void __launch_bounds__(256)
+k_s2s_unit_velocity(const float* __restrict__ x, float* __restrict__ dst, int64_t n_points) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_points) return;
+    const float vx = x[n * 4 + 2], vy = x[n * 4 + 3];
+    const float nrm = fmaxf(sqrtf(vx * vx + vy * vy), 1e-12f);
+    dst[n * 16] = vx / nrm;
+    dst[n * 16 + 1] = vy / nrm;
+#pragma unroll
+    for (int c = 2; c < 16; ++c) dst[n * 16 + c] = 0.0f;
 }
 
 // dst[i] = src[i] * s

@@ -1,0 +1,119 @@
+"""MI355X prediction path of the reference's variable-N model:
+``nn.dynamicvars.aether_dynamicvars.AetherDynamicVars`` (aether_dynamicvars.py:15-273) -- ``predict_field``,
+``single_step_forward`` and ``predict_future``, the path experiments/ind runs for its forecasting metrics.
+
+Sub-modules carry the reference's names (``encoder``, ``decoder``, ``field_net``, ``coordinate_embedding``,
+``angular_embedding``) and are created in its order, so a seeded construction or ``load_state_dict`` of a reference
+checkpoint gives the same weights.  The training loss (``calculate_loss``) and the posterior encoder are not part
+of this path.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ..seq2seq.encoder import gumbel_softmax_hard
+from ..seq2seq.field import _CoordinateEmbedding
+from .decoder import Decoder
+from .encoder import Encoder
+
+
+class _DynFieldQueryParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("B", "ang_w", "ang_b", "w0", "b0", "w2", "b2", "w4", "b4")]
+
+
+class AetherDynamicVars(nn.Module):
+    def __init__(self, params, device="cuda"):
+        super().__init__()
+        self.encoder = Encoder(params, device=None)                       # creation order of :19-62
+        self.decoder = Decoder(params, device=None)
+        self.num_edge_types = params.get("num_edge_types")
+        self.gumbel_temp = params.get("gumbel_temp")
+        self.num_dims = 2
+        self.field_hidden = hidden_size = params["field_hidden"]
+        if hidden_size % 32 != 0:
+            raise ValueError("field_hidden must be a multiple of 32")
+        self.field_net = nn.Sequential(nn.Linear(2 * hidden_size, hidden_size), nn.SiLU(),
+                                       nn.Linear(hidden_size, hidden_size), nn.SiLU(), nn.Linear(hidden_size, 2))
+        self.coordinate_embedding = _CoordinateEmbedding(2, hidden_size // 2, params.get("rff_std", 1.0))
+        self.angular_embedding = nn.Linear(2, hidden_size)
+        self._ws = None
+        if device is not None:
+            self.to(device)
+
+    @torch.no_grad()
+    def predict_field(self, x, masks=None):
+        """:64-79.  x [..., Nmax, 4] -> (field [..., Nmax, 2], zero where masks is 0; coords of the present objects)."""
+        if not x.is_cuda:
+            raise _lib.AetherHipError("aether_amd AetherDynamicVars runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        lib = _lib.load()
+        if masks is None:
+            masks = torch.ones_like(x[..., 0], dtype=torch.bool)
+        m = masks.to(x.device).bool()
+        predicted_field = torch.zeros_like(x[..., :2], dtype=torch.float32)
+        xs = x[m].detach().to(torch.float32).contiguous()
+        coords = torch.cat([xs[..., :2], nn.functional.normalize(xs[..., 2:], dim=-1)], -1)
+        n = xs.shape[0]
+        if n == 0:
+            return predicted_field, coords
+        h = self.field_hidden
+        fn = self.field_net
+        tensors = [self.coordinate_embedding.B, self.angular_embedding.weight, self.angular_embedding.bias, fn[0].weight,
+                   fn[0].bias, fn[2].weight, fn[2].bias, fn[4].weight, fn[4].bias]
+        for t in tensors:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise _lib.AetherHipError("field parameters must be contiguous fp32 CUDA tensors")
+        ps = _DynFieldQueryParams(*[t.data_ptr() for t in tensors])
+        need = lib.aether_dyn_field_workspace_bytes(n, h)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        out = torch.empty(n, 2, dtype=torch.float32, device=x.device)
+        st = lib.aether_dyn_field(C.byref(ps), h, n, xs.data_ptr(), self._ws.data_ptr(), self._ws.numel(), out.data_ptr(),
+                                  torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(st, "aether_dyn_field")
+        predicted_field[m] = out
+        return predicted_field, coords
+
+    @torch.no_grad()
+    def single_step_forward(self, inputs, node_masks, graph_info, decoder_hidden, edge_logits, hard_sample, current_field,
+                            uniform=None):
+        """:133-145.  ``uniform``: the U(0,1) draw of gumbel_softmax ([E, K]); drawn on the device when omitted."""
+        if not hard_sample:
+            raise _lib.AetherHipError("only hard_sample=True (evaluation / prediction) is part of this path")
+        if edge_logits.nelement() != 0:
+            if uniform is None:
+                uniform = torch.rand(edge_logits.shape, device=edge_logits.device)
+            edges = gumbel_softmax_hard(edge_logits, uniform.reshape(edge_logits.shape).to(edge_logits.device), self.gumbel_temp)
+        else:
+            edges = torch.empty_like(edge_logits)
+        predictions, decoder_hidden = self.decoder(inputs, decoder_hidden, edges, node_masks, graph_info, current_field)
+        return predictions, decoder_hidden, edges
+
+    @torch.no_grad()
+    def predict_future(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
+        """:245-273.  inputs [1, T, Nmax, 4], masks / burn_in_masks [1, T, Nmax], node_inds[0][t], graph_info[0][t]: the
+        present objects and their graph per time step.  ``uniform``: per-step Gumbel draws (list of [E_t, K])."""
+        total_timesteps = inputs.size(1)
+        prior_hidden = self.encoder.get_initial_hidden(inputs)
+        decoder_hidden = self.decoder.get_initial_hidden(inputs)
+        predictions = inputs[:, 0]
+        preds = []
+        for step in range(total_timesteps - 1):
+            current_masks = masks[:, step]
+            current_burn_in_masks = burn_in_masks[:, step].unsqueeze(-1).type(inputs.dtype)
+            current_inps = inputs[:, step]
+            current_node_inds = node_inds[0][step]
+            current_graph_info = graph_info[0][step]
+            encoder_inp = current_burn_in_masks * current_inps + (1 - current_burn_in_masks) * predictions
+            current_field, _ = self.predict_field(encoder_inp, current_masks)
+            current_edge_logits, prior_hidden = self.encoder.single_step_forward(
+                encoder_inp, current_masks, current_node_inds, current_graph_info, prior_hidden, current_field)
+            predictions, decoder_hidden, _ = self.single_step_forward(
+                encoder_inp, current_masks, current_graph_info, decoder_hidden, current_edge_logits, True, current_field,
+                None if uniform is None else uniform[step])
+            preds.append(predictions)
+        return torch.stack(preds, dim=1)

@@ -467,6 +467,52 @@ int aether_dyn_decoder_step(const AetherDynDecoderParams* params, int hidden, in
                             void* workspace, size_t workspace_bytes, float* outputs, float* hidden_out, void* stream);
 
 /*
+ * Variable-N models, one step of the encoder's prior and the field query: with
+ * aether_knn_edges, aether_dyn_decoder_step and aether_s2s_gumbel_hard the whole prediction step of
+ * AetherDynamicVars.predict_future (nn/dynamicvars/aether_dynamicvars.py:245-273).
+ *
+ * aether_dyn_prior_step replaces Encoder.compute_feat_transform for one time step (:505-557) + the LSTM / prior
+ * half of Encoder.single_step_forward (:688-696) on the present objects of a scene: canonical states, edge features
+ * [9 | receiver's canonical state 6], anisotropic filter (ReLU hidden layer), SUM over the in-edges of an object +
+ * mlp1(canonical state), mlp3, [x_send | x_recv | edge] -> mlp4 (RefNRIMLP in eval mode; bn pointers may all be
+ * NULL: no_encoder_bn), one LSTM step per edge, prior_fc_out.
+ *   inputs [n][4], field [n][2] : the present objects, compacted;  send, recv int64[e] (compacted; features of
+ *   send -> recv in recv's frame, as aether_knn_edges lists them);  order, rowptr : edges grouped by recv (CSR)
+ *   h0, c0 [e][R] : the LSTM state rows of these edges (the reference keeps one slot per fully connected pair and
+ *   gathers / scatters them, :684-694: that indexing stays with the caller);  logits [e][K], h1, c1 [e][R]
+ * aether_dyn_field replaces AetherDynamicVars.predict_field (:64-79) on the present objects: Fourier features of the
+ * position (hidden/2 frequencies), angular_embedding Linear(2, hidden) of the unit velocity, field_net
+ * Linear(2 hidden, hidden)-SiLU-Linear-SiLU-Linear(hidden, 2).   x [n][4] -> field [n][2]
+ */
+typedef struct AetherDynPriorParams {
+    const float* mlp1_w0; const float* mlp1_b0; const float* mlp1_w3; const float* mlp1_b3;       /* [h][6], [h][h] */
+    const float* mlp1_bn_w; const float* mlp1_bn_b; const float* mlp1_bn_mean; const float* mlp1_bn_var;
+    const float* mlp3_w0; const float* mlp3_b0; const float* mlp3_w3; const float* mlp3_b3;       /* [h][h] */
+    const float* mlp3_bn_w; const float* mlp3_bn_b; const float* mlp3_bn_mean; const float* mlp3_bn_var;
+    const float* mlp4_w0; const float* mlp4_b0; const float* mlp4_w3; const float* mlp4_b3;       /* [h][3h], [h][h] */
+    const float* mlp4_bn_w; const float* mlp4_bn_b; const float* mlp4_bn_mean; const float* mlp4_bn_var;
+    const float* lstm_w_ih; const float* lstm_w_hh; const float* lstm_b_ih; const float* lstm_b_hh; /* [4R][h], [4R][R] */
+    const float* prior_w[4]; const float* prior_b[4];                                            /* prior_fc_out */
+    const float* filt_w0; const float* filt_b0;                                                  /* [h][3] */
+    const float* filt_w2; const float* filt_b2;                                                  /* [15 h][h] */
+} AetherDynPriorParams;
+size_t aether_dyn_prior_workspace_bytes(int hidden, int rnn_hidden, int prior_hidden, int64_t n_nodes, int64_t n_edges);
+int aether_dyn_prior_step(const AetherDynPriorParams* params, int hidden, int rnn_hidden, int prior_layers,
+                          int prior_hidden, int num_edge_types, int polar, int64_t n_nodes, int64_t n_edges,
+                          const float* inputs, const float* field, const float* h0, const float* c0,
+                          const int64_t* send, const int64_t* recv, const int64_t* order, const int64_t* rowptr,
+                          void* workspace, size_t workspace_bytes, float* logits, float* h1, float* c1, void* stream);
+typedef struct AetherDynFieldQueryParams {
+    const float* B;                                            /* coordinate_embedding.B [2][hidden/2] */
+    const float* ang_w; const float* ang_b;                    /* angular_embedding [hidden][2], [hidden] */
+    const float* w0; const float* b0; const float* w2; const float* b2; const float* w4; const float* b4;
+                                                               /* field_net.{0,2,4}: [h][2h], [h][h], [2][h] */
+} AetherDynFieldQueryParams;
+size_t aether_dyn_field_workspace_bytes(int64_t n_points, int hidden);
+int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_t n_points, const float* x,
+                     void* workspace, size_t workspace_bytes, float* field, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

@@ -82,3 +82,137 @@ def decoder_step(sd, inputs, hidden, edges, node_masks, graph_info, predicted_fi
     pred_all = torch.zeros_like(inputs)
     pred_all[0, node_inds] = pred[0]
     return pred_all, new_hidden
+
+
+# ---------------------------------------------------------------------------------------------
+# Encoder prior step, field query and predict_future of the variable-N model
+#   Encoder.compute_feat_transform    <- aether_dynamicvars.py:505-557 (one time step: kNN graph of the present
+#                                        objects, anisotropic filter with a ReLU hidden layer, SUM over receivers
+#                                        + mlp1(rel_feat), mlp3, node2edge | skip, mlp4; RefNRIMLP in eval mode)
+#   Encoder.single_step_forward       <- :672-699 (LSTM state kept per fully-connected edge slot
+#                                        send * (Nmax - 1) + recv - (recv >= send), gathered / scattered per step)
+#   AetherDynamicVars.predict_field   <- :64-79 (Fourier features of the position, a Linear on the unit velocity)
+#   AetherDynamicVars.predict_future  <- :245-273 (burn-in masks choose observation or own prediction per object)
+# The feature rows follow the kNN graph the encoder builds from the CURRENT inputs (:528), the state slots follow
+# the caller's graph_info -- as in the reference.
+# Parity status: PINNED by tests/golden/dyn_model.npz (imported reference AetherDynamicVars).
+# ---------------------------------------------------------------------------------------------
+def _refnri(sd, prefix, x):
+    x = F.elu(F.linear(x, sd[prefix + ".model.0.weight"], sd[prefix + ".model.0.bias"]))
+    x = F.elu(F.linear(x, sd[prefix + ".model.3.weight"], sd[prefix + ".model.3.bias"]))
+    if prefix + ".bn.weight" in sd:
+        x = F.batch_norm(x.reshape(-1, x.shape[-1]), sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"],
+                         sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], False, 0.0, 1e-5).view(x.shape)
+    return x
+
+
+def _lstm_cell(sd, prefix, x, h, c):
+    g = F.linear(x, sd[prefix + "weight_ih_l0"], sd[prefix + "bias_ih_l0"]) + \
+        F.linear(h, sd[prefix + "weight_hh_l0"], sd[prefix + "bias_hh_l0"])
+    i, f, gg, o = g.chunk(4, -1)
+    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+    return torch.sigmoid(o) * torch.tanh(c), c
+
+
+def encoder_features(sd, inputs, node_masks, predicted_field, pos_representation="cart", k=10):
+    """compute_feat_transform for one time step: inputs [1, Nmax, 4] -> per-edge features [E, h] (kNN edges of the
+    present objects, query object first) and the edge lists."""
+    try:
+        from .knn_oracle import knn_edges
+    except ImportError:
+        from knn_oracle import knn_edges
+    ext = torch.cat([inputs, predicted_field], -1)[0]                                  # :507
+    mask = node_masks.reshape(-1)
+    s, r, _ = knn_edges(ext.numpy()[None, None], mask.numpy()[None, None], k)          # :528
+    send, recv = torch.from_numpy(s), torch.from_numpy(r)
+    flat = ext[mask.bool()]
+    rel_feat, _ = canonicalize_augmented(flat[None], False)
+    ea = augmented_edge_attr(flat[None], send, recv, False)                            # :535-536
+    edge_pos = ea[..., EDGE_POS_IDX[(False, pos_representation)]]
+    ea = torch.cat([ea, rel_feat[:, recv]], -1)[0]
+    lin = lambda name, v: F.linear(v, sd[name + ".weight"], sd[name + ".bias"])
+    w = lin("edge_filter.edge_filter.2", torch.relu(lin("edge_filter.edge_filter.0", edge_pos[0])))
+    w = w.reshape(w.shape[0], ea.shape[-1], -1)
+    e = (ea.unsqueeze(-2) @ w).squeeze(-2)                                             # :539
+    x = torch.zeros(flat.shape[0], e.shape[-1], dtype=e.dtype).index_add_(0, recv, e) + _refnri(sd, "mlp1", rel_feat[0])
+    x = _refnri(sd, "mlp3", x)
+    x = torch.cat([x[send], x[recv], e], -1)                                           # :545-546
+    return _refnri(sd, "mlp4", x), send, recv
+
+
+def encoder_single_step(sd, inputs, node_masks, node_inds, graph_info, forward_state, predicted_field,
+                        pos_representation="cart"):
+    """Encoder.single_step_forward: -> (prior logits [1, E, K], (h, c) [1, Nmax (Nmax - 1), R])."""
+    Nmax = inputs.shape[1]
+    lin = lambda name, v: F.linear(v, sd[name + ".weight"], sd[name + ".bias"])
+    if len(node_inds) <= 1:
+        K = [v for k_, v in sd.items() if k_.startswith("prior_fc_out") and k_.endswith("weight")][-1].shape[0]
+        return torch.empty(1, 0, K), forward_state
+    x, _, _ = encoder_features(sd, inputs, node_masks, predicted_field, pos_representation)
+    send, recv, _ = graph_info
+    gs, gr = node_inds[send], node_inds[recv]
+    slot = gs * (Nmax - 1) + gr - (gr >= gs).long()                                   # :684
+    h, c = _lstm_cell(sd, "forward_rnn.", x, forward_state[0][0, slot], forward_state[1][0, slot])
+    h_all, c_all = forward_state[0].clone(), forward_state[1].clone()
+    h_all[0, slot], c_all[0, slot] = h, c
+    y = h
+    names = sorted({k_.rsplit(".", 1)[0] for k_ in sd if k_.startswith("prior_fc_out")},
+                   key=lambda n: int(n.split(".")[-1]) if n.split(".")[-1].isdigit() else 0)
+    for j, n in enumerate(names):
+        y = lin(n, y)
+        if j + 1 < len(names):
+            y = F.elu(y)
+    return y.unsqueeze(0), (h_all, c_all)
+
+
+def predict_field(sd, x, masks=None):
+    """AetherDynamicVars.predict_field: x [1, Nmax, 4] -> field [1, Nmax, 2] (zero for absent objects)."""
+    try:
+        from .seq2seq_oracle import fourier_features
+    except ImportError:
+        from seq2seq_oracle import fourier_features
+    if masks is None:
+        masks = torch.ones_like(x[..., 0])
+    m = masks.reshape(x.shape[:-1]).bool()
+    out = torch.zeros_like(x[..., :2])
+    xs = x[m]
+    rff = fourier_features(xs[..., :2], sd["coordinate_embedding.B"])
+    ang = F.linear(F.normalize(xs[..., 2:], dim=-1), sd["angular_embedding.weight"], sd["angular_embedding.bias"])
+    hcat = torch.cat([rff, ang], -1)
+    hcat = F.silu(F.linear(hcat, sd["field_net.0.weight"], sd["field_net.0.bias"]))
+    hcat = F.silu(F.linear(hcat, sd["field_net.2.weight"], sd["field_net.2.bias"]))
+    out[m] = F.linear(hcat, sd["field_net.4.weight"], sd["field_net.4.bias"])
+    return out
+
+
+def predict_future(sd, inputs, masks, node_inds, graph_info, burn_in_masks, uniform, tau, skip_first=False,
+                   pos_representation="cart"):
+    """inputs [1, T, Nmax, 4], masks / burn_in_masks [1, T, Nmax], node_inds / graph_info: per time step;
+    uniform: the U(0,1) draws of gumbel_softmax per step (list of [E_t, K])."""
+    try:
+        from .seq2seq_oracle import gumbel_hard
+    except ImportError:
+        from seq2seq_oracle import gumbel_hard
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    dec = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    T, Nmax = inputs.shape[1], inputs.shape[2]
+    R, hdec = enc["forward_rnn.weight_hh_l0"].shape[1], dec["hidden_r.weight"].shape[0]
+    prior = (torch.zeros(1, Nmax * (Nmax - 1), R), torch.zeros(1, Nmax * (Nmax - 1), R))
+    dh = torch.zeros(1, Nmax, hdec)
+    predictions = inputs[:, 0]
+    preds = []
+    for step in range(T - 1):
+        cm = masks[:, step]
+        bm = burn_in_masks[:, step].unsqueeze(-1).type(inputs.dtype)
+        enc_inp = bm * inputs[:, step] + (1 - bm) * predictions                       # :264
+        field = predict_field(sd, enc_inp, cm)
+        logits, prior = encoder_single_step(enc, enc_inp, cm, node_inds[step], graph_info[step], prior, field,
+                                            pos_representation)
+        if logits.numel():
+            edges = gumbel_hard(logits.reshape(-1, logits.shape[-1]), uniform[step], tau).view(logits.shape)
+        else:
+            edges = torch.empty_like(logits)
+        predictions, dh = decoder_step(dec, enc_inp, dh, edges, cm, graph_info[step], field, skip_first,
+                                       pos_representation)
+        preds.append(predictions)
+    return torch.stack(preds, dim=1)

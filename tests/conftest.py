@@ -184,3 +184,30 @@ def load_dyn_decoder(name):
     case = {k[len(name) + 1:]: _torch.from_numpy(d[k]) for k in d.files
             if k.startswith(name + ".") and not any(t in k for t in (".sum.", ".abs.", ".keys", ".seed"))}
     return case, dec, params
+
+
+def load_dyn_model():
+    """Golden fixture of the reference's ``AetherDynamicVars`` + the model recreated from the stored seed through the
+    drop-in constructor (key order and checksums verified; BatchNorm statistics perturbed as in the fixture script)."""
+    import numpy as _np
+    import torch as _torch
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_dynamicvars import MODEL_PARAMS, perturb_bn_
+    from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+    d = _np.load(os.path.join(GOLDEN, "dyn_model.npz"))
+    _torch.manual_seed(int(d["seed"]))
+    model = AetherDynamicVars(dict(MODEL_PARAMS), device=None).eval()
+    perturb_bn_(model)
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in d["keys"]]
+    for k, v in sd.items():
+        if "sum." + k in d:
+            tol = 1e-6 if "edge_filter" in k and k.endswith("weight") else 1e-9       # see load_dyn_decoder
+            assert abs(float(v.double().sum()) - float(d["sum." + k])) <= tol * max(1.0, float(d["abs." + k])), k
+    T = int(d["T"])
+    t = lambda k: _torch.from_numpy(d[k])
+    case = {"inputs": t("inputs"), "masks": t("masks"), "burn": t("burn"),
+            "graph_info": [tuple(t(f"{n}.{i}") for n in ("send", "recv", "e2n")) for i in range(T)],
+            "uniform": [t(f"uniform.{i}") for i in range(T - 1)]}
+    case["node_inds"] = [case["masks"][0, i].nonzero()[:, -1] for i in range(T)]
+    return d, case, model, dict(MODEL_PARAMS)

@@ -68,3 +68,65 @@ def test_decoder_errors():
         dec(torch.randn(2, 4, 4).cuda(), h.cuda(), None, one, None, f.cuda())
     with pytest.raises(ValueError):
         Decoder(dict(params, decoder_hidden=96), device="cuda")
+
+
+# ---------------------------------------------------------------- encoder prior step, field query, predict_future
+def test_model_prediction_path_matches_reference():
+    from conftest import load_dyn_model
+    d, c, model, params = load_dyn_model()
+    model = model.cuda()
+    t = lambda k: torch.from_numpy(d[k])
+    x0, m0 = c["inputs"][:, 0].cuda(), c["masks"][:, 0].cuda()
+    field0, coords = model.predict_field(x0, m0)
+    assert scale_rel_err(field0.cpu(), t("ref.field0")) <= TOL
+    assert coords.shape == (int(c["masks"][0, 0].sum()), 4)
+    gi0 = tuple(g.cuda() for g in c["graph_info"][0])
+    logits0, (h1, c1) = model.encoder.single_step_forward(x0, m0, c["node_inds"][0].cuda(), gi0,
+                                                          (t("state0.h").cuda(), t("state0.c").cuda()), t("ref.field0").cuda())
+    assert scale_rel_err(logits0.cpu(), t("ref.logits0")) <= TOL
+    assert scale_rel_err(h1.cpu(), t("ref.state1.h")) <= TOL and scale_rel_err(c1.cpu(), t("ref.state1.c")) <= TOL
+    node_inds = [[n.cuda() for n in c["node_inds"]]]
+    graph_info = [[tuple(g.cuda() for g in gi) for gi in c["graph_info"]]]
+    preds = model.predict_future(c["inputs"].cuda(), c["masks"].cuda(), node_inds, graph_info, c["burn"].cuda(),
+                                 uniform=[u.cuda() for u in c["uniform"]])
+    assert preds.shape == t("ref.predictions").shape
+    assert scale_rel_err(preds.cpu(), t("ref.predictions")) <= TOL
+    free = model.predict_future(c["inputs"].cuda(), c["masks"].cuda(), node_inds, graph_info, c["burn"].cuda())
+    assert torch.isfinite(free).all()
+
+
+def test_model_vs_oracle_ind_sizes():
+    """inD-like sizes: hidden 256, 4 edge types (first skipped), 30 object slots, kNN graphs with k = 10 built on the
+    device; BatchNorm with perturbed statistics; polar edge positions."""
+    from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+    import sys, os
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_dynamicvars import MODEL_PARAMS, perturb_bn_
+    params = dict(MODEL_PARAMS, decoder_hidden=256, encoder_hidden=256, num_edge_types=4, pos_representation="polar",
+                  field_hidden=128, encoder_rnn_hidden=64)
+    torch.manual_seed(23)
+    model = AetherDynamicVars(params, device=None).eval()
+    perturb_bn_(model)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    g = torch.Generator().manual_seed(24)
+    T, N = 4, 30
+    inputs = torch.randn(1, T, N, 4, generator=g)
+    masks = (torch.rand(1, T, N, generator=g) < 0.7).float()
+    masks[:, :, :3] = 1
+    burn = torch.ones(1, T, N)
+    burn[:, 2:] = 0
+    node_inds, graph_info, U = [], [], []
+    for step in range(T):
+        nv = int(masks[0, step].sum())
+        send, recv = get_knn_graph_info(inputs[0, step].cuda(), masks[0, step].cuda(), nv)
+        e2n = torch.argsort(recv, stable=True).view(-1, min(10, nv - 1))
+        graph_info.append((send.cpu(), recv.cpu(), e2n.cpu()))
+        node_inds.append(masks[0, step].nonzero()[:, -1])
+        U.append(torch.rand(send.numel(), 4, generator=g))
+    want = DO.predict_future(sd, inputs, masks, node_inds, graph_info, burn, U[:T - 1], 0.5, True, "polar")
+    got = model.predict_future(inputs.cuda(), masks.cuda(), [[n.cuda() for n in node_inds]],
+                               [[tuple(x.cuda() for x in gi) for gi in graph_info]], burn.cuda(),
+                               uniform=[u.cuda() for u in U[:T - 1]])
+    assert scale_rel_err(got.cpu(), want) <= 2 * TOL

@@ -288,3 +288,23 @@ def test_dynamicvars_decoder_step(name):
     pred, hid = DO.decoder_step(sd, c["inputs"], c["hidden"], c["edges"], c["masks"], gi, c["field"],
                                 params["skip_first"], params["pos_representation"])
     assert scale_rel_err(pred, c["ref.pred"]) <= 2e-6 and scale_rel_err(hid, c["ref.hidden"]) <= 2e-6
+
+
+def test_dynamicvars_model_prediction_path():
+    """field query, encoder prior step and the whole predict_future of the imported reference
+    AetherDynamicVars (objects appearing / disappearing, own predictions fed back after the burn-in)."""
+    from conftest import load_dyn_model
+    from oracle import dynamicvars_oracle as DO
+    d, c, model, params = load_dyn_model()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    t = lambda k: torch.from_numpy(d[k])
+    field0 = DO.predict_field(sd, c["inputs"][:, 0], c["masks"][:, 0])
+    assert scale_rel_err(field0, t("ref.field0")) <= 2e-6
+    logits0, (h1, c1) = DO.encoder_single_step(enc, c["inputs"][:, 0], c["masks"][:, 0], c["node_inds"][0],
+                                               c["graph_info"][0], (t("state0.h"), t("state0.c")), t("ref.field0"))
+    assert scale_rel_err(logits0, t("ref.logits0")) <= 5e-6
+    assert scale_rel_err(h1, t("ref.state1.h")) <= 5e-6 and scale_rel_err(c1, t("ref.state1.c")) <= 5e-6
+    preds = DO.predict_future(sd, c["inputs"], c["masks"], c["node_inds"], c["graph_info"], c["burn"], c["uniform"], 0.5,
+                              True, "cart")
+    assert scale_rel_err(preds, t("ref.predictions")) <= 2e-6
