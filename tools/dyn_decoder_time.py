@@ -33,3 +33,34 @@ for N in (20, 40, 400):
     torch.cuda.synchronize()
     dk = (time.perf_counter() - t0) / 50
     print("N=%3d (%5d edges): decoder step %.3f ms, kNN graph %.3f ms" % (N, send.numel(), dt * 1e3, dk * 1e3))
+
+# the whole prediction step of AetherDynamicVars.predict_future at inD sizes (scripts/ind_aether.sh)
+import sys as _sys
+_sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+mp = {"input_size": 4, "gpu": True, "decoder_hidden": 256, "num_edge_types": 4, "skip_first": True, "decoder_dropout": 0.0,
+      "pos_representation": "cart", "no_encoder_bn": False, "encoder_dropout": 0.0, "encoder_hidden": 256,
+      "encoder_rnn_hidden": 64, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 128,
+      "prior_num_layers": 3, "prior_hidden_size": 128, "encoder_normalize_mode": "normalize_all", "train_data_len": 50,
+      "field_hidden": 256, "gumbel_temp": 0.5}
+model = AetherDynamicVars(mp, device="cuda").eval()
+for N in (20, 40):
+    T = 50
+    g = torch.Generator().manual_seed(N)
+    inputs = torch.randn(1, T, N, 4, generator=g).cuda()
+    masks = torch.ones(1, T, N).cuda()
+    burn = torch.ones(1, T, N).cuda()
+    burn[:, 10:] = 0
+    node_inds, graph_info = [[]], [[]]
+    for t in range(T):
+        send, recv = get_knn_graph_info(inputs[0, t], masks[0, t], N)
+        graph_info[0].append((send, recv, torch.argsort(recv, stable=True).view(-1, 10)))
+        node_inds[0].append(torch.arange(N, device="cuda"))
+    model.predict_future(inputs[:, :5], masks[:, :5], node_inds, graph_info, burn[:, :5])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.predict_future(inputs, masks, node_inds, graph_info, burn)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("predict_future N=%d, %d steps: %.1f ms (%.2f ms per step: field + kNN + prior step + sample + decoder step)"
+          % (N, T - 1, dt * 1e3, dt * 1e3 / (T - 1)))
