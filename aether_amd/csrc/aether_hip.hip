@@ -1426,6 +1426,23 @@ int aether_sim_electrostatic(const double* loc0, const double* vel0, const doubl
     return AETHER_OK;
 }
 
+int aether_sim_charged(const double* loc0, const double* vel0, const double* charges, int64_t n_sims, int n_balls, int T,
+                       int sample_freq, double interaction_strength, double delta_T, double max_F, int ext_mode,
+                       const double* ext, double* loc, double* vel, void* stream) {
+    if (!loc0 || !vel0 || !charges || (T / (sample_freq > 0 ? sample_freq : 1) > 1 && (!loc || !vel)))
+        return fail(AETHER_EINVAL, "sim_charged: null pointer");
+    if (int rc = sim_check(n_sims, n_balls, n_balls, 3, T, sample_freq)) return rc;
+    if (ext_mode < 0 || ext_mode > 2 || (ext_mode != 0 && !ext)) return fail(AETHER_EINVAL, "sim_charged: bad ext_mode / ext");
+    hipStream_t st = (hipStream_t)stream;
+    const int spw = 64 / n_balls;
+    const dim3 grid((unsigned)((n_sims + spw - 1) / spw));
+    k_sim_charged<<<grid, dim3(64), 0, st>>>(loc0, vel0, charges, n_sims, n_balls, T, sample_freq, interaction_strength, delta_T,
+                                             max_F, ext_mode, ext_mode ? ext[0] : 0.0, ext_mode ? ext[1] : 0.0,
+                                             ext_mode ? ext[2] : 0.0, loc, vel);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
 int aether_sim_gravitational(const double* pos0, const double* vel0, const double* mass, int64_t n_sims, int n_balls,
                              int total_balls, int dim, int T, int sample_freq, double interaction_strength, double dt,
                              double softening, double* pos, double* vel, double* force, void* stream) {

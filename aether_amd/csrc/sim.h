@@ -193,4 +193,98 @@ k_sim_gravitational(const double* __restrict__ pos0, const double* __restrict__ 
     }
 }
 
+// The n-body simulators behind the state2state runner's data sets (experiments/lorentz/dataset/synthetic_sim.py):
+//   ChargedParticlesSim.sample_trajectory :221-300   ('charged':  Coulomb forces only)
+//   GravitySim.sample_trajectory          :375-460   ('static':   + a constant force 0.098 on z)
+//   DynamicSim.sample_trajectory          :536-622   ('dynamic':  + the Lorentz force q (v x B), B = 0.5 (1, 1, 1))
+// 3-D, all balls move, squared distances from the expansion |a|^2 + |b|^2 - 2 a.b + 1e-6 (:167-178), every force
+// COMPONENT clipped to +-max_F (:276-277), leap-frog; frames are stored [T_save][3][n] as the reference does.
+// ext_mode 0: none, 1: F += ext (constant vector), 2: F += q (v x ext).
+__global__ void __launch_bounds__(64)
+k_sim_charged(const double* __restrict__ loc0, const double* __restrict__ vel0, const double* __restrict__ charges,
+              int64_t n_sims, int M, int T, int sample_freq, double strength, double dt, double max_F, int ext_mode,
+              double e0, double e1, double e2, double* __restrict__ loc, double* __restrict__ vel) {
+#pragma clang fp contract(off)
+    constexpr int D = 3;
+    __shared__ double pos[64 * D];
+    __shared__ double nrm[64];
+    __shared__ double qs[64];
+    const int lane = threadIdx.x;
+    const int spw = 64 / M;
+    const int sl = lane / M, i = lane - sl * M;
+    const int64_t s = (int64_t)blockIdx.x * spw + sl;
+    const bool active = sl < spw && s < n_sims;
+    const int T_save = T / sample_freq - 1;
+    double x[D] = {0.0, 0.0, 0.0}, v[D] = {0.0, 0.0, 0.0}, q = 0.0;
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {                                  // inputs [S][3][M], as the reference lays them out
+            x[d] = loc0[((size_t)s * D + d) * M + i];
+            v[d] = vel0[((size_t)s * D + d) * M + i];
+        }
+        q = charges[(size_t)s * M + i];
+        if (T_save > 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {                              // frame 0 = the initial state until the first save
+                loc[(((size_t)s * T_save) * D + d) * M + i] = x[d];
+                vel[(((size_t)s * T_save) * D + d) * M + i] = v[d];
+            }
+        }
+    }
+    double* mine = pos + (size_t)sl * M * D;
+    double* myn = nrm + sl * M;
+    qs[lane] = q;
+    const double* myq = qs + sl * M;
+    int counter = 0;
+    for (int step = 0; step < T; ++step) {
+        if (step > 0) {
+            if (active) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) x[d] = x[d] + dt * v[d];
+            }
+            if (step % sample_freq == 0) {
+                if (active) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        loc[(((size_t)s * T_save + counter) * D + d) * M + i] = x[d];
+                        vel[(((size_t)s * T_save + counter) * D + d) * M + i] = v[d];
+                    }
+                }
+                ++counter;
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) mine[i * D + d] = x[d];
+            myn[i] = (x[0] * x[0] + x[1] * x[1]) + x[2] * x[2];
+        }
+        __syncthreads();
+        if (active) {
+            double F[D] = {0.0, 0.0, 0.0};
+            const double ni = myn[i];
+            for (int j = 0; j < M; ++j) {
+                const double dot = (x[0] * mine[j * D] + x[1] * mine[j * D + 1]) + x[2] * mine[j * D + 2];
+                const double l2 = ((ni + myn[j]) - 2.0 * dot) + 1e-6;                   // _l2, :167-178
+                const double fs = j == i ? 0.0 : (strength * (q * myq[j])) / (l2 * sqrt(l2));
+#pragma unroll
+                for (int d = 0; d < D; ++d) F[d] = F[d] + fs * (x[d] - mine[j * D + d]);
+            }
+            if (ext_mode == 1) {
+                F[0] = F[0] + e0; F[1] = F[1] + e1; F[2] = F[2] + e2;
+            } else if (ext_mode == 2) {                                                  // np.cross(v, B) * q
+                F[0] = F[0] + (v[1] * e2 - v[2] * e1) * q;
+                F[1] = F[1] + (v[2] * e0 - v[0] * e2) * q;
+                F[2] = F[2] + (v[0] * e1 - v[1] * e0) * q;
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                F[d] = F[d] > max_F ? max_F : F[d];
+                F[d] = F[d] < -max_F ? -max_F : F[d];
+                v[d] = v[d] + dt * F[d];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace

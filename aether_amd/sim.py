@@ -11,6 +11,8 @@ simulations -- runs in ``aether_sim_electrostatic`` / ``aether_sim_gravitational
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -201,3 +203,123 @@ class GravitationalFieldSim(object):
         """gravitational_field_sim.py:75-131: (pos, vel, force [T_save, M, D], mass [M, 1])."""
         pos, vel, force, mass = self.sample_trajectories(1, T, sample_freq)
         return pos[0], vel[0], force[0], mass[0]
+
+
+class _LorentzFamilySim(object):
+    """Common part of experiments/lorentz/dataset/synthetic_sim.py's ChargedParticlesSim / GravitySim / DynamicSim
+    (the data sets of the state2state runner): constructor, ``_clamp`` and the random draws of ``sample_trajectory``
+    on the host (global numpy generator, seeded per trajectory as the reference does), integration in
+    ``aether_sim_charged``."""
+
+    _ext_mode, _ext = 0, (0.0, 0.0, 0.0)
+
+    def __init__(self, n_balls=5, box_size=5., loc_std=1., vel_norm=0.5, interaction_strength=1., noise_var=0.,
+                 device="cuda"):
+        self.n_balls = n_balls
+        self.box_size = box_size
+        self.loc_std = loc_std * (float(n_balls) / 5.) ** (1 / 3)
+        print(self.loc_std)                                                 # synthetic_sim.py:156
+        self.vel_norm = vel_norm
+        self.interaction_strength = interaction_strength
+        self.noise_var = noise_var
+        self._charge_types = np.array([-1., 0., 1.])
+        self._delta_T = 0.001
+        self._max_F = 0.1 / self._delta_T
+        self.dim = 3
+        self.device = device
+        if n_balls > 64:
+            raise ValueError("at most 64 balls per simulation")
+
+    def _clamp(self, loc, vel):
+        assert (np.all(loc < self.box_size * 3))                           # :196-219
+        assert (np.all(loc > -self.box_size * 3))
+        over = loc > self.box_size
+        loc[over] = 2 * self.box_size - loc[over]
+        assert (np.all(loc <= self.box_size))
+        vel[over] = -np.abs(vel[over])
+        under = loc < -self.box_size
+        loc[under] = -2 * self.box_size - loc[under]
+        assert (np.all(loc >= -self.box_size))
+        vel[under] = np.abs(vel[under])
+        return loc, vel
+
+    def _draw_initial(self, seed, charge_prob):
+        n = self.n_balls
+        np.random.seed(seed)                                               # :229
+        charges = np.random.choice(self._charge_types, size=(n, 1), p=charge_prob)
+        loc0 = np.random.randn(self.dim, n) * self.loc_std
+        vel0 = np.random.randn(self.dim, n)
+        vel0 = vel0 * self.vel_norm / np.sqrt((vel0 ** 2).sum(axis=0)).reshape(1, -1)
+        loc0, vel0 = self._clamp(loc0, vel0)
+        if n > 1:                                                          # the reference's start-up assertion (:258 / :571-572)
+            A = loc0.transpose()
+            an = (A ** 2).sum(axis=1)
+            l2 = an.reshape(n, 1) + an.reshape(1, n) - 2 * A.dot(A.transpose()) + 1e-6
+            with np.errstate(divide="ignore"):
+                fs = self.interaction_strength * charges.dot(charges.transpose()) / np.power(l2, 1.5)
+            assert np.abs(fs[~np.eye(n, dtype=bool)]).min() > 1e-10
+        return charges, loc0, vel0
+
+    def sample_trajectories(self, seeds, T=10000, sample_freq=10, charge_prob=[1. / 2, 0, 1. / 2], as_tensor=False):
+        """One ``sample_trajectory(seed, ...)`` per entry of ``seeds`` in one launch: loc, vel [S, T_save, 3, n],
+        edges [S, n, n], charges [S, n, 1].  (The reference reseeds the global generator per trajectory, so the
+        draws of a batch are those of the individual calls; with noise_var > 0 the noise of trajectory k is drawn
+        right after its initial state, as in the reference.)"""
+        assert T % sample_freq == 0
+        lib = _lib.load()
+        dev = _device(self.device)
+        T_save = int(T / sample_freq - 1)
+        n = self.n_balls
+        draws = []
+        for seed in seeds:
+            c, l0, v0 = self._draw_initial(seed, charge_prob)
+            noise = None
+            if self.noise_var > 0:                                         # :293-295
+                noise = (np.random.randn(T_save, self.dim, n) * self.noise_var, np.random.randn(T_save, self.dim, n) * self.noise_var)
+            draws.append((c, l0, v0, noise))
+        S = len(draws)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        charges = np.stack([d[0] for d in draws])
+        l0, v0, q = up(np.stack([d[1] for d in draws])), up(np.stack([d[2] for d in draws])), up(charges[..., 0])
+        loc = torch.empty(S, max(T_save, 0), 3, n, dtype=torch.float64, device=dev)
+        vel = torch.empty_like(loc)
+        ext = (C.c_double * 3)(*self._ext)
+        st = lib.aether_sim_charged(l0.data_ptr(), v0.data_ptr(), q.data_ptr(), S, n, T, sample_freq,
+                                    float(self.interaction_strength), float(self._delta_T), float(self._max_F),
+                                    int(self._ext_mode), ext, loc.data_ptr(), vel.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_sim_charged")
+        if self.noise_var > 0:
+            loc += up(np.stack([d[3][0] for d in draws]))
+            vel += up(np.stack([d[3][1] for d in draws]))
+        edges = charges @ charges.transpose(0, 2, 1)
+        if as_tensor:
+            return loc, vel, torch.from_numpy(edges).to(dev), torch.from_numpy(charges).to(dev)
+        return loc.cpu().numpy(), vel.cpu().numpy(), edges, charges
+
+    def sample_trajectory(self, seed, T=10000, sample_freq=10, charge_prob=[1. / 2, 0, 1. / 2]):
+        """synthetic_sim.py:221-300 / :375-460 / :536-622: (loc, vel [T_save, 3, n], edges [n, n], charges [n, 1])."""
+        loc, vel, edges, charges = self.sample_trajectories([seed], T, sample_freq, charge_prob)
+        return loc[0], vel[0], edges[0], charges[0]
+
+
+class ChargedParticlesSim(_LorentzFamilySim):
+    """'charged' (synthetic_sim.py:149-300)."""
+
+
+class GravitySim(_LorentzFamilySim):
+    """'static': a constant force 0.098 on z (synthetic_sim.py:303-460)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.gravity_constant = 0.098
+        self._ext_mode, self._ext = 1, (0.0, 0.0, self.gravity_constant)
+
+
+class DynamicSim(_LorentzFamilySim):
+    """'dynamic': the Lorentz force q (v x B), B = 0.5 (1, 1, 1) (synthetic_sim.py:463-622)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.lorentz_field = np.ones([1, 3]) * 0.5
+        self._ext_mode, self._ext = 2, tuple(self.lorentz_field[0])

@@ -28,6 +28,12 @@ ELECTRO_CASES = {   # name: (ctor kwargs, T, sample_freq, number of simulations,
     "free2d_noise": (dict(noise_var=0.01, n_balls=7, static_balls=0, dim=2), 200, 20, 2, None),
     "dense3d": (dict(noise_var=0.0, n_balls=12, static_balls=20, box_size=1.0, loc_std=0.5, dim=3), 300, 10, 1, 3),
 }
+LORENTZ_CASES = {   # name: (class name, ctor kwargs, T, sample_freq, seeds)
+    "charged5": ("ChargedParticlesSim", dict(noise_var=0.0, n_balls=5, vel_norm=0.5), 500, 10, [3, 4]),
+    "static5": ("GravitySim", dict(noise_var=0.0, n_balls=5, vel_norm=0.5), 400, 20, [5]),
+    "dynamic5": ("DynamicSim", dict(noise_var=0.0, n_balls=5, vel_norm=0.5), 500, 10, [6, 7]),
+    "dynamic20_noise": ("DynamicSim", dict(noise_var=0.01, n_balls=20, vel_norm=0.5), 300, 10, [8]),
+}
 GRAV_CASES = {      # name: (ctor kwargs, T, sample_freq, number of simulations, numpy seed)
     "grav3d": (dict(n_balls=5, static_balls=3, dim=3, static_mass=2.0, noise_var=0.0), 300, 10, 2, 5),
     "grav2d_noise": (dict(n_balls=6, static_balls=0, dim=2, noise_var=0.01, softening=0.05), 200, 20, 2, 6),
@@ -67,6 +73,16 @@ def main():
             out[f"{name}.{key}"] = np.stack([r[k] for r in res])
         print(name, out[f"{name}.pos"].shape)
     np.savez(os.path.join(args.out, "sim_gravitational.npz"), **out)
+    import experiments.lorentz.dataset.synthetic_sim as LS
+    out = {}
+    for name, (cls, kw, T, sf, seeds) in LORENTZ_CASES.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim = getattr(LS, cls)(**kw)
+        res = [sim.sample_trajectory(seed, T=T, sample_freq=sf) for seed in seeds]
+        for k, key in enumerate(("loc", "vel", "edges", "charges")):
+            out[f"{name}.{key}"] = np.stack([r[k] for r in res])
+        print(name, out[f"{name}.loc"].shape, "max |F-limited| frames ok")
+    np.savez(os.path.join(args.out, "sim_charged.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -8,10 +8,13 @@ TEST INFRASTRUCTURE ONLY: imported by tests/ (and by nothing under aether_amd/).
 * ``gravitational_trajectory`` <- experiments/gravitational/dataset/gravitational_field_sim.py:34-43,99-125
   (``compute_acceleration`` and the kick-drift-kick loop of ``sample_trajectory``).
 
-Both take the initial state explicitly (the random draws before and after the integration are the caller's,
+* ``charged_trajectory``       <- experiments/lorentz/dataset/synthetic_sim.py:167-178,221-300 (``ChargedParticlesSim``),
+  :375-460 (``GravitySim``: + 0.098 on z), :536-622 (``DynamicSim``: + q (v x B)); frames [T_save, 3, n].
+
+All take the initial state explicitly (the random draws before and after the integration are the caller's,
 see aether_amd/sim.py) and work in fp64 numpy with the reference's operation order, without scipy's cdist /
 einsum.  Parity status: PINNED by tests/golden/sim_{electrostatic,gravitational}.npz (the imported reference
-classes, oracle/make_golden_sim.py).
+classes, oracle/make_golden_sim.py); the lorentz-family simulators by tests/golden/sim_charged.npz.
 """
 from __future__ import annotations
 
@@ -91,3 +94,43 @@ def gravitational_trajectory(pos0, vel0, mass, n_balls, T, sample_freq, G=1.0, d
         acc = _gravity(pos, mass, G, softening)
         vel[:N] += acc[:N] * dt / 2.0
     return pos_save, vel_save, force_save
+
+
+def charged_trajectory(loc0, vel0, charges, T, sample_freq, strength=1.0, dt=0.001, max_F=100.0, ext_mode=0,
+                       ext=(0.0, 0.0, 0.0)):
+    """loc0, vel0 [3, n] (already clamped to the box, :240), charges [n, 1] -> loc, vel [T/sample_freq - 1, 3, n]."""
+    n = loc0.shape[1]
+    T_save = T // sample_freq - 1
+    q = np.asarray(charges, dtype=np.float64).reshape(n, 1)
+    edges = q.dot(q.transpose())
+    ext = np.asarray(ext, dtype=np.float64).reshape(1, 3)
+    loc, vel = np.zeros((T_save, 3, n)), np.zeros((T_save, 3, n))
+    x, v = np.array(loc0, dtype=np.float64), np.array(vel0, dtype=np.float64)
+    if T_save > 0:
+        loc[0], vel[0] = x, v
+
+    def force(x, v):
+        A = x.transpose()
+        an = (A ** 2).sum(axis=1)
+        l2 = an.reshape(n, 1) + an.reshape(1, n) - 2 * A.dot(A.transpose()) + 1e-6       # _l2
+        with np.errstate(divide="ignore"):
+            fs = strength * edges / np.power(l2, 1.5)
+        np.fill_diagonal(fs, 0)
+        F = np.zeros((3, n))
+        for j in range(n):                                                               # sum over the last axis
+            F = F + fs[:, j].reshape(1, n) * (x - x[:, [j]])
+        if ext_mode == 1:
+            F = F + ext.transpose()
+        elif ext_mode == 2:
+            F = F + (np.cross(v.transpose(), ext) * q).transpose()
+        return np.clip(F, -max_F, max_F)
+
+    v += dt * force(x, v)
+    counter = 0
+    for i in range(1, T):
+        x += dt * v
+        if i % sample_freq == 0:
+            loc[counter], vel[counter] = x, v
+            counter += 1
+        v += dt * force(x, v)
+    return loc, vel

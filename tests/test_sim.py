@@ -7,9 +7,13 @@ import pytest
 import torch
 
 from conftest import GOLDEN
+import contextlib
+import io
+
+import aether_amd.sim as AS
 from aether_amd.sim import ElectrostaticFieldSim, GravitationalFieldSim
 from oracle import sim_oracle as SO
-from oracle.make_golden_sim import ELECTRO_CASES, GRAV_CASES
+from oracle.make_golden_sim import ELECTRO_CASES, GRAV_CASES, LORENTZ_CASES
 
 
 def _rel(a, b):
@@ -62,7 +66,44 @@ def test_gravitational_oracle_and_host_protocol(name):
             assert _rel(out, d[f"{name}.{key}"][i]) <= 1e-11, key
 
 
+def _lorentz_sim(name):
+    cls, kw, T, sf, seeds = LORENTZ_CASES[name]
+    with contextlib.redirect_stdout(io.StringIO()):             # the constructor prints loc_std, as the reference's
+        sim = getattr(AS, cls)(**kw)
+    return sim, T, sf, seeds
+
+
+@pytest.mark.parametrize("name", list(LORENTZ_CASES))
+def test_lorentz_family_oracle_and_host_protocol(name):
+    """experiments/lorentz/dataset/synthetic_sim.py: charged / static (gravity) / dynamic (Lorentz force) data sets."""
+    d = np.load(os.path.join(GOLDEN, "sim_charged.npz"))
+    sim, T, sf, seeds = _lorentz_sim(name)
+    for k, seed in enumerate(seeds):
+        charges, loc0, vel0 = sim._draw_initial(seed, [1. / 2, 0, 1. / 2])
+        assert np.array_equal(charges, d[name + ".charges"][k])
+        loc, vel = SO.charged_trajectory(loc0, vel0, charges, T, sf, sim.interaction_strength, sim._delta_T, sim._max_F,
+                                         sim._ext_mode, sim._ext)
+        if sim.noise_var > 0:
+            loc += np.random.randn(*loc.shape) * sim.noise_var
+            vel += np.random.randn(*vel.shape) * sim.noise_var
+        assert _rel(loc, d[name + ".loc"][k]) <= 1e-10 and _rel(vel, d[name + ".vel"][k]) <= 1e-10
+
+
 # ----------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(LORENTZ_CASES))
+def test_lorentz_family_sim_matches_reference(name):
+    d = np.load(os.path.join(GOLDEN, "sim_charged.npz"))
+    sim, T, sf, seeds = _lorentz_sim(name)
+    loc, vel, edges, charges = sim.sample_trajectories(seeds, T, sf)
+    assert loc.shape == d[name + ".loc"].shape and np.array_equal(charges, d[name + ".charges"])
+    assert np.array_equal(edges, d[name + ".edges"])
+    assert _rel(loc, d[name + ".loc"]) <= 1e-9 and _rel(vel, d[name + ".vel"]) <= 1e-9
+    l1, v1, e1, c1 = sim.sample_trajectory(seeds[0], T=T, sample_freq=sf)       # the reference's call
+    if sim.noise_var == 0:
+        assert np.array_equal(l1, loc[0]) and np.array_equal(v1, vel[0])
+    assert l1.shape == (T // sf - 1, 3, sim.n_balls)
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(ELECTRO_CASES))
 def test_electrostatic_sim_matches_reference(name, capsys):
