@@ -199,6 +199,15 @@ class GravitationalFieldSim(object):
             return pos, vel, force, torch.from_numpy(mass).to(pos.device)
         return pos.cpu().numpy(), vel.cpu().numpy(), force.cpu().numpy(), mass
 
+    def _energy_total(self, pos, vel, mass):
+        """Kinetic + softened potential energy of one frame (the quantity the integrator conserves; the reference's
+        ``_energy`` (:45-73) uses the unsoftened potential)."""
+        ke = 0.5 * np.sum(mass * vel ** 2)
+        d = pos[None, :, :] - pos[:, None, :]
+        r = np.sqrt((d ** 2).sum(-1) + self.softening ** 2)
+        pe = -self.interaction_strength * np.sum(np.triu((mass * mass.T) / r, 1))
+        return ke + pe
+
     def sample_trajectory(self, T=10000, sample_freq=10):
         """gravitational_field_sim.py:75-131: (pos, vel, force [T_save, M, D], mass [M, 1])."""
         pos, vel, force, mass = self.sample_trajectories(1, T, sample_freq)

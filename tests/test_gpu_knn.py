@@ -67,3 +67,40 @@ def test_knn_edges_empty_and_errors():
     with pytest.raises(ValueError):
         knn_edges(torch.randn(2, 30, 4, device="cuda"), torch.ones(2, 30, device="cuda"), k=17)
     assert get_knn_graph_info(x[0, 0], one[0, 0], 1) == (None, None)
+
+
+def test_knn_full_size_properties():
+    """cfg4's full size (64 scenes x 49 time steps x 40 agent slots, k = 10), checked through properties that do
+    not need the oracle: every present object lists min(k, present - 1) distinct present neighbours of its own
+    scene, never itself, in non-decreasing distance; the lists are contiguous and ordered by object; a second
+    call returns the same edges; masking an object removes exactly its edges."""
+    g = torch.Generator().manual_seed(99)
+    B, T, N, k = 64, 49, 40, 10
+    x = (torch.randn(B, T, N, 4, generator=g) * 20).cuda()
+    m = (torch.rand(B, T, N, generator=g) < 0.6).float().cuda()
+    send, recv, num = knn_edges(x, m, k=k)
+    present = m.reshape(-1, N).sum(-1).long()                                  # per scene
+    want_edges = (present * torch.clamp(present - 1, max=k)).sum()
+    assert send.numel() == int(want_edges) and int(num.sum()) == send.numel() and num.shape == (B,)
+    # compacted numbering -> (scene, object)
+    flat_mask = m.reshape(-1).bool()
+    obj_of = torch.arange(B * T * N, device="cuda")[flat_mask]                  # compacted id -> global slot
+    gs, gr = obj_of[send], obj_of[recv]
+    assert torch.equal(gs // N, gr // N) and (gs != gr).all()                  # same scene, no self edges
+    assert (send[1:] >= send[:-1]).all()                                       # grouped by querying object, in order
+    pos = x.reshape(-1, 4)[:, :2]
+    d = (pos[gs] - pos[gr]).norm(dim=-1)
+    same = send[1:] == send[:-1]
+    assert (d[1:][same] >= d[:-1][same]).all()                                 # nearest first
+    deg = torch.bincount(send, minlength=int(flat_mask.sum()))
+    scene_of = (obj_of // N)
+    assert torch.equal(deg, torch.clamp(present[scene_of] - 1, max=k))
+    pair = send * (B * T * N) + recv
+    assert pair.unique().numel() == pair.numel()                               # distinct neighbours
+    s2, r2, _ = knn_edges(x, m, k=k)
+    assert torch.equal(send, s2) and torch.equal(recv, r2)                     # deterministic
+    m2 = m.clone()
+    victim = int(obj_of[0])
+    m2.view(-1)[victim] = 0
+    s3, r3, _ = knn_edges(x, m2, k=k)
+    assert not ((obj_of[1:][s3] == victim).any() or (obj_of[1:][r3] == victim).any())

@@ -177,3 +177,24 @@ def test_sim_batches_vs_oracle_and_errors():
         sim.sample_trajectories(1, T=105, sample_freq=10)
     lib = _lib.load()
     assert lib.aether_sim_electrostatic(None, None, None, 1, 1, 1, 2, 10, 10, 1.0, 0.001, 100.0, None, None, None, None) != 0
+
+
+@pytest.mark.gpu
+def test_sim_conservation_properties_at_dataset_size():
+    """Properties that hold at the data sets' full length (T = 5000, sample_freq = 100, 49 frames) without an oracle:
+    the gravitational simulator without static masses keeps the total momentum at zero and its energy within the
+    integrator's drift; the electrostatic simulator conserves energy while no force is capped; static field sources
+    never move; saved frames are finite."""
+    np.random.seed(11)
+    g = GravitationalFieldSim(n_balls=8, static_balls=0, dim=3, softening=0.1)
+    pos, vel, force, mass = g.sample_trajectories(16, T=5000, sample_freq=100)
+    assert pos.shape == (16, 50, 8, 3) and np.isfinite(pos).all() and np.isfinite(vel).all()
+    mom = (mass[:, None] * vel).sum(axis=2)                                  # [S, T_save, 3]
+    assert np.abs(mom[:, 1:]).max() <= 1e-10
+    e = np.array([[g._energy_total(pos[s, t], vel[s, t], mass[s]) for t in range(1, 50)] for s in range(16)])
+    assert np.abs(e - e[:, :1]).max() <= 2e-3 * np.abs(e[:, :1]).max()
+    sim = ElectrostaticFieldSim(n_balls=3, static_balls=4, dim=2, box_size=5.0, loc_std=2.0)
+    loc, vel, edges, charges = sim.sample_trajectories(32, T=5000, sample_freq=100)
+    assert np.isfinite(loc).all() and np.isfinite(vel).all()
+    assert np.array_equal(loc[:, :, 3:], np.repeat(loc[:, :1, 3:], loc.shape[1], axis=1))      # field sources fixed
+    assert np.abs(vel[:, :, 3:]).max() == 0.0
