@@ -206,6 +206,7 @@ constexpr int OUTER_MAX_CHUNKS = 256;      // workgroups (= partials) per task
 // Up to this many edges the backward keeps the operands of every layer's weight gradients alive and
 // multiplies all of them in one launch at the end (12 more [E, 64] buffers: 3 KiB per edge).
 int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defer_max_edges", n)
+int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the filter GEMM
 
 
 struct WsLayout {
@@ -820,7 +821,7 @@ struct S2SPriorLayout {
     static int filter_splits(int h, int64_t E) {
         const int64_t base = ((E + 127) / 128) * (h / 128);
         int s = 1;
-        while (s < 16 && base * s < 768 && (h / 16) % (2 * s) == 0) s *= 2;
+        while (s < 16 && base * s < g_filter_wg_target && (h / 16) % (2 * s) == 0) s *= 2;
         return s;
     }
     S2SPriorLayout(int D, int h, int R, int ph, int64_t Nn, int64_t E) {
@@ -1480,6 +1481,11 @@ int aether_set_option(const char* name, int value) {
     if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces
         if (value < 0) return fail(AETHER_EINVAL, "set_option: outer_defer_max_edges must be >= 0");
         g_outer_defer_max_edges = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "filter_wg_target")) {        // changes the seq2seq / variable-N prior and decoder workspace sizes
+        if (value < 1) return fail(AETHER_EINVAL, "set_option: filter_wg_target must be >= 1");
+        g_filter_wg_target = value;
         return AETHER_OK;
     }
     return fail(AETHER_EINVAL, "set_option: unknown option");

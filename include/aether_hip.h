@@ -529,7 +529,10 @@ int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and
- * multiplies them in one launch when n_edges <= n, default 2^20; changes aether_workspace_bytes).
+ * multiplies them in one launch when n_edges <= n, default 2^20; changes aether_workspace_bytes),
+ * "filter_wg_target" n (the anisotropic-filter GEMM of the seq2seq / variable-N steps splits its k-groups, up to
+ * 16 ways, until it launches at least n workgroups; default 768, measured best at 2,560 edges; changes the prior /
+ * decoder workspace sizes).
  */
 int aether_set_option(const char* name, int value);
 

@@ -13,8 +13,12 @@ ap.add_argument("--dims", type=int, default=2)
 ap.add_argument("--nodes", type=int, default=20)
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--decoder-hidden", type=int, default=512)
+ap.add_argument("--filter-wg-target", type=int, default=0)
 a = ap.parse_args()
 D, N, B, H, R = a.dims, a.nodes, a.batch, 512, 128
+if a.filter_wg_target:
+    from aether_amd import _lib
+    _lib.load().aether_set_option(b"filter_wg_target", a.filter_wg_target)
 dparams = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": a.decoder_hidden, "num_edge_types": 2,
            "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3}
 eparams = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H, "encoder_rnn_hidden": R,
