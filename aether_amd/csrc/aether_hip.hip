@@ -206,6 +206,7 @@ constexpr int OUTER_MAX_CHUNKS = 256;      // workgroups (= partials) per task
 // Up to this many edges the backward keeps the operands of every layer's weight gradients alive and
 // multiplies all of them in one launch at the end (12 more [E, 64] buffers: 3 KiB per edge).
 int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defer_max_edges", n)
+int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
 int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the filter GEMM
 
 
@@ -680,7 +681,10 @@ int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X,
                const int64_t* yidx, const int* n_dev, const float* post_scale, const float* post_shift,
                const float* film_gamma, const float* film_beta, int film_rows) {
     if (K % 16 != 0) return fail(AETHER_EINVAL, "s2s_linear: K must be a multiple of 16");
-    const bool big = M >= 128;
+    // A wave's k-step costs (MT x NT) MFMAs x 32 cycles whatever the problem size: with few rows (the reference's
+    // 5-object graphs: 640 nodes, 2,560 edges) 64 x 32 blocks per wave leave most SIMDs idle and every GEMM takes the
+    // 32 k-steps x 0.43 us of one wave; 16 x 32 blocks give four times the waves.
+    const bool big = M >= 128 && ((N + 63) / 64) * ((M + 127) / 128) >= g_linear_small_wgs;
     const bool wide = big && N >= 16384;             // 64 points per wave once there are enough workgroups
     const int nt = wide ? 4 : 2;
     const dim3 grid((unsigned)((N + 32 * nt - 1) / (32 * nt)), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
@@ -1481,6 +1485,10 @@ int aether_set_option(const char* name, int value) {
     if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces
         if (value < 0) return fail(AETHER_EINVAL, "set_option: outer_defer_max_edges must be >= 0");
         g_outer_defer_max_edges = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "linear_small_wgs")) {
+        g_linear_small_wgs = value;
         return AETHER_OK;
     }
     if (!strcmp(name, "filter_wg_target")) {        // changes the seq2seq / variable-N prior and decoder workspace sizes

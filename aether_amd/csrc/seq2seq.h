@@ -39,7 +39,7 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
 // Epilogue: v = act([FiLM per graph](acc + b)) [affine per channel] [* scale[n * sstride]] [+ Y]
 // (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU).
 // Optional row lists gather X rows / scatter Y rows (edges of one type, compacted on the device).
-template <int ACT, int MT, int NT>
+template <int ACT, int MT, int NT, int PF = 2>
 __global__ void __launch_bounds__(256)
 k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ X,
              float* __restrict__ Y, int M, int K, int ldw, int64_t N, int ldy,
@@ -53,7 +53,6 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
              const float* __restrict__ film_beta  /* g = n / film_rows (FiLM per graph, nn/nn/film.py:58-60)   */,
              int film_rows) {
     if (n_dev != nullptr) N = *n_dev;
-    constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m0 = (int)blockIdx.y * (32 * MT) + 16 * MT * (wave >> 1);

@@ -532,7 +532,9 @@ int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_
  * multiplies them in one launch when n_edges <= n, default 2^20; changes aether_workspace_bytes),
  * "filter_wg_target" n (the anisotropic-filter GEMM of the seq2seq / variable-N steps splits its k-groups, up to
  * 16 ways, until it launches at least n workgroups; default 768, measured best at 2,560 edges; changes the prior /
- * decoder workspace sizes).
+ * decoder workspace sizes), "linear_small_wgs" n (dense layers of the seq2seq / variable-N steps whose 64 x 32-per-wave
+ * tiling would launch fewer than n workgroups use 16 x 32 blocks per wave instead: four times the waves for the
+ * 5-object graphs; default 128).
  */
 int aether_set_option(const char* name, int value);
 
