@@ -610,871 +610,12 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
 // =================================================================== C ABI
 extern "C" {
 
-const char* aether_version(void) { return "aether_hip 0.2 (gfx950, fp32 MFMA 16x16x4, fused + streamed)"; }
+const char* aether_version(void) { return "aether_hip 0.3 (gfx950; state2state fused + streamed + backward, seq2seq / variable-N steps, kNN, simulators)"; }
 const char* aether_last_error(void) { return g_err; }
 
-namespace {
-int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
-               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st,
-               const int64_t* xidx = nullptr, const int64_t* yidx = nullptr, const int* n_dev = nullptr,
-               const float* post_scale = nullptr, const float* post_shift = nullptr,
-               const float* film_gamma = nullptr, const float* film_beta = nullptr, int film_rows = 1);
-}  // namespace
-
-size_t aether_s2s_field_workspace_bytes(int64_t n_points, int hidden) {
-    if (n_points <= 0 || hidden <= 0) return 0;
-    return (size_t)3 * (size_t)n_points * (size_t)hidden * sizeof(float) + 768;
-}
-
-int aether_s2s_field(const AetherS2SFieldParams* p, int num_dims, int hidden, int64_t n_points, const float* x,
-                     int x_stride, void* workspace, size_t workspace_bytes, float* field, void* stream) {
-    if (!p || !x || !workspace || !field || !p->B || !p->w0 || !p->b0 || !p->w2 || !p->b2 || !p->w4 || !p->b4)
-        return fail(AETHER_EINVAL, "s2s_field: null pointer");
-    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_field: num_dims must be 2 or 3");
-    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "s2s_field: hidden must be a multiple of 32");
-    if (n_points <= 0 || x_stride < num_dims) return fail(AETHER_EINVAL, "s2s_field: bad sizes");
-    if (workspace_bytes < aether_s2s_field_workspace_bytes(n_points, hidden))
-        return fail(AETHER_ESPACE, "s2s_field: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    const size_t plane = align_up((size_t)n_points * hidden * sizeof(float), 256);
-    float* gamma = reinterpret_cast<float*>(workspace);
-    float* h1 = reinterpret_cast<float*>((char*)workspace + plane);
-    float* h2 = reinterpret_cast<float*>((char*)workspace + 2 * plane);
-    const int half = hidden / 2;
-    const unsigned rb = (unsigned)((n_points * half + 255) / 256);
-    if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
-    else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
-    if (s2s_linear(1, p->w0, hidden, p->b0, gamma, h1, hidden, hidden, n_points, hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(1, p->w2, hidden, p->b2, h1, h2, hidden, hidden, n_points, hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->w4, hidden, p->b4, h2, field, num_dims, hidden, n_points, num_dims, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-int aether_s2s_localize(int num_dims, int64_t n_nodes, int64_t n_edges, const float* x, const int64_t* send,
-                        const int64_t* recv, int polar, float* rel_feat, float* Rinv, float* edge_attr,
-                        float* edge_pos, void* stream) {
-    if (!x || !rel_feat || !Rinv) return fail(AETHER_EINVAL, "s2s_localize: null pointer");
-    if (n_edges > 0 && (!send || !recv || !edge_attr || !edge_pos))
-        return fail(AETHER_EINVAL, "s2s_localize: null edge pointer");
-    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_localize: num_dims must be 2 or 3");
-    if (n_nodes <= 0 || n_edges < 0) return fail(AETHER_EINVAL, "s2s_localize: bad sizes");
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned nb = (unsigned)((n_nodes + 255) / 256), eb = (unsigned)((n_edges + 255) / 256);
-    if (num_dims == 2) {
-        k_s2s_aug_nodes<2><<<dim3(nb), dim3(256), 0, st>>>(x, rel_feat, Rinv, n_nodes);
-        if (n_edges > 0)
-            k_s2s_aug_edges<2><<<dim3(eb), dim3(256), 0, st>>>(x, send, recv, rel_feat, polar, edge_attr, edge_pos, n_edges);
-    } else {
-        k_s2s_aug_nodes<3><<<dim3(nb), dim3(256), 0, st>>>(x, rel_feat, Rinv, n_nodes);
-        if (n_edges > 0)
-            k_s2s_aug_edges<3><<<dim3(eb), dim3(256), 0, st>>>(x, send, recv, rel_feat, polar, edge_attr, edge_pos, n_edges);
-    }
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-namespace {
-// Y[N][ldy] = act(X[N][K] W^T + b) [* scale] [+ Y]; act: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU
-int s2s_linear(int act, const float* W, int ldw, const float* b, const float* X, float* Y, int M, int K, int64_t N,
-               int ldy, const float* scale, int sstride, int accumulate, hipStream_t st, const int64_t* xidx,
-               const int64_t* yidx, const int* n_dev, const float* post_scale, const float* post_shift,
-               const float* film_gamma, const float* film_beta, int film_rows) {
-    if (K % 16 != 0) return fail(AETHER_EINVAL, "s2s_linear: K must be a multiple of 16");
-    // A wave's k-step costs (MT x NT) MFMAs x 32 cycles whatever the problem size: with few rows (the reference's
-    // 5-object graphs: 640 nodes, 2,560 edges) 64 x 32 blocks per wave leave most SIMDs idle and every GEMM takes the
-    // 32 k-steps x 0.43 us of one wave; 16 x 32 blocks give four times the waves.
-    const bool big = M >= 128 && ((N + 63) / 64) * ((M + 127) / 128) >= g_linear_small_wgs;
-    const bool wide = big && N >= 16384;             // 64 points per wave once there are enough workgroups
-    const int nt = wide ? 4 : 2;
-    const dim3 grid((unsigned)((N + 32 * nt - 1) / (32 * nt)), (unsigned)(big ? (M + 127) / 128 : (M + 31) / 32));
-#define S2S_ARGS W, b, X, Y, M, K, ldw, N, ldy, scale, sstride, accumulate, xidx, yidx, n_dev, post_scale, post_shift, \
-                 film_gamma, film_beta, film_rows
-#define S2S_CASE(A)                                                                     \
-    if (wide) k_s2s_linear<A, 4, 4><<<grid, dim3(256), 0, st>>>(S2S_ARGS);              \
-    else if (big) k_s2s_linear<A, 4, 2><<<grid, dim3(256), 0, st>>>(S2S_ARGS);          \
-    else k_s2s_linear<A, 1, 2><<<grid, dim3(256), 0, st>>>(S2S_ARGS)
-    if (act == 0) { S2S_CASE(0); } else if (act == 1) { S2S_CASE(1); } else if (act == 2) { S2S_CASE(2); }
-    else if (act == 3) { S2S_CASE(3); } else { S2S_CASE(4); }
-#undef S2S_ARGS
-#undef S2S_CASE
-    return AETHER_OK;
-}
-
-struct S2SDecLayout {
-    size_t A[4], S[4], T1, M, agg_h, agg_p, ext, rel, relp, Rinv, ea, eap, epos, rp, ip, np_, hh, o1, o2, pred,
-        p1p[4], irp, iip, inp, list[4], counts, total;
-    int RF, RFp, EA, EAp, EP;
-    S2SDecLayout(int D, int h, int64_t Nn, int64_t E) {
-        const int O = D * (D - 1) / 2, NF = 4 * D + O;
-        RF = 3 * D + NF; EA = NF + RF; EP = D + O;
-        RFp = (RF + 15) / 16 * 16; EAp = (EA + 15) / 16 * 16;
-        size_t off = 0;
-        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-        const size_t nn = (size_t)Nn, ee = (size_t)E, hh_ = (size_t)h;
-        for (auto& v : A) v = take(nn * hh_);
-        for (auto& v : S) v = take(nn * hh_);
-        T1 = take(ee * hh_); M = take(ee * hh_);
-        agg_h = take(nn * hh_); agg_p = take(nn * hh_);
-        ext = take(nn * 3 * D); rel = take(nn * RF); relp = take(nn * RFp); Rinv = take(nn * D * D);
-        ea = take(ee * EA); eap = take(ee * EAp); epos = take(ee * EP);
-        rp = take(nn * hh_); ip = take(nn * hh_); np_ = take(nn * hh_); hh = take(nn * hh_);
-        o1 = take(nn * hh_); o2 = take(nn * hh_); pred = take(nn * 2 * D);
-        for (auto& v : p1p) v = take(hh_ * EAp);
-        irp = take(hh_ * RFp); iip = take(hh_ * RFp); inp = take(hh_ * RFp);
-        for (auto& v : list) v = take(ee * 2);           // int64 edge ids of one type
-        counts = take(64);
-        total = off;
-    }
-};
-}  // namespace
-
-size_t aether_s2s_decoder_workspace_bytes(int num_dims, int hidden, int64_t n_nodes, int64_t n_edges) {
-    if ((num_dims != 2 && num_dims != 3) || hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
-    return S2SDecLayout(num_dims, hidden, n_nodes, n_edges).total;
-}
-
-int aether_s2s_decoder_step(const AetherS2SDecoderParams* p, int num_dims, int hidden, int num_edge_types,
-                            int skip_first, int64_t n_nodes, int64_t n_edges, const float* inputs,
-                            const float* hidden_in, const float* edge_w, const float* field, const int64_t* send,
-                            const int64_t* recv, const int64_t* order, const int64_t* rowptr, void* workspace,
-                            size_t workspace_bytes, float* outputs, float* hidden_out, void* stream) {
-    if (!p || !inputs || !hidden_in || !field || !workspace || !outputs || !hidden_out || !rowptr)
-        return fail(AETHER_EINVAL, "s2s_decoder: null pointer");
-    if (n_edges > 0 && (!edge_w || !send || !recv || !order)) return fail(AETHER_EINVAL, "s2s_decoder: null edge pointer");
-    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_decoder: num_dims must be 2 or 3");
-    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "s2s_decoder: hidden must be a multiple of 32");
-    if (num_edge_types < 1 || num_edge_types > 4) return fail(AETHER_EINVAL, "s2s_decoder: 1..4 edge types");
-    if (n_nodes <= 0 || n_edges < 0) return fail(AETHER_EINVAL, "s2s_decoder: bad sizes");
-    const int D = num_dims, h = hidden, K = num_edge_types, k0 = skip_first ? 1 : 0;
-    S2SDecLayout L(D, h, n_nodes, n_edges);
-    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "s2s_decoder: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
-    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    const int64_t Nn = n_nodes, E = n_edges;
-    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    // ---- edges per type: with one-hot types every edge is evaluated for its own type only (the other
-    // term of the reference's sum is multiplied by zero, aether.py:613,632)
-    int* counts = reinterpret_cast<int*>(ws + L.counts);
-    auto elist = [&](int k) { return reinterpret_cast<int64_t*>(ws + L.list[k]); };
-    if (E > 0) {
-        HIP_OK(hipMemsetAsync(counts, 0, 64 * sizeof(int), st));
-        for (int k = k0; k < K; ++k)
-            k_s2s_select<<<blocks(E), dim3(256), 0, st>>>(edge_w, K, k, E, elist(k), counts + k);
-    }
-    // ---- messages from the hidden states (aether.py:596-617)
-    if (E > 0) {
-        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
-        for (int k = k0; k < K; ++k) {
-            if (s2s_linear(0, p->msg_fc1_w[k], 2 * h, p->msg_fc1_b[k], hidden_in, wp(L.A[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-            if (s2s_linear(0, p->msg_fc1_w[k] + h, 2 * h, nullptr, hidden_in, wp(L.S[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-            k_s2s_pair_tanh<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.A[k]), wp(L.S[k]), send, recv, elist(k), counts + k, wp(L.T1), h);
-            if (s2s_linear(3, p->msg_fc2_w[k], h, p->msg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, 1, st,
-                           nullptr, elist(k), counts + k)) return AETHER_EINVAL;
-        }
-    }
-    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_h), h, 0.0f);
-    // ---- local frames of [inputs | field] (:620-622) and the messages from the present state (:624-635)
-    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
-    int rc = aether_s2s_localize(D, Nn, E, wp(L.ext), send, recv, 1, wp(L.rel), wp(L.Rinv), wp(L.ea), wp(L.epos), stream);
-    if (rc != AETHER_OK) return rc;
-    k_s2s_pad_rows<<<blocks(Nn * L.RFp), dim3(256), 0, st>>>(wp(L.rel), L.RF, L.RF, wp(L.relp), L.RFp, Nn);
-    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->input_r_w, L.RF, L.RF, wp(L.irp), L.RFp, h);
-    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->input_i_w, L.RF, L.RF, wp(L.iip), L.RFp, h);
-    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->input_n_w, L.RF, L.RF, wp(L.inp), L.RFp, h);
-    if (E > 0) {
-        k_s2s_pad_rows<<<blocks(E * L.EAp), dim3(256), 0, st>>>(wp(L.ea), L.EA, L.EA, wp(L.eap), L.EAp, E);
-        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
-        for (int k = k0; k < K; ++k) {
-            k_s2s_pad_rows<<<blocks((int64_t)h * L.EAp), dim3(256), 0, st>>>(p->pmsg_fc1_w[k], L.EA, L.EA, wp(L.p1p[k]), L.EAp, h);
-            if (s2s_linear(2, wp(L.p1p[k]), L.EAp, p->pmsg_fc1_b[k], wp(L.eap), wp(L.T1), h, L.EAp, E, h, nullptr, 0, 0, st,
-                           elist(k), nullptr, counts + k)) return AETHER_EINVAL;
-            if (s2s_linear(2, p->pmsg_fc2_w[k], h, p->pmsg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, edge_w + k, K, 1, st,
-                           nullptr, elist(k), counts + k)) return AETHER_EINVAL;
-        }
-    }
-    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), order, rowptr, wp(L.agg_p), h, 0.0f);
-    // ---- GRU-style gate (:638-646)
-    struct Gate { const float *iw, *ib, *pw, *pb, *hw; float* y; };
-    const Gate gates[3] = {{wp(L.irp), p->input_r_b, p->present_r_w, p->present_r_b, p->hidden_r_w, wp(L.rp)},
-                           {wp(L.iip), p->input_i_b, p->present_i_w, p->present_i_b, p->hidden_i_w, wp(L.ip)},
-                           {wp(L.inp), p->input_n_b, p->present_n_w, p->present_n_b, nullptr, wp(L.np_)}};
-    for (const Gate& g : gates) {
-        if (s2s_linear(0, g.iw, L.RFp, g.ib, wp(L.relp), g.y, h, L.RFp, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-        if (s2s_linear(0, g.pw, h, g.pb, wp(L.agg_p), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
-        if (g.hw && s2s_linear(0, g.hw, h, nullptr, wp(L.agg_h), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
-    }
-    if (s2s_linear(0, p->hidden_h_w, h, nullptr, wp(L.agg_h), wp(L.hh), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    k_s2s_gate<<<blocks(Nn * h), dim3(256), 0, st>>>(wp(L.rp), wp(L.ip), wp(L.np_), wp(L.hh), hidden_in, hidden_out, Nn * h);
-    // ---- output MLP, globalise, residual (:649-654)
-    if (s2s_linear(2, p->out0_w, h, p->out0_b, hidden_out, wp(L.o1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(2, p->out3_w, h, p->out3_b, wp(L.o1), wp(L.o2), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->out6_w, h, p->out6_b, wp(L.o2), wp(L.pred), 2 * D, h, Nn, 2 * D, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (D == 2) k_s2s_globalize<2><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
-    else k_s2s_globalize<3><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-namespace {
-struct S2SPriorLayout {
-    size_t ext, rel, relp, Rinv, ea, epos, hw, eaf, X0, X1, X3, Ps, Pr, T1, X4, G, Y1, Y2, bn, res1p, fpart, total;
-    int RF, RFp, EA, EP, splits;
-    // k-splits of the filter GEMM: with few edges its (E / 128) x (h / 128) workgroups do not fill 256 CUs
-    static int filter_splits(int h, int64_t E) {
-        const int64_t base = ((E + 127) / 128) * (h / 128);
-        int s = 1;
-        while (s < 16 && base * s < g_filter_wg_target && (h / 16) % (2 * s) == 0) s *= 2;
-        return s;
-    }
-    S2SPriorLayout(int D, int h, int R, int ph, int64_t Nn, int64_t E) {
-        const int O = D * (D - 1) / 2, NF = 4 * D + O;
-        RF = 3 * D + NF; EA = NF + RF; EP = D + O;
-        RFp = (RF + 15) / 16 * 16;
-        size_t off = 0;
-        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-        const size_t nn = (size_t)Nn, ee = (size_t)E, hh = (size_t)h;
-        ext = take(nn * 3 * D); rel = take(nn * RF); relp = take(nn * RFp); Rinv = take(nn * D * D);
-        ea = take(ee * EA); epos = take(ee * EP); hw = take(ee * hh); eaf = take(ee * hh);
-        X0 = take(nn * hh); X1 = take(nn * hh); X3 = take(nn * hh); Ps = take(nn * hh); Pr = take(nn * hh);
-        T1 = take(ee * hh); X4 = take(ee * hh); G = take(ee * 4 * (size_t)R);
-        Y1 = take(ee * (size_t)(ph > 0 ? ph : 1)); Y2 = take(ee * (size_t)(ph > 0 ? ph : 1));
-        bn = take(4 * hh); res1p = take(hh * RFp);
-        splits = filter_splits(h, E);
-        fpart = take(splits > 1 ? ee * hh * splits : 0);
-        total = off;
-    }
-};
-}  // namespace
-
-size_t aether_s2s_prior_workspace_bytes(int num_dims, int hidden, int rnn_hidden, int prior_hidden,
-                                        int64_t n_nodes, int64_t n_edges) {
-    if ((num_dims != 2 && num_dims != 3) || hidden <= 0 || rnn_hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
-    return S2SPriorLayout(num_dims, hidden, rnn_hidden, prior_hidden, n_nodes, n_edges).total;
-}
-
-int aether_s2s_prior_step(const AetherS2SPriorParams* p, int num_dims, int hidden, int rnn_hidden, int prior_layers,
-                          int prior_hidden, int num_edge_types, int polar, int num_vars, int64_t n_nodes,
-                          int64_t n_edges, const float* inputs, const float* field, const float* h0, const float* c0,
-                          const int64_t* send, const int64_t* recv, const int64_t* order, const int64_t* rowptr,
-                          void* workspace, size_t workspace_bytes, float* logits, float* h1, float* c1, void* stream) {
-    if (!p || !inputs || !field || !h0 || !c0 || !send || !recv || !order || !rowptr || !workspace || !logits || !h1 || !c1)
-        return fail(AETHER_EINVAL, "s2s_prior: null pointer");
-    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_prior: num_dims must be 2 or 3");
-    if (hidden < 128 || hidden % 128 != 0) return fail(AETHER_EINVAL, "s2s_prior: hidden must be a multiple of 128");
-    if (rnn_hidden < 16 || rnn_hidden % 16 != 0) return fail(AETHER_EINVAL, "s2s_prior: rnn_hidden must be a multiple of 16");
-    if (prior_layers < 1 || prior_layers > 4) return fail(AETHER_EINVAL, "s2s_prior: 1..4 prior layers");
-    if (prior_layers > 1 && (prior_hidden < 16 || prior_hidden % 16 != 0))
-        return fail(AETHER_EINVAL, "s2s_prior: prior_hidden must be a multiple of 16");
-    if (num_edge_types < 1 || num_edge_types > 4 || num_vars < 2 || n_nodes <= 0 || n_edges <= 0)
-        return fail(AETHER_EINVAL, "s2s_prior: bad sizes");
-    const int D = num_dims, h = hidden, R = rnn_hidden, K = num_edge_types;
-    S2SPriorLayout L(D, h, R, prior_hidden, n_nodes, n_edges);
-    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "s2s_prior: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
-    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    const int64_t Nn = n_nodes, E = n_edges;
-    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    // ---- local frames (:385-388) and the anisotropic edge filter (:391)
-    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
-    int rc = aether_s2s_localize(D, Nn, E, wp(L.ext), send, recv, polar, wp(L.rel), wp(L.Rinv), wp(L.ea), wp(L.epos), stream);
-    if (rc != AETHER_OK) return rc;
-    k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0, p->filt_b0, wp(L.epos), L.EP, wp(L.hw), h, E);
-    {
-        constexpr int NB = 4;
-        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128), (unsigned)L.splits);
-        float* dst = L.splits > 1 ? wp(L.fpart) : wp(L.eaf);
-        if (L.splits > 1) {
-            if (D == 2) k_s2s_filter<24, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
-            else k_s2s_filter<39, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
-        } else {
-            if (D == 2) k_s2s_filter<24, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
-            else k_s2s_filter<39, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea), wp(L.hw), dst, h, E);
-        }
-        if (L.splits > 1) k_s2s_sum_planes<<<blocks(E * h / 4), dim3(256), 0, st>>>(dst, L.splits, E * (int64_t)h, wp(L.eaf));
-    }
-    // ---- x = edge2node(edge_attr) + res1(rel_feat) (:393-395): sum over in-edges / (num_vars - 1)
-    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.eaf), order, rowptr, wp(L.X0), h, (float)(num_vars - 1));
-    k_s2s_pad_rows<<<blocks(Nn * L.RFp), dim3(256), 0, st>>>(wp(L.rel), L.RF, L.RF, wp(L.relp), L.RFp, Nn);
-    k_s2s_pad_rows<<<blocks((int64_t)h * L.RFp), dim3(256), 0, st>>>(p->res1_w, L.RF, L.RF, wp(L.res1p), L.RFp, h);
-    if (s2s_linear(0, wp(L.res1p), L.RFp, p->res1_b, wp(L.relp), wp(L.X0), h, L.RFp, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
-    // ---- mlp3 (RefNRIMLP, eval): Linear-ELU-Linear-ELU-BatchNorm
-    float *bn3s = wp(L.bn), *bn3b = wp(L.bn) + h, *bn4s = wp(L.bn) + 2 * h, *bn4b = wp(L.bn) + 3 * h;
-    k_s2s_bn_affine<<<blocks(h), dim3(256), 0, st>>>(p->mlp3_bn_w, p->mlp3_bn_b, p->mlp3_bn_mean, p->mlp3_bn_var, bn3s, bn3b, h);
-    k_s2s_bn_affine<<<blocks(h), dim3(256), 0, st>>>(p->mlp4_bn_w, p->mlp4_bn_b, p->mlp4_bn_mean, p->mlp4_bn_var, bn4s, bn4b, h);
-    if (s2s_linear(4, p->mlp3_w0, h, p->mlp3_b0, wp(L.X0), wp(L.X1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(4, p->mlp3_w3, h, p->mlp3_b3, wp(L.X1), wp(L.X3), h, h, Nn, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr, bn3s, bn3b)) return AETHER_EINVAL;
-    // ---- mlp4 on [x_send | x_recv | edge] (:396-398): the first Linear split per node / per edge
-    if (s2s_linear(0, p->mlp4_w0, 3 * h, p->mlp4_b0, wp(L.X3), wp(L.Ps), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->mlp4_w0 + h, 3 * h, nullptr, wp(L.X3), wp(L.Pr), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->mlp4_w0 + 2 * h, 3 * h, nullptr, wp(L.eaf), wp(L.T1), h, h, E, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    k_s2s_edge_sum_elu<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.T1), wp(L.Ps), wp(L.Pr), send, recv, h, E);
-    if (s2s_linear(4, p->mlp4_w3, h, p->mlp4_b3, wp(L.T1), wp(L.X4), h, h, E, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr, bn4s, bn4b)) return AETHER_EINVAL;
-    // ---- one LSTM step per edge (:400-407)
-    if (s2s_linear(0, p->lstm_w_ih, h, p->lstm_b_ih, wp(L.X4), wp(L.G), 4 * R, h, E, 4 * R, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->lstm_w_hh, R, p->lstm_b_hh, h0, wp(L.G), 4 * R, R, E, 4 * R, nullptr, 0, 1, st)) return AETHER_EINVAL;
-    k_s2s_lstm_cell<<<blocks(E * R), dim3(256), 0, st>>>(wp(L.G), c0, h1, c1, R, E);
-    // ---- prior_fc_out (:408)
-    const float* cur = h1;
-    int cur_k = R;
-    for (int l = 0; l < prior_layers; ++l) {
-        const bool last = l + 1 == prior_layers;
-        float* dst = last ? logits : wp(l % 2 == 0 ? L.Y1 : L.Y2);
-        const int M = last ? K : prior_hidden;
-        if (s2s_linear(last ? 0 : 4, p->prior_w[l], cur_k, p->prior_b[l], cur, dst, M, cur_k, E, M, nullptr, 0, 0, st)) return AETHER_EINVAL;
-        cur = dst;
-        cur_k = M;
-    }
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-// ------------------------------------------------------------------ variable-N decoder step (N2)
-namespace {
-struct DynDecLayout {
-    size_t A[4], S[4], T1, M, agg_h, agg_p, ext, rel, relp, Rinv, ea, ea15, epos, hw, fout, fpart, ewn, rp, ip, np_, hh, o1,
-        o2, pred, irp, iip, inp, list[4], counts, total;
-    int splits;
-    DynDecLayout(int h, int64_t Nn, int64_t E) {
-        size_t off = 0;
-        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-        const size_t nn = (size_t)Nn, ee = (size_t)E, hh_ = (size_t)h;
-        for (auto& v : A) v = take(nn * hh_);
-        for (auto& v : S) v = take(nn * hh_);
-        T1 = take(ee * hh_); M = take(ee * hh_);
-        agg_h = take(nn * hh_); agg_p = take(nn * hh_);
-        ext = take(nn * 6); rel = take(nn * 15); relp = take(nn * 16); Rinv = take(nn * 4);
-        ea = take(ee * 24); ea15 = take(ee * 15); epos = take(ee * 3); hw = take(ee * hh_); fout = take(ee * hh_);
-        splits = S2SPriorLayout::filter_splits(h, E);
-        fpart = take(splits > 1 ? ee * hh_ * splits : 0);
-        ewn = take(ee * 4);
-        rp = take(nn * hh_); ip = take(nn * hh_); np_ = take(nn * hh_); hh = take(nn * hh_);
-        o1 = take(nn * hh_); o2 = take(nn * hh_); pred = take(nn * 4);
-        irp = take(hh_ * 16); iip = take(hh_ * 16); inp = take(hh_ * 16);
-        for (auto& v : list) v = take(ee * 2);
-        counts = take(64);
-        total = off;
-    }
-};
-}  // namespace
-
-size_t aether_dyn_decoder_workspace_bytes(int hidden, int64_t n_nodes, int64_t n_edges) {
-    if (hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
-    return DynDecLayout(hidden, n_nodes, n_edges).total;
-}
-
-int aether_dyn_decoder_step(const AetherDynDecoderParams* p, int hidden, int num_edge_types, int skip_first, int polar,
-                            int64_t n_nodes, int64_t n_edges, const float* inputs, const float* hidden_in,
-                            const float* edge_w, const float* field, const float* edge_state, const int64_t* send,
-                            const int64_t* recv, const int64_t* agg_order, const int64_t* agg_rowptr, float agg_div,
-                            void* workspace, size_t workspace_bytes, float* outputs, float* hidden_out, void* stream) {
-    if (!p || !inputs || !hidden_in || !field || !workspace || !outputs || !hidden_out)
-        return fail(AETHER_EINVAL, "dyn_decoder: null pointer");
-    if (n_edges > 0 && (!edge_w || !send || !recv || !agg_order || !agg_rowptr))
-        return fail(AETHER_EINVAL, "dyn_decoder: null edge pointer");
-    if (hidden < 128 || hidden % 128 != 0) return fail(AETHER_EINVAL, "dyn_decoder: hidden must be a multiple of 128");
-    if (num_edge_types < 1 || num_edge_types > 4) return fail(AETHER_EINVAL, "dyn_decoder: 1..4 edge types");
-    if (skip_first && num_edge_types < 2) return fail(AETHER_EINVAL, "dyn_decoder: skip_first needs two edge types");
-    if (n_nodes <= 0 || n_edges < 0) return fail(AETHER_EINVAL, "dyn_decoder: bad sizes");
-    if (n_edges > 0 && !(agg_div > 0.0f)) return fail(AETHER_EINVAL, "dyn_decoder: agg_div must be positive");
-    constexpr int D = 2;
-    const int h = hidden, K = num_edge_types, k0 = skip_first ? 1 : 0;
-    DynDecLayout L(h, n_nodes, n_edges);
-    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "dyn_decoder: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
-    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    const int64_t Nn = n_nodes, E = n_edges;
-    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    int* counts = reinterpret_cast<int*>(ws + L.counts);
-    auto elist = [&](int k) { return reinterpret_cast<int64_t*>(ws + L.list[k]); };
-    // ---- canonical state and frames of the present objects (:790)
-    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
-    k_s2s_aug_nodes<2><<<blocks(Nn), dim3(256), 0, st>>>(wp(L.ext), wp(L.rel), wp(L.Rinv), Nn);
-    if (E > 0) {
-        HIP_OK(hipMemsetAsync(counts, 0, 64 * sizeof(int), st));
-        for (int k = k0; k < K; ++k)
-            k_s2s_select<<<blocks(E), dim3(256), 0, st>>>(edge_w, K, k, E, elist(k), counts + k);
-        // ---- messages from the hidden states, each type / norm (:797-814)
-        k_s2s_scale<<<blocks(E * K), dim3(256), 0, st>>>(edge_w, 1.0f / (float)(K - k0), wp(L.ewn), E * K);
-        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
-        for (int k = k0; k < K; ++k) {
-            if (s2s_linear(0, p->msg_fc1_w[k], 2 * h, p->msg_fc1_b[k], hidden_in, wp(L.A[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-            if (s2s_linear(0, p->msg_fc1_w[k] + h, 2 * h, nullptr, hidden_in, wp(L.S[k]), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-            k_s2s_pair_tanh<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.A[k]), wp(L.S[k]), send, recv, elist(k), counts + k, wp(L.T1), h);
-            if (s2s_linear(3, p->msg_fc2_w[k], h, p->msg_fc2_b[k], wp(L.T1), wp(L.M), h, h, E, h, wp(L.ewn) + k, K, 1, st,
-                           nullptr, elist(k), counts + k)) return AETHER_EINVAL;
-        }
-        k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), agg_order, agg_rowptr, wp(L.agg_h), h, agg_div);
-        // ---- edge features [9 | canonical state of the receiver 6] and positions (:821-825): the first 15 of the
-        // 24 columns aether_s2s_localize's edge kernel writes (edge | canonical | origin-edge features)
-        k_s2s_aug_edges<2><<<blocks(E), dim3(256), 0, st>>>(edge_state ? edge_state : wp(L.ext), send, recv, wp(L.rel), polar,
-                                                           wp(L.ea), wp(L.epos), E);
-        k_s2s_pad_rows<<<blocks(E * 15), dim3(256), 0, st>>>(wp(L.ea), 15, 24, wp(L.ea15), 15, E);
-        // ---- messages from the present state: one anisotropic filter per edge type, ReLU (:827-835)
-        HIP_OK(hipMemsetAsync(wp(L.M), 0, (size_t)E * h * 4, st));
-        constexpr int NB = 4;
-        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128), (unsigned)L.splits);
-        for (int k = k0; k < K; ++k) {
-            k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0[k], p->filt_b0[k], wp(L.epos), 3, wp(L.hw), h, E, 1);
-            if (L.splits > 1) {
-                k_s2s_filter<15, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2[k], p->filt_b2[k], wp(L.ea15), wp(L.hw), wp(L.fpart), h, E);
-                k_s2s_sum_planes<<<blocks(E * h / 4), dim3(256), 0, st>>>(wp(L.fpart), L.splits, E * (int64_t)h, wp(L.fout));
-            } else {
-                k_s2s_filter<15, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2[k], p->filt_b2[k], wp(L.ea15), wp(L.hw), wp(L.fout), h, E);
-            }
-            k_s2s_relu_scale_acc<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.fout), edge_w + k, K, wp(L.M), h, E);
-        }
-        k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.M), agg_order, agg_rowptr, wp(L.agg_p), h, agg_div);
-    } else {
-        HIP_OK(hipMemsetAsync(wp(L.agg_h), 0, (size_t)Nn * h * 4, st));
-        HIP_OK(hipMemsetAsync(wp(L.agg_p), 0, (size_t)Nn * h * 4, st));
-    }
-    // ---- GRU-style gate (:845-852): input_* see the canonical state (6 columns of rel_feat)
-    k_s2s_pad_rows<<<blocks(Nn * 16), dim3(256), 0, st>>>(wp(L.rel), 6, 15, wp(L.relp), 16, Nn);
-    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->input_r_w, 6, 6, wp(L.irp), 16, h);
-    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->input_i_w, 6, 6, wp(L.iip), 16, h);
-    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->input_n_w, 6, 6, wp(L.inp), 16, h);
-    struct Gate { const float *iw, *ib, *pw, *pb, *hw; float* y; };
-    const Gate gates[3] = {{wp(L.irp), p->input_r_b, p->present_r_w, p->present_r_b, p->hidden_r_w, wp(L.rp)},
-                           {wp(L.iip), p->input_i_b, p->present_i_w, p->present_i_b, p->hidden_i_w, wp(L.ip)},
-                           {wp(L.inp), p->input_n_b, p->present_n_w, p->present_n_b, nullptr, wp(L.np_)}};
-    for (const Gate& g : gates) {
-        if (s2s_linear(0, g.iw, 16, g.ib, wp(L.relp), g.y, h, 16, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-        if (s2s_linear(0, g.pw, h, g.pb, wp(L.agg_p), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
-        if (g.hw && s2s_linear(0, g.hw, h, nullptr, wp(L.agg_h), g.y, h, h, Nn, h, nullptr, 0, 1, st)) return AETHER_EINVAL;
-    }
-    if (s2s_linear(0, p->hidden_h_w, h, nullptr, wp(L.agg_h), wp(L.hh), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    k_s2s_gate<<<blocks(Nn * h), dim3(256), 0, st>>>(wp(L.rp), wp(L.ip), wp(L.np_), wp(L.hh), hidden_in, hidden_out, Nn * h);
-    // ---- output MLP, rotate back, residual (:855-861)
-    if (s2s_linear(2, p->out1_w, h, p->out1_b, hidden_out, wp(L.o1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(2, p->out2_w, h, p->out2_b, wp(L.o1), wp(L.o2), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->out3_w, h, p->out3_b, wp(L.o2), wp(L.pred), 2 * D, h, Nn, 2 * D, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    k_s2s_globalize<2><<<blocks(Nn), dim3(256), 0, st>>>(inputs, wp(L.pred), wp(L.Rinv), outputs, Nn);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-// ------------------------------------------------------------------ variable-N encoder prior step and field (N2)
-namespace {
-struct DynPriorLayout {
-    size_t ext, rel, relp, Rinv, ea, ea15, epos, hw, eaf, fpart, X0, X1, X3, Ps, Pr, T1, X4, G, Y1, Y2, bn, w0p, total;
-    int splits;
-    DynPriorLayout(int h, int R, int ph, int64_t Nn, int64_t E) {
-        size_t off = 0;
-        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-        const size_t nn = (size_t)Nn, ee = (size_t)E, hh = (size_t)h;
-        ext = take(nn * 6); rel = take(nn * 15); relp = take(nn * 16); Rinv = take(nn * 4);
-        ea = take(ee * 24); ea15 = take(ee * 15); epos = take(ee * 3); hw = take(ee * hh); eaf = take(ee * hh);
-        splits = S2SPriorLayout::filter_splits(h, E);
-        fpart = take(splits > 1 ? ee * hh * splits : 0);
-        X0 = take(nn * hh); X1 = take(nn * hh); X3 = take(nn * hh); Ps = take(nn * hh); Pr = take(nn * hh);
-        T1 = take(ee * hh); X4 = take(ee * hh); G = take(ee * 4 * (size_t)R);
-        Y1 = take(ee * (size_t)(ph > 0 ? ph : 1)); Y2 = take(ee * (size_t)(ph > 0 ? ph : 1));
-        bn = take(6 * hh); w0p = take(hh * 16);
-        total = off;
-    }
-};
-}  // namespace
-
-size_t aether_dyn_prior_workspace_bytes(int hidden, int rnn_hidden, int prior_hidden, int64_t n_nodes, int64_t n_edges) {
-    if (hidden <= 0 || rnn_hidden <= 0 || n_nodes <= 0 || n_edges < 0) return 0;
-    return DynPriorLayout(hidden, rnn_hidden, prior_hidden, n_nodes, n_edges).total;
-}
-
-int aether_dyn_prior_step(const AetherDynPriorParams* p, int hidden, int rnn_hidden, int prior_layers, int prior_hidden,
-                          int num_edge_types, int polar, int64_t n_nodes, int64_t n_edges, const float* inputs,
-                          const float* field, const float* h0, const float* c0, const int64_t* send, const int64_t* recv,
-                          const int64_t* order, const int64_t* rowptr, void* workspace, size_t workspace_bytes,
-                          float* logits, float* h1, float* c1, void* stream) {
-    if (!p || !inputs || !field || !h0 || !c0 || !send || !recv || !order || !rowptr || !workspace || !logits || !h1 || !c1)
-        return fail(AETHER_EINVAL, "dyn_prior: null pointer");
-    if (hidden < 128 || hidden % 128 != 0) return fail(AETHER_EINVAL, "dyn_prior: hidden must be a multiple of 128");
-    if (rnn_hidden < 16 || rnn_hidden % 16 != 0) return fail(AETHER_EINVAL, "dyn_prior: rnn_hidden must be a multiple of 16");
-    if (prior_layers < 1 || prior_layers > 4) return fail(AETHER_EINVAL, "dyn_prior: 1..4 prior layers");
-    if (prior_layers > 1 && (prior_hidden < 16 || prior_hidden % 16 != 0))
-        return fail(AETHER_EINVAL, "dyn_prior: prior_hidden must be a multiple of 16");
-    if (num_edge_types < 1 || num_edge_types > 4 || n_nodes <= 0 || n_edges <= 0)
-        return fail(AETHER_EINVAL, "dyn_prior: bad sizes");
-    constexpr int D = 2;
-    const int h = hidden, R = rnn_hidden, K = num_edge_types;
-    DynPriorLayout L(h, R, prior_hidden, n_nodes, n_edges);
-    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "dyn_prior: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
-    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    const int64_t Nn = n_nodes, E = n_edges;
-    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    // ---- canonical states, edge features, anisotropic filter (:531-539)
-    k_s2s_extend<<<blocks(Nn * 3 * D), dim3(256), 0, st>>>(inputs, field, wp(L.ext), D, Nn);
-    k_s2s_aug_nodes<2><<<blocks(Nn), dim3(256), 0, st>>>(wp(L.ext), wp(L.rel), wp(L.Rinv), Nn);
-    k_s2s_aug_edges<2><<<blocks(E), dim3(256), 0, st>>>(wp(L.ext), send, recv, wp(L.rel), polar, wp(L.ea), wp(L.epos), E);
-    k_s2s_pad_rows<<<blocks(E * 15), dim3(256), 0, st>>>(wp(L.ea), 15, 24, wp(L.ea15), 15, E);
-    k_s2s_pos_hidden<<<blocks(E * h), dim3(256), 0, st>>>(p->filt_w0, p->filt_b0, wp(L.epos), 3, wp(L.hw), h, E, 1);
-    {
-        constexpr int NB = 4;
-        const dim3 grid((unsigned)((E + 32 * NB - 1) / (32 * NB)), (unsigned)(h / 128), (unsigned)L.splits);
-        if (L.splits > 1) {
-            k_s2s_filter<15, NB, true><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea15), wp(L.hw), wp(L.fpart), h, E);
-            k_s2s_sum_planes<<<blocks(E * h / 4), dim3(256), 0, st>>>(wp(L.fpart), L.splits, E * (int64_t)h, wp(L.eaf));
-        } else {
-            k_s2s_filter<15, NB, false><<<grid, dim3(256), 0, st>>>(p->filt_w2, p->filt_b2, wp(L.ea15), wp(L.hw), wp(L.eaf), h, E);
-        }
-    }
-    // ---- x = sum over in-edges + mlp1(canonical state) (:541-542); RefNRIMLP (eval): Linear-ELU-Linear-ELU-BatchNorm
-    float* bns[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    const float* bnp[3][4] = {{p->mlp1_bn_w, p->mlp1_bn_b, p->mlp1_bn_mean, p->mlp1_bn_var},
-                              {p->mlp3_bn_w, p->mlp3_bn_b, p->mlp3_bn_mean, p->mlp3_bn_var},
-                              {p->mlp4_bn_w, p->mlp4_bn_b, p->mlp4_bn_mean, p->mlp4_bn_var}};
-    for (int j = 0; j < 3; ++j) {
-        if (!bnp[j][0]) continue;
-        if (!bnp[j][1] || !bnp[j][2] || !bnp[j][3]) return fail(AETHER_EINVAL, "dyn_prior: incomplete BatchNorm pointers");
-        bns[j][0] = wp(L.bn) + 2 * j * h; bns[j][1] = wp(L.bn) + (2 * j + 1) * h;
-        k_s2s_bn_affine<<<blocks(h), dim3(256), 0, st>>>(bnp[j][0], bnp[j][1], bnp[j][2], bnp[j][3], bns[j][0], bns[j][1], h);
-    }
-    k_s2s_segment_mean<<<dim3((unsigned)Nn), dim3(128), 0, st>>>(wp(L.eaf), order, rowptr, wp(L.X0), h, 1.0f);
-    k_s2s_pad_rows<<<blocks(Nn * 16), dim3(256), 0, st>>>(wp(L.rel), 6, 15, wp(L.relp), 16, Nn);
-    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->mlp1_w0, 6, 6, wp(L.w0p), 16, h);
-    if (s2s_linear(4, wp(L.w0p), 16, p->mlp1_b0, wp(L.relp), wp(L.X1), h, 16, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(4, p->mlp1_w3, h, p->mlp1_b3, wp(L.X1), wp(L.X0), h, h, Nn, h, nullptr, 0, 1, st, nullptr, nullptr, nullptr,
-                   bns[0][0], bns[0][1])) return AETHER_EINVAL;
-    if (s2s_linear(4, p->mlp3_w0, h, p->mlp3_b0, wp(L.X0), wp(L.X1), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(4, p->mlp3_w3, h, p->mlp3_b3, wp(L.X1), wp(L.X3), h, h, Nn, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr,
-                   bns[1][0], bns[1][1])) return AETHER_EINVAL;
-    // ---- mlp4 on [x_send | x_recv | edge] (:545-547)
-    if (s2s_linear(0, p->mlp4_w0, 3 * h, p->mlp4_b0, wp(L.X3), wp(L.Ps), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->mlp4_w0 + h, 3 * h, nullptr, wp(L.X3), wp(L.Pr), h, h, Nn, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->mlp4_w0 + 2 * h, 3 * h, nullptr, wp(L.eaf), wp(L.T1), h, h, E, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    k_s2s_edge_sum_elu<<<blocks(E * (h / 4)), dim3(256), 0, st>>>(wp(L.T1), wp(L.Ps), wp(L.Pr), send, recv, h, E);
-    if (s2s_linear(4, p->mlp4_w3, h, p->mlp4_b3, wp(L.T1), wp(L.X4), h, h, E, h, nullptr, 0, 0, st, nullptr, nullptr, nullptr,
-                   bns[2][0], bns[2][1])) return AETHER_EINVAL;
-    // ---- one LSTM step per edge, prior_fc_out (:688-696)
-    if (s2s_linear(0, p->lstm_w_ih, h, p->lstm_b_ih, wp(L.X4), wp(L.G), 4 * R, h, E, 4 * R, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->lstm_w_hh, R, p->lstm_b_hh, h0, wp(L.G), 4 * R, R, E, 4 * R, nullptr, 0, 1, st)) return AETHER_EINVAL;
-    k_s2s_lstm_cell<<<blocks(E * R), dim3(256), 0, st>>>(wp(L.G), c0, h1, c1, R, E);
-    const float* cur = h1;
-    int cur_k = R;
-    for (int l = 0; l < prior_layers; ++l) {
-        const bool last = l + 1 == prior_layers;
-        float* dst = last ? logits : wp(l % 2 == 0 ? L.Y1 : L.Y2);
-        const int M = last ? K : prior_hidden;
-        if (s2s_linear(last ? 0 : 4, p->prior_w[l], cur_k, p->prior_b[l], cur, dst, M, cur_k, E, M, nullptr, 0, 0, st)) return AETHER_EINVAL;
-        cur = dst;
-        cur_k = M;
-    }
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-size_t aether_dyn_field_workspace_bytes(int64_t n_points, int hidden) {
-    if (n_points <= 0 || hidden <= 0) return 0;
-    const size_t n = (size_t)n_points, h = (size_t)hidden;
-    return align_up(n * 16 * 4, 256) + align_up(h * 16 * 4, 256) + align_up(n * 2 * h * 4, 256) + 2 * align_up(n * h * 4, 256) + 256;
-}
-
-int aether_dyn_field(const AetherDynFieldQueryParams* p, int hidden, int64_t n_points, const float* x, void* workspace,
-                     size_t workspace_bytes, float* field, void* stream) {
-    if (!p || !x || !workspace || !field || !p->B || !p->ang_w || !p->ang_b || !p->w0 || !p->b0 || !p->w2 || !p->b2 ||
-        !p->w4 || !p->b4)
-        return fail(AETHER_EINVAL, "dyn_field: null pointer");
-    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "dyn_field: hidden must be a multiple of 32");
-    if (n_points <= 0) return fail(AETHER_EINVAL, "dyn_field: bad sizes");
-    if (workspace_bytes < aether_dyn_field_workspace_bytes(n_points, hidden))
-        return fail(AETHER_ESPACE, "dyn_field: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    const int h = hidden, half = hidden / 2;
-    const size_t n = (size_t)n_points;
-    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
-    size_t off = 0;
-    auto take = [&](size_t bytes) { char* q = ws + off; off += align_up(bytes, 256); return reinterpret_cast<float*>(q); };
-    float* dir = take(n * 16 * 4);
-    float* awp = take((size_t)h * 16 * 4);
-    float* cat = take(n * 2 * h * 4);                               // [rff (h) | angular embedding (h)]
-    float* h1 = take(n * h * 4);
-    float* h2 = take(n * h * 4);
-    auto blocks = [](int64_t c) { return dim3((unsigned)((c + 255) / 256)); };
-    k_s2s_rff<2><<<blocks(n_points * half), dim3(256), 0, st>>>(x, 4, p->B, half, cat, n_points, 2 * h);
-    k_s2s_unit_velocity<<<blocks(n_points), dim3(256), 0, st>>>(x, dir, n_points);
-    k_s2s_pad_rows<<<blocks((int64_t)h * 16), dim3(256), 0, st>>>(p->ang_w, 2, 2, awp, 16, h);
-    if (s2s_linear(0, awp, 16, p->ang_b, dir, cat + h, h, 16, n_points, 2 * h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(1, p->w0, 2 * h, p->b0, cat, h1, h, 2 * h, n_points, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(1, p->w2, h, p->b2, h1, h2, h, h, n_points, h, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->w4, h, p->b4, h2, field, 2, h, n_points, 2, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-// ------------------------------------------------------------------ seq2seq dynamic-field variant (N3)
-namespace {
-struct S2SSummaryLayout {
-    size_t xp, wep, emb, gi, gh, h, aug, g0p, n0p, gate, total;
-    int inp, Kp;
-    S2SSummaryLayout(int64_t B, int N, int T, int in, int H) {
-        inp = (in + 15) / 16 * 16; Kp = (in + H + 15) / 16 * 16;
-        const size_t S = (size_t)B * N, R = S * T, hh = (size_t)H;
-        size_t off = 0;
-        auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
-        xp = take(R * inp); wep = take(hh * inp); emb = take(R * hh);
-        gi = take(R * 3 * hh);                  // after the GRU: T1 | T2 | V of the attention nets
-        gh = take(S * 3 * hh); h = take(S * hh);
-        aug = take(R * Kp); g0p = take(hh * Kp); n0p = take(hh * Kp); gate = take(R);
-        total = off;
-    }
-};
-}  // namespace
-
-size_t aether_s2s_graph_summary_workspace_bytes(int64_t batch, int num_objects, int timesteps, int input_size,
-                                                int hidden) {
-    if (batch <= 0 || num_objects <= 0 || timesteps <= 0 || input_size <= 0 || hidden <= 0) return 0;
-    return S2SSummaryLayout(batch, num_objects, timesteps, input_size, hidden).total + 256;
-}
-
-int aether_s2s_graph_summary(const AetherS2SGraphSummaryParams* p, int64_t batch, int num_objects, int timesteps,
-                             int input_size, int hidden, int pe_len, const float* x, void* workspace,
-                             size_t workspace_bytes, float* summary, void* stream) {
-    if (!p || !x || !workspace || !summary || !p->emb_w || !p->emb_b || !p->gru_w_ih || !p->gru_w_hh || !p->gru_b_ih ||
-        !p->gru_b_hh || !p->pe || !p->gate_w0 || !p->gate_b0 || !p->gate_w2 || !p->gate_b2 || !p->nn_w0 || !p->nn_b0 ||
-        !p->nn_w2 || !p->nn_b2)
-        return fail(AETHER_EINVAL, "s2s_graph_summary: null pointer");
-    if (batch <= 0 || num_objects <= 0 || timesteps <= 0 || input_size <= 0)
-        return fail(AETHER_EINVAL, "s2s_graph_summary: bad sizes");
-    if (hidden < 16 || hidden % 16 != 0) return fail(AETHER_EINVAL, "s2s_graph_summary: hidden must be a multiple of 16");
-    if (timesteps > pe_len)
-        return fail(AETHER_EINVAL, "s2s_graph_summary: more time steps than rows of the positional encoding");
-    const S2SSummaryLayout L(batch, num_objects, timesteps, input_size, hidden);
-    if (workspace_bytes < L.total) return fail(AETHER_ESPACE, "s2s_graph_summary: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
-    auto wp = [&](size_t o) { return reinterpret_cast<float*>(ws + o); };
-    const int in = input_size, H = hidden, T = timesteps;
-    const int64_t S = batch * num_objects, R = S * T;
-    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    // particle embedding and the input half of the GRU for every time step at once (graph_pool.py:62-63)
-    k_s2s_pad_rows<<<blocks(R * L.inp), dim3(256), 0, st>>>(x, in, in, wp(L.xp), L.inp, R);
-    k_s2s_pad_rows<<<blocks((int64_t)H * L.inp), dim3(256), 0, st>>>(p->emb_w, in, in, wp(L.wep), L.inp, H);
-    if (s2s_linear(0, wp(L.wep), L.inp, p->emb_b, wp(L.xp), wp(L.emb), H, L.inp, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->gru_w_ih, H, p->gru_b_ih, wp(L.emb), wp(L.gi), 3 * H, H, R, 3 * H, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    HIP_OK(hipMemsetAsync(wp(L.h), 0, (size_t)S * H * sizeof(float), st));
-    for (int t = 0; t < T; ++t) {
-        if (s2s_linear(0, p->gru_w_hh, H, p->gru_b_hh, wp(L.h), wp(L.gh), 3 * H, H, S, 3 * H, nullptr, 0, 0, st)) return AETHER_EINVAL;
-        k_s2s_gru_gate<<<blocks(S * H), dim3(256), 0, st>>>(wp(L.gi) + (size_t)t * 3 * H, (int64_t)T * 3 * H, wp(L.gh),
-                                                            wp(L.h), H, S);
-    }
-    // [x | last hidden] + pe, then the two nets of the attention pooling (:66-70)
-    k_s2s_augment<<<blocks(R * L.Kp), dim3(256), 0, st>>>(x, wp(L.h), p->pe, wp(L.aug), in, H, L.Kp, T, R);
-    k_s2s_pad_rows<<<blocks((int64_t)H * L.Kp), dim3(256), 0, st>>>(p->gate_w0, in + H, in + H, wp(L.g0p), L.Kp, H);
-    k_s2s_pad_rows<<<blocks((int64_t)H * L.Kp), dim3(256), 0, st>>>(p->nn_w0, in + H, in + H, wp(L.n0p), L.Kp, H);
-    float* T1 = wp(L.gi);
-    float* T2 = T1 + (size_t)R * H;
-    float* V = T2 + (size_t)R * H;
-    if (s2s_linear(1, wp(L.g0p), L.Kp, p->gate_b0, wp(L.aug), T1, H, L.Kp, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->gate_w2, H, p->gate_b2, T1, wp(L.gate), 1, H, R, 1, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(1, wp(L.n0p), L.Kp, p->nn_b0, wp(L.aug), T2, H, L.Kp, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->nn_w2, H, p->nn_b2, T2, V, H, H, R, H, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    k_s2s_attn_pool<<<dim3((unsigned)batch, (unsigned)((H + 255) / 256)), dim3(256), 0, st>>>(
-        wp(L.gate), V, summary, num_objects * T, H);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-size_t aether_s2s_film_modulation_bytes(int64_t batch, int mlp_hidden) {
-    if (batch <= 0 || mlp_hidden <= 0) return 0;
-    return (size_t)5 * (size_t)batch * (size_t)mlp_hidden * sizeof(float);
-}
-
-int aether_s2s_film_modulation(const AetherS2SFilmParams* p, int graph_hidden, int mlp_hidden, int64_t batch,
-                               const float* summary, float* mod, size_t mod_bytes, void* stream) {
-    if (!p || !summary || !mod) return fail(AETHER_EINVAL, "s2s_film_modulation: null pointer");
-    for (int k = 0; k < 4; ++k)
-        if (!p->mod_w0[k] || !p->mod_b0[k] || !p->mod_w2[k] || !p->mod_b2[k])
-            return fail(AETHER_EINVAL, "s2s_film_modulation: null pointer");
-    if (batch <= 0 || graph_hidden < 16 || graph_hidden % 16 != 0 || mlp_hidden < 16 || mlp_hidden % 16 != 0)
-        return fail(AETHER_EINVAL, "s2s_film_modulation: graph_hidden and mlp_hidden must be multiples of 16");
-    if (mod_bytes < aether_s2s_film_modulation_bytes(batch, mlp_hidden))
-        return fail(AETHER_ESPACE, "s2s_film_modulation: mod buffer too small");
-    hipStream_t st = (hipStream_t)stream;
-    const size_t plane = (size_t)batch * mlp_hidden;
-    float* tmp = mod + 4 * plane;
-    for (int k = 0; k < 4; ++k) {
-        if (s2s_linear(1, p->mod_w0[k], graph_hidden, p->mod_b0[k], summary, tmp, mlp_hidden, graph_hidden, batch,
-                       mlp_hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
-        if (s2s_linear(0, p->mod_w2[k], mlp_hidden, p->mod_b2[k], tmp, mod + k * plane, mlp_hidden, mlp_hidden, batch,
-                       mlp_hidden, nullptr, 0, 0, st)) return AETHER_EINVAL;
-    }
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-size_t aether_s2s_film_field_workspace_bytes(int64_t n_points, int hidden, int mlp_hidden) {
-    if (n_points <= 0 || hidden <= 0 || mlp_hidden <= 0) return 0;
-    return align_up((size_t)n_points * hidden * 4, 256) + 2 * align_up((size_t)n_points * mlp_hidden * 4, 256) + 256;
-}
-
-int aether_s2s_film_field(const AetherS2SFilmParams* p, int num_dims, int hidden, int mlp_hidden, int64_t n_points,
-                          int64_t rows_per_graph, const float* x, int x_stride, const float* mod, int64_t batch,
-                          void* workspace, size_t workspace_bytes, float* field, void* stream) {
-    if (!p || !x || !mod || !workspace || !field || !p->B || !p->lin1_w || !p->lin1_b || !p->lin2_w || !p->lin2_b ||
-        !p->lin3_w || !p->lin3_b)
-        return fail(AETHER_EINVAL, "s2s_film_field: null pointer");
-    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "s2s_film_field: num_dims must be 2 or 3");
-    if (hidden < 32 || hidden % 32 != 0) return fail(AETHER_EINVAL, "s2s_film_field: hidden must be a multiple of 32");
-    if (mlp_hidden < 16 || mlp_hidden % 16 != 0) return fail(AETHER_EINVAL, "s2s_film_field: mlp_hidden must be a multiple of 16");
-    if (n_points <= 0 || x_stride < num_dims || rows_per_graph <= 0 || batch <= 0 ||
-        (n_points + rows_per_graph - 1) / rows_per_graph > batch || rows_per_graph > INT32_MAX)
-        return fail(AETHER_EINVAL, "s2s_film_field: bad sizes (n_points must fit batch * rows_per_graph)");
-    if (workspace_bytes < aether_s2s_film_field_workspace_bytes(n_points, hidden, mlp_hidden))
-        return fail(AETHER_ESPACE, "s2s_film_field: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
-    const size_t gplane = align_up((size_t)n_points * hidden * 4, 256), hplane = align_up((size_t)n_points * mlp_hidden * 4, 256);
-    float* gamma = reinterpret_cast<float*>(ws);
-    float* h1 = reinterpret_cast<float*>(ws + gplane);
-    float* h2 = reinterpret_cast<float*>(ws + gplane + hplane);
-    const size_t plane = (size_t)batch * mlp_hidden;
-    const int half = hidden / 2, rows = (int)rows_per_graph;
-    const unsigned rb = (unsigned)((n_points * half + 255) / 256);
-    if (num_dims == 2) k_s2s_rff<2><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
-    else k_s2s_rff<3><<<dim3(rb), dim3(256), 0, st>>>(x, x_stride, p->B, half, gamma, n_points);
-    if (s2s_linear(1, p->lin1_w, hidden, p->lin1_b, gamma, h1, mlp_hidden, hidden, n_points, mlp_hidden, nullptr, 0, 0, st,
-                   nullptr, nullptr, nullptr, nullptr, nullptr, mod, mod + plane, rows)) return AETHER_EINVAL;
-    if (s2s_linear(1, p->lin2_w, mlp_hidden, p->lin2_b, h1, h2, mlp_hidden, mlp_hidden, n_points, mlp_hidden, nullptr, 0, 0, st,
-                   nullptr, nullptr, nullptr, nullptr, nullptr, mod + 2 * plane, mod + 3 * plane, rows)) return AETHER_EINVAL;
-    if (s2s_linear(0, p->lin3_w, mlp_hidden, p->lin3_b, h2, field, num_dims, mlp_hidden, n_points, num_dims, nullptr, 0, 0, st))
-        return AETHER_EINVAL;
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-// ------------------------------------------------------------------ kNN edge builder (N2)
-namespace {
-struct KnnLayout {
-    size_t nbr, cnt, node_off, edge_off, total;
-    KnnLayout(int64_t S, int N, int k) {
-        size_t off = 0;
-        auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-        nbr = take((size_t)S * N * k * 4); cnt = take((size_t)S * N * 4);
-        node_off = take((size_t)S * 8); edge_off = take((size_t)S * 8);
-        total = off;
-    }
-};
-}  // namespace
-
-size_t aether_knn_workspace_bytes(int64_t n_scenes, int n_objects, int k) {
-    if (n_scenes <= 0 || n_objects <= 0 || k <= 0) return 0;
-    return KnnLayout(n_scenes, n_objects, k).total + 256;
-}
-
-int aether_knn_edges(const float* x, int x_stride, const float* masks, int64_t n_scenes, int n_objects, int k,
-                     int64_t* send, int64_t* recv, int64_t* scene_edges, int64_t* scene_nodes, int64_t* totals,
-                     void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !masks || !send || !recv || !scene_edges || !scene_nodes || !totals || !workspace)
-        return fail(AETHER_EINVAL, "knn_edges: null pointer");
-    if (n_scenes <= 0 || n_scenes > INT32_MAX || n_objects <= 0 || n_objects > KNN_MAX_OBJECTS || x_stride < 2)
-        return fail(AETHER_EINVAL, "knn_edges: bad sizes (at most 8192 objects per scene, x_stride >= 2)");
-    if (k < 1 || k > KNN_MAX_K) return fail(AETHER_EINVAL, "knn_edges: k must be in 1..16");
-    const KnnLayout L(n_scenes, n_objects, k);
-    if (workspace_bytes < L.total + 256) return fail(AETHER_ESPACE, "knn_edges: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = reinterpret_cast<char*>(align_up((size_t)workspace, 256));
-    int* nbr = reinterpret_cast<int*>(ws + L.nbr);
-    int* cnt = reinterpret_cast<int*>(ws + L.cnt);
-    int64_t* node_off = reinterpret_cast<int64_t*>(ws + L.node_off);
-    int64_t* edge_off = reinterpret_cast<int64_t*>(ws + L.edge_off);
-    const int N = n_objects;
-    const size_t lds_sel = (size_t)3 * N * 4 + 257 * 4, lds_wr = (size_t)2 * N * 4 + 257 * 4;
-    if (ensure_dynamic_lds((const void*)k_knn_select, lds_sel) || ensure_dynamic_lds((const void*)k_knn_write, lds_wr))
-        return AETHER_EHIP;
-    HIP_OK(hipMemsetAsync(scene_nodes, 0, (size_t)n_scenes * sizeof(int64_t), st));
-    HIP_OK(hipMemsetAsync(scene_edges, 0, (size_t)n_scenes * sizeof(int64_t), st));
-    // few large scenes: several workgroups per scene (each stages the scene and takes a slice of its objects)
-    int per_scene = 1;
-    while (per_scene * 256 < N && n_scenes * per_scene < 512) per_scene *= 2;
-    k_knn_select<<<dim3((unsigned)n_scenes, (unsigned)per_scene), dim3(256), lds_sel, st>>>(x, x_stride, masks, N, k, nbr, cnt,
-                                                                                           scene_nodes, scene_edges);
-    k_knn_scan<<<dim3(1), dim3(1024), 0, st>>>(scene_nodes, scene_edges, n_scenes, node_off, edge_off, totals);
-    k_knn_write<<<dim3((unsigned)n_scenes), dim3(256), lds_wr, st>>>(masks, nbr, cnt, N, k, node_off, edge_off, send, recv);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-// ------------------------------------------------------------------ simulators (N4)
-namespace {
-int sim_check(int64_t n_sims, int n_balls, int total_balls, int dim, int T, int sample_freq) {
-    if (n_sims <= 0 || n_balls < 0 || total_balls <= 0 || n_balls > total_balls || total_balls > SIM_MAX_BALLS)
-        return fail(AETHER_EINVAL, "simulator: bad sizes (at most 64 balls per simulation)");
-    if (dim != 2 && dim != 3) return fail(AETHER_EINVAL, "simulator: dim must be 2 or 3");
-    if (T <= 0 || sample_freq <= 0 || T % sample_freq != 0)
-        return fail(AETHER_EINVAL, "simulator: T must be a positive multiple of sample_freq");
-    return AETHER_OK;
-}
-}  // namespace
-
-int aether_sim_electrostatic(const double* loc0, const double* vel0, const double* charges, int64_t n_sims, int n_balls,
-                             int total_balls, int dim, int T, int sample_freq, double interaction_strength,
-                             double delta_T, double max_F, double* loc, double* vel, int64_t* maxed_out, void* stream) {
-    if (!loc0 || !vel0 || !charges || !maxed_out || (T / (sample_freq > 0 ? sample_freq : 1) > 1 && (!loc || !vel)))
-        return fail(AETHER_EINVAL, "sim_electrostatic: null pointer");
-    if (int rc = sim_check(n_sims, n_balls, total_balls, dim, T, sample_freq)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    HIP_OK(hipMemsetAsync(maxed_out, 0, (size_t)n_sims * sizeof(int64_t), st));
-    const int spw = 64 / total_balls;
-    const dim3 grid((unsigned)((n_sims + spw - 1) / spw));
-    if (dim == 2)
-        k_sim_electrostatic<2><<<grid, dim3(64), 0, st>>>(loc0, vel0, charges, n_sims, n_balls, total_balls, T, sample_freq,
-                                                          interaction_strength, delta_T, max_F, loc, vel, maxed_out);
-    else
-        k_sim_electrostatic<3><<<grid, dim3(64), 0, st>>>(loc0, vel0, charges, n_sims, n_balls, total_balls, T, sample_freq,
-                                                          interaction_strength, delta_T, max_F, loc, vel, maxed_out);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-int aether_sim_charged(const double* loc0, const double* vel0, const double* charges, int64_t n_sims, int n_balls, int T,
-                       int sample_freq, double interaction_strength, double delta_T, double max_F, int ext_mode,
-                       const double* ext, double* loc, double* vel, void* stream) {
-    if (!loc0 || !vel0 || !charges || (T / (sample_freq > 0 ? sample_freq : 1) > 1 && (!loc || !vel)))
-        return fail(AETHER_EINVAL, "sim_charged: null pointer");
-    if (int rc = sim_check(n_sims, n_balls, n_balls, 3, T, sample_freq)) return rc;
-    if (ext_mode < 0 || ext_mode > 2 || (ext_mode != 0 && !ext)) return fail(AETHER_EINVAL, "sim_charged: bad ext_mode / ext");
-    hipStream_t st = (hipStream_t)stream;
-    const int spw = 64 / n_balls;
-    const dim3 grid((unsigned)((n_sims + spw - 1) / spw));
-    k_sim_charged<<<grid, dim3(64), 0, st>>>(loc0, vel0, charges, n_sims, n_balls, T, sample_freq, interaction_strength, delta_T,
-                                             max_F, ext_mode, ext_mode ? ext[0] : 0.0, ext_mode ? ext[1] : 0.0,
-                                             ext_mode ? ext[2] : 0.0, loc, vel);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-int aether_sim_gravitational(const double* pos0, const double* vel0, const double* mass, int64_t n_sims, int n_balls,
-                             int total_balls, int dim, int T, int sample_freq, double interaction_strength, double dt,
-                             double softening, double* pos, double* vel, double* force, void* stream) {
-    if (!pos0 || !vel0 || !mass || !pos || !vel || !force) return fail(AETHER_EINVAL, "sim_gravitational: null pointer");
-    if (int rc = sim_check(n_sims, n_balls, total_balls, dim, T, sample_freq)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const int spw = 64 / total_balls;
-    const dim3 grid((unsigned)((n_sims + spw - 1) / spw));
-    if (dim == 2)
-        k_sim_gravitational<2><<<grid, dim3(64), 0, st>>>(pos0, vel0, mass, n_sims, n_balls, total_balls, T, sample_freq,
-                                                          interaction_strength, dt, softening, pos, vel, force);
-    else
-        k_sim_gravitational<3><<<grid, dim3(64), 0, st>>>(pos0, vel0, mass, n_sims, n_balls, total_balls, T, sample_freq,
-                                                          interaction_strength, dt, softening, pos, vel, force);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
-
-int aether_s2s_gumbel_hard(const float* logits, const float* uniform, float tau, int num_edge_types, int64_t n_edges,
-                           float* edges, void* stream) {
-    if (!logits || !uniform || !edges) return fail(AETHER_EINVAL, "s2s_gumbel: null pointer");
-    if (num_edge_types < 1 || num_edge_types > 4 || n_edges <= 0 || !(tau > 0.0f)) return fail(AETHER_EINVAL, "s2s_gumbel: bad sizes");
-    k_s2s_gumbel_hard<<<dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        logits, uniform, tau, num_edge_types, edges, n_edges);
-    HIP_OK(hipGetLastError());
-    return AETHER_OK;
-}
+#include "host_seq2seq.inc"
+#include "host_dynamicvars.inc"
+#include "host_sim.inc"
 
 int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");
