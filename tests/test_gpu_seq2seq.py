@@ -383,3 +383,30 @@ def test_evaluation_runner_surface():
     summary = torch.from_numpy(d["ref.summary"])
     want = S.film_field(sd, grid.unsqueeze(0).repeat(inputs.shape[0], 1, 1), summary, 3)
     assert scale_rel_err(got.cpu(), want) <= 2 * TOL
+
+
+def test_gravitational_config_shape_vs_oracle():
+    """BASELINE config 3's shape for the seq2seq family: 3-D, N=20 fully connected, the runner's hidden sizes
+    (encoder / decoder / graph / mlp hidden 512, rnn 128), dynamic-field model; B=32 graphs (the oracle materialises
+    the reference's [E, 39, 512] filter bank: 1 GB here), two burn-in steps + two prediction steps."""
+    from aether_amd.nn.seq2seq.dynamic_field_aether import DynamicFieldAether
+    D, B, N, T, steps, H = 3, 32, 20, 3, 2, 512
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H, "encoder_rnn_hidden": 128,
+              "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 256,
+              "prior_num_layers": 3, "prior_hidden_size": 256, "use_3d": True, "pos_representation": "cart", "gpu": True,
+              "decoder_hidden": H, "skip_first": False, "decoder_dropout": 0.0, "gumbel_temp": 0.5, "graph_hidden": H,
+              "mlp_hidden": H, "field": None}
+    torch.manual_seed(3)
+    model = DynamicFieldAether(params, device="cuda").eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    inputs = torch.randn(B, T, N, 2 * D, generator=g)
+    U = torch.rand(T - 1 + steps, B * N * (N - 1), 2, generator=g)
+    want, want_edges = S.predict_future_dynamic_field(sd, inputs, steps, U, 0.5, True, "cart", 3, return_edges=True)
+    got, got_edges = model.predict_future(inputs.cuda(), steps, return_edges=True, uniform=U.cuda().view(-1, B, N * (N - 1), 2))
+    same = got_edges.cpu().argmax(-1) == want_edges.argmax(-1)
+    # a sampled edge type may flip where the two Gumbel scores are within rounding of each other; trajectories are
+    # compared on the graphs whose samples all agree (all of them for this seed)
+    ok = same.reshape(B, -1).all(dim=1)
+    assert ok.float().mean() >= 0.9
+    assert scale_rel_err(got.cpu()[ok], want[ok]) <= 2 * TOL
