@@ -125,6 +125,9 @@ SIGNATURES = {
     "aether_sim_charged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    "aether_rollout_dynamic_field": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int] +
+                                     [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                                         C.c_void_p]),
     "aether_s2s_gumbel_hard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "aether_dynamic_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -901,10 +901,10 @@ int aether_dynamic_field(const AetherDynFieldParams* p, int num_dims, int64_t n_
     return AETHER_OK;
 }
 
-int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x0,
-                   const float* vel0, const float* charges, const void* graph, const AetherGraphInfo* info,
-                   void* workspace, size_t workspace_bytes, float* trajectory, int steps, float dt,
-                   int flags, void* stream) {
+static int rollout_common(const AetherParams* params, const AetherDynFieldParams* dyn, int nodes_per_graph, float* field_buf,
+                          int num_dims, int64_t n_nodes, int64_t n_edges, const float* x0, const float* vel0,
+                          const float* charges, const void* graph, const AetherGraphInfo* info, void* workspace,
+                          size_t workspace_bytes, float* trajectory, int steps, float dt, int flags, void* stream) {
     if (!params || !x0 || !vel0 || !charges || !graph || !info || !workspace || !trajectory)
         return fail(AETHER_EINVAL, "rollout: null pointer");
     if (info->n_nodes != n_nodes || info->n_edges != n_edges)
@@ -915,6 +915,8 @@ int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, in
     if (flags & AETHER_FLAG_KEEP_INTERMEDIATES) return fail(AETHER_EINVAL, "rollout: inference only");
     if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 0))
         return fail(AETHER_ESPACE, "rollout: workspace too small");
+    if (dyn && (!field_buf || nodes_per_graph <= 0 || n_nodes % nodes_per_graph != 0))
+        return fail(AETHER_EINVAL, "rollout: n_nodes must be a multiple of nodes_per_graph (and a field buffer given)");
     hipStream_t st = (hipStream_t)stream;
     const bool fused = info->n_groups > 0 && n_edges > 0 && !(flags & AETHER_FLAG_FORCE_STREAMED);
     if ((flags & AETHER_FLAG_FORCE_FUSED) && !fused)
@@ -926,7 +928,11 @@ int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, in
         const float* x = t == 0 ? x0 : trajectory + (size_t)(t - 1) * stride;
         const float* v = t == 0 ? vel0 : reinterpret_cast<const float*>(ws + W.velbuf[(t - 1) & 1]);
         float* out = trajectory + (size_t)t * stride;
-        StepExtras ex{charges, reinterpret_cast<float*>(ws + W.velbuf[t & 1]), dt, nullptr};
+        if (dyn) {              // the dynamic-field model: LatentFieldNetwork on the current state, then the step
+            int rc = aether_dynamic_field(dyn, num_dims, n_nodes / nodes_per_graph, nodes_per_graph, x, v, charges, field_buf, stream);
+            if (rc != AETHER_OK) return rc;
+        }
+        StepExtras ex{charges, reinterpret_cast<float*>(ws + W.velbuf[t & 1]), dt, dyn ? field_buf : nullptr};
         const bool reused = t > 0 || (flags & AETHER_FLAG_WORKSPACE_REUSED);   // the step before re-armed the flags
         int rc;
         if (fused)
@@ -942,6 +948,24 @@ int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, in
         if (rc != AETHER_OK) return rc;
     }
     return AETHER_OK;
+}
+
+int aether_rollout(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x0,
+                   const float* vel0, const float* charges, const void* graph, const AetherGraphInfo* info,
+                   void* workspace, size_t workspace_bytes, float* trajectory, int steps, float dt,
+                   int flags, void* stream) {
+    return rollout_common(params, nullptr, 0, nullptr, num_dims, n_nodes, n_edges, x0, vel0, charges, graph, info, workspace,
+                          workspace_bytes, trajectory, steps, dt, flags, stream);
+}
+
+int aether_rollout_dynamic_field(const AetherParams* params, const AetherDynFieldParams* dyn_params, int num_dims,
+                                 int64_t n_nodes, int64_t n_edges, int nodes_per_graph, const float* x0, const float* vel0,
+                                 const float* charges, const void* graph, const AetherGraphInfo* info, void* workspace,
+                                 size_t workspace_bytes, float* field_scratch, float* trajectory, int steps, float dt,
+                                 int flags, void* stream) {
+    if (!dyn_params) return fail(AETHER_EINVAL, "rollout_dynamic_field: null pointer");
+    return rollout_common(params, dyn_params, nodes_per_graph, field_scratch, num_dims, n_nodes, n_edges, x0, vel0, charges,
+                          graph, info, workspace, workspace_bytes, trajectory, steps, dt, flags, stream);
 }
 
 int aether_backward(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,

@@ -241,6 +241,42 @@ class DynamicFieldAether(nn.Module):
         self.last_field = field
         return out, field, ws
 
+    @torch.no_grad()
+    def rollout(self, x, vel, edges, charges, steps, dt=1.0, num_nodes=None):
+        """``steps`` autoregressive steps on the device (``aether_rollout_dynamic_field``), the protocol of
+        ``aether_amd.rollout``: x_{t+1} = self(x_t, v_t), v_{t+1} = (x_{t+1} - x_t) / dt, edge attributes rebuilt in the
+        kernels, the latent field recomputed from the current state every step.  -> [steps, n_nodes, D]."""
+        if not x.is_cuda:
+            raise _lib.AetherHipError("aether_amd.DynamicFieldAether runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        if num_nodes is None:
+            raise ValueError("num_nodes (objects per graph) is required, as in forward")
+        lib = _lib.load()
+        send, recv = edges
+        n_nodes, D = x.shape
+        E = send.numel()
+        if D != self.num_dims or vel.shape != x.shape or charges.numel() != n_nodes or n_nodes % int(num_nodes) != 0:
+            raise ValueError("x/vel must be [B * num_nodes, num_dims], charges [B * num_nodes, 1]")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        x, vel, charges = f32(x), f32(vel), f32(charges)
+        graph, ginfo = self._graphs.get(send.contiguous(), recv.contiguous(), n_nodes)
+        ps, fps = self._structs(x.device)
+        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 0)
+        if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
+            self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        self._ws_key = None
+        traj = torch.empty(int(steps), n_nodes, D, dtype=torch.float32, device=x.device)
+        if int(steps) <= 0:
+            return traj
+        field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
+        st = lib.aether_rollout_dynamic_field(C.byref(ps), C.byref(fps), D, n_nodes, E, int(num_nodes), x.data_ptr(),
+                                              vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                              self._ws.data_ptr(), self._ws.numel(), field.data_ptr(), traj.data_ptr(),
+                                              int(steps), float(dt), self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES,
+                                              torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(st, "aether_rollout_dynamic_field")
+        return traj
+
     def forward(self, h, x, edges, vel, edge_attr_orig, charges, num_nodes):
         """``h`` is ignored, as in the reference (dynamic_field_aether.py:79-100)."""
         if not x.is_cuda:

@@ -197,6 +197,15 @@ int aether_forward_field(const AetherParams* params, int num_dims, int64_t n_nod
                          const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
                          void* workspace, size_t workspace_bytes, float* out, int flags, void* stream);
 /*
+ * aether_rollout for the dynamic-field model: every step runs aether_dynamic_field on the current state (into
+ * field_scratch, float[n_nodes][D]) and then the step with that field; otherwise as aether_rollout.
+ */
+int aether_rollout_dynamic_field(const AetherParams* params, const AetherDynFieldParams* dyn_params, int num_dims,
+                                 int64_t n_nodes, int64_t n_edges, int nodes_per_graph, const float* x0,
+                                 const float* vel0, const float* charges, const void* graph,
+                                 const AetherGraphInfo* info, void* workspace, size_t workspace_bytes,
+                                 float* field_scratch, float* trajectory, int steps, float dt, int flags, void* stream);
+/*
  * Training of the dynamic-field variant.  aether_backward_field = aether_backward for a step that ran through
  * aether_forward_field with AETHER_FLAG_KEEP_INTERMEDIATES: gradients of the GNN / res / out-MLP tensors into
  * `grads` (grads->field_* are not written) and dL/dfield into grad_field [n_nodes][D].

@@ -121,3 +121,37 @@ def test_dynamic_field_training_step_reduces_loss():
     torch.nn.functional.mse_loss(m(*args), target).backward()
     assert all(p.grad is None for p in frozen)
     assert all(p.grad is not None for n, p in m.named_parameters() if n.startswith("field_net."))
+
+
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_FORCE_STREAMED])
+def test_dynamic_field_device_rollout(flags):
+    """aether_rollout_dynamic_field: 20 steps on the device vs the loop of module calls (same arithmetic up to fma
+    contraction) and vs the oracle's rollout protocol with the dynamic field."""
+    D, B, N, T = 2, 6, 20, 20
+    d, sd, m = _load(D)
+    m.flags = flags
+    inp = make_batch(B, N, D, seed=41, device="cuda")
+    traj = m.rollout(inp["x"], inp["vel"], inp["edges"], inp["charges"], T, 0.5, num_nodes=N)
+    assert traj.shape == (T, B * N, D)
+    x, v = inp["x"], inp["vel"]
+    rows, cols = inp["edges"]
+    qprod = inp["charges"][rows] * inp["charges"][cols]
+    loop = []
+    with torch.no_grad():
+        for _ in range(T):
+            ea = torch.cat([qprod, (x[rows] - x[cols]).norm(dim=1, keepdim=True)], 1)
+            xn = m(None, x, inp["edges"], v, ea, inp["charges"], N)
+            v, x = (xn - x) / 0.5, xn
+            loop.append(x)
+    loop = torch.stack(loop)
+    assert scale_rel_err(traj[0].cpu(), loop[0].cpu()) <= 1e-6 and scale_rel_err(traj.cpu(), loop.cpu()) <= TOL
+    # oracle, a few steps
+    xo, vo = inp["x"].cpu(), inp["vel"].cpu()
+    eo = [e.cpu() for e in inp["edges"]]
+    qo = inp["charges"].cpu()
+    for t in range(3):
+        ea = torch.cat([qo[eo[0]] * qo[eo[1]], (xo[eo[0]] - xo[eo[1]]).norm(dim=1, keepdim=True)], 1)
+        xn = O.dynamic_field_aether_forward(sd, xo, vo, eo, ea, qo, N)
+        vo, xo = (xn - xo) / 0.5, xn
+        assert scale_rel_err(traj[t].cpu(), xo) <= TOL, t
+    assert m.rollout(inp["x"], inp["vel"], inp["edges"], inp["charges"], 0, num_nodes=N).shape == (0, B * N, D)
