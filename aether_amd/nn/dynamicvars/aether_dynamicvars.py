@@ -32,6 +32,7 @@ class AetherDynamicVars(nn.Module):
         self.decoder = Decoder(params, device=None)
         self.num_edge_types = params.get("num_edge_types")
         self.gumbel_temp = params.get("gumbel_temp")
+        self.kl_coef = params.get("kl_coef", 1.)                      # read by the training scripts
         self.num_dims = 2
         self.field_hidden = hidden_size = params["field_hidden"]
         if hidden_size % 32 != 0:
@@ -43,6 +44,12 @@ class AetherDynamicVars(nn.Module):
         self._ws = None
         if device is not None:
             self.to(device)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)                       # as the reference's save / load
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path))
 
     @torch.no_grad()
     def predict_field(self, x, masks=None):

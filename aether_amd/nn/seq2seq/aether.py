@@ -132,6 +132,7 @@ class Aether(_StepLoop, nn.Module):
         self.decoder = RecurrentDecoder(params, device=None)
         self.num_edge_types = params.get("num_edge_types")
         self.gumbel_temp = params.get("gumbel_temp")
+        self.kl_coef = params.get("kl_coef", 1.)                      # read by the training scripts
         self.use_3d = params.get("use_3d", False)
         self.num_dims = 3 if self.use_3d else 2
         fq = FieldQuery(self.num_dims, params["encoder_hidden"], params.get("rff_std", 1.0), device=None)
@@ -139,6 +140,12 @@ class Aether(_StepLoop, nn.Module):
         self._fq = [fq]                                                    # not a registered sub-module: no duplicate keys
         if device is not None:
             self.to(device)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)                       # as the reference's save / load
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path))
 
     def predict_field(self, x):
         return self._fq[0](x)

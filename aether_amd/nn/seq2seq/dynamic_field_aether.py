@@ -134,6 +134,7 @@ class DynamicFieldAether(_StepLoop, nn.Module):
         self.decoder = RecurrentDecoder(params, device=None)
         self.num_edge_types = params.get("num_edge_types")
         self.gumbel_temp = params.get("gumbel_temp")
+        self.kl_coef = params.get("kl_coef", 1.)                      # read by the training scripts
         self.use_3d = params.get("use_3d", False)
         self.num_dims = 3 if self.use_3d else 2
         self.hidden_size = hidden_size = params["encoder_hidden"]
@@ -154,6 +155,12 @@ class DynamicFieldAether(_StepLoop, nn.Module):
         experiments/electrostatic/evaluate.py:42-45 inspects it (``charges`` is then passed to ``predict_future``)."""
         raise _lib.AetherHipError("calculate_loss (posterior encoder + training loss) is not part of this path; "
                                   "predict_future is")
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)                       # as the reference's save / load
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path))
 
     def create_grid_points(self, box_size=5.0, grid_size=21, normalize=True):
         """dynamic_field_aether.py:89-95: the grid of the data-side ``field`` object (``params['field']``)."""

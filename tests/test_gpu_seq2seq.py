@@ -373,6 +373,15 @@ def test_evaluation_runner_surface():
         def _normalize(data):
             return data / 5.0
 
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as tmp:                    # save / load round trip, kl_coef as the scripts read it
+        path = os.path.join(tmp, "m.pt")
+        base.save(path)
+        w = base.field_net[0].weight.detach().clone()
+        with torch.no_grad():
+            base.field_net[0].weight.zero_()
+        base.load(path)
+        assert torch.equal(base.field_net[0].weight, w) and base.kl_coef == 1.0
     model.field = FieldStub()
     model = model.cuda()
     inputs = torch.from_numpy(d["in.inputs"]).cuda()
