@@ -122,9 +122,9 @@ SIGNATURES = {
                               [C.c_size_t] + [C.c_void_p] * 4),
     "aether_dyn_field_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "aether_dyn_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
-    "aether_sim_charged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
-                                     C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p]),
+    "aether_sim_charged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                     C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_double, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "aether_rollout_dynamic_field": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int] +
                                      [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
                                                          C.c_void_p]),

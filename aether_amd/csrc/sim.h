@@ -199,11 +199,15 @@ k_sim_gravitational(const double* __restrict__ pos0, const double* __restrict__ 
 //   DynamicSim.sample_trajectory          :536-622   ('dynamic':  + the Lorentz force q (v x B), B = 0.5 (1, 1, 1))
 // 3-D, all balls move, squared distances from the expansion |a|^2 + |b|^2 - 2 a.b + 1e-6 (:167-178), every force
 // COMPONENT clipped to +-max_F (:276-277), leap-frog; frames are stored [T_save][3][n] as the reference does.
-// ext_mode 0: none, 1: F += ext (constant vector), 2: F += q (v x ext).
+//   FixCharge.sample_trajectory           :700-790   ('fixcharge': + the Coulomb force of a fixed charge at ext)
+//   SpringSim.sample_trajectory           :74-146    ('springs':  pair forces -k edges_ij (x_i - x_j), no charges)
+// ext_mode 0: none, 1: F += ext (constant vector), 2: F += q (v x ext), 3: F += ext_strength q (x - ext) / |x - ext|^3.
+// pair != NULL: the pair force is -strength * pair[s][i][j] (x_i - x_j) instead of Coulomb's (springs).
 __global__ void __launch_bounds__(64)
 k_sim_charged(const double* __restrict__ loc0, const double* __restrict__ vel0, const double* __restrict__ charges,
-              int64_t n_sims, int M, int T, int sample_freq, double strength, double dt, double max_F, int ext_mode,
-              double e0, double e1, double e2, double* __restrict__ loc, double* __restrict__ vel) {
+              const double* __restrict__ pair, int64_t n_sims, int M, int T, int sample_freq, double strength, double dt,
+              double max_F, int ext_mode, double e0, double e1, double e2, double ext_strength,
+              double* __restrict__ loc, double* __restrict__ vel) {
 #pragma clang fp contract(off)
     constexpr int D = 3;
     __shared__ double pos[64 * D];
@@ -222,7 +226,7 @@ k_sim_charged(const double* __restrict__ loc0, const double* __restrict__ vel0, 
             x[d] = loc0[((size_t)s * D + d) * M + i];
             v[d] = vel0[((size_t)s * D + d) * M + i];
         }
-        q = charges[(size_t)s * M + i];
+        q = charges != nullptr ? charges[(size_t)s * M + i] : 0.0;
         if (T_save > 0) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {                              // frame 0 = the initial state until the first save
@@ -262,12 +266,21 @@ k_sim_charged(const double* __restrict__ loc0, const double* __restrict__ vel0, 
         if (active) {
             double F[D] = {0.0, 0.0, 0.0};
             const double ni = myn[i];
-            for (int j = 0; j < M; ++j) {
-                const double dot = (x[0] * mine[j * D] + x[1] * mine[j * D + 1]) + x[2] * mine[j * D + 2];
-                const double l2 = ((ni + myn[j]) - 2.0 * dot) + 1e-6;                   // _l2, :167-178
-                const double fs = j == i ? 0.0 : (strength * (q * myq[j])) / (l2 * sqrt(l2));
+            if (pair != nullptr) {                                                      // springs, :98-110
+                const double* prow = pair + ((size_t)s * M + i) * M;
+                for (int j = 0; j < M; ++j) {
+                    const double fs = j == i ? 0.0 : -strength * prow[j];
 #pragma unroll
-                for (int d = 0; d < D; ++d) F[d] = F[d] + fs * (x[d] - mine[j * D + d]);
+                    for (int d = 0; d < D; ++d) F[d] = F[d] + fs * (x[d] - mine[j * D + d]);
+                }
+            } else {
+                for (int j = 0; j < M; ++j) {
+                    const double dot = (x[0] * mine[j * D] + x[1] * mine[j * D + 1]) + x[2] * mine[j * D + 2];
+                    const double l2 = ((ni + myn[j]) - 2.0 * dot) + 1e-6;               // _l2, :167-178
+                    const double fs = j == i ? 0.0 : (strength * (q * myq[j])) / (l2 * sqrt(l2));
+#pragma unroll
+                    for (int d = 0; d < D; ++d) F[d] = F[d] + fs * (x[d] - mine[j * D + d]);
+                }
             }
             if (ext_mode == 1) {
                 F[0] = F[0] + e0; F[1] = F[1] + e1; F[2] = F[2] + e2;
@@ -275,6 +288,11 @@ k_sim_charged(const double* __restrict__ loc0, const double* __restrict__ vel0, 
                 F[0] = F[0] + (v[1] * e2 - v[2] * e1) * q;
                 F[1] = F[1] + (v[2] * e0 - v[0] * e2) * q;
                 F[2] = F[2] + (v[0] * e1 - v[1] * e0) * q;
+            } else if (ext_mode == 3) {                                                  // FixCharge, :742-746
+                const double d0 = x[0] - e0, d1 = x[1] - e1, d2 = x[2] - e2;
+                const double r2 = (d0 * d0 + d1 * d1) + d2 * d2;
+                const double c = (ext_strength * q) / (r2 * sqrt(r2));
+                F[0] = F[0] + c * d0; F[1] = F[1] + c * d1; F[2] = F[2] + c * d2;
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) {

@@ -220,7 +220,7 @@ class _LorentzFamilySim(object):
     on the host (global numpy generator, seeded per trajectory as the reference does), integration in
     ``aether_sim_charged``."""
 
-    _ext_mode, _ext = 0, (0.0, 0.0, 0.0)
+    _ext_mode, _ext, _ext_strength = 0, (0.0, 0.0, 0.0), 0.0
 
     def __init__(self, n_balls=5, box_size=5., loc_std=1., vel_norm=0.5, interaction_strength=1., noise_var=0.,
                  device="cuda"):
@@ -293,9 +293,9 @@ class _LorentzFamilySim(object):
         loc = torch.empty(S, max(T_save, 0), 3, n, dtype=torch.float64, device=dev)
         vel = torch.empty_like(loc)
         ext = (C.c_double * 3)(*self._ext)
-        st = lib.aether_sim_charged(l0.data_ptr(), v0.data_ptr(), q.data_ptr(), S, n, T, sample_freq,
+        st = lib.aether_sim_charged(l0.data_ptr(), v0.data_ptr(), q.data_ptr(), None, S, n, T, sample_freq,
                                     float(self.interaction_strength), float(self._delta_T), float(self._max_F),
-                                    int(self._ext_mode), ext, loc.data_ptr(), vel.data_ptr(),
+                                    int(self._ext_mode), ext, float(self._ext_strength), loc.data_ptr(), vel.data_ptr(),
                                     torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(st, "aether_sim_charged")
         if self.noise_var > 0:
@@ -332,3 +332,75 @@ class DynamicSim(_LorentzFamilySim):
         super().__init__(*a, **k)
         self.lorentz_field = np.ones([1, 3]) * 0.5
         self._ext_mode, self._ext = 2, tuple(self.lorentz_field[0])
+
+
+class FixCharge(_LorentzFamilySim):
+    """'fixcharge': the Coulomb force of a fixed charge at (10, 10, 10) with strength 0.1 (synthetic_sim.py:626-790)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.fix_pos = np.array([10, 10, 10])
+        self.interaction_stren_fix = 0.1
+        self._ext_mode, self._ext, self._ext_strength = 3, tuple(float(v) for v in self.fix_pos), self.interaction_stren_fix
+
+
+class SpringSim(object):
+    """'springs' (synthetic_sim.py:6-146): random spring constants {0, 0.5, 1} between pairs, no charges; draws from the
+    global numpy generator without reseeding, noise drawn even when noise_var is 0 -- as the reference."""
+
+    def __init__(self, n_balls=5, box_size=5., loc_std=.5, vel_norm=.5, interaction_strength=.1, noise_var=0., device="cuda"):
+        self.n_balls, self.box_size, self.loc_std, self.vel_norm = n_balls, box_size, loc_std, vel_norm
+        self.interaction_strength, self.noise_var = interaction_strength, noise_var
+        self._spring_types = np.array([0., 0.5, 1.])
+        self._delta_T = 0.001
+        self._max_F = 0.1 / self._delta_T
+        self.dim = 3
+        self.device = device
+        if n_balls > 64:
+            raise ValueError("at most 64 balls per simulation")
+
+    _clamp = _LorentzFamilySim._clamp
+
+    def _draw_initial(self, spring_prob):
+        n = self.n_balls
+        edges = np.random.choice(self._spring_types, size=(n, n), p=spring_prob)          # :83-87
+        edges = np.tril(edges) + np.tril(edges, -1).T
+        np.fill_diagonal(edges, 0)
+        loc0 = np.random.randn(self.dim, n) * self.loc_std
+        vel0 = np.random.randn(self.dim, n)
+        vel0 = vel0 * self.vel_norm / np.sqrt((vel0 ** 2).sum(axis=0)).reshape(1, -1)
+        loc0, vel0 = self._clamp(loc0, vel0)
+        return edges, loc0, vel0
+
+    def sample_trajectories(self, num_sims, T=10000, sample_freq=10, spring_prob=[1. / 2, 0, 1. / 2], as_tensor=False):
+        """``num_sims`` consecutive ``sample_trajectory`` calls in one launch: loc, vel [S, T_save, 3, n], edges [S, n, n]."""
+        assert T % sample_freq == 0
+        lib = _lib.load()
+        dev = _device(self.device)
+        T_save = int(T / sample_freq - 1)
+        n = self.n_balls
+        draws = []
+        for _ in range(num_sims):
+            e, l0, v0 = self._draw_initial(spring_prob)
+            draws.append((e, l0, v0, np.random.randn(T_save, self.dim, n) * self.noise_var,
+                          np.random.randn(T_save, self.dim, n) * self.noise_var))           # :143-144
+        S = len(draws)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        edges = np.stack([d[0] for d in draws])
+        l0, v0, pair = up(np.stack([d[1] for d in draws])), up(np.stack([d[2] for d in draws])), up(edges)
+        loc = torch.empty(S, max(T_save, 0), 3, n, dtype=torch.float64, device=dev)
+        vel = torch.empty_like(loc)
+        st = lib.aether_sim_charged(l0.data_ptr(), v0.data_ptr(), None, pair.data_ptr(), S, n, T, sample_freq,
+                                    float(self.interaction_strength), float(self._delta_T), float(self._max_F), 0, None, 0.0,
+                                    loc.data_ptr(), vel.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_sim_charged")
+        if self.noise_var != 0:
+            loc += up(np.stack([d[3] for d in draws]))
+            vel += up(np.stack([d[4] for d in draws]))
+        if as_tensor:
+            return loc, vel, torch.from_numpy(edges).to(dev)
+        return loc.cpu().numpy(), vel.cpu().numpy(), edges
+
+    def sample_trajectory(self, T=10000, sample_freq=10, spring_prob=[1. / 2, 0, 1. / 2]):
+        loc, vel, edges = self.sample_trajectories(1, T, sample_freq, spring_prob)
+        return loc[0], vel[0], edges[0]

@@ -438,14 +438,17 @@ int aether_sim_electrostatic(const double* loc0, const double* vel0, const doubl
  * (experiments/lorentz/dataset/synthetic_sim.py: ChargedParticlesSim :221-300, GravitySim :375-460, DynamicSim
  * :536-622): 3-D Coulomb forces between n_balls moving charges, squared distances |a|^2 + |b|^2 - 2 a.b + 1e-6, plus
  * ext_mode 0: nothing ('charged'), 1: the constant force ext ('static': (0, 0, 0.098)), 2: the Lorentz force
- * q (v x ext) ('dynamic': ext = (0.5, 0.5, 0.5)); every force component clipped to +-max_F; leap-frog.
+ * q (v x ext) ('dynamic': ext = (0.5, 0.5, 0.5)), 3: a fixed charge at ext, ext_strength q (x - ext) / |x - ext|^3
+ * (FixCharge :626-790: ext = (10, 10, 10), ext_strength 0.1).  pair != NULL (double[n_sims][n_balls][n_balls]): the pair
+ * force is -interaction_strength * pair_ij (x_i - x_j) instead of Coulomb's and charges may be NULL (SpringSim :6-146).
+ * Every force component is clipped to +-max_F; leap-frog.
  *   loc0, vel0 : double[n_sims][3][n_balls] (the reference's layout);  charges : double[n_sims][n_balls]
  *   ext        : HOST pointer to 3 doubles (read during the call; may be NULL for ext_mode 0)
  *   loc, vel   : double[n_sims][T/sample_freq - 1][3][n_balls]
  */
-int aether_sim_charged(const double* loc0, const double* vel0, const double* charges, int64_t n_sims, int n_balls,
-                       int T, int sample_freq, double interaction_strength, double delta_T, double max_F, int ext_mode,
-                       const double* ext, double* loc, double* vel, void* stream);
+int aether_sim_charged(const double* loc0, const double* vel0, const double* charges, const double* pair, int64_t n_sims,
+                       int n_balls, int T, int sample_freq, double interaction_strength, double delta_T, double max_F,
+                       int ext_mode, const double* ext, double ext_strength, double* loc, double* vel, void* stream);
 int aether_sim_gravitational(const double* pos0, const double* vel0, const double* mass, int64_t n_sims, int n_balls,
                              int total_balls, int dim, int T, int sample_freq, double interaction_strength,
                              double dt, double softening, double* pos, double* vel, double* force, void* stream);

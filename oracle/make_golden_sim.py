@@ -33,7 +33,9 @@ LORENTZ_CASES = {   # name: (class name, ctor kwargs, T, sample_freq, seeds)
     "static5": ("GravitySim", dict(noise_var=0.0, n_balls=5, vel_norm=0.5), 400, 20, [5]),
     "dynamic5": ("DynamicSim", dict(noise_var=0.0, n_balls=5, vel_norm=0.5), 500, 10, [6, 7]),
     "dynamic20_noise": ("DynamicSim", dict(noise_var=0.01, n_balls=20, vel_norm=0.5), 300, 10, [8]),
+    "fixcharge5": ("FixCharge", dict(noise_var=0.0, n_balls=5, vel_norm=0.5), 400, 10, [9, 10]),
 }
+SPRING_CASES = {"springs5": (dict(noise_var=0.0, n_balls=5), 400, 10, 2, 12), "springs10_noise": (dict(noise_var=0.02, n_balls=10), 300, 20, 1, 13)}
 GRAV_CASES = {      # name: (ctor kwargs, T, sample_freq, number of simulations, numpy seed)
     "grav3d": (dict(n_balls=5, static_balls=3, dim=3, static_mass=2.0, noise_var=0.0), 300, 10, 2, 5),
     "grav2d_noise": (dict(n_balls=6, static_balls=0, dim=2, noise_var=0.01, softening=0.05), 200, 20, 2, 6),
@@ -82,6 +84,13 @@ def main():
         for k, key in enumerate(("loc", "vel", "edges", "charges")):
             out[f"{name}.{key}"] = np.stack([r[k] for r in res])
         print(name, out[f"{name}.loc"].shape, "max |F-limited| frames ok")
+    for name, (kw, T, sf, S, seed) in SPRING_CASES.items():          # SpringSim: global generator, no reseeding inside
+        np.random.seed(seed)
+        sim = LS.SpringSim(**kw)
+        res = [sim.sample_trajectory(T=T, sample_freq=sf) for _ in range(S)]
+        for k, key in enumerate(("loc", "vel", "edges")):
+            out[f"{name}.{key}"] = np.stack([r[k] for r in res])
+        print(name, out[f"{name}.loc"].shape)
     np.savez(os.path.join(args.out, "sim_charged.npz"), **out)
 
 

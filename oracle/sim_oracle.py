@@ -97,11 +97,12 @@ def gravitational_trajectory(pos0, vel0, mass, n_balls, T, sample_freq, G=1.0, d
 
 
 def charged_trajectory(loc0, vel0, charges, T, sample_freq, strength=1.0, dt=0.001, max_F=100.0, ext_mode=0,
-                       ext=(0.0, 0.0, 0.0)):
-    """loc0, vel0 [3, n] (already clamped to the box, :240), charges [n, 1] -> loc, vel [T/sample_freq - 1, 3, n]."""
+                       ext=(0.0, 0.0, 0.0), ext_strength=0.0, pair=None):
+    """loc0, vel0 [3, n] (already clamped to the box, :240), charges [n, 1] -> loc, vel [T/sample_freq - 1, 3, n].
+    ext_mode 3: FixCharge (:742-746); pair [n, n]: SpringSim's pair forces (:98-110) instead of Coulomb's."""
     n = loc0.shape[1]
     T_save = T // sample_freq - 1
-    q = np.asarray(charges, dtype=np.float64).reshape(n, 1)
+    q = np.zeros((n, 1)) if charges is None else np.asarray(charges, dtype=np.float64).reshape(n, 1)
     edges = q.dot(q.transpose())
     ext = np.asarray(ext, dtype=np.float64).reshape(1, 3)
     loc, vel = np.zeros((T_save, 3, n)), np.zeros((T_save, 3, n))
@@ -111,10 +112,14 @@ def charged_trajectory(loc0, vel0, charges, T, sample_freq, strength=1.0, dt=0.0
 
     def force(x, v):
         A = x.transpose()
-        an = (A ** 2).sum(axis=1)
-        l2 = an.reshape(n, 1) + an.reshape(1, n) - 2 * A.dot(A.transpose()) + 1e-6       # _l2
-        with np.errstate(divide="ignore"):
-            fs = strength * edges / np.power(l2, 1.5)
+        if pair is not None:
+            fs = -strength * np.asarray(pair, dtype=np.float64)
+        else:
+            an = (A ** 2).sum(axis=1)
+            l2 = an.reshape(n, 1) + an.reshape(1, n) - 2 * A.dot(A.transpose()) + 1e-6   # _l2
+            with np.errstate(divide="ignore"):
+                fs = strength * edges / np.power(l2, 1.5)
+        fs = np.array(fs)
         np.fill_diagonal(fs, 0)
         F = np.zeros((3, n))
         for j in range(n):                                                               # sum over the last axis
@@ -123,6 +128,9 @@ def charged_trajectory(loc0, vel0, charges, T, sample_freq, strength=1.0, dt=0.0
             F = F + ext.transpose()
         elif ext_mode == 2:
             F = F + (np.cross(v.transpose(), ext) * q).transpose()
+        elif ext_mode == 3:
+            l2f = np.power(np.sum((A - ext) ** 2, axis=-1), 3 / 2)
+            F = F + ((ext_strength * q / l2f[:, None]) * (A - ext)).transpose()
         return np.clip(F, -max_F, max_F)
 
     v += dt * force(x, v)
