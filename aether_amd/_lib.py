@@ -128,6 +128,11 @@ SIGNATURES = {
     "aether_rollout_dynamic_field": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int] +
                                      [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
                                                          C.c_void_p]),
+    "aether_s2s_encoder_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64] +
+                                    [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p, C.c_void_p]),
+    "aether_s2s_lstm_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 7),
+    "aether_s2s_mlp_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aether_s2s_gumbel_hard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "aether_dynamic_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

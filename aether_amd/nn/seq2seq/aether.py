@@ -9,6 +9,8 @@ the posterior encoder (reverse LSTM, ``encoder_fc_out``) and the training loss a
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -133,6 +135,22 @@ class Aether(_StepLoop, nn.Module):
         self.num_edge_types = params.get("num_edge_types")
         self.gumbel_temp = params.get("gumbel_temp")
         self.kl_coef = params.get("kl_coef", 1.)                      # read by the training scripts
+        # the loss configuration of aether.py:27-58 (evaluation-mode calculate_loss)
+        self.val_teacher_forcing_steps = params.get("val_teacher_forcing_steps", -1)
+        self.normalize_kl = params.get("normalize_kl", False)
+        self.normalize_kl_per_var = params.get("normalize_kl_per_var", False)
+        self.normalize_nll = params.get("normalize_nll", False)
+        self.normalize_nll_per_var = params.get("normalize_nll_per_var", False)
+        self.nll_loss_type = params.get("nll_loss_type", "crossent")
+        self.prior_variance = params.get("prior_variance")
+        self.add_uniform_prior = params.get("add_uniform_prior")
+        if self.add_uniform_prior:
+            K = params["num_edge_types"]
+            prior = torch.full((K,), 1.0 / K)
+            if params.get("no_edge_prior") is not None:
+                prior = torch.full((K,), (1 - params["no_edge_prior"]) / (K - 1))
+                prior[0] = params["no_edge_prior"]
+            self.log_prior = torch.log(prior).view(1, 1, K)
         self.use_3d = params.get("use_3d", False)
         self.num_dims = 3 if self.use_3d else 2
         fq = FieldQuery(self.num_dims, params["encoder_hidden"], params.get("rff_std", 1.0), device=None)
@@ -150,13 +168,81 @@ class Aether(_StepLoop, nn.Module):
     def predict_field(self, x):
         return self._fq[0](x)
 
+    @torch.no_grad()
     def calculate_loss(self, inputs, is_train=False, teacher_forcing=True, return_edges=False, return_logits=False,
-                       use_prior_logits=False):
-        """aether.py:103-153 (ELBO of the full-sequence posterior): not part of the prediction path.  The signature is
-        kept because experiments/electrostatic/evaluate.py:42-45 inspects it to decide which keyword arguments
-        ``predict_future`` takes."""
-        raise _lib.AetherHipError("calculate_loss (posterior encoder + training loss) is not part of this path; "
-                                  "predict_future / predict_from_state are")
+                       use_prior_logits=False, uniform=None):
+        """aether.py:103-153 in evaluation mode (the validation metrics of experiments/electrostatic/train.py): the
+        full-sequence encoder's prior / posterior logits, the decoder stepped through the sequence with hard samples of
+        the posterior (teacher forcing per ``val_teacher_forcing_steps``), negative log-likelihood and KL term as the
+        params dictionary selects.  ``is_train=True`` (gradients, soft samples) is not part of this library.
+        ``uniform`` [T - 1, B, E, K]: the Gumbel draws (drawn on the device when omitted)."""
+        if is_train:
+            raise _lib.AetherHipError("calculate_loss(is_train=True) (training of the seq2seq model) is not part of this "
+                                      "library; evaluation (is_train=False), predict_future and predict_field are")
+        B, T, N, _ = inputs.shape
+        decoder_hidden = self.decoder.get_initial_hidden(inputs)
+        x = inputs[:, :-1].transpose(2, 1).contiguous()
+        predicted_field, _ = self.predict_field(x)                                   # [B, N, T - 1, D]
+        prior_logits, posterior_logits, _ = self.encoder(inputs[:, :-1], predicted_field)
+        tf_steps = self.val_teacher_forcing_steps
+        all_predictions, edges, predictions = [], None, None
+        for step in range(T - 1):
+            if (teacher_forcing and (tf_steps == -1 or step < tf_steps)) or step == 0:
+                current_inputs, current_field = inputs[:, step], predicted_field[:, :, step].contiguous()
+            else:
+                current_inputs = predictions
+                current_field, _ = self.predict_field(predictions)
+            logits = (prior_logits if use_prior_logits else posterior_logits)[:, step].contiguous()
+            predictions, decoder_hidden, edges = self.single_step_forward(
+                current_inputs, decoder_hidden, logits, True, current_field, None if uniform is None else uniform[step])
+            all_predictions.append(predictions)
+        all_predictions = torch.stack(all_predictions, dim=1)
+        target = inputs[:, 1:].to(torch.float32)
+        loss_nll = self.nll(all_predictions, target)
+        prob = torch.softmax(posterior_logits, dim=-1)
+        loss_kl = self.kl_categorical_learned(prob, prior_logits)
+        if self.add_uniform_prior:
+            loss_kl = 0.5 * loss_kl + 0.5 * self.kl_categorical_avg(prob)
+        loss = (loss_nll + self.kl_coef * loss_kl).mean()
+        if return_edges:
+            return loss, loss_nll, loss_kl, edges
+        if return_logits:
+            return loss, loss_nll, loss_kl, posterior_logits, all_predictions
+        return loss, loss_nll, loss_kl
+
+    # losses, aether.py:186-236 (scalar reductions: plain torch on the device)
+    def nll(self, preds, target):
+        if self.nll_loss_type == "crossent":
+            e = nn.functional.binary_cross_entropy_with_logits(preds, target, reduction="none").view(preds.size(0), -1)
+        elif self.nll_loss_type == "poisson":
+            e = nn.functional.poisson_nll_loss(preds, target, reduction="none").view(preds.size(0), -1)
+        elif self.nll_loss_type == "gaussian":
+            neg_log_p = (preds - target) ** 2 / (2 * self.prior_variance)
+            const = 0.5 * math.log(2 * math.pi * self.prior_variance)
+            if self.normalize_nll_per_var:
+                return neg_log_p.sum() / (target.size(0) * target.size(2))
+            if self.normalize_nll:
+                return (neg_log_p.sum(-1) + const).view(preds.size(0), -1).mean(dim=1)
+            return neg_log_p.view(target.size(0), -1).sum() / target.size(1)
+        else:
+            raise ValueError("nll_loss_type must be 'crossent', 'gaussian' or 'poisson'")
+        return e.mean(dim=1) if self.normalize_nll else e.sum(dim=1)
+
+    def _kl_reduce(self, kl_div, batch):
+        if self.normalize_kl:
+            return kl_div.sum(-1).view(batch, -1).mean(dim=1)
+        if self.normalize_kl_per_var:
+            return kl_div.sum() / (self.num_vars * batch)
+        return kl_div.view(batch, -1).sum(dim=1)
+
+    def kl_categorical_learned(self, preds, prior_logits):
+        kl_div = preds * (torch.log(preds + 1e-16) - torch.log_softmax(prior_logits, dim=-1))
+        return self._kl_reduce(kl_div, preds.size(0))
+
+    def kl_categorical_avg(self, preds, eps=1e-16):
+        avg_preds = preds.mean(dim=2)
+        kl_div = avg_preds * (torch.log(avg_preds + eps) - self.log_prior.to(preds.device))
+        return self._kl_reduce(kl_div, preds.size(0))
 
     @torch.no_grad()
     def single_step_forward(self, inputs, decoder_hidden, edge_logits, hard_sample, predicted_field, uniform=None):

@@ -159,6 +159,85 @@ class Encoder(nn.Module):
             hit = self._cache[key] = (send, recv, order, rowptr)
         return hit
 
+    def _head(self, lib, seq, x, out_size, dev):
+        """prior_fc_out / encoder_fc_out (aether.py:286-300) on the rows of x: aether_s2s_mlp_head."""
+        layers = [seq] if isinstance(seq, nn.Linear) else [m for m in seq if isinstance(m, nn.Linear)]
+        n = len(layers)
+        w = (C.c_void_p * n)(*[l.weight.data_ptr() for l in layers])
+        b = (C.c_void_p * n)(*[l.bias.data_ptr() for l in layers])
+        hid = layers[0].out_features if n > 1 else 0
+        rows = x.shape[0]
+        scratch = torch.empty(2 * rows * max(hid, 1), dtype=torch.float32, device=dev)
+        out = torch.empty(rows, out_size, dtype=torch.float32, device=dev)
+        st = lib.aether_s2s_mlp_head(w, b, n, x.shape[1], hid, out_size, rows, x.data_ptr(), scratch.data_ptr(), out.data_ptr(),
+                                     torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_s2s_mlp_head")
+        return out
+
+    @torch.no_grad()
+    def forward(self, inputs, predicted_field, max_edges_per_call=400_000):
+        """The full-sequence encoder, aether.py:350-382 (evaluation: BatchNorm running statistics).  inputs
+        [B, T, N, 2D], predicted_field [B, N, T, D] -> (prior_logits [B, T, E, K], posterior_logits [B, T, E, K],
+        prior_state (h, c) each [B, E, rnn]: the forward LSTM's final state, in the layout ``single_step_forward``
+        takes).  The per-time-step features are independent across time: T x B graphs go through
+        ``aether_s2s_encoder_features`` in chunks of time steps; the two LSTMs step through time with
+        ``aether_s2s_lstm_step``; the heads run once over all (time, edge) rows."""
+        if not inputs.is_cuda:
+            raise _lib.AetherHipError("aether_amd Encoder runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        if self.training:
+            raise _lib.AetherHipError("the encoder uses BatchNorm running statistics: call .eval() first")
+        lib = _lib.load()
+        dev = inputs.device
+        B, T, N, _ = inputs.shape
+        D, h, R, K = self.num_dims, self.hidden_size, self.rnn_hidden_size, self.num_edges
+        E1 = self.recv_edges.shape[0]
+        if inputs.shape[-1] != 2 * D or predicted_field.shape != (B, N, T, D):
+            raise ValueError("encoder: input shapes do not match the module")
+        x = inputs.detach().to(torch.float32).transpose(0, 1).contiguous()                # [T, B, N, 2D]
+        f = predicted_field.detach().to(torch.float32).permute(2, 0, 1, 3).contiguous()   # [T, B, N, D]
+        ps, _, _ = self._param_struct()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        feats = torch.empty(T, B * E1, h, dtype=torch.float32, device=dev)
+        chunk = max(1, int(max_edges_per_call) // (B * E1))
+        for t0 in range(0, T, chunk):
+            t1 = min(T, t0 + chunk)
+            G = (t1 - t0) * B                                                              # independent graphs
+            send, recv, order, rowptr = self._graph(G, N, dev)
+            need = lib.aether_s2s_prior_workspace_bytes(D, h, R, 0, G * N, G * E1)
+            ws = self._cache.get("ws")
+            if ws is None or ws.numel() < need or ws.device != dev:
+                ws = self._cache["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            st = lib.aether_s2s_encoder_features(C.byref(ps), D, h, 1 if self.pos_representation == "polar" else 0, N,
+                                                 G * N, G * E1, x[t0:t1].data_ptr(), f[t0:t1].data_ptr(), send.data_ptr(),
+                                                 recv.data_ptr(), order.data_ptr(), rowptr.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), feats[t0:t1].data_ptr(), stream)
+            _lib.check(st, "aether_s2s_encoder_features")
+        rows = B * E1
+        gates = torch.empty(rows, 4 * R, dtype=torch.float32, device=dev)
+
+        def run(rnn, order_t):
+            hs = torch.empty(T, rows, R, dtype=torch.float32, device=dev)
+            hprev = torch.zeros(rows, R, dtype=torch.float32, device=dev)
+            cprev = torch.zeros(rows, R, dtype=torch.float32, device=dev)
+            cnext = torch.empty_like(cprev)
+            for t in order_t:
+                st = lib.aether_s2s_lstm_step(rnn.weight_ih_l0.data_ptr(), rnn.weight_hh_l0.data_ptr(),
+                                              rnn.bias_ih_l0.data_ptr(), rnn.bias_hh_l0.data_ptr(), h, R, rows,
+                                              feats[t].data_ptr(), hprev.data_ptr(), cprev.data_ptr(), gates.data_ptr(),
+                                              hs[t].data_ptr(), cnext.data_ptr(), stream)
+                _lib.check(st, "aether_s2s_lstm_step")
+                hprev = hs[t]
+                cprev, cnext = cnext, (cprev if cprev.data_ptr() != cnext.data_ptr() else torch.empty_like(cprev))
+            return hs, hprev, cprev
+
+        fwd, h_last, c_last = run(self.forward_rnn, range(T))
+        rev, _, _ = run(self.reverse_rnn, range(T - 1, -1, -1))
+        prior = self._head(lib, self.prior_fc_out, fwd.reshape(T * rows, R), K, dev)
+        post = self._head(lib, self.encoder_fc_out, torch.cat([fwd, rev], -1).reshape(T * rows, 2 * R), K, dev)
+        to_bt = lambda y: y.view(T, B, E1, K).transpose(0, 1).contiguous()
+        return to_bt(prior), to_bt(post), (h_last.view(B, E1, R).clone(), c_last.view(B, E1, R).clone())
+
     @torch.no_grad()
     def single_step_forward(self, inputs, prior_state, predicted_field):
         """aether.py:384-410.  inputs [B, N, 2D], prior_state (h, c) each [B, E, rnn], predicted_field

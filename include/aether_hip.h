@@ -339,6 +339,26 @@ int aether_s2s_prior_step(const AetherS2SPriorParams* params, int num_dims, int 
                           float* logits, float* h1, float* c1, void* stream);
 int aether_s2s_gumbel_hard(const float* logits, const float* uniform, float tau, int num_edge_types,
                            int64_t n_edges, float* edges, void* stream);
+/*
+ * The pieces of aether_s2s_prior_step on their own, for the full-sequence encoder (Encoder.forward,
+ * nn/seq2seq/aether.py:350-382: the same per-time-step features, then a forward and a reverse LSTM over time and the two
+ * heads prior_fc_out / encoder_fc_out):
+ *   aether_s2s_encoder_features : everything up to mlp4 (:354-369) -> features float[n_edges][hidden]; workspace as for
+ *                                 aether_s2s_prior_step (aether_s2s_prior_workspace_bytes with any rnn / prior sizes)
+ *   aether_s2s_lstm_step        : one nn.LSTM cell step on n_rows rows (gate order i, f, g, o); gates: scratch
+ *                                 float[n_rows][4 rnn_hidden]
+ *   aether_s2s_mlp_head         : Linear (- ELU - Linear)* as prior_fc_out / encoder_fc_out build it (:286-300); w, b: HOST
+ *                                 arrays of `layers` device pointers; scratch float[2][n_rows][hidden_size] when layers > 1
+ */
+int aether_s2s_encoder_features(const AetherS2SPriorParams* params, int num_dims, int hidden, int polar, int num_vars,
+                                int64_t n_nodes, int64_t n_edges, const float* inputs, const float* field,
+                                const int64_t* send, const int64_t* recv, const int64_t* order, const int64_t* rowptr,
+                                void* workspace, size_t workspace_bytes, float* features, void* stream);
+int aether_s2s_lstm_step(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int in_size,
+                         int rnn_hidden, int64_t n_rows, const float* x, const float* h0, const float* c0, float* gates,
+                         float* h1, float* c1, void* stream);
+int aether_s2s_mlp_head(const float* const* w, const float* const* b, int layers, int in_size, int hidden_size,
+                        int out_size, int64_t n_rows, const float* x, float* scratch, float* out, void* stream);
 
 /*
  * seq2seq dynamic-field variant: nn/seq2seq/dynamic_field_aether.py, the model

@@ -321,6 +321,84 @@ def dynfield_future_fixture(out_dir):
 
 DYN_SEED = 9753
 
+LOSS_SEED = 1111
+LOSS_CONFIGS = {   # name: extra params of the loss (aether.py:27-58)
+    "gaussian_norm": {"nll_loss_type": "gaussian", "prior_variance": 5e-5, "normalize_nll": True, "normalize_kl": True,
+                      "kl_coef": 1.0, "val_teacher_forcing_steps": -1},
+    "crossent_tf2_uniform": {"nll_loss_type": "crossent", "kl_coef": 0.5, "val_teacher_forcing_steps": 2,
+                             "add_uniform_prior": True, "no_edge_prior": 0.7, "normalize_kl_per_var": True},
+}
+
+
+def loss_params(name):
+    D, N, H, R = 2, 5, 128, 64
+    params = dict(enc_params(N, D, H, R))
+    params.update({"gpu": False, "decoder_hidden": H, "skip_first": False, "decoder_dropout": 0.0, "gumbel_temp": 0.5,
+                   "encoder_mlp_hidden": 64, "prior_hidden_size": 64, "rff_std": 1.0})
+    params.update(LOSS_CONFIGS[name])
+    return params
+
+
+def loss_fixture(out_dir):
+    """The imported reference ``Encoder.forward`` (full sequence: forward + reverse LSTM, both heads) and
+    ``Aether.calculate_loss(is_train=False)`` for two loss configurations; Gumbel draws regenerated as in
+    ``future_fixture``."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import contextlib, io
+    import make_golden as MG
+    import seq2seq_oracle as S
+    MG._install_scatter_standin()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from nn.seq2seq.aether import Aether
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    try:
+        B, T, N, D = 3, 6, 5, 2
+        E = N * (N - 1)
+        g = torch.Generator().manual_seed(902)
+        inputs = torch.randn(B, T, N, 2 * D, generator=g)
+        out["in.inputs"] = inputs.numpy()
+        for name in LOSS_CONFIGS:
+            params = loss_params(name)
+            torch.manual_seed(LOSS_SEED)
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = Aether(params).eval()
+            for noise_seed in range(50):
+                torch.manual_seed(3000 + noise_seed)
+                with torch.no_grad():
+                    loss, nll, kl, post, preds = model.calculate_loss(inputs, is_train=False, return_logits=True)
+                torch.manual_seed(3000 + noise_seed)
+                U = torch.stack([torch.rand(B * E, 2) for _ in range(T - 1)])
+                sd = {k: v.detach() for k, v in model.state_dict().items()}
+                o = S.calculate_loss_eval(sd, params, inputs, U, False, "polar")
+                if float((o[4] - preds).abs().max()) <= 1e-5:            # no sample flipped between the two evaluations
+                    break
+            else:
+                raise RuntimeError("no noise seed with unambiguous samples")
+            with torch.no_grad():
+                x = inputs[:, :-1].transpose(2, 1).contiguous()
+                field, _ = model.predict_field(x)
+                prior, post2, state = model.encoder(inputs[:, :-1], field)
+            assert torch.equal(post2, post)
+            for k, v in (("uniform", U), ("loss", loss), ("nll", nll), ("kl", kl), ("posterior", post), ("predictions", preds),
+                         ("prior", prior), ("field", field), ("state.h", state[0]), ("state.c", state[1])):
+                out[f"{name}.{k}"] = v.detach().numpy()
+            if name == list(LOSS_CONFIGS)[0]:
+                for k, v in model.state_dict().items():
+                    if v.dtype.is_floating_point:
+                        out["sum." + k] = np.float64(v.double().sum().item())
+                        out["abs." + k] = np.float64(v.double().abs().sum().item())
+                out["keys"] = np.array(list(model.state_dict().keys()))
+            print(name, "loss", float(loss), "oracle", float(o[0]), "noise seed", 3000 + noise_seed)
+        out["seed"] = np.int64(LOSS_SEED)
+        np.savez(os.path.join(out_dir, "s2s_loss_D2.npz"), **out)
+        print("wrote s2s_loss_D2.npz")
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
 FUT_SEED = 1357
 
 
@@ -341,3 +419,4 @@ if __name__ == "__main__":
     prior_fixtures(os.path.join(REPO, "tests", "golden"))
     future_fixture(os.path.join(REPO, "tests", "golden"))
     dynfield_future_fixture(os.path.join(REPO, "tests", "golden"))
+    loss_fixture(os.path.join(REPO, "tests", "golden"))

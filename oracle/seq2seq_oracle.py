@@ -394,3 +394,141 @@ def predict_future_dynamic_field(sd, inputs, prediction_steps, uniform, tau, use
     summary = graph_summary(gp, inputs[:, :-1].transpose(2, 1).contiguous())
     return predict_future(sd, inputs, prediction_steps, uniform, tau, use_3d, pos_representation, prior_layers,
                           return_edges=return_edges, field_fn=lambda x: film_field(sd, x, summary, D))
+
+
+# ---------------------------------------------------------------------------------------------
+# Full-sequence encoder and the evaluation-mode loss (validation metrics of experiments/electrostatic/train.py)
+#   Encoder.forward          <- nn/seq2seq/aether.py:350-382 (per-time-step features as in prior_step, a forward and
+#                               a reverse LSTM over time, prior_fc_out on the forward states, encoder_fc_out on both)
+#   Aether.calculate_loss    <- :103-153 with is_train=False (hard samples of the posterior, teacher forcing per
+#                               val_teacher_forcing_steps), nll_* :186-216, kl_categorical_learned / _avg :218-236
+# Parity status: PINNED by tests/golden/s2s_loss_D2.npz (the imported reference Aether.calculate_loss).
+# ---------------------------------------------------------------------------------------------
+def _encoder_features(sd, inputs, predicted_field, use_3d, pos_representation):
+    """prior_step up to mlp4 for one time step: [B, E, h]."""
+    B, N, _ = inputs.shape
+    send, recv = torch.where(~torch.eye(N, dtype=bool))
+    ext = torch.cat([inputs, predicted_field], -1)
+    rel_feat, _, edge_attr, edge_pos = augmented_localizer(ext, use_3d, pos_representation)
+    hw = F.elu(F.linear(edge_pos, sd["edge_filter.edge_filter.0.weight"], sd["edge_filter.edge_filter.0.bias"]))
+    ew = F.linear(hw, sd["edge_filter.edge_filter.2.weight"], sd["edge_filter.edge_filter.2.bias"])
+    nrf = edge_attr.shape[-1]
+    ew = ew.reshape(ew.shape[:-1] + (nrf, ew.shape[-1] // nrf))
+    ea = (edge_attr.unsqueeze(-2) @ ew).squeeze(-2)
+    x = torch.zeros(B, N, ea.shape[-1], dtype=ea.dtype).index_add_(1, recv, ea) / (N - 1) + \
+        F.linear(rel_feat, sd["res1.weight"], sd["res1.bias"])
+    x = _refnri_mlp(sd, "mlp3", x)
+    return _refnri_mlp(sd, "mlp4", torch.cat([x[:, send], x[:, recv], ea], -1))
+
+
+def _lstm_seq(sd, prefix, xs):
+    """nn.LSTM(batch_first) from the zero state over a list of [rows, h] inputs -> list of hidden states, final (h, c)."""
+    R = sd[prefix + "weight_hh_l0"].shape[1]
+    h = torch.zeros(xs[0].shape[:-1] + (R,), dtype=xs[0].dtype)
+    c = torch.zeros_like(h)
+    out = []
+    for x in xs:
+        g = F.linear(x, sd[prefix + "weight_ih_l0"], sd[prefix + "bias_ih_l0"]) + \
+            F.linear(h, sd[prefix + "weight_hh_l0"], sd[prefix + "bias_hh_l0"])
+        i, f, gg, o = g.chunk(4, -1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out.append(h)
+    return out, (h, c)
+
+
+def _head(sd, name, x):
+    keys = sorted({k.rsplit(".", 1)[0] for k in sd if k.startswith(name)},
+                  key=lambda n: int(n.split(".")[-1]) if n.split(".")[-1].isdigit() else 0)
+    for j, n in enumerate(keys):
+        x = F.linear(x, sd[n + ".weight"], sd[n + ".bias"])
+        if j + 1 < len(keys):
+            x = F.elu(x)
+    return x
+
+
+def encoder_forward(sd, inputs, predicted_field, use_3d=False, pos_representation="cart"):
+    """``sd``: the Encoder's state_dict.  inputs [B, T, N, 2D], predicted_field [B, N, T, D] ->
+    (prior_logits [B, T, E, K], posterior_logits [B, T, E, K], (h, c) of the forward LSTM [B, E, R])."""
+    T = inputs.shape[1]
+    xs = [_encoder_features(sd, inputs[:, t], predicted_field[:, :, t], use_3d, pos_representation) for t in range(T)]
+    fwd, state = _lstm_seq(sd, "forward_rnn.", xs)
+    rev, _ = _lstm_seq(sd, "reverse_rnn.", xs[::-1])
+    rev = rev[::-1]
+    prior = torch.stack([_head(sd, "prior_fc_out", h) for h in fwd], 1)
+    post = torch.stack([_head(sd, "encoder_fc_out", torch.cat([a, b], -1)) for a, b in zip(fwd, rev)], 1)
+    return prior, post, state
+
+
+def nll_and_kl(cfg, preds, target, posterior_logits, prior_logits, num_vars):
+    """nll (:186-216) and kl_categorical_learned (:218-226) as ``cfg`` selects."""
+    kind = cfg.get("nll_loss_type", "crossent")
+    if kind == "gaussian":
+        neg = (preds - target) ** 2 / (2 * cfg["prior_variance"])
+        const = 0.5 * math.log(2 * math.pi * cfg["prior_variance"])
+        if cfg.get("normalize_nll_per_var", False):
+            nll = neg.sum() / (target.size(0) * target.size(2))
+        elif cfg.get("normalize_nll", False):
+            nll = (neg.sum(-1) + const).view(preds.size(0), -1).mean(dim=1)
+        else:
+            nll = neg.view(target.size(0), -1).sum() / target.size(1)
+    elif kind == "crossent":
+        e = F.binary_cross_entropy_with_logits(preds, target, reduction="none").view(preds.size(0), -1)
+        nll = e.mean(dim=1) if cfg.get("normalize_nll", False) else e.sum(dim=1)
+    else:
+        e = F.poisson_nll_loss(preds, target, reduction="none").view(preds.size(0), -1)
+        nll = e.mean(dim=1) if cfg.get("normalize_nll", False) else e.sum(dim=1)
+    prob = F.softmax(posterior_logits, dim=-1)
+    kl_div = prob * (torch.log(prob + 1e-16) - F.log_softmax(prior_logits, dim=-1))
+    if cfg.get("normalize_kl", False):
+        kl = kl_div.sum(-1).view(prob.size(0), -1).mean(dim=1)
+    elif cfg.get("normalize_kl_per_var", False):
+        kl = kl_div.sum() / (num_vars * prob.size(0))
+    else:
+        kl = kl_div.view(prob.size(0), -1).sum(dim=1)
+    if cfg.get("add_uniform_prior"):                                                   # :139-140, :40-58, :228-236
+        K = prob.shape[-1]
+        prior = np.full(K, 1.0 / K)
+        if cfg.get("no_edge_prior") is not None:
+            prior = np.full(K, (1 - cfg["no_edge_prior"]) / (K - 1))
+            prior[0] = cfg["no_edge_prior"]
+        log_prior = torch.FloatTensor(np.log(prior)).view(1, 1, K)
+        avg = prob.mean(dim=2)
+        kd = avg * (torch.log(avg + 1e-16) - log_prior)
+        if cfg.get("normalize_kl", False):
+            kl_avg = kd.sum(-1).view(prob.size(0), -1).mean(dim=1)
+        elif cfg.get("normalize_kl_per_var", False):
+            kl_avg = kd.sum() / (num_vars * prob.size(0))
+        else:
+            kl_avg = kd.view(prob.size(0), -1).sum(dim=1)
+        kl = 0.5 * kl + 0.5 * kl_avg
+    return nll, kl
+
+
+def calculate_loss_eval(sd, cfg, inputs, uniform, use_3d=False, pos_representation="cart", teacher_forcing=True,
+                        use_prior_logits=False):
+    """Aether.calculate_loss(inputs, is_train=False, ...): -> (loss, nll, kl, posterior_logits, predictions).
+    ``cfg``: the params dictionary entries the loss reads; ``uniform`` [T - 1, B E, K]: gumbel draws per step."""
+    D = 3 if use_3d else 2
+    B, T, N, _ = inputs.shape
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    dec = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    x = inputs[:, :-1].transpose(2, 1).contiguous()
+    field = predict_field(sd, x, D)                                                   # [B, N, T - 1, D]
+    prior, post, _ = encoder_forward(enc, inputs[:, :-1], field, use_3d, pos_representation)
+    hidden = torch.zeros(B, N, dec["hidden_r.weight"].shape[0], dtype=inputs.dtype)
+    tf_steps = cfg.get("val_teacher_forcing_steps", -1)
+    preds = []
+    for step in range(T - 1):
+        if (teacher_forcing and (tf_steps == -1 or step < tf_steps)) or step == 0:
+            cur, cur_f = inputs[:, step], field[:, :, step]
+        else:
+            cur, cur_f = predictions, predict_field(sd, predictions, D)
+        logits = (prior if use_prior_logits else post)[:, step]
+        z = gumbel_hard(logits.reshape(-1, logits.shape[-1]), uniform[step], cfg["gumbel_temp"]).view(logits.shape)
+        predictions, hidden = decoder_step(dec, cur, hidden, z, cur_f, use_3d, cfg.get("skip_first", False))
+        preds.append(predictions)
+    preds = torch.stack(preds, 1)
+    nll, kl = nll_and_kl(cfg, preds, inputs[:, 1:], post, prior, N)
+    loss = (nll + cfg.get("kl_coef", 1.0) * kl).mean()
+    return loss, nll, kl, post, preds

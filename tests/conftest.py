@@ -211,3 +211,26 @@ def load_dyn_model():
             "uniform": [t(f"uniform.{i}") for i in range(T - 1)]}
     case["node_inds"] = [case["masks"][0, i].nonzero()[:, -1] for i in range(T)]
     return d, case, model, dict(MODEL_PARAMS)
+
+
+def load_s2s_loss(name):
+    """Golden fixture of the reference's ``Encoder.forward`` / ``Aether.calculate_loss(is_train=False)`` for one loss
+    configuration + the model recreated from the stored seed (checksums verified for the first configuration; the
+    configurations share the seed and the architecture)."""
+    import numpy as _np
+    import torch as _torch
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_seq2seq import loss_params
+    from aether_amd.nn.seq2seq.aether import Aether
+    d = _np.load(os.path.join(GOLDEN, "s2s_loss_D2.npz"))
+    params = loss_params(name)
+    _torch.manual_seed(int(d["seed"]))
+    model = Aether(params, device=None).eval()
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in d["keys"]]
+    for k, v in sd.items():
+        if "sum." + k in d:
+            assert abs(float(v.double().sum()) - float(d["sum." + k])) <= 1e-9 * max(1.0, float(d["abs." + k])), k
+    case = {k[len(name) + 1:]: _torch.from_numpy(_np.asarray(d[k])) for k in d.files if k.startswith(name + ".")}
+    case["inputs"] = _torch.from_numpy(d["in.inputs"])
+    return case, model, params

@@ -359,7 +359,7 @@ def test_evaluation_runner_surface():
     args = inspect.getfullargspec(base.calculate_loss).args
     assert "charges" not in args and "field" not in args
     with pytest.raises(_lib.AetherHipError):
-        base.calculate_loss(None)
+        base.calculate_loss(None, is_train=True)
     d, model, params = load_s2s_dynfield()
     assert "charges" in inspect.getfullargspec(model.calculate_loss).args
 
@@ -419,3 +419,35 @@ def test_gravitational_config_shape_vs_oracle():
     ok = same.reshape(B, -1).all(dim=1)
     assert ok.float().mean() >= 0.9
     assert scale_rel_err(got.cpu()[ok], want[ok]) <= 2 * TOL
+
+
+@pytest.mark.parametrize("name", ["gaussian_norm", "crossent_tf2_uniform"])
+def test_encoder_forward_and_eval_loss_match_reference(name):
+    """Encoder.forward (full sequence) and calculate_loss(is_train=False) vs the imported reference's outputs, with the
+    reference's Gumbel draws; chunked feature calls give the same result as one call."""
+    from conftest import load_s2s_loss
+    c, model, params = load_s2s_loss(name)
+    model = model.cuda()
+    inputs = c["inputs"].cuda()
+    B, T, N, _ = inputs.shape
+    prior, post, (h, cc) = model.encoder(inputs[:, :-1], c["field"].cuda())
+    assert scale_rel_err(prior.cpu(), c["prior"]) <= TOL and scale_rel_err(post.cpu(), c["posterior"]) <= TOL
+    assert scale_rel_err(h.cpu().reshape(c["state.h"].shape), c["state.h"]) <= TOL
+    assert scale_rel_err(cc.cpu().reshape(c["state.c"].shape), c["state.c"]) <= TOL
+    p2, q2, _ = model.encoder(inputs[:, :-1], c["field"].cuda(), max_edges_per_call=B * N * (N - 1) * 2)     # 3 chunks
+    assert torch.equal(p2, prior) and torch.equal(q2, post)
+    U = c["uniform"].cuda().view(T - 1, B, N * (N - 1), 2)
+    loss, nll, kl, post3, preds = model.calculate_loss(inputs, is_train=False, return_logits=True, uniform=U)
+    assert scale_rel_err(preds.cpu(), c["predictions"]) <= TOL and scale_rel_err(post3.cpu(), c["posterior"]) <= TOL
+    assert abs(float(loss) - float(c["loss"])) <= 5e-4 * abs(float(c["loss"]))        # Gaussian NLL: errors / 1e-4 variance
+    assert scale_rel_err(kl.cpu().reshape(c["kl"].shape), c["kl"]) <= 1e-4
+    l3 = model.calculate_loss(inputs, is_train=False)                                 # noise drawn on the device
+    assert len(l3) == 3 and torch.isfinite(l3[0])
+    # the state the full-sequence encoder leaves equals the chained single steps (what predict_future relies on)
+    R = model.encoder.rnn_hidden_size
+    st = (torch.zeros(B, N * (N - 1), R, device="cuda"), torch.zeros(B, N * (N - 1), R, device="cuda"))
+    fld = c["field"].cuda()
+    for t in range(T - 1):
+        lg, st = model.encoder.single_step_forward(inputs[:, t], st, fld[:, :, t].contiguous())
+        assert scale_rel_err(lg.cpu(), prior[:, t].cpu()) <= 2e-6
+    assert scale_rel_err(st[0].cpu(), h.cpu()) <= 2e-6

@@ -308,3 +308,22 @@ def test_dynamicvars_model_prediction_path():
     preds = DO.predict_future(sd, c["inputs"], c["masks"], c["node_inds"], c["graph_info"], c["burn"], c["uniform"], 0.5,
                               True, "cart")
     assert scale_rel_err(preds, t("ref.predictions")) <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["gaussian_norm", "crossent_tf2_uniform"])
+def test_seq2seq_encoder_forward_and_eval_loss(name):
+    """The full-sequence encoder (forward + reverse LSTM, both heads) and Aether.calculate_loss(is_train=False) of the
+    imported reference: Gaussian NLL with per-batch normalisation, and cross-entropy NLL with two teacher-forced
+    steps, a non-uniform edge prior and per-variable KL normalisation."""
+    from conftest import load_s2s_loss
+    from oracle import seq2seq_oracle as S
+    c, model, params = load_s2s_loss(name)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    prior, post, (h, cc) = S.encoder_forward(enc, c["inputs"][:, :-1], c["field"], False, "polar")
+    assert scale_rel_err(prior, c["prior"]) <= 5e-6 and scale_rel_err(post, c["posterior"]) <= 5e-6
+    assert scale_rel_err(h.reshape(c["state.h"].shape), c["state.h"]) <= 5e-6
+    loss, nll, kl, post2, preds = S.calculate_loss_eval(sd, params, c["inputs"], c["uniform"], False, "polar")
+    assert scale_rel_err(preds, c["predictions"]) <= 5e-6
+    assert abs(float(loss) - float(c["loss"])) <= 1e-5 * abs(float(c["loss"]))
+    assert scale_rel_err(nll.reshape(c["nll"].shape), c["nll"]) <= 1e-5 and scale_rel_err(kl.reshape(c["kl"].shape), c["kl"]) <= 1e-5
