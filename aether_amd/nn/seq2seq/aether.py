@@ -4,8 +4,9 @@ Mirrors the parts of ``nn.seq2seq.aether.Aether`` (aether.py:14-191) that run on
 ``predict_field`` (:86-90), ``single_step_forward`` (:92-101) and the prediction loop of
 ``predict_future`` (:175-185).  Sub-modules carry the reference's names -- ``encoder``, ``decoder``,
 ``field_net``, ``coordinate_embedding`` -- so ``load_state_dict(reference_model.state_dict())`` works.
-``predict_future`` runs its burn-in half with the same step (the prior path of the encoder is causal);
-the posterior encoder (reverse LSTM, ``encoder_fc_out``) and the training loss are not part of this path.
+``predict_future`` runs its burn-in half with the same step (the prior path of the encoder is causal).
+``calculate_loss(is_train=False)`` (:103-153) evaluates the validation loss with the full-sequence encoder
+(``Encoder.forward``); training (``is_train=True``) is not part of this library.
 """
 from __future__ import annotations
 
@@ -124,18 +125,11 @@ class _StepLoop:
         return preds, edges, state
 
 
-class Aether(_StepLoop, nn.Module):
-    def __init__(self, params, device="cuda"):
-        super().__init__()
-        self.num_vars = params["num_vars"]
-        self.encoder = Encoder(params, device=None)                       # creation order of aether.py:19-24,71-84
-        if params.get("decoder_type", None) == "ref_mlp":
-            raise ValueError("decoder_type 'ref_mlp' (MarkovDecoder) is not part of this path")
-        self.decoder = RecurrentDecoder(params, device=None)
-        self.num_edge_types = params.get("num_edge_types")
-        self.gumbel_temp = params.get("gumbel_temp")
-        self.kl_coef = params.get("kl_coef", 1.)                      # read by the training scripts
-        # the loss configuration of aether.py:27-58 (evaluation-mode calculate_loss)
+class _EvalLoss:
+    """Mixin of the two seq2seq models: the loss configuration of the params dictionary (aether.py:27-58) and
+    ``calculate_loss`` in evaluation mode (:103-153) with its NLL / KL terms (:186-236)."""
+
+    def _init_loss_config(self, params):
         self.val_teacher_forcing_steps = params.get("val_teacher_forcing_steps", -1)
         self.normalize_kl = params.get("normalize_kl", False)
         self.normalize_kl_per_var = params.get("normalize_kl_per_var", False)
@@ -151,24 +145,13 @@ class Aether(_StepLoop, nn.Module):
                 prior = torch.full((K,), (1 - params["no_edge_prior"]) / (K - 1))
                 prior[0] = params["no_edge_prior"]
             self.log_prior = torch.log(prior).view(1, 1, K)
-        self.use_3d = params.get("use_3d", False)
-        self.num_dims = 3 if self.use_3d else 2
-        fq = FieldQuery(self.num_dims, params["encoder_hidden"], params.get("rff_std", 1.0), device=None)
-        self.field_net, self.coordinate_embedding = fq.field_net, fq.coordinate_embedding
-        self._fq = [fq]                                                    # not a registered sub-module: no duplicate keys
-        if device is not None:
-            self.to(device)
 
-    def save(self, path):
-        torch.save(self.state_dict(), path)                       # as the reference's save / load
+    def _sequence_field(self, inputs):
+        """(field of inputs[:, :-1] as [B, N, T - 1, D], function giving the field of a later state [B, N, 2D])."""
+        x = inputs[:, :-1].transpose(2, 1).contiguous()
+        predicted_field, _ = self.predict_field(x)
+        return predicted_field, lambda state: self.predict_field(state)[0]
 
-    def load(self, path):
-        self.load_state_dict(torch.load(path))
-
-    def predict_field(self, x):
-        return self._fq[0](x)
-
-    @torch.no_grad()
     def calculate_loss(self, inputs, is_train=False, teacher_forcing=True, return_edges=False, return_logits=False,
                        use_prior_logits=False, uniform=None):
         """aether.py:103-153 in evaluation mode (the validation metrics of experiments/electrostatic/train.py): the
@@ -179,10 +162,13 @@ class Aether(_StepLoop, nn.Module):
         if is_train:
             raise _lib.AetherHipError("calculate_loss(is_train=True) (training of the seq2seq model) is not part of this "
                                       "library; evaluation (is_train=False), predict_future and predict_field are")
+        with torch.no_grad():           # (not a decorator: evaluate.py:42-45 inspects this method's argument names)
+            return self._calculate_loss_eval(inputs, teacher_forcing, return_edges, return_logits, use_prior_logits, uniform)
+
+    def _calculate_loss_eval(self, inputs, teacher_forcing, return_edges, return_logits, use_prior_logits, uniform):
         B, T, N, _ = inputs.shape
         decoder_hidden = self.decoder.get_initial_hidden(inputs)
-        x = inputs[:, :-1].transpose(2, 1).contiguous()
-        predicted_field, _ = self.predict_field(x)                                   # [B, N, T - 1, D]
+        predicted_field, field_fn = self._sequence_field(inputs)                     # [B, N, T - 1, D]
         prior_logits, posterior_logits, _ = self.encoder(inputs[:, :-1], predicted_field)
         tf_steps = self.val_teacher_forcing_steps
         all_predictions, edges, predictions = [], None, None
@@ -191,10 +177,11 @@ class Aether(_StepLoop, nn.Module):
                 current_inputs, current_field = inputs[:, step], predicted_field[:, :, step].contiguous()
             else:
                 current_inputs = predictions
-                current_field, _ = self.predict_field(predictions)
+                current_field = field_fn(predictions)
             logits = (prior_logits if use_prior_logits else posterior_logits)[:, step].contiguous()
             predictions, decoder_hidden, edges = self.single_step_forward(
-                current_inputs, decoder_hidden, logits, True, current_field, None if uniform is None else uniform[step])
+                current_inputs, decoder_hidden, logits, True, current_field,
+                uniform=None if uniform is None else uniform[step])
             all_predictions.append(predictions)
         all_predictions = torch.stack(all_predictions, dim=1)
         target = inputs[:, 1:].to(torch.float32)
@@ -243,6 +230,37 @@ class Aether(_StepLoop, nn.Module):
         avg_preds = preds.mean(dim=2)
         kl_div = avg_preds * (torch.log(avg_preds + eps) - self.log_prior.to(preds.device))
         return self._kl_reduce(kl_div, preds.size(0))
+
+
+
+class Aether(_StepLoop, _EvalLoss, nn.Module):
+    def __init__(self, params, device="cuda"):
+        super().__init__()
+        self.num_vars = params["num_vars"]
+        self.encoder = Encoder(params, device=None)                       # creation order of aether.py:19-24,71-84
+        if params.get("decoder_type", None) == "ref_mlp":
+            raise ValueError("decoder_type 'ref_mlp' (MarkovDecoder) is not part of this path")
+        self.decoder = RecurrentDecoder(params, device=None)
+        self.num_edge_types = params.get("num_edge_types")
+        self.gumbel_temp = params.get("gumbel_temp")
+        self.kl_coef = params.get("kl_coef", 1.)                      # read by the training scripts
+        self._init_loss_config(params)
+        self.use_3d = params.get("use_3d", False)
+        self.num_dims = 3 if self.use_3d else 2
+        fq = FieldQuery(self.num_dims, params["encoder_hidden"], params.get("rff_std", 1.0), device=None)
+        self.field_net, self.coordinate_embedding = fq.field_net, fq.coordinate_embedding
+        self._fq = [fq]                                                    # not a registered sub-module: no duplicate keys
+        if device is not None:
+            self.to(device)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)                       # as the reference's save / load
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path))
+
+    def predict_field(self, x):
+        return self._fq[0](x)
 
     @torch.no_grad()
     def single_step_forward(self, inputs, decoder_hidden, edge_logits, hard_sample, predicted_field, uniform=None):

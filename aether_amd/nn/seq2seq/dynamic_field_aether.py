@@ -21,7 +21,7 @@ import torch.nn as nn
 from ... import _lib
 from ..state2state.dynamic_field_aether import _AttentionalAggregation
 from .decoder import RecurrentDecoder
-from .aether import _StepLoop
+from .aether import _EvalLoss, _StepLoop
 from .encoder import Encoder, gumbel_softmax_hard
 from .field import _CoordinateEmbedding
 
@@ -122,7 +122,7 @@ class _FilmedNetwork(nn.Module):
         self.film_2 = _FiLM(hidden_size, z_size, hidden_size)
 
 
-class DynamicFieldAether(_StepLoop, nn.Module):
+class DynamicFieldAether(_StepLoop, _EvalLoss, nn.Module):
     def __init__(self, params, device="cuda"):
         super().__init__()
         if params.get("use_charges", False):
@@ -135,6 +135,7 @@ class DynamicFieldAether(_StepLoop, nn.Module):
         self.num_edge_types = params.get("num_edge_types")
         self.gumbel_temp = params.get("gumbel_temp")
         self.kl_coef = params.get("kl_coef", 1.)                      # read by the training scripts
+        self._init_loss_config(params)
         self.use_3d = params.get("use_3d", False)
         self.num_dims = 3 if self.use_3d else 2
         self.hidden_size = hidden_size = params["encoder_hidden"]
@@ -150,17 +151,20 @@ class DynamicFieldAether(_StepLoop, nn.Module):
             self.to(device)
 
     def calculate_loss(self, inputs, is_train=False, teacher_forcing=True, return_edges=False, return_logits=False,
-                       use_prior_logits=False, charges=None):
-        """dynamic_field_aether.py:151-205: not part of the prediction path; the signature is kept because
-        experiments/electrostatic/evaluate.py:42-45 inspects it (``charges`` is then passed to ``predict_future``)."""
-        raise _lib.AetherHipError("calculate_loss (posterior encoder + training loss) is not part of this path; "
-                                  "predict_future is")
+                       use_prior_logits=False, charges=None, uniform=None):
+        """dynamic_field_aether.py:151-205 in evaluation mode: as ``Aether.calculate_loss`` with the field conditioned on
+        the summary of ``inputs[:, :-1]``.  (experiments/electrostatic/evaluate.py:42-45 inspects the signature for
+        ``charges``, which must stay None: use_charges is not part of this path.)"""
+        if charges is not None:
+            raise _lib.AetherHipError("charges (use_charges) are not part of this path")
+        return _EvalLoss.calculate_loss(self, inputs, is_train, teacher_forcing, return_edges, return_logits,
+                                        use_prior_logits, uniform)
 
-    def save(self, path):
-        torch.save(self.state_dict(), path)                       # as the reference's save / load
-
-    def load(self, path):
-        self.load_state_dict(torch.load(path))
+    def _sequence_field(self, inputs):
+        x = inputs[:, :-1].transpose(2, 1).contiguous()                    # :160-166
+        gr_summary = self.graph_pooler(x)
+        predicted_field, _ = self.predict_field(x, gr_summary)
+        return predicted_field, lambda state: self.predict_field(state, gr_summary)[0]
 
     def create_grid_points(self, box_size=5.0, grid_size=21, normalize=True):
         """dynamic_field_aether.py:89-95: the grid of the data-side ``field`` object (``params['field']``)."""

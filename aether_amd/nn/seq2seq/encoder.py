@@ -5,8 +5,10 @@ prediction path: same ``params`` dictionary, sub-modules and parameters created 
 reference's order (same seed -> same weights; ``state_dict`` keys / order match a reference checkpoint,
 including the bidirectional-encoder tensors this path does not use), and
 ``single_step_forward(inputs, prior_state, predicted_field) -> (prior_logits, prior_state)``.
-The computation runs in libaether_hip.so (``aether_s2s_prior_step``); there is no CPU fallback, and the
-full-sequence ``forward`` (posterior encoder, training) is not part of this path.
+``forward(inputs, predicted_field)`` is the full-sequence encoder in evaluation mode (aether.py:350-382: prior and
+posterior logits).  The computation runs in libaether_hip.so (``aether_s2s_prior_step``,
+``aether_s2s_encoder_features`` / ``aether_s2s_lstm_step`` / ``aether_s2s_mlp_head``); there is no CPU fallback, and
+training (gradients) is not part of this library.
 """
 from __future__ import annotations
 

@@ -451,3 +451,33 @@ def test_encoder_forward_and_eval_loss_match_reference(name):
         lg, st = model.encoder.single_step_forward(inputs[:, t], st, fld[:, :, t].contiguous())
         assert scale_rel_err(lg.cpu(), prior[:, t].cpu()) <= 2e-6
     assert scale_rel_err(st[0].cpu(), h.cpu()) <= 2e-6
+
+
+def test_dynamic_field_eval_loss_vs_oracle():
+    """calculate_loss(is_train=False) of the seq2seq dynamic-field model (field conditioned on the sequence's summary)
+    vs the oracle's loss with the film field."""
+    from conftest import load_s2s_dynfield
+    d, model, params = load_s2s_dynfield()
+    params = dict(params, nll_loss_type="gaussian", prior_variance=5e-5, normalize_nll=True, normalize_kl=True,
+                  kl_coef=1.0, val_teacher_forcing_steps=2)
+    model._init_loss_config(params)
+    model = model.cuda()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    inputs = torch.from_numpy(d["in.inputs"])
+    B, T, N, _ = inputs.shape
+    g = torch.Generator().manual_seed(8)
+    U = torch.rand(T - 1, B * N * (N - 1), 2, generator=g)
+    # oracle: the loss of oracle/seq2seq_oracle.py with the film field substituted
+    gp = {k[len("graph_pooler."):]: v for k, v in sd.items() if k.startswith("graph_pooler.")}
+    summary = S.graph_summary(gp, inputs[:, :-1].transpose(2, 1).contiguous())
+    orig = S.predict_field
+    S.predict_field = lambda sd_, x_, D_: S.film_field(sd_, x_, summary, D_)
+    try:
+        want = S.calculate_loss_eval(sd, params, inputs, U, True, "cart")
+    finally:
+        S.predict_field = orig
+    got = model.calculate_loss(inputs.cuda(), is_train=False, return_logits=True, uniform=U.cuda().view(T - 1, B, -1, 2))
+    assert scale_rel_err(got[4].cpu(), want[4]) <= TOL and scale_rel_err(got[3].cpu(), want[3]) <= TOL
+    assert abs(float(got[0]) - float(want[0])) <= 5e-4 * abs(float(want[0]))
+    with pytest.raises(Exception):
+        model.calculate_loss(inputs.cuda(), is_train=True)
