@@ -276,10 +276,11 @@ class Aether(_StepLoop, _EvalLoss, nn.Module):
 
     @torch.no_grad()
     def predict_future(self, inputs, prediction_steps, return_edges=False, uniform=None, graph=False):
-        """aether.py:155-191.  inputs [B, T, N, 2D] (burn-in observations).  The burn-in half runs the prior
-        step by step: the encoder's prior path is causal (forward LSTM from the zero state, BatchNorm in eval
-        mode), so the chained ``single_step_forward`` equals ``Encoder.forward``'s prior logits and state
-        (pinned against the reference's own ``predict_future``).  ``uniform`` [T - 1 + steps, B, E, K].
+        """aether.py:155-191.  inputs [B, T, N, 2D] (burn-in observations).  The burn-in half takes its prior logits
+        and LSTM state from the full-sequence encoder, as the reference does; with ``graph=True`` it chains the
+        captured single step instead (the encoder's prior path is causal -- forward LSTM from the zero state,
+        BatchNorm in eval mode -- so both give the same logits and state to rounding; both are pinned against the
+        reference's own ``predict_future``).  ``uniform`` [T - 1 + steps, B, E, K].
         ``graph``: replay the step from a captured hipGraph (``_StepRunner``) instead of launching it kernel by kernel."""
         B, T, N, _ = inputs.shape
         E = N * (N - 1)
@@ -291,12 +292,15 @@ class Aether(_StepLoop, _EvalLoss, nn.Module):
                                             inputs[:, T - 1].float(), decoder_hidden, prior_hidden,
                                             int(prediction_steps), uniform, return_edges)
             return (preds, edges) if return_edges else preds
-        for step in range(T - 1):
-            current_inputs = inputs[:, step]
-            field, _ = self.predict_field(current_inputs)
-            logits, prior_hidden = self.encoder.single_step_forward(current_inputs, prior_hidden, field)
-            _, decoder_hidden, _ = self.single_step_forward(current_inputs, decoder_hidden, logits, True, field,
-                                                            None if uniform is None else uniform[step])
+        if T > 1:
+            # burn-in as the reference runs it (aether.py:161-173): field and prior logits of the whole observed
+            # sequence at once (the per-step features batch over T - 1 time steps), then the decoder step by step
+            field_all, _ = self.predict_field(inputs[:, :-1].transpose(2, 1).contiguous())       # [B, N, T - 1, D]
+            prior_logits, _, prior_hidden = self.encoder(inputs[:, :-1], field_all)
+            for step in range(T - 1):
+                _, decoder_hidden, _ = self.single_step_forward(
+                    inputs[:, step], decoder_hidden, prior_logits[:, step].contiguous(), True,
+                    field_all[:, :, step].contiguous(), None if uniform is None else uniform[step])
         return self.predict_from_state(inputs[:, T - 1], decoder_hidden, prior_hidden, prediction_steps,
                                        None if uniform is None else uniform[T - 1:], return_edges, graph=False)
 

@@ -295,12 +295,14 @@ class DynamicFieldAether(_StepLoop, _EvalLoss, nn.Module):
                                             int(prediction_steps), uniform, return_edges, extra_key=(mod.data_ptr(),))
             return (preds, edges) if return_edges else preds
         all_predictions, all_edges = [], []
+        if T > 1:
+            prior_logits, _, prior_hidden = self.encoder(inputs[:, :-1], predicted_field)        # :221-222
         for step in range(T - 1):
             current_inputs = inputs[:, step]
             field = predicted_field[:, :, step].contiguous()
-            logits, prior_hidden = self.encoder.single_step_forward(current_inputs, prior_hidden, field)
             predictions, decoder_hidden, edges = self.single_step_forward(
-                current_inputs, decoder_hidden, logits, True, field, None, None if uniform is None else uniform[step])
+                current_inputs, decoder_hidden, prior_logits[:, step].contiguous(), True, field, None,
+                None if uniform is None else uniform[step])
             if return_everything:
                 all_edges.append(edges)
                 all_predictions.append(predictions)
