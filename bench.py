@@ -296,6 +296,25 @@ def main():
                     for _ in range(S):
                         out = call()
                 group = gs.replay
+            if world > 1:
+                # Guard for ranks that share one GPU (rehearsals with --share-gpu): hipGraph replays from two
+                # processes on the same device serialise pathologically (71 ms per step measured, against 0.1 ms for
+                # eager launches).  Every rank times both ways for a few steps; if graph replay is not faster on some
+                # rank, all ranks launch eagerly.  One process per GPU keeps the graph.
+                def _timed(fn, n):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / n
+                (group if S > 1 else step)()
+                t_graph = _timed(group, 2) / S if S > 1 else _timed(step, 10)
+                t_eager = _timed(call, 10)
+                flag = torch.tensor([1.0 if t_graph > 1.5 * t_eager else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if float(flag.item()) > 0:
+                    use_graph, step, S = False, call, 1
         else:
             step = call
             S = 1
