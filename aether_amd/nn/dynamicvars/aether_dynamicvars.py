@@ -104,23 +104,20 @@ class AetherDynamicVars(nn.Module):
     def predict_future(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
         """:245-273.  inputs [1, T, Nmax, 4], masks / burn_in_masks [1, T, Nmax], node_inds[0][t], graph_info[0][t]: the
         present objects and their graph per time step.  ``uniform``: per-step Gumbel draws (list of [E_t, K])."""
-        total_timesteps = inputs.size(1)
-        prior_hidden = self.encoder.get_initial_hidden(inputs)
-        decoder_hidden = self.decoder.get_initial_hidden(inputs)
-        predictions = inputs[:, 0]
+        n_steps = inputs.size(1) - 1
+        prior_state = self.encoder.get_initial_hidden(inputs)
+        dec_state = self.decoder.get_initial_hidden(inputs)
+        last = inputs[:, 0]
         preds = []
-        for step in range(total_timesteps - 1):
-            current_masks = masks[:, step]
-            current_burn_in_masks = burn_in_masks[:, step].unsqueeze(-1).type(inputs.dtype)
-            current_inps = inputs[:, step]
-            current_node_inds = node_inds[0][step]
-            current_graph_info = graph_info[0][step]
-            encoder_inp = current_burn_in_masks * current_inps + (1 - current_burn_in_masks) * predictions
-            current_field, _ = self.predict_field(encoder_inp, current_masks)
-            current_edge_logits, prior_hidden = self.encoder.single_step_forward(
-                encoder_inp, current_masks, current_node_inds, current_graph_info, prior_hidden, current_field)
-            predictions, decoder_hidden, _ = self.single_step_forward(
-                encoder_inp, current_masks, current_graph_info, decoder_hidden, current_edge_logits, True, current_field,
-                None if uniform is None else uniform[step])
-            preds.append(predictions)
+        for t in range(n_steps):
+            present = masks[:, t]
+            observed = burn_in_masks[:, t].unsqueeze(-1).type(inputs.dtype)
+            # observed objects are fed their ground truth, the others the model's own last prediction (:264)
+            state = observed * inputs[:, t] + (1 - observed) * last
+            field, _ = self.predict_field(state, present)
+            logits, prior_state = self.encoder.single_step_forward(state, present, node_inds[0][t], graph_info[0][t],
+                                                                   prior_state, field)
+            last, dec_state, _ = self.single_step_forward(state, present, graph_info[0][t], dec_state, logits, True, field,
+                                                          None if uniform is None else uniform[t])
+            preds.append(last)
         return torch.stack(preds, dim=1)

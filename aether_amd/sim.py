@@ -240,16 +240,15 @@ class _LorentzFamilySim(object):
             raise ValueError("at most 64 balls per simulation")
 
     def _clamp(self, loc, vel):
-        assert (np.all(loc < self.box_size * 3))                           # :196-219
-        assert (np.all(loc > -self.box_size * 3))
-        over = loc > self.box_size
-        loc[over] = 2 * self.box_size - loc[over]
-        assert (np.all(loc <= self.box_size))
-        vel[over] = -np.abs(vel[over])
-        under = loc < -self.box_size
-        loc[under] = -2 * self.box_size - loc[under]
-        assert (np.all(loc >= -self.box_size))
-        vel[under] = np.abs(vel[under])
+        """Reflect positions outside the box back inside, velocities pointing inwards (synthetic_sim.py:196-219;
+        in place, as the reference: the clamped arrays are the initial state of the integration)."""
+        lim = self.box_size
+        assert np.all(np.abs(loc) < 3 * lim)
+        hi, lo = loc > lim, loc < -lim
+        loc[hi] = 2 * lim - loc[hi]
+        vel[hi] = -np.abs(vel[hi])
+        loc[lo] = -2 * lim - loc[lo]
+        vel[lo] = np.abs(vel[lo])
         return loc, vel
 
     def _draw_initial(self, seed, charge_prob):
