@@ -505,7 +505,8 @@ def main():
         value = 4.0 * E * world / (dt / args.steps)
         step_flops = E * FLOP_PER_EDGE_STEP[D] + Nn * FLOP_PER_NODE_STEP[D]
         line = {
-            "metric": "edge-messages/sec (forward, electrostatic N=20 batch=128 per GPU)",
+            "metric": ("edge-messages/sec (forward, electrostatic N=20 batch=128 per GPU)" if (B, N, D) == (128, 20, 2)
+                       else f"edge-messages/sec (forward, {D}-D N={N} batch={B} per GPU)"),
             "value": value, "unit": "edge-messages/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
