@@ -228,3 +228,18 @@ def test_sim_conservation_properties_at_dataset_size():
     assert np.isfinite(loc).all() and np.isfinite(vel).all()
     assert np.array_equal(loc[:, :, 3:], np.repeat(loc[:, :1, 3:], loc.shape[1], axis=1))      # field sources fixed
     assert np.abs(vel[:, :, 3:]).max() == 0.0
+
+
+def test_oracle_speed(capsys):
+    """Informative: the speed of the numpy restatement of the electrostatic simulator on one host core (the CPU figure
+    DESIGN.md quotes next to the device simulators); checks only that 200 steps of 15 balls finish."""
+    import time
+    sim = ElectrostaticFieldSim(n_balls=5, static_balls=10, dim=3)
+    charges, loc0, vel0 = sim._draw_initial([0.5, 0.0, 0.5], None)
+    t0 = time.perf_counter()
+    loc, vel, _ = SO.electrostatic_trajectory(loc0, vel0, charges[:, 0], 5, 200, 100)
+    dt = time.perf_counter() - t0
+    with capsys.disabled():
+        print("\n[oracle] electrostatic, 15 balls: %.1f us per step on one core -> %.2f s per 5000-step simulation"
+              % (dt / 200 * 1e6, dt / 200 * 5000))
+    assert loc.shape == (1, 15, 3) and np.isfinite(loc).all()

@@ -35,8 +35,6 @@ for N in (20, 40, 400):
     print("N=%3d (%5d edges): decoder step %.3f ms, kNN graph %.3f ms" % (N, send.numel(), dt * 1e3, dk * 1e3))
 
 # the whole prediction step of AetherDynamicVars.predict_future at inD sizes (scripts/ind_aether.sh)
-import sys as _sys
-_sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
 mp = {"input_size": 4, "gpu": True, "decoder_hidden": 256, "num_edge_types": 4, "skip_first": True, "decoder_dropout": 0.0,
       "pos_representation": "cart", "no_encoder_bn": False, "encoder_dropout": 0.0, "encoder_hidden": 256,

@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
 """Time the device-side dataset simulators at the reference's dataset sizes
-(generate_dataset.py: 5 balls + 10 field sources, T = 5000, sample_freq = 100) next to the numpy restatement of
-the reference on one host core."""
+(generate_dataset.py: 5 balls + 10 field sources, T = 5000, sample_freq = 100).  (The CPU figure quoted next to these
+in DESIGN.md comes from tests/test_sim.py::test_oracle_speed -- tools do not touch oracle/.)"""
 import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aether_amd.sim import ElectrostaticFieldSim, GravitationalFieldSim
-from oracle import sim_oracle as SO
 
 T, SF = 5000, 100
 for dim in (2, 3):
@@ -24,11 +23,6 @@ for dim in (2, 3):
         pairs = S * T * 15.0 * 15.0
         print("electrostatic %d-D  %6d simulations x %d steps: %.3f s  (%.0f sims/s, %.1f G pair-forces/s, capped %d)" %
               (dim, S, T, dt, S / dt, pairs / dt / 1e9, int(maxed.sum())))
-    c, l, v = draws[0]
-    t0 = time.perf_counter()
-    SO.electrostatic_trajectory(l, v, c[:, 0], 5, 1000, SF)
-    dt1 = (time.perf_counter() - t0) * (T / 1000)
-    print("   numpy restatement, one core: %.2f s per simulation (%.2f sims/s)" % (dt1, 1 / dt1))
 np.random.seed(0)
 g = GravitationalFieldSim(n_balls=5, static_balls=10, dim=3)
 g.sample_trajectories(8, T=200, sample_freq=100)
