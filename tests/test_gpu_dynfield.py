@@ -155,3 +155,27 @@ def test_dynamic_field_device_rollout(flags):
         vo, xo = (xn - xo) / 0.5, xn
         assert scale_rel_err(traj[t].cpu(), xo) <= TOL, t
     assert m.rollout(inp["x"], inp["vel"], inp["edges"], inp["charges"], 0, num_nodes=N).shape == (0, B * N, D)
+
+
+def test_dynamic_field_graphed_train_step():
+    """GraphedTrainStep (forward + both HIP backward halves + fused AdamW in one hipGraph) on the dynamic-field model:
+    same parameters as the eager loop."""
+    from aether_amd.training import GraphedTrainStep
+    D, B, N = 2, 16, 20
+    d, sd, m1 = _load(D)
+    _, _, m2 = _load(D)
+    b = make_batch(B, N, D, seed=91, device="cuda")
+    args = (None, b["x"], b["edges"], b["vel"], b["edge_attr"], b["charges"], N)
+    step = GraphedTrainStep(m1, args, b["target"], lr=1e-3, warmup=1)
+    opt = torch.optim.AdamW(m2.parameters(), lr=1e-3, weight_decay=1e-12, capturable=True, fused=True)
+    for k in range(4):
+        if k > 0:
+            lg = float(step.step().detach())
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(m2(*args), b["target"])
+        loss.backward()
+        opt.step()
+        if k > 0:
+            assert abs(lg - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
+    for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert scale_rel_err(p.detach().cpu(), q.detach().cpu()) <= 1e-5, k

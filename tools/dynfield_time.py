@@ -36,3 +36,9 @@ for D in (3, 2):
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
         t = timed(lambda: train_step(model, args, opt, tgt), reps=50)
         print("   eager training step, %-14s: %.3f ms" % (name, t))
+    from aether_amd.training import GraphedTrainStep
+    for name, model, args in (("dynamic field", m, (inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"], N)),
+                              ("built-in field", a, (inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]))):
+        gs = GraphedTrainStep(model, args, tgt, lr=1e-4)
+        t = timed(gs.step, reps=100)
+        print("   graphed training step (aether_amd.training), %-14s: %.3f ms" % (name, t))
