@@ -262,3 +262,39 @@ def test_random_multigraphs_match_oracle(D, seed):
             outs[name] = m(inp["h"].to(dev), inp["x"].to(dev), edges, inp["vel"].to(dev),
                            inp["edge_attr"].to(dev), inp["charges"].to(dev)).cpu()
         assert scale_rel_err(outs[name], want) <= TOL, (name, seed)
+
+
+def test_cfg5_full_shard_properties():
+    """BASELINE config 5 at its full per-GPU size (32 fully connected graphs of 1,024 bodies: 32,768 nodes, 33.5 M
+    edges, the streamed path), through properties that need no oracle: graphs are independent (graph 0 of the batch
+    = the same graph run alone), a second run is bit-identical, relabelling the bodies of a graph permutes its
+    outputs, everything is finite.  (Parity against the oracle at this shape: the N=512 test above.)"""
+    D, B, N = 2, 32, 1024
+    m = _model(D)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    scale = (N / 5.0) ** (1.0 / 3.0)
+    x = torch.randn(B * N, D, device="cuda", generator=g) * scale
+    v = torch.randn(B * N, D, device="cuda", generator=g)
+    v = 0.5 * v / v.norm(dim=-1, keepdim=True)
+    q = (torch.randint(0, 2, (B * N, 1), device="cuda", generator=g).float() * 2 - 1)
+    edges = get_edges(B, N, device="cuda")
+    assert edges[0].numel() == B * N * (N - 1) == 33_521_664
+    ea = prepare_edge_attr(x, edges, q[edges[0]] * q[edges[1]])
+    h = v.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        out = m(h, x, edges, v, ea, q)
+        assert out.shape == (B * N, D) and torch.isfinite(out).all()
+        out2 = m(h, x, edges, v, ea, q)
+        assert torch.equal(out, out2)                                         # deterministic
+        del out2
+        # graph 0 alone
+        e1 = get_edges(1, N, device="cuda")
+        ea1 = prepare_edge_attr(x[:N], e1, q[:N][e1[0]] * q[:N][e1[1]])
+        alone = m(h[:N], x[:N], e1, v[:N], ea1, q[:N])
+        assert scale_rel_err(out[:N].cpu(), alone.cpu()) <= 1e-6               # no cross-graph term
+        # relabel the bodies of that graph
+        perm = torch.randperm(N, device="cuda", generator=g)
+        xp, vp, qp = x[:N][perm], v[:N][perm], q[:N][perm]
+        eap = prepare_edge_attr(xp, e1, qp[e1[0]] * qp[e1[1]])
+        outp = m(vp.norm(dim=-1, keepdim=True), xp, e1, vp, eap, qp)
+        assert scale_rel_err(outp.cpu(), alone[perm].cpu()) <= TOL             # sums over 1,023 in-edges reorder
