@@ -481,3 +481,31 @@ def test_dynamic_field_eval_loss_vs_oracle():
     assert abs(float(got[0]) - float(want[0])) <= 5e-4 * abs(float(want[0]))
     with pytest.raises(Exception):
         model.calculate_loss(inputs.cuda(), is_train=True)
+
+
+def test_rollout_mse_protocol_burn_in_29_predict_20():
+    """SURVEY 8(d) metric 2 with the protocol of experiments/electrostatic/evaluate.py:33-70: burn-in 29 frames, predict
+    20, per-step MSE over (sample, particle, feature).  HIP vs oracle with identical weights, inputs and Gumbel draws:
+    sampled edge types equal at every step, trajectories and per-step MSE within 1e-5 (scale-relative)."""
+    from aether_amd.nn.seq2seq.aether import Aether
+    D, B, N, T0, steps, H = 2, 16, 5, 29, 20, 128
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H, "encoder_rnn_hidden": 64,
+              "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 64,
+              "prior_num_layers": 3, "prior_hidden_size": 64, "use_3d": False, "pos_representation": "polar", "gpu": True,
+              "decoder_hidden": H, "skip_first": False, "decoder_dropout": 0.0, "gumbel_temp": 0.5}
+    torch.manual_seed(41)
+    model = Aether(params, device="cuda").eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    frames = torch.randn(B, T0 + steps, N, 2 * D, generator=g) * 0.5
+    frames = frames.cumsum(1) * 0.2                                           # smooth-ish trajectories
+    U = torch.rand(T0 - 1 + steps, B * N * (N - 1), 2, generator=g)
+    want, want_e = S.predict_future(sd, frames[:, :T0], steps, U, 0.5, False, "polar", 3, return_edges=True)
+    got, got_e = model.predict_future(frames[:, :T0].cuda(), steps, return_edges=True,
+                                      uniform=U.cuda().view(-1, B, N * (N - 1), 2))
+    assert torch.equal(got_e.cpu().argmax(-1), want_e.argmax(-1))
+    assert scale_rel_err(got.cpu(), want) <= TOL
+    truth = frames[:, T0:]
+    mse_hip = ((got.cpu() - truth) ** 2).mean(dim=(0, 2, 3))                  # per predicted step
+    mse_ref = ((want - truth) ** 2).mean(dim=(0, 2, 3))
+    assert ((mse_hip - mse_ref).abs() / mse_ref).max() <= 1e-5
