@@ -243,3 +243,39 @@ def test_oracle_speed(capsys):
         print("\n[oracle] electrostatic, 15 balls: %.1f us per step on one core -> %.2f s per 5000-step simulation"
               % (dt / 200 * 1e6, dt / 200 * 5000))
     assert loc.shape == (1, 15, 3) and np.isfinite(loc).all()
+
+
+@pytest.mark.gpu
+def test_simulated_dataset_feeds_the_training_loop():
+    """aether_amd.data.SimulatedNBodyDataset: the runner's data set surface (dataset4newton.py:7-94) over trajectories
+    simulated on the device; its items equal what the reference's preprocessing makes of the simulator's arrays, and a
+    few optimizer steps on its batches reduce the loss (simulator -> data set -> HIP training step, nothing on the host)."""
+    import torch
+    from aether_amd.data import SimulatedNBodyDataset
+    from aether_amd.nn.state2state.aether import Aether
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = SimulatedNBodyDataset(range(100, 164), simulation="dynamic", n_balls=5, length=5000, sample_freq=100)
+        ref = AS.DynamicSim(noise_var=0.0, n_balls=5, vel_norm=0.5)
+    assert len(ds) == 64 and ds.get_n_nodes() == 5
+    loc, vel, edges, charges = ref.sample_trajectory(103, T=5000, sample_freq=100)       # the arrays the files would hold
+    l0, v0, ea, q, lT = ds[3]
+    assert l0.is_cuda and l0.shape == (5, 3) and ea.shape == (20, 1) and q.shape == (5, 1)
+    assert np.allclose(l0.cpu().numpy(), loc[30].T.astype(np.float32)) and np.allclose(lT.cpu().numpy(), loc[40].T.astype(np.float32))
+    assert np.allclose(v0.cpu().numpy(), vel[30].T.astype(np.float32))
+    want_ea = np.array([edges[i, j] for i in range(5) for j in range(5) if i != j], dtype=np.float32)   # :56-61
+    assert np.array_equal(ea.cpu().numpy()[:, 0], want_ea) and np.array_equal(q.cpu().numpy(), charges.astype(np.float32))
+    e = ds.get_edges(2, 5)
+    assert e[0].tolist()[:4] == [0, 0, 0, 0] and e[1].tolist()[:4] == [1, 2, 3, 4] and e[0][20] == 5
+    torch.manual_seed(0)
+    model = Aether(6, 64, 0.0, 3, device="cuda")
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    losses = []
+    for epoch in range(6):
+        for b in ds.batches(32):
+            opt.zero_grad()
+            loss = torch.nn.functional.mse_loss(model(b["h"], b["x"], b["edges"], b["vel"], b["edge_attr"], b["charges"]),
+                                                b["target"])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and np.mean(losses[-2:]) < np.mean(losses[:2])
