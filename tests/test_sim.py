@@ -279,3 +279,47 @@ def test_simulated_dataset_feeds_the_training_loop():
             opt.step()
             losses.append(float(loss.detach()))
     assert np.isfinite(losses).all() and np.mean(losses[-2:]) < np.mean(losses[:2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm", ["default", "same_data_norm", "vel_norm_norm", "no_data_norm", "symmetric_data_norm"])
+def test_simulated_field_dataset_and_forward_prediction_metric(norm):
+    """aether_amd.data.SimulatedFieldDataset (the seq2seq runners' data set over device-simulated trajectories, all four
+    normalisation modes + the symmetric variant) and aether_amd.evaluate.eval_forward_prediction (evaluate.py:14-79):
+    normalise / un-normalise round trip, training-set statistics reused for another split, and the 20-step MSE of a
+    model equals the same metric computed from the oracle's predictions."""
+    import torch
+    from aether_amd.data import SimulatedFieldDataset
+    from aether_amd.evaluate import eval_forward_prediction
+    from aether_amd.nn.seq2seq.aether import Aether
+    from oracle import seq2seq_oracle as S
+    params = {} if norm == "default" else {norm: True}
+    train = SimulatedFieldDataset(24, params, n_balls=5, static_balls=8, ndim=2, length=5000, sample_freq=100)
+    test = SimulatedFieldDataset(6, params, n_balls=5, static_balls=8, ndim=2, length=5000, sample_freq=100,
+                                 particle_seed=3, stats_from=train)
+    assert train.feats.shape == (24, 49, 5, 4) and train.feats.is_cuda and torch.isfinite(train.feats).all()
+    assert torch.equal(train.static_field, test.static_field)                       # the same field for every split
+    back = train.torch_unnormalize(train.feats)
+    assert torch.allclose(back, train._raw, rtol=1e-5, atol=1e-5)
+    if norm in ("default", "same_data_norm", "symmetric_data_norm"):
+        assert float(train.feats.max()) <= 1.0 + 1e-6 and float(train.feats.min()) >= -1.0 - 1e-6
+    item = test[2]
+    assert item["inputs"].shape == (49, 5, 4) and item["edges"].shape == (5, 5) and item["charges"].shape == (5,)
+    H = 128
+    mp = {"num_vars": 5, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H, "encoder_rnn_hidden": 64,
+          "encoder_rnn_type": "lstm", "input_size": 4, "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 64,
+          "prior_num_layers": 3, "prior_hidden_size": 64, "use_3d": False, "pos_representation": "polar", "gpu": True,
+          "decoder_hidden": H, "skip_first": False, "decoder_dropout": 0.0, "gumbel_temp": 0.5}
+    torch.manual_seed(1)
+    model = Aether(mp, device="cuda").eval()
+    g = torch.Generator().manual_seed(2)
+    U = torch.rand(28 + 20, 6 * 20, 2, generator=g)
+    mse, pos_mse, vel_mse = eval_forward_prediction(model, test, 29, 20, batch_size=6,
+                                                    uniform=U.cuda().view(-1, 6, 20, 2))
+    assert mse.shape == (20,) and torch.isfinite(mse).all()
+    assert torch.allclose(mse, 0.5 * (pos_mse + vel_mse), rtol=1e-5)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = S.predict_future(sd, test.feats[:, :29].cpu(), 20, U, 0.5, False, "polar", 3)
+    p, gt = test.torch_unnormalize(want.cuda()), test.torch_unnormalize(test.feats[:, 29:49])
+    want_mse = ((p - gt) ** 2).flatten(2).mean(-1).mean(0)
+    assert ((mse - want_mse).abs() / want_mse).max() <= 1e-4
