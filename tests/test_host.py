@@ -95,3 +95,18 @@ def test_params_struct_layout_matches_header():
     assert names == [n for n, _ in _lib.PARAM_FIELDS]
     n_ptr = sum(3 if "{}" in k else 1 for _, k in _lib.PARAM_FIELDS)
     assert ctypes.sizeof(_lib.AetherParams) == 8 * n_ptr == 8 * 47
+
+
+def test_public_header_is_valid_c99_and_cpp(tmp_path):
+    """include/aether_hip.h is the drop-in boundary: it must compile on its own as C99 (cgo / ctypes-style bindings)
+    and as C++."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "hdr_check.c"
+    src.write_text('#include "%s"\nint main(void) { return (int)sizeof(AetherParams) == 0; }\n'
+                   % os.path.join(REPO, "include", "aether_hip.h"))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "a.o")],
+                   check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")], check=True)
