@@ -101,6 +101,16 @@ def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0):
     }
 
 
+def _seq2seq_traffic(workload):
+    """HBM bytes per launch of the filter GEMM from the committed PMC passes (profiles/traffic.json), or None."""
+    try:
+        import json
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("k_s2s_filter_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def _seq2seq_line(args):
     """One autoregressive step of the seq2seq model (field query -> prior step -> hard Gumbel sample ->
     decoder step; nn/seq2seq/aether.py:175-185) on one GPU, B x N from --batch / --nodes, h = 512.  A
@@ -158,7 +168,8 @@ def _seq2seq_line(args):
                        "graphs_per_gpu": B, "edges_per_gpu": B * E, "hidden": H, "launch": "eager"},
             "roofline": {"bound": "mfma", "kernel": "prior step (k_s2s_filter dominates)", "unit": "TFLOP/s",
                          "achieved": filt_flop / (prior_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "frac": filt_flop / (prior_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": filt_flop / (prior_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": _seq2seq_traffic(f"seq2seq-{D}d-N{N}-B{B}-h{H}"),
                          "avg_launch_us": prior_ms * 1e3,
                          "algorithmic_flop_per_launch": filt_flop,
                          "note": "algorithmic = the filter contraction alone (R h^2 MACs per edge); the time is the "
