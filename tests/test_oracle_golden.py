@@ -327,3 +327,56 @@ def test_seq2seq_encoder_forward_and_eval_loss(name):
     assert scale_rel_err(preds, c["predictions"]) <= 5e-6
     assert abs(float(loss) - float(c["loss"])) <= 1e-5 * abs(float(c["loss"]))
     assert scale_rel_err(nll.reshape(c["nll"].shape), c["nll"]) <= 1e-5 and scale_rel_err(kl.reshape(c["kl"].shape), c["kl"]) <= 1e-5
+
+
+def test_knn_oracle_against_an_independent_formulation():
+    """The loop-based kNN oracle vs a vectorised numpy formulation (argsort of the masked distance matrix) on random
+    scenes with presence masks: two independent statements of the same definition must agree index for index."""
+    from oracle import knn_oracle as K
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        S, N, k = int(rng.integers(1, 5)), int(rng.integers(2, 30)), int(rng.integers(1, 12))
+        x = rng.normal(size=(S, N, 3)).astype(np.float32) * 10
+        m = (rng.random((S, N)) < 0.7).astype(np.float32)
+        send, recv, num = K.knn_edges(x, m, k)
+        ws, wr, base = [], [], 0
+        for s in range(S):
+            idx = np.nonzero(m[s])[0]
+            p = x[s, idx, :2].astype(np.float32)
+            d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1, dtype=np.float32))
+            np.fill_diagonal(d, np.inf)
+            kk = min(k, N - 1, max(len(idx) - 1, 0))
+            order = np.argsort(d, axis=1, kind="stable")[:, :kk]
+            for a in range(len(idx)):
+                for b in order[a]:
+                    ws.append(base + a)
+                    wr.append(base + int(b))
+            base += len(idx)
+        assert np.array_equal(send, np.asarray(ws, dtype=np.int64)) and np.array_equal(recv, np.asarray(wr, dtype=np.int64))
+        assert int(np.sum(num)) == len(ws)
+
+
+def test_simulator_oracles_conserve_what_physics_conserves():
+    """Oracle sanity beyond the fixtures: without capped forces the electrostatic leap-frog conserves energy to the
+    integrator's order; the gravitational kick-drift-kick keeps the total momentum at zero and conserves the softened
+    energy."""
+    from oracle import sim_oracle as SO
+    rng = np.random.default_rng(3)
+    loc0 = rng.normal(size=(4, 2)) * 2.0
+    vel0 = rng.normal(size=(4, 2)) * 0.3
+    q = np.array([1.0, -1.0, 1.0, -1.0])
+    loc, vel, capped = SO.electrostatic_trajectory(loc0, vel0, q, 4, 2000, 100)
+    assert capped == 0
+
+    def energy(x, v):
+        d = np.sqrt(((x[:, None] - x[None]) ** 2).sum(-1))
+        np.fill_diagonal(d, np.inf)
+        return 0.5 * (v ** 2).sum() + 0.5 * (np.outer(q, q) / d).sum()
+    e = np.array([energy(loc[t], vel[t]) for t in range(len(loc))])
+    assert np.abs(e - e[0]).max() <= 2e-3 * max(1.0, np.abs(e[0]))
+    pos0 = rng.normal(size=(6, 3))
+    v0 = rng.normal(size=(6, 3))
+    mass = np.ones((6, 1))
+    v0 -= v0.mean(0)
+    pos, vel, force = SO.gravitational_trajectory(pos0, v0, mass, 6, 2000, 100)
+    assert np.abs((mass * vel[1:]).sum(1)).max() <= 1e-12
