@@ -1033,10 +1033,10 @@ int aether_dynamic_field_backward(const AetherDynFieldParams* p, const AetherDyn
     float* partial = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
     if (num_dims == 2) {
         kb_dynfield<2><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph);
-        k_dynfield_reduce<2><<<dim3((DynOff<2>::total + 255) / 256), dim3(256), 0, st>>>(partial, n_graphs, *grads);
+        k_dynfield_reduce<2><<<dim3((DynOff<2>::total + 31) / 32), dim3(256), 0, st>>>(partial, n_graphs, *grads);
     } else {
         kb_dynfield<3><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph);
-        k_dynfield_reduce<3><<<dim3((DynOff<3>::total + 255) / 256), dim3(256), 0, st>>>(partial, n_graphs, *grads);
+        k_dynfield_reduce<3><<<dim3((DynOff<3>::total + 31) / 32), dim3(256), 0, st>>>(partial, n_graphs, *grads);
     }
     HIP_OK(hipGetLastError());
     return AETHER_OK;

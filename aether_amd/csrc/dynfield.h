@@ -503,15 +503,31 @@ kb_dynfield(AetherDynFieldParams P, const float* __restrict__ x, const float* __
     if (tid < DFH) g[OF::nn_b2 + tid] = dsum[tid] * wsum;
 }
 
-// grads.<tensor>[i] = sum over graphs of partial[graph][offset + i], graphs in order
+// grads.<tensor>[i] = sum over graphs of partial[graph][offset + i].  A thread summing all graphs one after the other
+// is a chain of n_graphs dependent loads (34 us at 128 graphs): eight threads share an element instead, thread group j
+// adds the graphs j, j + 8, ... in order (independent loads, unrolled), and the eight partial sums are combined through
+// LDS in a fixed order -- the same tree for every launch, so the result is reproducible.
 template <int D>
 __global__ void __launch_bounds__(256)
 k_dynfield_reduce(const float* __restrict__ partial, int64_t n_graphs, AetherDynFieldParams G) {
     using OF = DynOff<D>;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= OF::total) return;
+    __shared__ float red[8][32];
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31), j = threadIdx.x >> 5;      // 32 consecutive elements per row read
     float s = 0.0f;
-    for (int64_t k = 0; k < n_graphs; ++k) s += partial[(size_t)k * OF::total + e];
+    if (e < OF::total) {
+        int64_t k = j;
+        for (; k + 24 < n_graphs; k += 32) {
+            const float a0 = partial[(size_t)k * OF::total + e], a1 = partial[(size_t)(k + 8) * OF::total + e];
+            const float a2 = partial[(size_t)(k + 16) * OF::total + e], a3 = partial[(size_t)(k + 24) * OF::total + e];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; k < n_graphs; k += 8) s += partial[(size_t)k * OF::total + e];
+    }
+    red[j][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (e >= OF::total || j != 0) return;
+    s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) +
+        ((red[4][threadIdx.x] + red[5][threadIdx.x]) + (red[6][threadIdx.x] + red[7][threadIdx.x]));   // a fixed tree
     const float* ptrs[27] = {G.gate_w0, G.gate_b0, G.gate_w2, G.gate_b2, G.nn_w0, G.nn_b0, G.nn_w2, G.nn_b2, G.lin1_w, G.lin1_b,
                              G.lin2_w, G.lin2_b, G.lin3_w, G.lin3_b, G.film1_w0, G.film1_b0, G.film1_w2, G.film1_b2, G.film1_w4,
                              G.film1_b4, G.film2_w0, G.film2_b0, G.film2_w2, G.film2_b2, G.film2_w4, G.film2_b4, G.emb};
