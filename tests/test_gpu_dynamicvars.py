@@ -130,3 +130,35 @@ def test_model_vs_oracle_ind_sizes():
                                [[tuple(x.cuda() for x in gi) for gi in graph_info]], burn.cuda(),
                                uniform=[u.cuda() for u in U[:T - 1]])
     assert scale_rel_err(got.cpu(), want) <= 2 * TOL
+
+
+def test_decoder_and_encoder_two_objects():
+    """The smallest scene the reference accepts: two present objects (one edge each way)."""
+    from aether_amd.nn.dynamicvars.encoder import Encoder
+    import sys, os
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_dynamicvars import MODEL_PARAMS
+    params = dict(MODEL_PARAMS)
+    torch.manual_seed(3)
+    dec = Decoder(params, device="cuda").eval()
+    enc = Encoder(params, device="cuda").eval()
+    sdd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    sde = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    N = 5
+    inputs, hidden, field = torch.randn(1, N, 4, generator=g), torch.randn(1, N, 128, generator=g) * 0.2, torch.randn(1, N, 2, generator=g) * 0.2
+    masks = torch.tensor([0., 1., 0., 1., 0.])
+    send, recv = get_knn_graph_info(inputs[0].cuda(), masks.cuda(), 2)
+    e2n = torch.argsort(recv, stable=True).view(-1, 1)
+    edges = torch.softmax(torch.randn(1, 2, 3, generator=g), -1)
+    gi = (send.cpu(), recv.cpu(), e2n.cpu())
+    wp, wh = DO.decoder_step(sdd, inputs, hidden, edges, masks, gi, field, True, "cart")
+    gp, gh = dec(inputs.cuda(), hidden.cuda(), edges.cuda(), masks.cuda(), (send, recv, e2n), field.cuda())
+    assert scale_rel_err(gp.cpu(), wp) <= TOL and scale_rel_err(gh.cpu(), wh) <= TOL
+    node_inds = masks.nonzero()[:, -1]
+    st = (torch.randn(1, N * (N - 1), 64, generator=g) * 0.2, torch.randn(1, N * (N - 1), 64, generator=g) * 0.2)
+    wl, (wh0, wc0) = DO.encoder_single_step(sde, inputs, masks, node_inds, gi, st, field, "cart")
+    gl, (gh0, gc0) = enc.single_step_forward(inputs.cuda(), masks.cuda(), node_inds.cuda(), (send, recv, e2n),
+                                             (st[0].cuda(), st[1].cuda()), field.cuda())
+    assert scale_rel_err(gl.cpu(), wl) <= TOL and scale_rel_err(gh0.cpu(), wh0) <= TOL and scale_rel_err(gc0.cpu(), wc0) <= TOL

@@ -104,3 +104,22 @@ def test_knn_full_size_properties():
     m2.view(-1)[victim] = 0
     s3, r3, _ = knn_edges(x, m2, k=k)
     assert not ((obj_of[1:][s3] == victim).any() or (obj_of[1:][r3] == victim).any())
+
+
+def test_knn_tiny_scenes():
+    """One object slot (k = min(10, 0) = 0: no edges), two slots, and k larger than the number of present objects."""
+    x1 = torch.randn(3, 4, 1, 2, device="cuda")
+    s, r, n = knn_edges(x1, torch.ones(3, 4, 1, device="cuda"))
+    assert s.numel() == 0 and r.numel() == 0 and n.tolist() == [0, 0, 0]
+    x2 = torch.randn(2, 3, 2, 2, device="cuda")
+    m2 = torch.ones(2, 3, 2, device="cuda")
+    m2[1, 2, 0] = 0
+    s, r, n = knn_edges(x2, m2)
+    ws, wr, wn = K.knn_edges(x2.cpu().numpy(), m2.cpu().numpy(), 10)
+    assert np.array_equal(s.cpu().numpy(), ws) and np.array_equal(r.cpu().numpy(), wr) and n.tolist() == wn.tolist()
+    x3 = torch.randn(1, 1, 12, 3, device="cuda")
+    m3 = torch.zeros(1, 1, 12, device="cuda")
+    m3[..., [1, 4, 9]] = 1                                             # 3 present of 12 slots, k = 10
+    s, r, n = knn_edges(x3, m3)
+    ws, wr, wn = K.knn_edges(x3.cpu().numpy(), m3.cpu().numpy(), 10)
+    assert s.numel() == 6 and np.array_equal(s.cpu().numpy(), ws) and np.array_equal(r.cpu().numpy(), wr)
