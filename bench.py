@@ -241,7 +241,16 @@ def main():
     ap.add_argument("--nodes", type=int, default=WORKLOAD["N"])
     ap.add_argument("--seq2seq", action="store_true",
                     help="time the seq2seq model's autoregressive step (SURVEY 8a rows A8-A10) instead: its own JSON line")
+    ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg5shard"], default=None,
+                    help="BASELINE.json configuration: cfg1 2-D N=5 B=1, cfg2 (default) 2-D N=20 B=128, cfg3 3-D N=20 B=128, "
+                         "cfg5shard 2-D N=1024 B=32 (one GPU's share of config 5, streamed path)")
     args = ap.parse_args()
+    if args.config is not None:
+        args.dims, args.nodes, args.batch = {"cfg1": (2, 5, 1), "cfg2": (2, 20, 128), "cfg3": (3, 20, 128),
+                                             "cfg5shard": (2, 1024, 32)}[args.config]
+        if args.config == "cfg5shard":                # 33.5 M edges: a step is 25 ms, the CPU legs would take minutes
+            args.no_cpu_baseline, args.no_train, args.no_rollout = True, True, True
+            args.steps, args.warmup = min(args.steps, 20), min(args.warmup, 3)
     if args.seq2seq:
         return _seq2seq_line(args)
 
