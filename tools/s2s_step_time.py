@@ -60,4 +60,4 @@ def step():
 t_all = timed(step)
 edges = B * E
 print("field %.3f ms | prior step %.3f ms (filter GEMM %.0f GFLOP) | decoder step %.3f ms | whole step %.3f ms = %.2f M edge-steps/s"
-      % (t_field, t_prior, edges * 24 * H * H * 2 / 1e9, t_dec, t_all, edges / t_all / 1e3))
+      % (t_field, t_prior, edges * (24 if D == 2 else 39) * H * H * 2 / 1e9, t_dec, t_all, edges / t_all / 1e3))
