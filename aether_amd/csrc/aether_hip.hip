@@ -207,6 +207,7 @@ constexpr int OUTER_MAX_CHUNKS = 256;      // workgroups (= partials) per task
 // multiplies all of them in one launch at the end (12 more [E, 64] buffers: 3 KiB per edge).
 int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defer_max_edges", n)
 int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
+int g_linear_kwaves = 4;                        // aether_set_option("linear_kwaves", 1 | 4): waves of a workgroup that split a small layer's k-groups
 int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the filter GEMM
 
 
@@ -630,6 +631,11 @@ int aether_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "linear_small_wgs")) {
         g_linear_small_wgs = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "linear_kwaves")) {
+        if (value != 1 && value != 4) return fail(AETHER_EINVAL, "set_option: linear_kwaves must be 1 or 4");
+        g_linear_kwaves = value;
         return AETHER_OK;
     }
     if (!strcmp(name, "filter_wg_target")) {        // changes the seq2seq / variable-N prior and decoder workspace sizes

@@ -39,7 +39,10 @@ k_s2s_rff(const float* __restrict__ x, int x_stride, const float* __restrict__ B
 // Epilogue: v = act([FiLM per graph](acc + b)) [affine per channel] [* scale[n * sstride]] [+ Y]
 // (ACT: 0 none, 1 SiLU, 2 ReLU, 3 tanh, 4 ELU).
 // Optional row lists gather X rows / scatter Y rows (edges of one type, compacted on the device).
-template <int ACT, int MT, int NT, int PF = 2>
+// KW = 4 (few rows: the loop of K / 16 dependent k-steps is the whole run time): the four waves share ONE
+// 16 MT x 16 NT block, wave w takes the k-groups w, w + 4, ...; the partial blocks meet in LDS and wave 0 adds
+// them in wave order (deterministic) before the epilogue.  grid = (ceil(N / (16 NT)), ceil(M / (16 MT))).
+template <int ACT, int MT, int NT, int PF = 2, int KW = 1>
 __global__ void __launch_bounds__(256)
 k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ X,
              float* __restrict__ Y, int M, int K, int ldw, int64_t N, int ldy,
@@ -55,9 +58,9 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
     if (n_dev != nullptr) N = *n_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int m0 = (int)blockIdx.y * (32 * MT) + 16 * MT * (wave >> 1);
-    const int64_t n0 = (int64_t)blockIdx.x * (32 * NT) + 16 * NT * (wave & 1);
-    if (m0 >= M || n0 >= N) return;
+    const int m0 = KW == 1 ? (int)blockIdx.y * (32 * MT) + 16 * MT * (wave >> 1) : (int)blockIdx.y * (16 * MT);
+    const int64_t n0 = KW == 1 ? (int64_t)blockIdx.x * (32 * NT) + 16 * NT * (wave & 1) : (int64_t)blockIdx.x * (16 * NT);
+    if (m0 >= M || n0 >= N) return;                    // the same for every wave of the workgroup when KW > 1
     // rows / points past the end are clamped for the loads and masked at the store
     const float* wrow[MT];
     const float* xrow[NT];
@@ -80,16 +83,18 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * mb + 4 * q + r;
-            b4[r] = (bias != nullptr && m < M) ? bias[m] : 0.0f;
+            b4[r] = (bias != nullptr && m < M && (KW == 1 || wave == 0)) ? bias[m] : 0.0f;
         }
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = b4;
     }
-    const int steps = K >> 4;
+    // this wave's k-groups: kg(a) for a < steps (the host launches KW > 1 only with K / 16 >= KW)
+    const int steps = KW == 1 ? K >> 4 : ((K >> 4) - wave + KW - 1) / KW;
+    auto kg = [&](int a) { return KW == 1 ? a : wave + KW * a; };
     f32x4 wq[PF][MT], xq[PF][NT];                      // ring of prefetched fragments
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-        const int a = p < steps ? p : steps - 1;
+        const int a = kg(p < steps ? p : steps - 1);
 #pragma unroll
         for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * a);
 #pragma unroll
@@ -104,7 +109,7 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
                 for (int t = 0; t < MT; ++t) wv[t] = wq[p][t];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xv[t] = xq[p][t];
-                const int an = a0 + p + PF < steps ? a0 + p + PF : steps - 1;
+                const int an = kg(a0 + p + PF < steps ? a0 + p + PF : steps - 1);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * an);
 #pragma unroll
@@ -117,6 +122,23 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
                         for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = mfma16(wv[mb][b], xv[nb][b], acc[mb][nb]);
             }
         }
+    }
+    if constexpr (KW > 1) {
+        __shared__ f32x4 red[KW - 1][MT * NT][64];
+        if (wave != 0) {
+#pragma unroll
+            for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) red[wave - 1][mb * NT + nb][lane] = acc[mb][nb];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 0; w < KW - 1; ++w)
+#pragma unroll
+            for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) acc[mb][nb] += red[w][mb * NT + nb][lane];
     }
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) {

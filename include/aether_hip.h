@@ -566,7 +566,8 @@ int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_
  * 16 ways, until it launches at least n workgroups; default 768, measured best at 2,560 edges; changes the prior /
  * decoder workspace sizes), "linear_small_wgs" n (dense layers of the seq2seq / variable-N steps whose 64 x 32-per-wave
  * tiling would launch fewer than n workgroups use 16 x 32 blocks per wave instead: four times the waves for the
- * 5-object graphs; default 128).
+ * 5-object graphs; default 128), "linear_kwaves" 1|4 (when even those blocks are few, the four waves of a workgroup
+ * share one block and split its k-groups, partial sums added in wave order; default 4, 1 turns it off).
  */
 int aether_set_option(const char* name, int value);
 

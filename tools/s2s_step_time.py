@@ -15,11 +15,15 @@ ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--decoder-hidden", type=int, default=512)
 ap.add_argument("--filter-wg-target", type=int, default=0)
 ap.add_argument("--linear-small-wgs", type=int, default=-1)
+ap.add_argument("--linear-kwaves", type=int, default=0)
 a = ap.parse_args()
 D, N, B, H, R = a.dims, a.nodes, a.batch, 512, 128
 if a.linear_small_wgs >= 0:
     from aether_amd import _lib
     _lib.load().aether_set_option(b"linear_small_wgs", a.linear_small_wgs)
+if a.linear_kwaves:
+    from aether_amd import _lib
+    _lib.load().aether_set_option(b"linear_kwaves", a.linear_kwaves)
 if a.filter_wg_target:
     from aether_amd import _lib
     _lib.load().aether_set_option(b"filter_wg_target", a.filter_wg_target)
