@@ -735,11 +735,15 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                         st4(psb + (off + 16 * tn4 + i) * LDW + 16 * mb3 + 4 * q, accs);
                         float* gps = dbg.ps[layer - 1] + (int64_t)(nb + 16 * tn4 + i) * H + 16 * mb3 + 4 * q;
                         if (wg.partner >= 0) {       // write-through (sc1) payload: no release fence needed
-                            typedef unsigned long long u64;
-                            const u64 lo = ((u64)__float_as_uint(accs[1]) << 32) | __float_as_uint(accs[0]);
-                            const u64 hi = ((u64)__float_as_uint(accs[3]) << 32) | __float_as_uint(accs[2]);
-                            __hip_atomic_store((u64*)gps, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store((u64*)gps + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            // ONE 16-byte sc1 store per lane (aux 16): an 8-byte sc1 store is a fabric write of its
+                            // own, 2.7 x the time per byte (MI355X_MICROARCH.md, visibility price list)
+                            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                                dbg.ps[layer - 1] + (int64_t)nb * H, 0, n * H * 4, 0x00020000);
+                            u32x4 bits;
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) bits[r4] = __float_as_uint(accs[r4]);
+                            __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, ((16 * tn4 + i) * H + 16 * mb3 + 4 * q) * 4, 0, 16);
                         } else if (keep) {
                             st4(gps, accs);
                         }
