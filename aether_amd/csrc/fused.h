@@ -552,8 +552,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         };
         auto receive_partner_rows = [&]() {
             // second half of the hand-off (first half: end of the previous node phase): one lane polls the
-            // partner's flag (bounded), then every wave reads its share of the partner's rows with sc1
-            // (L1-bypassing) 8-byte loads -- the only loads of those bytes in this launch.
+            // partner's flag (bounded), then the waves read the partner's rows with sc1
+            // (L1-bypassing) 16-byte buffer loads -- the only loads of those bytes in this launch.
             if (tid == 0) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(dbg.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < layer - 1) {
@@ -564,15 +564,17 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
             lds_barrier();
             const int np = nv - n;                              // partner rows = visible slots outside [off, off + n)
-            for (int idx = tid; idx < np * 32; idx += THREADS) {
-                typedef unsigned long long u64;
-                int slot = idx >> 5;
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dbg.ps[layer - 2] + (int64_t)vb * H, 0, nv * H * 4, 0x00020000);
+            for (int idx = tid; idx < np * 16; idx += THREADS) {
+                int slot = idx >> 4;
                 if (slot >= off) slot += n;
-                const int c = (idx & 31) * 2;
-                const u64 v = __hip_atomic_load((const u64*)(dbg.ps[layer - 2] + (int64_t)(vb + slot) * H + c),
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                psb[slot * LDW + c] = __uint_as_float((unsigned)v);
-                psb[slot * LDW + c + 1] = __uint_as_float((unsigned)(v >> 32));
+                const int c = (idx & 15) * 4;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (slot * H + c) * 4, 0, 16);   // aux 16 = sc1
+                f32x4 f;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) f[r4] = __uint_as_float(v[r4]);
+                st4(psb + slot * LDW + c, f);
             }
             lds_barrier();
         };
