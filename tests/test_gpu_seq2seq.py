@@ -49,6 +49,32 @@ def test_field_query_fresh_inputs_and_ragged_sizes(D):
         m(torch.zeros(3, 2 * D))                      # CPU tensor: no fallback
 
 
+@pytest.mark.parametrize("hidden", [128, 512])
+def test_small_dense_layers_split_k_groups_over_waves(hidden):
+    """Few rows x K >= 128: the four waves of a workgroup share one block and split its k-groups
+    (`linear_kwaves`).  Both settings against the oracle, the default one bit-reproducible."""
+    from aether_amd import _lib
+    D = 3
+    torch.manual_seed(11)
+    m = FieldQuery(D, hidden, 1.0, device="cuda")
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(6)
+    try:
+        for shape in [(1, 2 * D), (63, 2 * D), (128, 5, 2 * D), (1000, 2 * D)]:
+            x = torch.randn(*shape, generator=g) * 2.0
+            want = S.predict_field(sd, x, D)
+            got = {}
+            for kw in (1, 4):
+                _lib.check(lib.aether_set_option(b"linear_kwaves", kw), "set_option")
+                got[kw] = m(x.cuda())[0].cpu()
+                assert scale_rel_err(got[kw], want) <= TOL, (shape, kw)
+            assert torch.equal(m(x.cuda())[0].cpu(), got[4]), shape          # fixed summation order
+        assert lib.aether_set_option(b"linear_kwaves", 3) != 0               # only 1 or 4
+    finally:
+        lib.aether_set_option(b"linear_kwaves", 4)
+
+
 @pytest.mark.parametrize("rep", ["polar", "cart"])
 @pytest.mark.parametrize("D", [2, 3])
 def test_augmented_localizer_matches_reference(D, rep):
