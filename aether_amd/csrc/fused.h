@@ -764,7 +764,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             }
             // First half of the hand-off of the own P_s rows to the partner workgroup
             // (cdna_hip_programming.md Guideline 16, form R1 with write-through payload): every byte of
-            // the payload was stored sc1 (8-byte agent-scope stores above); every wave drains its stores
+            // the payload was stored sc1 (16-byte buffer stores above); every wave drains its stores
             // before the barrier, then one lane raises the flag.  The partner picks the rows up after
             // the first GEMM of its next edge phase (receive_partner_rows), as this workgroup does with
             // the partner's: the flag's flight time hides behind those 64 MFMAs.
