@@ -47,7 +47,101 @@ def _dist_env():
     return rank, world, local
 
 
-def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0):
+def _rollout_parity(sd, inp, model, dev, T=20):
+    """20-step rollout (SURVEY.md 8d metric 2 protocol) of the HIP path and of the fp32 oracle, both against
+    the oracle in fp64, on `inp` with the weights `sd` (loaded into `model`).  A graph is *cut-exposed* when the
+    fp64 trajectory passes within 2e-5 rad of a branch cut of the reference's own feature map (oracle
+    cut_margin: anti-parallel headings / sender exactly behind the receiver): the step is discontinuous there
+    and an fp32 evaluation's side is decided by its last bit, so errors are quoted with and without them."""
+    from oracle import aether_oracle as O
+    from aether_amd.rollout import rollout
+    N = inp["meta"]["N"]
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        t64, margins = O.rollout(sd64, inp["x"].double(), inp["vel"].double(), inp["edges"], inp["charges"].double(), T,
+                                 with_margin=True)
+        t32 = O.rollout(sd, inp["x"], inp["vel"], inp["edges"], inp["charges"], T)
+        got = rollout(model, inp["x"].to(dev), inp["vel"].to(dev), [e.to(dev) for e in inp["edges"]],
+                      inp["charges"].to(dev), T).cpu()
+    recv = inp["edges"][1]
+    exposed = sorted({int(recv[e]) // N for t in range(T) for e in torch.nonzero(margins[t] < 2e-5).flatten().tolist()})
+    clean = torch.ones(t64.shape[1], dtype=torch.bool)
+    for g in exposed:
+        clean[g * N:(g + 1) * N] = False
+    scale = float(t64.abs().max())
+    rel = lambda a, m=None: float(((a.double() - t64).abs() if m is None else (a.double() - t64).abs()[:, m]).max()) / scale
+    mse = lambda a: float(((a.double() - t64) ** 2).mean())
+    return {"steps": T, "hip_vs_fp64_max_rel_err": rel(got), "oracle_fp32_vs_fp64_max_rel_err": rel(t32),
+            "hip_vs_oracle_fp32_max_rel_err": float((got - t32).abs().max()) / scale,
+            "cut_exposed_graphs": exposed, "n_graphs": int(t64.shape[1] // N),
+            "hip_vs_fp64_max_rel_err_outside_exposed": rel(got, clean),
+            "oracle_fp32_vs_fp64_max_rel_err_outside_exposed": rel(t32, clean),
+            "hip_vs_fp64_mse": mse(got), "oracle_fp32_vs_fp64_mse": mse(t32), "tolerance": 1e-5}
+
+
+def _mse_vs_simulated_truth(sd, model, dev, B, N, D, burn_in=29, pred=20):
+    """Metric 2 as experiments/electrostatic/evaluate.py:33-70 runs it, for the state2state module:
+    trajectories from the build's own electrostatic simulator (aether_sim_electrostatic: N charged balls + 20 static
+    field charges in a +-5 box, 5,000 leap-frog steps sampled every 100 -> 49 frames); the model sees frame
+    `burn_in - 1` (velocity = the last frame difference, dt = one frame) and predicts `pred` frames; per-step MSE
+    over (sample, particle, feature) on un-normalised values, HIP rollout and fp64 oracle side by side."""
+    from oracle import aether_oracle as O
+    from aether_amd.edges import get_edges
+    from aether_amd.rollout import rollout
+    from aether_amd.sim import ElectrostaticFieldSim
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = ElectrostaticFieldSim(n_balls=N, loc_std=(N / 5.0) ** (1.0 / 3.0), dim=D, static_balls=20, device=dev)
+        loc, vel, _, charges = sim.sample_trajectories(B, T=5000, sample_freq=100, as_tensor=True)
+    loc = loc[:, :, :N].float()                                  # [B, 49, N, D] moving balls only
+    q = charges[:, :N].float().reshape(B * N, 1)
+    x0 = loc[:, burn_in - 1].reshape(B * N, D).contiguous()
+    v0 = (loc[:, burn_in - 1] - loc[:, burn_in - 2]).reshape(B * N, D).contiguous()
+    truth = loc[:, burn_in:burn_in + pred].permute(1, 0, 2, 3).reshape(pred, B * N, D).cpu()
+    edges = get_edges(B, N)
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    with torch.no_grad():
+        got = rollout(model, x0, v0, [e.to(dev) for e in edges], q, pred).cpu()
+        sd64 = {k: v.double() for k, v in sd.items()}
+        want = O.rollout(sd64, x0.cpu().double(), v0.cpu().double(), edges, q.cpu().double(), pred)
+    m_hip = ((got.double() - truth.double()) ** 2).mean(dim=(1, 2))
+    m_ora = ((want - truth.double()) ** 2).mean(dim=(1, 2))
+    pick = [0, 9, pred - 1]
+    return {"protocol": f"burn-in {burn_in} frames, predict {pred}; electrostatic simulator, {B} x {N} balls + 20 static charges",
+            "mse_hip_steps_1_10_20": [float(m_hip[k]) for k in pick],
+            "mse_oracle_fp64_steps_1_10_20": [float(m_ora[k]) for k in pick],
+            "max_rel_mse_difference_over_steps": float(((m_hip - m_ora).abs() / m_ora).max()), "tolerance": 1e-5,
+            "trajectory_max_rel_err": float((got.double() - want).abs().max() / want.abs().max())}
+
+
+def _parity(sd, inp, model, dev, sd_trained=None):
+    """The oracle as the checker of the HIP path on the benchmark batch: one step, the 20-step rollout against
+    fp64 (HIP and the fp32 oracle side by side), and metric 2 against simulated ground truth -- all with the
+    stated seed-1 weights; the rollout again with the weights the training section left (`sd_trained`)."""
+    from oracle import aether_oracle as O
+    args = (sd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    with torch.no_grad():
+        want = O.aether_forward(*args)
+        w64 = O.aether_forward({k: v.double() for k, v in sd.items()}, *[a.double() if torch.is_tensor(a) and a.is_floating_point() else a
+                                                                       for a in args[1:]])
+        got = model(inp["h"].to(dev), inp["x"].to(dev), [e.to(dev) for e in inp["edges"]], inp["vel"].to(dev),
+                    inp["edge_attr"].to(dev), inp["charges"].to(dev)).cpu()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.abs().max())
+    B, N, D = inp["meta"]["B"], inp["meta"]["N"], inp["meta"]["D"]
+    out = {"weights": "torch.manual_seed(1) default init (the runner's seed, main.py:28)",
+           "step_max_rel_err": rel(got, want), "step_hip_vs_fp64": rel(got, w64), "step_oracle_fp32_vs_fp64": rel(want, w64),
+           "step_tolerance": 1e-5,
+           "rollout20": _rollout_parity(sd, inp, model, dev),
+           "rollout20_mse_vs_simulated_truth": _mse_vs_simulated_truth(sd, model, dev, B, N, D),
+           "checker": "oracle/aether_oracle.py (pinned to the reference's golden vectors)"}
+    if sd_trained is not None:
+        out["rollout20_after_training"] = _rollout_parity(sd_trained, inp, model, dev)
+    return out
+
+
+def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0, sd_trained=None):
     """Oracle forward on the host cores; bounded sample of the same workload.  With `model`, the
     oracle also serves as the checker of the HIP path on this very batch (one step and the 20-step
     rollout of SURVEY.md 8d, scale-relative max error: the 1e-5 bar of the north star)."""
@@ -72,31 +166,52 @@ def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0):
             if el > budget_s or n >= 400:
                 break
     E = inp["edges"][0].numel()
+    # ---- the same forward on ONE thread (SURVEY.md 8d asks for both), bounded
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        O.aether_forward(*args)
+        t1 = time.perf_counter()
+        n1 = 0
+        while True:
+            O.aether_forward(*args)
+            n1 += 1
+            el1 = time.perf_counter() - t1
+            if el1 > budget_s / 3 or n1 >= 50:
+                break
+    torch.set_num_threads(cores)
+    # ---- forward + backward + AdamW on the host cores (what the runner's training loop does per batch,
+    # experiments/lorentz/main.py:289-292), torch autograd through the oracle, bounded
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(psd.values()), lr=5e-4, weight_decay=1e-12)
+    tgt = inp["target"]
+
+    def cpu_train_step():
+        opt.zero_grad(set_to_none=True)
+        o = O.aether_forward(psd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+        torch.nn.functional.mse_loss(o, tgt).backward()
+        opt.step()
+    cpu_train_step()
+    t2 = time.perf_counter()
+    n2 = 0
+    while True:
+        cpu_train_step()
+        n2 += 1
+        el2 = time.perf_counter() - t2
+        if el2 > budget_s / 2 or n2 >= 50:
+            break
     parity = None
     if model is not None:
-        from aether_amd.rollout import rollout
-        with torch.no_grad():
-            want = O.aether_forward(*args)
-            d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items() if k != "edges"}
-            edges_d = [e.to(dev) for e in inp["edges"]]
-            got = model(d["h"], d["x"], edges_d, d["vel"], d["edge_attr"], d["charges"]).cpu()
-            traj_w = O.rollout(sd, inp["x"], inp["vel"], inp["edges"], inp["charges"], 20)
-            traj_g = rollout(model, d["x"], d["vel"], edges_d, d["charges"], 20).cpu()
-        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-        mse = float(((traj_g - traj_w) ** 2).mean())
-        parity = {"step_max_rel_err": rel(got, want), "step_tolerance": 1e-5,
-                  "rollout20_mse_between_paths": mse,
-                  "rollout20_rel_mse": mse / float((traj_w ** 2).mean()),
-                  "rollout20_max_rel_err": rel(traj_g, traj_w),
-                  "note": "single step: the 1e-5 bar; rollout: fp32 round-off of step 1 fed back through 20 "
-                          "autoregressive steps of a random-init model (the MSE between the two paths is the "
-                          "quantity SURVEY 8d bounds by 1e-5)",
-                  "checker": "oracle/aether_oracle.py (pinned to the reference's golden vectors)"}
+        parity = _parity(sd, inp, model, dev, sd_trained)
+    B, N, D = inp["meta"]["B"], inp["meta"]["N"], inp["meta"]["D"]
     return {
         "value": 4.0 * E * n / el, "unit": "edge-messages/s", "cores": cores, "kind": "port",
         "ms_per_step": 1e3 * el / n,
-        "sample": f"{n} forward steps of the same B=128 N=20 D=2 batch in {el:.1f} s, "
-                  f"torch CPU fp32, {cores} threads",
+        "sample": f"{n} forward steps of the same B={B} N={N} D={D} batch in {el:.1f} s, "
+                  f"torch CPU fp32, {cores} threads, seed-1 weights",
+        "one_thread": {"value": 4.0 * E * n1 / el1, "ms_per_step": 1e3 * el1 / n1, "cores": 1,
+                       "sample": f"{n1} forward steps in {el1:.1f} s"},
+        "train_step": {"value": 4.0 * E * n2 / el2, "ms_per_step": 1e3 * el2 / n2, "cores": cores,
+                       "sample": f"{n2} steps of forward + autograd backward + AdamW in {el2:.1f} s"},
         "parity": parity,
     }
 
@@ -280,6 +395,7 @@ def main():
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         model = Aether(2 * D, 64, 0.0, D, device=dev)
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}     # the stated seed-1 weights
     if args.streamed:
         model.flags = _lib.FLAG_FORCE_STREAMED
     for kv in args.opt:
@@ -539,8 +655,8 @@ def main():
             "roofline": roof, "kernels": kernels, "rollout": roll, "train": train,
         }
         if world == 1 and not args.no_cpu_baseline:
-            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            line["cpu_baseline"] = _cpu_baseline(sd, host, model, dev)
+            sd_tr = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if train is not None else None
+            line["cpu_baseline"] = _cpu_baseline(sd0, host, model, dev, sd_trained=sd_tr)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         else:
             line["cpu_baseline"] = None

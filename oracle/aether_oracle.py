@@ -230,17 +230,42 @@ def dynamic_field_aether_forward(sd, x, vel, edges, edge_attr_orig, charges, num
                           field=dynamic_field(sd, x, vel, charges, num_nodes))
 
 
-def rollout(sd, x, vel, edges, charges, steps, dt=1.0):
+def cut_margin(edge_attr_local, D):
+    """Distance (radians) of every edge's local-frame features from the branch cuts of the reference's own
+    feature map: the relative-orientation angles atan2(.)/pi of euler_from_matrix (geometry.py:87-100) jump
+    from +1 to -1 when sender and receiver headings are anti-parallel, and the un-normalised bearing
+    atan2(r_y, r_x) (aether.py:72-75, symmetric theta) jumps by 2 pi when the sender sits exactly behind the
+    receiver.  Two evaluations whose states differ by less than this margin's worth can land on different
+    sides; the step is discontinuous there, in the reference as much as anywhere else."""
+    a = edge_attr_local
+    if D == 2:
+        m = torch.minimum((1.0 - a[:, 2].abs()) * math.pi, math.pi - a[:, 4].abs())
+    else:
+        m = torch.minimum((1.0 - a[:, 3].abs()) * math.pi, (1.0 - a[:, 5].abs()) * math.pi)
+        m = torch.minimum(m, math.pi - a[:, 7].abs())
+    return m
+
+
+def rollout(sd, x, vel, edges, charges, steps, dt=1.0, with_margin=False):
     """SURVEY.md 8(d) metric 2 for the state2state module:
-    x_{t+1} = Aether(x_t, v_t); v_{t+1} = (x_{t+1} - x_t) / dt."""
+    x_{t+1} = Aether(x_t, v_t); v_{t+1} = (x_{t+1} - x_t) / dt.
+    ``with_margin``: also returns ``[steps, E]`` -- every edge's distance from a branch cut (``cut_margin``)."""
     rows, cols = edges
     qprod = charges[rows] * charges[cols]
-    traj = []
+    traj, margins = [], []
+    D = x.shape[-1]
     for _ in range(steps):
         dist = torch.sqrt(torch.sum((x[rows] - x[cols]) ** 2, 1)).unsqueeze(1)
         ea = torch.cat([qprod, dist], 1)
-        xn = aether_forward(sd, x, vel, edges, ea, charges)
+        if with_margin:
+            r = aether_forward(sd, x, vel, edges, ea, charges, return_all=True)
+            xn = r["out"]
+            margins.append(cut_margin(r["edge_attr_local"], D))
+        else:
+            xn = aether_forward(sd, x, vel, edges, ea, charges)
         vel = (xn - x) / dt
         x = xn
         traj.append(x)
+    if with_margin:
+        return torch.stack(traj), torch.stack(margins)
     return torch.stack(traj)

@@ -43,6 +43,69 @@ def test_rollout_20_steps_matches_reference(D, flags):
     assert float(((a - b).abs() / b).max()) <= 1e-5
 
 
+def _cut_exposed_graphs(margins, N, width):
+    """Graphs in which some edge comes within `width` radians of a branch cut of the reference's feature map
+    (oracle cut_margin) at some step: from that step on, two evaluations that agree to ~width may legitimately
+    sit on different sides of the discontinuity."""
+    recv = get_edges(margins.shape[1] // (N * (N - 1)), N)[1]
+    first = {}
+    for t in range(margins.shape[0]):
+        for e in torch.nonzero(margins[t] < width).flatten().tolist():
+            first.setdefault(int(recv[e]) // N, t)
+    return first
+
+
+@pytest.mark.parametrize("trained", [False, True])
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_FORCE_STREAMED])
+def test_headline_rollout_20_steps_vs_fp64_oracle(flags, trained):
+    """BASELINE.json's headline shape (2-D, N=20, B=128), 20 steps, against the oracle in fp64 -- with the
+    seed-1 weights and with the weights bench.py holds when it checks parity (60 AdamW steps on the batch).
+    Bound: 1e-5 scale-relative on every node, except in graphs where the fp64 trajectory itself passes within
+    2e-5 rad of a branch cut of the feature map (anti-parallel headings: relative orientation +1 <-> -1,
+    geometry.py:87-100; sender exactly behind the receiver: bearing +pi <-> -pi, aether.py:72-75): there the
+    step is discontinuous and which side an fp32 evaluation takes is decided by its last bit.  DESIGN.md 5.1:
+    that is what the 7.7e-5 of BENCH_r01 was -- the ORACLE's fp32 trajectory crossing such a cut at step 15
+    (graph 50, edge 1004 -> 1006), not the HIP path, which stays within 2.1e-6 of fp64.  The fp32 oracle is
+    held to the same rule here, so the exemption is shown to be a property of the map, not of the kernels."""
+    B, N, D, T = 128, 20, 2, 20
+    torch.manual_seed(1)
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    m.flags = flags
+    host = make_batch(B, N, D, seed=0)
+    inp = {k: v.cuda() for k, v in host.items() if torch.is_tensor(v)}
+    edges_d = [e.cuda() for e in host["edges"]]
+    if trained:
+        opt = torch.optim.AdamW(m.parameters(), lr=5e-4, weight_decay=1e-12)
+        for _ in range(60):
+            opt.zero_grad(set_to_none=True)
+            o = m(inp["h"], inp["x"], edges_d, inp["vel"], inp["edge_attr"], inp["charges"])
+            torch.nn.functional.mse_loss(o, inp["target"]).backward()
+            opt.step()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        t64, margins = O.rollout(sd64, host["x"].double(), host["vel"].double(), host["edges"],
+                                 host["charges"].double(), T, with_margin=True)
+        t32 = O.rollout(sd, host["x"], host["vel"], host["edges"], host["charges"], T)
+        got = rollout(m, inp["x"], inp["vel"], edges_d, inp["charges"], T).cpu()
+    # width: the fp32 paths drift up to ~3e-5 (positions) / ~5e-6 rad (headings) from fp64 over 20 steps
+    exposed = _cut_exposed_graphs(margins, N, 2e-5)
+    assert len(exposed) <= B // 5, exposed              # ~1e6 edge-steps x 2 cuts x 2e-5/pi: about a dozen graphs
+    scale = float(t64.abs().max())
+    for name, tr in (("hip", got), ("oracle_fp32", t32)):
+        err = (tr.double() - t64).abs().amax(dim=2)      # [T, Nn]
+        bad = torch.nonzero(err > TOL * scale)
+        for t, nd in bad.tolist():
+            g = nd // N
+            assert g in exposed and t >= exposed[g], (name, t, nd, float(err[t, nd]) / scale, exposed)
+        clean = torch.ones(B * N, dtype=torch.bool)
+        for g in exposed:
+            clean[g * N:(g + 1) * N] = False
+        assert float(err[:, clean].max()) <= TOL * scale, (name, float(err[:, clean].max()) / scale)
+    if not exposed:
+        assert scale_rel_err(got, t64.float()) <= TOL
+
+
 @pytest.mark.parametrize("flags", [0, _lib.FLAG_FORCE_STREAMED])
 @pytest.mark.parametrize("D", [2, 3])
 def test_device_rollout_equals_loop_of_module_calls(D, flags):
