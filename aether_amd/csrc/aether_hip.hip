@@ -31,6 +31,7 @@
 #include "streamed.h"
 #include "fused.h"
 #include "backward.h"
+#include "fused_bwd.h"
 #include "seq2seq.h"
 #include "dynfield.h"
 #include "s2s_dynfield.h"
@@ -63,10 +64,11 @@ int fail(int code, const char* msg) {
 // Optional (aether_profile_enable): brackets every launch with a pair of events on the
 // launch stream so bench.py can report the dominant kernel's average duration.
 enum KernelId { K_NODE_PREP = 0, K_EDGE_L1, K_NODE_UPDATE, K_EDGE_LN, K_NODE_LAST, K_FUSED, KB_OUT, KB_NODE,
-                KB_EDGE, KB_GATHER, KB_FIELD, KB_OUTER, K_SEGMEAN, K_COUNT };
+                KB_EDGE, KB_GATHER, KB_FIELD, KB_OUTER, K_SEGMEAN, KB_FUSED, KB_FBRED, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_node_prep", "k_edge_layer1", "k_node_update", "k_edge_layer",
                                            "k_node_update_last", "k_fused", "kb_out", "kb_node", "kb_edge",
-                                           "kb_gather", "kb_field", "k_outer+reduce", "k_segment_mean"};
+                                           "kb_gather", "kb_field", "k_outer+reduce", "k_segment_mean", "k_fused_bwd",
+                                           "k_fb_reduce"};
 struct ProfSlot { hipEvent_t a, b; int id; };
 constexpr int PROF_SLOTS = 8192;
 ProfSlot g_prof[PROF_SLOTS];
@@ -99,6 +101,33 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes) {
     for (const auto& d : done) if (d.first == kernel && d.second == dev) return AETHER_OK;
     HIP_OK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     done.emplace_back(kernel, dev);
+    return AETHER_OK;
+}
+
+// A kernel that gives up a bounded wait (the split-mode hand-off, fused.h) cannot return a status: it sets a
+// word in host-mapped memory instead.  Every entry point that launches looks at it first, so a timeout turns
+// into an AETHER_EHIP return of the NEXT call (aether_check_async_error asks explicitly after a sync).
+int* g_async_host = nullptr;
+int* g_async_dev = nullptr;
+int* async_error_word() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return;
+        memset(h, 0, 64);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return; }
+        g_async_host = (int*)h;
+        g_async_dev = (int*)d;
+    });
+    return g_async_dev;
+}
+int take_async_error() {
+    if (g_async_host && *(volatile int*)g_async_host) {
+        *(volatile int*)g_async_host = 0;
+        return fail(AETHER_EHIP, "an earlier launch gave up waiting for its partner workgroup (split-mode hand-off): "
+                                 "the results of that launch are invalid");
+    }
     return AETHER_OK;
 }
 
@@ -165,8 +194,8 @@ constexpr int64_t FUSED_TABLE_MAX_EDGES = 4 << 20;
 int g_fused_split = 1;        // aether_set_option("fused_split", 0|1): two workgroups per group when CUs are idle
 
 struct GraphLayout {
-    size_t perm, send_s, recv_s, rowptr, gsel, wgdesc, tdesc, tsel, tdst, sperm, srowptr, keys, vals, diff, cross,
-        flag, cub, total, cub_bytes;
+    size_t perm, send_s, recv_s, rowptr, gsel, wgdesc, tdesc, tsel, tdst, lorder, nrange, hflags, sperm, srowptr, keys,
+        vals, diff, cross, flag, cub, total, cub_bytes;
     int64_t max_wgs, max_tiles;
     GraphLayout(int64_t E, int64_t Nn, bool with_sort_scratch = true) {
         size_t off = 0;
@@ -183,6 +212,9 @@ struct GraphLayout {
         tdesc = take((size_t)max_tiles * sizeof(FusedTile) + 4);
         tsel = take((size_t)max_tiles * 64 * 4 + 4);
         tdst = take((size_t)max_tiles * 64 * 4 + 4);
+        lorder = take(tables ? e4 : 4);         // local edge order of every fused workgroup (FusedWG)
+        nrange = take(tables ? (size_t)Nn * 16 : 4);                 // per node: local index ranges of its two runs
+        hflags = take((size_t)(2 * max_wgs + 64) * 4);               // split-mode hand-off flags: forward | backward
         sperm = take(e4);                       // receiver-sorted positions grouped by sender (stable)
         srowptr = take((size_t)(Nn + 1) * 4);
         keys = take(e4); vals = take(e4);
@@ -221,6 +253,8 @@ struct WsLayout {
     // multiplied in ONE launch at the end of the backward); otherwise the layers share one set.
     size_t DXl[5], Ul[4], DPUl[4], Gl[4], H1l[4], DP2l[4], DPSl[4], DPRl[4];
     size_t wt, DN, O1, O2, DPO1, DPO2, DY, DE, DA, RELF, Z, H1f, H2f, DPH1, DPH2, DF, DZE, ONEHOT, partial;
+    size_t fpart, xchg;             // fused backward: per-workgroup weight-gradient partials, split-mode dP_s exchange
+    size_t fpart_wgs, xchg_wgs;     // workgroups they are sized for
     bool defer;
     size_t partial_cap;             // partials (OUTER_PART floats each)
     size_t total;
@@ -268,6 +302,12 @@ struct WsLayout {
             partial_cap = 9 * chunks_of(ee) + 48 * chunks_of(nn);     // 64 x 64 pieces
             partial = take(partial_cap * OUTER_PART);
         }
+        // fused backward (fused_bwd.h): one partial per workgroup and layer; a workgroup owns >= 1 node, split
+        // graphs have at most one workgroup per CU (<= 512 covers every CU count this library will see)
+        fpart_wgs = 2 * nn < (size_t)FB_MAX_WGS ? 2 * nn : (size_t)FB_MAX_WGS;
+        fpart = take(fpart_wgs * 4 * FB_PART);
+        xchg_wgs = 2 * nn < 512 ? 2 * nn : 512;
+        xchg = take(xchg_wgs * 3 * 4 * FUSED_MAX_NODES * H);
         total = training ? off : fwd_total;
     }
 };
@@ -279,13 +319,14 @@ template <int D, int NW, int ROUNDS, bool KEEP>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
                  const float* ea, const int32_t* perm, const int32_t* send_s, const int32_t* recv_s,
                  const int32_t* rowptr, const FusedWG* wgdesc, const uint32_t* tsel, const uint32_t* tdst,
-                 int n_groups, const FusedDebug& dbg, float* out, hipStream_t st) {
+                 const int32_t* lorder, const int32_t* nrange, int n_groups, const FusedDebug& dbg, float* out,
+                 hipStream_t st) {
     auto kern = k_fused<D, NW, ROUNDS, KEEP>;
     constexpr size_t lds = (size_t)FusedLds<NW, ROUNDS>::TOTAL * 4;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return AETHER_EHIP;
     ProfScope ps(K_FUSED, st);
     kern<<<dim3((unsigned)n_groups), dim3(NW * 64), lds, st>>>(P, x, vel, charges, ea, perm, send_s, recv_s,
-                                                              rowptr, wgdesc, tsel, tdst, dbg, out);
+                                                              rowptr, wgdesc, tsel, tdst, lorder, nrange, dbg, out);
     return AETHER_OK;
 }
 
@@ -305,22 +346,24 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     for (int k = 0; k < 3; ++k) { dbg.ps[k] = wp(W.ps[k]); dbg.pr[k] = wp(W.pr[k]); }
     dbg.feat = wp(W.feat);
     dbg.stamps = wp(W.stamps);
-    dbg.flags = reinterpret_cast<int*>(ws + W.flags);
+    // hand-off flags live with the graph view: zeroed when it is built, re-armed by every launch that used them,
+    // never touched by anything else -- no memset per call, whatever else the caller does with the workspace
+    dbg.flags = reinterpret_cast<int*>(const_cast<char*>(graph) + G.hflags);
+    dbg.errword = async_error_word();
     dbg.step = step;
     const FusedWG* wgd = reinterpret_cast<const FusedWG*>(graph + G.wgdesc);
     const uint32_t* tsel = reinterpret_cast<const uint32_t*>(graph + G.tsel);
     const uint32_t* tdst = reinterpret_cast<const uint32_t*>(graph + G.tdst);
-    if ((info.reserved & 1) && !ws_reused)      // split mode: every polled word is zero before the launch
-        HIP_OK(hipMemsetAsync(dbg.flags, 0, (size_t)info.n_groups * 4, st));
+    (void)ws_reused;
     const int tiles = (info.max_group_edges + 15) / 16;
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
                                               gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,            \
-                                              info.n_groups, dbg, out, st)                            \
+                                              gp(G.lorder), gp(G.nrange), info.n_groups, dbg, out, st) \
               : fused_launch<D, NWV, R, false>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),      \
                                                gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,           \
-                                               info.n_groups, dbg, out, st)
+                                               gp(G.lorder), gp(G.nrange), info.n_groups, dbg, out, st)
     if (tiles <= 8) { AETHER_FUSED_CASE(8, 1); }
     else if (tiles <= 16) { AETHER_FUSED_CASE(8, 2); }
     else { AETHER_FUSED_CASE(8, 3); }
@@ -606,12 +649,174 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     return AETHER_OK;
 }
 
+int g_fused_backward = 1;      // aether_set_option("fused_backward", 0|1): one-launch GNN backward for small-graph groups
+
+template <int D>
+bool fused_backward_applies(const AetherGraphInfo& info, int64_t Nn, int64_t E) {
+    if (!g_fused_backward || info.n_groups <= 0 || E <= 0) return false;
+    if (info.max_group_edges > 12 * 16) return false;         // three tiles per wave (split N=20 graphs: 12 tiles); beyond: backward.h
+    WsLayout W(Nn, E, D, true);
+    if (!W.defer) return false;                               // per-layer row tensors must exist
+    if ((size_t)info.n_groups > W.fpart_wgs) return false;
+    if ((info.reserved & 1) && (size_t)info.n_groups > W.xchg_wgs) return false;
+    return true;
+}
+
+// The GNN part of the backward as ONE launch (fused_bwd.h) between the out-MLP kernel and the field kernel; the
+// node-level weight-gradient products stay with k_outer, the edge-level ones come out of k_fb_reduce.
+template <int D>
+int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int64_t E, const AetherGraphInfo& info,
+                        const float* x, const float* vel, const float* charges, const char* graph, char* ws,
+                        const float* g_out, hipStream_t st, float* grad_field = nullptr) {
+    constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+    constexpr int FIN = 2 * D + 16;
+    GraphLayout G(E, Nn, false);
+    WsLayout W(Nn, E, D, true);
+    auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
+    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int32_t *recv_s = gp(G.recv_s), *rowptr = gp(G.rowptr);
+    const int32_t *sperm = gp(G.sperm), *srowptr = gp(G.srowptr);
+    OuterList L;
+    const unsigned ngrid = (unsigned)((Nn + 15) / 16);
+    // ---- transposed weight copies (one launch)
+    BwdWT WT;
+    {
+        float* base = wp(W.wt);
+        size_t off = 0;
+        TransposeBatch TB;
+        TB.n_tasks = 0;
+        auto add = [&](const float* src, int rows, int cols, int src_ld, int col0, int ldd, int cols_pad) {
+            float* dst = base + off;
+            TB.t[TB.n_tasks++] = TransposeTask{src, dst, rows, cols, src_ld, col0, ldd, cols_pad};
+            off += (size_t)cols_pad * ldd;
+            return (const float*)dst;
+        };
+        WT.out_w0t = add(P.out_w0, H, H, H, 0, H, H);
+        WT.out_w3t = add(P.out_w3, H, H, H, 0, H, H);
+        WT.out_w6t = add(P.out_w6, D, H, H, 0, 16, H);
+        for (int l = 1; l <= 4; ++l) {
+            const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
+            const float* w4 = l == 1 ? P.l1_upd_w2 : P.ln_upd_w2[l - 2];
+            const float* w2 = l == 1 ? P.l1_msg_w2 : P.ln_msg_w2[l - 2];
+            WT.upd_w2t[l - 1] = add(w4, H, 2 * H, 2 * H, 0, H, 2 * H);
+            WT.upd_w0t[l - 1] = add(w3, 2 * H, H, H, 0, 2 * H, H);
+            WT.msg_w2t[l - 1] = add(w2, H, H, H, 0, H, H);
+            if (l == 1) WT.msg_w0t[0] = add(P.l1_msg_w0, H, F1, F1, 0, H, FPAD);
+            else WT.msg_w0t[l - 1] = add(P.ln_msg_w0[l - 2], H, 3 * H, 3 * H, 0, H, 3 * H);
+        }
+        k_transpose<<<dim3(8, (unsigned)TB.n_tasks), dim3(256), 0, st>>>(TB);
+    }
+    // ---- out MLP
+    { ProfScope ps(KB_OUT, st);
+    kb_out<D><<<dim3(ngrid), dim3(64), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
+                                               wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
+    L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
+    L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
+    L.add(wp(W.DY), 16, D, wp(W.O2), H, H, Nn, Gr.out_w6, H, Gr.out_b6);
+    // ---- the four GNN layers: one launch
+    {
+        FbArgs A;
+        A.rowptr = rowptr; A.send_s = gp(G.send_s); A.recv_s = recv_s;
+        A.wgdesc = reinterpret_cast<const FusedWG*>(graph + G.wgdesc);
+        A.lorder = gp(G.lorder); A.nrange = gp(G.nrange);
+        for (int k = 0; k < 4; ++k) {                           // layer k + 1
+            FbLayer& Y = A.layer[k];
+            Y.e_prev = k == 0 ? wp(W.feat) : wp(W.e[k - 1]);
+            Y.n = wp(W.n[k]);
+            Y.ps = k == 0 ? nullptr : wp(W.ps[k - 1]);
+            Y.pr = k == 0 ? nullptr : wp(W.pr[k - 1]);
+            Y.msg_w0 = k == 0 ? P.l1_msg_w0 : P.ln_msg_w0[k - 1];
+            Y.msg_w2 = k == 0 ? P.l1_msg_w2 : P.ln_msg_w2[k - 1];
+            Y.msg_b2 = k == 0 ? P.l1_msg_b2 : P.ln_msg_b2[k - 1];
+            Y.upd_w0 = k == 0 ? P.l1_upd_w0 : P.ln_upd_w0[k - 1];
+            Y.upd_b0 = k == 0 ? P.l1_upd_b0 : P.ln_upd_b0[k - 1];
+            Y.w4t = WT.upd_w2t[k]; Y.w3t = WT.upd_w0t[k]; Y.w2t = WT.msg_w2t[k]; Y.w0t = WT.msg_w0t[k];
+            Y.U = wp(W.Ul[k]); Y.DPU = wp(W.DPUl[k]); Y.DPS = wp(W.DPSl[k]); Y.DPR = wp(W.DPRl[k]);
+            Y.DXout = k == 0 ? nullptr : wp(W.DXl[k]);         // layer k + 1 produces dL/dx_k
+        }
+        A.msg_b0_1 = P.l1_msg_b0;
+        A.f1 = F1;
+        A.dx4 = wp(W.DXl[4]);
+        A.DN1 = wp(W.DN);
+        A.DA = wp(W.DA);
+        A.DE = wp(W.DE);
+        A.partial = wp(W.fpart);
+        A.xchg = wp(W.xchg);
+        A.flags = reinterpret_cast<int*>(const_cast<char*>(graph) + G.hflags) + G.max_wgs + 32;
+        A.errword = async_error_word();
+        A.n_wgs = info.n_groups;
+        A.stamps = wp(W.stamps);
+        const int tiles = (info.max_group_edges + 15) / 16;
+        const size_t lds = (size_t)FbLds::TOTAL * 4;
+        ProfScope ps(KB_FUSED, st);
+#define AETHER_FB_CASE(R)                                                                                   \
+        do {                                                                                                \
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_fused_bwd<R>), lds)) return AETHER_EHIP; \
+            k_fused_bwd<R><<<dim3((unsigned)info.n_groups), dim3(FB_THREADS), lds, st>>>(A);              \
+        } while (0)
+        if (tiles <= 4) AETHER_FB_CASE(1);
+        else if (tiles <= 8) AETHER_FB_CASE(2);
+        else AETHER_FB_CASE(3);
+#undef AETHER_FB_CASE
+    }
+    // ---- node-level weight-gradient products of the layers
+    for (int l = 4; l >= 1; --l) {
+        float* gw3 = l == 1 ? Gr.l1_upd_w0 : Gr.ln_upd_w0[l - 2];
+        float* gb3 = l == 1 ? Gr.l1_upd_b0 : Gr.ln_upd_b0[l - 2];
+        float* gw4 = l == 1 ? Gr.l1_upd_w2 : Gr.ln_upd_w2[l - 2];
+        float* gb4 = l == 1 ? Gr.l1_upd_b2 : Gr.ln_upd_b2[l - 2];
+        L.add(wp(W.DXl[l]), H, H, wp(W.Ul[l - 1]), 2 * H, 2 * H, Nn, gw4, 2 * H, gb4);
+        L.add(wp(W.DPUl[l - 1]), 2 * H, 2 * H, wp(W.n[l - 1]), H, H, Nn, gw3, H, gb3);
+        if (l >= 2) {
+            L.add(wp(W.DPSl[l - 1]), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2], 3 * H, nullptr);
+            L.add(wp(W.DPRl[l - 1]), H, H, wp(W.x[l - 1]), H, H, Nn, Gr.ln_msg_w0[l - 2] + H, 3 * H, Gr.ln_msg_b0[l - 2]);
+        }
+    }
+    // ---- res + field net
+    { ProfScope ps(KB_FIELD, st);
+    if (grad_field != nullptr)
+        kb_field<D, true><<<dim3((unsigned)((Nn + 7) / 8)), dim3(256), 0, st>>>(
+            P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
+            wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
+            wp(W.ONEHOT), grad_field, Nn);
+    else
+        kb_field<D, false><<<dim3((unsigned)((Nn + 7) / 8)), dim3(256), 0, st>>>(
+            P, x, vel, charges, wp(W.nodeinfo), wp(W.DA), wp(W.DN), rowptr, recv_s, srowptr, sperm,
+            wp(W.RELF), wp(W.Z), wp(W.H1f), wp(W.H2f), wp(W.DPH1), wp(W.DPH2), wp(W.DF), wp(W.DZE),
+            wp(W.ONEHOT), nullptr, Nn); }
+    L.add(wp(W.DN), H, H, wp(W.RELF), 16, 3 * D, Nn, Gr.l1_res_w, 3 * D, Gr.l1_res_b);
+    if (grad_field == nullptr) {
+        L.add(wp(W.DF), 16, D, wp(W.H2f), 32, 32, Nn, Gr.field_w4, 32, Gr.field_b4);
+        L.add(wp(W.DPH2), 32, 32, wp(W.H1f), 32, 32, Nn, Gr.field_w2, 32, Gr.field_b2);
+        L.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
+        L.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
+    }
+    if (run_outer(L, wp(W.partial), W.partial_cap, st)) return AETHER_EHIP;
+    // ---- edge-level weight gradients: the workgroups' partials, added in workgroup order
+    {
+        FbReduceArgs R;
+        R.partial = wp(W.fpart);
+        R.n_wgs = info.n_groups;
+        for (int k = 0; k < 4; ++k) {
+            R.w2[k] = k == 0 ? Gr.l1_msg_w2 : Gr.ln_msg_w2[k - 1];
+            R.b2[k] = k == 0 ? Gr.l1_msg_b2 : Gr.ln_msg_b2[k - 1];
+            R.we[k] = k == 0 ? Gr.l1_msg_w0 : Gr.ln_msg_w0[k - 1] + 2 * H;
+        }
+        R.b1 = Gr.l1_msg_b0;
+        R.f1 = F1;
+        ProfScope ps(KB_FBRED, st);
+        k_fb_reduce<<<dim3((FB_PART + 255) / 256, 4), dim3(1024), 0, st>>>(R);
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
 }  // namespace
 
 // =================================================================== C ABI
 extern "C" {
 
-const char* aether_version(void) { return "aether_hip 0.3 (gfx950; state2state fused + streamed + backward, seq2seq / variable-N steps, kNN, simulators)"; }
+const char* aether_version(void) { return "aether_hip 0.4 (gfx950; state2state fused + streamed + backward, seq2seq / variable-N steps, kNN, simulators)"; }
 const char* aether_last_error(void) { return g_err; }
 
 #include "host_seq2seq.inc"
@@ -622,6 +827,10 @@ int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");
     if (!strcmp(name, "fused_split")) {      // takes effect at the next aether_graph_build
         g_fused_split = value != 0;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "fused_backward")) {   // 0: layer-by-layer backward kernels even for small-graph groups
+        g_fused_backward = value != 0;
         return AETHER_OK;
     }
     if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces
@@ -645,6 +854,8 @@ int aether_set_option(const char* name, int value) {
     }
     return fail(AETHER_EINVAL, "set_option: unknown option");
 }
+
+int aether_check_async_error(void) { return take_async_error(); }
 
 int aether_profile_enable(int on) {
     g_prof_on = on != 0;
@@ -787,12 +998,14 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
             mgn = 0; mge = 0;
             auto add_wg = [&](int vb, int ve, int nb, int ne, int partner) {
                 FusedWG w = {vb, ve, nb, ne, (int)tiles.size(), partner, 0, 0};
-                const int eb = h_rowptr[nb], m = h_rowptr[ne] - eb;
-                for (int t = 0; t < (m + 15) / 16; ++t) tiles.push_back(FusedTile{eb, m, nb, t});
+                const int m = h_rowptr[ne] - h_rowptr[nb];
+                for (int t = 0; t < (m + 15) / 16; ++t) tiles.push_back(FusedTile{(int)wgs.size(), t});
                 if (ne - nb > mgn) mgn = ne - nb;
                 if (m > mge) mge = m;
                 wgs.push_back(w);
             };
+            for (int pass = 0; pass < 2; ++pass) {
+            wgs.clear(); tiles.clear(); mgn = 0; mge = 0;
             for (int k = 0; k < n_grp; ++k) {
                 const int a = grp[k], b = grp[k + 1];
                 if (!split) { add_wg(a, b, a, b, -1); continue; }
@@ -807,13 +1020,22 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
                 add_wg(a, b, a, nm, idx + 1);
                 add_wg(a, b, nm, b, idx);
             }
+            // a split workgroup keeps two runs of partial rows in LDS (FusedLds::PART_ROWS): at most 16 tiles
+            if (split && mge > 16 * 16) { split = false; continue; }
+            break;
+            }
             if ((int64_t)tiles.size() <= G.max_tiles) {
                 HIP_OK(hipMemcpyAsync(g + G.wgdesc, wgs.data(), wgs.size() * sizeof(FusedWG), hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemsetAsync(g + G.hflags, 0, (size_t)(2 * G.max_wgs + 64) * 4, st));
+                k_graph_lorder<<<dim3((unsigned)wgs.size()), dim3(512), 0, st>>>(
+                    (FusedWG*)(g + G.wgdesc), (const int32_t*)(g + G.send_s), rowptr, (int32_t*)(g + G.lorder),
+                    (int32_t*)(g + G.nrange));
                 if (!tiles.empty()) {
                     HIP_OK(hipMemcpyAsync(g + G.tdesc, tiles.data(), tiles.size() * sizeof(FusedTile),
                                           hipMemcpyHostToDevice, st));
                     k_graph_tiles<<<dim3((unsigned)tiles.size()), dim3(64), 0, st>>>(
-                        (const FusedTile*)(g + G.tdesc), recv_s, (uint32_t*)(g + G.tsel), (uint32_t*)(g + G.tdst));
+                        (const FusedTile*)(g + G.tdesc), (const FusedWG*)(g + G.wgdesc), recv_s, rowptr,
+                        (const int32_t*)(g + G.lorder), (uint32_t*)(g + G.tsel), (uint32_t*)(g + G.tdst));
                 }
                 HIP_OK(hipStreamSynchronize(st));       // host vectors must outlive the copies
                 info->n_groups = (int32_t)wgs.size();
@@ -847,6 +1069,7 @@ static int forward_common(const AetherParams* params, int num_dims, int64_t n_no
                           const float* field) {
     if (!params || !x || !vel || !charges || !graph || !info || !workspace || !out)
         return fail(AETHER_EINVAL, "forward: null pointer");
+    if (take_async_error()) return AETHER_EHIP;
     if (info->n_nodes != n_nodes || info->n_edges != n_edges)
         return fail(AETHER_EINVAL, "forward: graph info does not match n_nodes / n_edges");
     if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "forward: num_dims must be 2 or 3");
@@ -913,6 +1136,7 @@ static int rollout_common(const AetherParams* params, const AetherDynFieldParams
                           size_t workspace_bytes, float* trajectory, int steps, float dt, int flags, void* stream) {
     if (!params || !x0 || !vel0 || !charges || !graph || !info || !workspace || !trajectory)
         return fail(AETHER_EINVAL, "rollout: null pointer");
+    if (take_async_error()) return AETHER_EHIP;
     if (info->n_nodes != n_nodes || info->n_edges != n_edges)
         return fail(AETHER_EINVAL, "rollout: graph info does not match n_nodes / n_edges");
     if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "rollout: num_dims must be 2 or 3");
@@ -986,9 +1210,17 @@ int aether_backward(const AetherParams* params, const AetherParams* grads, int n
     if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 1))
         return fail(AETHER_ESPACE, "backward: workspace too small (forward must run with KEEP_INTERMEDIATES)");
     hipStream_t st = (hipStream_t)stream;
-    if (num_dims == 2)
+    if (take_async_error()) return AETHER_EHIP;
+    if (num_dims == 2) {
+        if (fused_backward_applies<2>(*info, n_nodes, n_edges))
+            return backward_fused_impl<2>(*params, *grads, n_nodes, n_edges, *info, x, vel, charges, (const char*)graph,
+                                          (char*)workspace, grad_out, st);
         return backward_impl<2>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
                                 (char*)workspace, grad_out, st);
+    }
+    if (fused_backward_applies<3>(*info, n_nodes, n_edges))
+        return backward_fused_impl<3>(*params, *grads, n_nodes, n_edges, *info, x, vel, charges, (const char*)graph,
+                                      (char*)workspace, grad_out, st);
     return backward_impl<3>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
                             (char*)workspace, grad_out, st);
 }
@@ -1005,9 +1237,17 @@ int aether_backward_field(const AetherParams* params, const AetherParams* grads,
     if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 1))
         return fail(AETHER_ESPACE, "backward_field: workspace too small (forward must run with KEEP_INTERMEDIATES)");
     hipStream_t st = (hipStream_t)stream;
-    if (num_dims == 2)
+    if (take_async_error()) return AETHER_EHIP;
+    if (num_dims == 2) {
+        if (fused_backward_applies<2>(*info, n_nodes, n_edges))
+            return backward_fused_impl<2>(*params, *grads, n_nodes, n_edges, *info, x, vel, charges, (const char*)graph,
+                                          (char*)workspace, grad_out, st, grad_field);
         return backward_impl<2>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
                                 (char*)workspace, grad_out, st, grad_field);
+    }
+    if (fused_backward_applies<3>(*info, n_nodes, n_edges))
+        return backward_fused_impl<3>(*params, *grads, n_nodes, n_edges, *info, x, vel, charges, (const char*)graph,
+                                      (char*)workspace, grad_out, st, grad_field);
     return backward_impl<3>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
                             (char*)workspace, grad_out, st, grad_field);
 }

@@ -36,9 +36,13 @@ template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static constexpr int PS = NBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
     static constexpr int PR = PS + FUSED_MAX_NODES * LDW;          // [32][LDW]  W_r x + b1
     static constexpr int NINFO = PR + FUSED_MAX_NODES * LDW;       // [32][24]   NodeInfo records
-    static constexpr int PART_ROWS = FUSED_MAX_NODES + FUSED_MAX_TILES;
-    static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [56][LDW]  per-(receiver, tile) sums
-    static constexpr int SCRATCH = PART + PART_ROWS * LDW;         // aliased by the regions below
+    // one row per (receiver, tile).  A split workgroup walks its edges in two receiver-sorted runs (own senders,
+    // then the partner's: see FusedWG), whose rows are kept apart by an offset of n: 2 * 32 + 16 rows for up to
+    // 16 tiles; with 17-24 tiles (ROUNDS == 3) only unsplit workgroups are built: 32 + 24 rows.
+    static constexpr int PART_ROWS = ROUNDS == 3 ? FUSED_MAX_NODES + FUSED_MAX_TILES : 2 * FUSED_MAX_NODES + 16;
+    static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [PART_ROWS][LDW]  per-(receiver, tile) sums
+    static constexpr int ARRIVED = PART + PART_ROWS * LDW;         // [4] ints: split mode, layer whose partner rows are in LDS
+    static constexpr int SCRATCH = ARRIVED + 4;                    // aliased by the regions below
     static constexpr int FEAT_ROWS = 16 * ROUNDS;                              // per wave
     static constexpr int SCRATCH_SIZE =
         NW * FEAT_ROWS * LDF > NW * 16 * LDST ? NW * FEAT_ROWS * LDF : NW * 16 * LDST;
@@ -70,7 +74,9 @@ template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
 struct FusedDebug {
     float* nodeinfo; float* x[5]; float* e[4];
     float* n[4]; float* ps[3]; float* pr[3]; float* feat;     // saved for the backward
-    int* flags;             // [workgroups] split mode: layer whose P_s rows this workgroup has published
+    int* flags;             // [workgroups] split mode: layer whose P_s rows this workgroup has published (lives in the
+                            // graph buffer: zero when no launch is in flight, every launch re-arms what it consumed)
+    int* errword;           // host-mapped word: set when a bounded wait on the partner workgroup gave up
     float* stamps;          // [groups][FUSED_STAMPS] diagnostic build only
     StepExtras step;        // rollout: derived edge attributes, next velocity
 };
@@ -101,24 +107,81 @@ constexpr int FUSED_STAMPS = 512;
 // and owns nodes [nb, ne) -- their in-edges, their node updates, their outputs.  Unsplit: own = visible.
 // Split (two workgroups per group, when there are fewer groups than half the CUs): the partner owns
 // the rest and the two exchange their P_s rows once per layer through global memory.
-struct FusedWG { int vb, ve, nb, ne, tile0, partner, pad0, pad1; };
-struct FusedTile { int eb, m, nb, t; };      // first sorted edge of the owner, its edge count, owner's nb, tile index
+// A workgroup walks its m in-edges in a LOCAL order (lorder[eb + local] = offset into the receiver-sorted
+// range): first the `na` edges whose sender it owns, then the edges from the partner's nodes, each run
+// receiver-sorted (unsplit: na = m, the identity).  Tiles of the first run need nothing from the partner, so
+// the forward starts with them while the partner's rows are in flight -- and the backward starts with the
+// second run, whose sender-side sums the partner waits for.
+struct FusedWG { int vb, ve, nb, ne, tile0, partner, na, pad1; };
+struct FusedTile { int wg, t; };             // workgroup descriptor index, tile index within the workgroup
 
-// Per-tile structure of the receiver-sorted edge list, built once with the graph: for every lane of
+// Local edge order of every workgroup (one block per workgroup; m <= FUSED_MAX_EDGES <= blockDim.x) and the
+// local index ranges of every own node's in-edges in the two runs: nrange[node] = {a_beg, a_end, b_beg, b_end}.
+__global__ void __launch_bounds__(512)
+k_graph_lorder(FusedWG* __restrict__ wgdesc, const int32_t* __restrict__ send_s, const int32_t* __restrict__ rowptr,
+               int32_t* __restrict__ lorder, int32_t* __restrict__ nrange) {
+    __shared__ int wsum[2][8];
+    __shared__ int cnt_a[FUSED_MAX_NODES + 1], cnt_b[FUSED_MAX_NODES + 1];
+    const FusedWG wg = wgdesc[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int eb = rowptr[wg.nb], m = rowptr[wg.ne] - eb, n = wg.ne - wg.nb;
+    const bool valid = tid < m;
+    const bool split = wg.partner >= 0;
+    const int snd = valid ? send_s[eb + tid] : -1;
+    const bool own = valid && (!split || (snd >= wg.nb && snd < wg.ne));
+    const bool oth = valid && !own;
+    const unsigned long long bo = __ballot(own), bt = __ballot(oth);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) { wsum[0][wave] = __popcll(bo); wsum[1][wave] = __popcll(bt); }
+    if (tid <= FUSED_MAX_NODES) { cnt_a[tid] = 0; cnt_b[tid] = 0; }
+    __syncthreads();
+    int base_o = 0, base_t = 0, na = 0;
+    for (int w = 0; w < 8; ++w) {
+        if (w < wave) { base_o += wsum[0][w]; base_t += wsum[1][w]; }
+        na += wsum[0][w];
+    }
+    if (own) lorder[eb + base_o + __popcll(bo & below)] = tid;
+    if (oth) lorder[eb + na + base_t + __popcll(bt & below)] = tid;
+    if (tid == 0) wgdesc[blockIdx.x].na = na;
+    // per-node run lengths (thread per own node, a handful of edges each), then a serial prefix
+    if (tid < n) {
+        int ca = 0, cb = 0;
+        for (int k = rowptr[wg.nb + tid]; k < rowptr[wg.nb + tid + 1]; ++k) {
+            const int sd = send_s[k];
+            if (!split || (sd >= wg.nb && sd < wg.ne)) ++ca; else ++cb;
+        }
+        cnt_a[tid] = ca; cnt_b[tid] = cb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pa = 0, pb = na;
+        for (int s = 0; s < n; ++s) {
+            int32_t* o = nrange + 4 * (int64_t)(wg.nb + s);
+            o[0] = pa; o[1] = pa + cnt_a[s]; o[2] = pb; o[3] = pb + cnt_b[s];
+            pa += cnt_a[s]; pb += cnt_b[s];
+        }
+    }
+}
+
+// Per-tile structure of a workgroup's edge list in LOCAL order, built once with the graph: for every lane of
 // the tile's wave the 0/1 column of the segment matrix it feeds to the matrix core (tsel) and the
-// partial rows its four result registers go to (tdst, one byte each, 0xFF = none).
+// partial rows its four result registers go to (tdst, one byte each, 0xFF = none).  A segment = consecutive
+// rows with one receiver inside one run; its partial row is receiver + tile (+ n in the second run).
 __global__ void __launch_bounds__(64)
-k_graph_tiles(const FusedTile* __restrict__ tdesc, const int32_t* __restrict__ recv_s,
-              uint32_t* __restrict__ tsel, uint32_t* __restrict__ tdst) {
+k_graph_tiles(const FusedTile* __restrict__ tdesc, const FusedWG* __restrict__ wgdesc,
+              const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
+              const int32_t* __restrict__ lorder, uint32_t* __restrict__ tsel, uint32_t* __restrict__ tdst) {
     const FusedTile T = tdesc[blockIdx.x];
+    const FusedWG wg = wgdesc[T.wg];
+    const int eb = rowptr[wg.nb], m = rowptr[wg.ne] - eb, n = wg.ne - wg.nb;
+    const int na = wg.na;
     const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
     const int local = 16 * T.t + i;
-    const bool valid = local < T.m;
-    const int rcv = valid ? recv_s[T.eb + local] - T.nb : -1;
-    // rows are receiver-sorted.  smask bit j: row j starts a new segment; segment ids count up in
-    // row order; padding rows belong to no segment.
+    const bool valid = local < m;
+    const int rcv = valid ? recv_s[eb + lorder[eb + local]] - wg.nb : -1;
+    // smask bit j: row j starts a new segment; segment ids count up in row order; padding rows belong to no segment.
     const int prev = __shfl_up(rcv, 1, 16);
-    const unsigned smask = (unsigned)__ballot(q == 0 && i > 0 && rcv != prev) & 0xFFFFu;
+    const unsigned smask = (unsigned)__ballot(q == 0 && i > 0 && (rcv != prev || local == na)) & 0xFFFFu;
     const unsigned vmask = (unsigned)__ballot(q == 0 && valid) & 0xFFFFu;
     unsigned sb = 0, dp = 0;
 #pragma unroll
@@ -139,7 +202,8 @@ k_graph_tiles(const FusedTile* __restrict__ tdesc, const int32_t* __restrict__ r
             mm &= mm - 1;
         }
         const int node = __shfl(rcv, (lane & 48) + s0);           // owner-local receiver of row s0
-        const unsigned row = (exists && ((vmask >> s0) & 1u)) ? (unsigned)(node + T.t) : 0xFFu;
+        const int second = (wg.partner >= 0 && 16 * T.t + s0 >= na) ? n : 0;
+        const unsigned row = (exists && ((vmask >> s0) & 1u)) ? (unsigned)(node + T.t + second) : 0xFFu;
         dp |= row << (8 * r4);
     }
     tsel[(size_t)blockIdx.x * 64 + lane] = sb;
@@ -189,7 +253,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         const int32_t* __restrict__ perm, const int32_t* __restrict__ send_s,
         const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
         const FusedWG* __restrict__ wgdesc, const uint32_t* __restrict__ tsel,
-        const uint32_t* __restrict__ tdst, FusedDebug dbg, float* __restrict__ out) {
+        const uint32_t* __restrict__ tdst, const int32_t* __restrict__ lorder,
+        const int32_t* __restrict__ nrange, FusedDebug dbg, float* __restrict__ out) {
     constexpr bool keep = KEEP;      // inference build carries none of the save-for-backward stores
     using NI = NodeInfo<D>;
     using L = FusedLds<NW, ROUNDS>;
@@ -217,6 +282,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     const int eb = rowptr[nb], ee = rowptr[ne];
     const int m = ee - eb;
     const int n_tiles = (m + 15) >> 4;
+    const int na = wg.na;                                // edges [0, na) of the local order have own senders
+    volatile int* arrived = reinterpret_cast<volatile int*>(smem + L::ARRIVED);
+    if (tid == 0) arrived[0] = 0;                        // ordered before any use by the prologue's barriers
 #ifdef AETHER_FUSED_STAMPS
     const unsigned long long t_entry = wall_clock64();
     const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
@@ -388,6 +456,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     unsigned selbits[ROUNDS];                // bit s4: S[seg = i][edge = 4*s4 + q] of the tile
     unsigned destpack[ROUNDS];               // byte r4: partial row of segment 4q + r4, 0xFF = none
     f32x4 e[ROUNDS][4];                      // message tiles, MFMA accumulator layout
+    int ke[KEEP ? ROUNDS : 1];               // KEEP: receiver-sorted position of the lane's edge (row of the saved tensors)
     {
         float* scratch = smem + L::FEAT + wave * (L::FEAT_ROWS * LDF);
         if (lane < 16 * ROUNDS) {
@@ -395,7 +464,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             const int local = 16 * (NW * r + wave) + ii;
             float o[FPAD];
             if (local < m) {
-                const int k = eb + local;
+                const int k = eb + lorder[eb + local];       // position in the receiver-sorted edge list
                 const float* nj = ninfo + (send_s[k] - vb) * 24;
                 const float* nr = ninfo + (recv_s[k] - vb) * 24;
                 float njl[NI::STRIDE], nrl[NI::STRIDE];
@@ -438,9 +507,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile = NW * r + wave;
             const int local = 16 * tile + i;
-            const int k = eb + (local < m ? local : 0);
+            const int k = m > 0 ? eb + lorder[eb + (local < m ? local : 0)] : 0;
             sl[r] = m > 0 ? send_s[k] - vb : 0;
             rl[r] = m > 0 ? recv_s[k] - nb : 0;
+            if constexpr (KEEP) ke[r] = local < m ? k : -1;
             const bool have = tile < n_tiles;
             selbits[r] = have ? tsel[(size_t)(wg.tile0 + tile) * 64 + lane] : 0u;
             destpack[r] = have ? tdst[(size_t)(wg.tile0 + tile) * 64 + lane] : 0xFFFFFFFFu;
@@ -451,14 +521,18 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 
     // node-sum ownership (step 1 of the node phase): thread -> (node slot, 4 columns).  The in-edge
     // sum of a node arrives as per-(receiver, tile) partial rows `part[node + tile]`.
+    // Two runs of tiles per node (own senders / partner's senders, see FusedWG); the second run's rows are offset by n.
     const int aslot = (tid >> 4) & (FUSED_MAX_NODES - 1), ac4 = (tid & 15) * 4;
-    int at0 = 0, at1 = 0;
+    int at0 = 0, at1 = 0, bt0 = 0, bt1 = 0;
     float adeg = 1.0f;
     if (aslot < n) {
-        const int beg = rowptr[nb + aslot] - eb, end = rowptr[nb + aslot + 1] - eb;
-        at0 = beg >> 4;
-        at1 = end > beg ? ((end - 1) >> 4) + 1 : at0;
-        adeg = (float)(end - beg > 1 ? end - beg : 1);
+        const int4 nr = *reinterpret_cast<const int4*>(nrange + 4 * (int64_t)(nb + aslot));
+        at0 = nr.x >> 4;
+        at1 = nr.y > nr.x ? ((nr.y - 1) >> 4) + 1 : at0;
+        bt0 = (nr.z >> 4) + n;
+        bt1 = nr.w > nr.z ? ((nr.w - 1) >> 4) + 1 + n : bt0;
+        const int deg = (nr.y - nr.x) + (nr.w - nr.z);
+        adeg = (float)(deg > 1 ? deg : 1);
     }
 
     f32x4 wsv[4], wrv[4];        // next layer's W_s / W_r fragments; after layer 4: out_w0 / out_w3
@@ -529,11 +603,13 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
         };
-        // Split mode, layers 2-4: the partner workgroup's P_s rows arrive while the FIRST tile's first
-        // Linear runs.  `late` tiles start from P_r and the own senders' P_s only; the partner's rows
-        // are fetched into LDS after that GEMM (receive_partner_rows) and added before the SiLU.
+        // Split mode, layers 2-4: the partner workgroup's P_s rows are in flight when the edge phase starts.  The
+        // workgroup walks the tiles whose senders it owns first (local order, FusedWG); the LAST wave -- it has the
+        // fewest tiles, and its only one needs the partner -- polls the partner's flag, copies the rows into LDS and
+        // sets an LDS word; a wave waits on that word only before its first tile with a partner sender.  No
+        // workgroup barrier, and nobody waits while there is work that does not need the rows.
         const bool xch = wg.partner >= 0 && layer > 1;
-        auto front_gemm = [&](int r, f32x4 (&acc)[4], bool last, bool late) {
+        auto front_gemm = [&](int r, f32x4 (&acc)[4], bool last) {
             if (last) issue_loads(0);
             if (layer == 1) {
 #pragma unroll
@@ -541,32 +617,34 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 f32x4 bop[2] = {e[r][0], e[r][1]};
                 gemm_tile<4, 2>(wA, LDF, bop, acc, i, q);
             } else {
-                const bool own_s = !late || (sl[r] >= off && sl[r] < off + n);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    acc[mb] = ld4(prb + rl[r] * LDW + 16 * mb + 4 * q);
-                    if (own_s) acc[mb] += ld4(psb + sl[r] * LDW + 16 * mb + 4 * q);
-                }
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb] = ld4(prb + rl[r] * LDW + 16 * mb + 4 * q) + ld4(psb + sl[r] * LDW + 16 * mb + 4 * q);
                 gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
             }
         };
         auto receive_partner_rows = [&]() {
-            // second half of the hand-off (first half: end of the previous node phase): one lane polls the
-            // partner's flag (bounded), then the waves read the partner's rows with sc1
-            // (L1-bypassing) 16-byte buffer loads -- the only loads of those bytes in this launch.
-            if (tid == 0) {
+            // second half of the hand-off (first half: end of the previous node phase), run by ONE wave: lane 0
+            // polls the partner's flag (bounded: a wait that gives up reports through dbg.errword), then the wave
+            // reads the partner's rows with sc1 (L1-bypassing) 16-byte buffer loads -- the only loads of those
+            // bytes in this launch -- into LDS and publishes them to the other waves through an LDS word
+            // (cdna_hip_programming.md Guideline 16: "the other waves load after ... an LDS word it then sets").
+            if (lane == 0) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(dbg.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < layer - 1) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) break;           // partner not resident: give up, never hang
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) {                // partner not resident: give up, never hang -- and say so
+                        if (dbg.errword) __hip_atomic_store(dbg.errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            lds_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const int np = nv - n;                              // partner rows = visible slots outside [off, off + n)
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dbg.ps[layer - 2] + (int64_t)vb * H, 0, nv * H * 4, 0x00020000);
-            for (int idx = tid; idx < np * 16; idx += THREADS) {
+            for (int idx = lane; idx < np * 16; idx += 64) {
                 int slot = idx >> 4;
                 if (slot >= off) slot += n;
                 const int c = (idx & 15) * 4;
@@ -576,13 +654,15 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 for (int r4 = 0; r4 < 4; ++r4) f[r4] = __uint_as_float(v[r4]);
                 st4(psb + slot * LDW + c, f);
             }
-            lds_barrier();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // rows are in LDS before the word says so
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) arrived[0] = layer;
         };
-        auto front_act = [&](int r, f32x4 (&acc)[4], f32x4 (&h1)[4], bool last, bool late) {
-            if (late && !(sl[r] >= off && sl[r] < off + n)) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[mb] += ld4(psb + sl[r] * LDW + 16 * mb + 4 * q);
-            }
+        auto wait_partner_rows = [&]() {
+            while (__builtin_amdgcn_readfirstlane(arrived[0]) < layer) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        };
+        auto front_act = [&](int r, f32x4 (&acc)[4], f32x4 (&h1)[4], bool last) {
             if (last) issue_loads(1);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
@@ -597,12 +677,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             if (last) issue_loads(3);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
-            if (keep) {
-                const int local = 16 * tile + i;
-                if (local < m) {
+            if constexpr (KEEP) {
+                if (ke[r] >= 0) {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
-                        st4(dbg.e[layer - 1] + (int64_t)(eb + local) * H + 16 * mb + 4 * q, e[r][mb]);
+                        st4(dbg.e[layer - 1] + (int64_t)ke[r] * H + 16 * mb + 4 * q, e[r][mb]);
                 }
             }
             // Per-receiver sums of the tile on the matrix core: park the tile in 16 LDS rows (one set
@@ -640,22 +719,26 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                 for (int part = 0; part < 5; ++part) issue_loads(part);
             }
+            if (xch && wave == NW - 1) receive_partner_rows();
+            bool have_rows = !xch || wave == NW - 1;
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 if (r < nvalid) {
                     const bool last = r == nvalid - 1;
                     FUSED_WSTAMP(layer, r, 0);
+                    if (!have_rows && 16 * (NW * r + wave + 1) > na) {      // first tile with a partner sender
+                        wait_partner_rows();
+                        have_rows = true;
+                    }
+                    FUSED_WSTAMP(layer, r, 1);
                     f32x4 acc[4], h1[4];
-                    const bool late = xch && r == 0;
-                    front_gemm(r, acc, last, late);
-                    if (late) receive_partner_rows();           // every wave passes here exactly once per layer
-                    front_act(r, acc, h1, last, late);
+                    front_gemm(r, acc, last);
+                    front_act(r, acc, h1, last);
                     FUSED_WSTAMP(layer, r, 2);
                     back(r, h1, last);
                     FUSED_WSTAMP(layer, r, 5);
                 }
             }
-            if (xch && nvalid == 0) receive_partner_rows();
         }
         FUSED_STAMP(4 + 8 * (layer - 1) + 2);
         // ------------------------------------------------------------ node phase (locs.py:240-241)
@@ -665,6 +748,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         if (tid < FUSED_MAX_NODES * 16) {
             f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int t = at0; t < at1; ++t) sum += ld4(part + (aslot + t) * LDW + ac4);
+            for (int t = bt0; t < bt1; ++t) sum += ld4(part + (aslot + t) * LDW + ac4);
             const f32x4 nv = ld4(xbuf + aslot * LDW + ac4) + sum / adeg;
             st4(nbuf + aslot * LDW + ac4, nv);
             if (keep && aslot < n) st4(dbg.n[layer - 1] + (int64_t)(nb + aslot) * H + ac4, nv);

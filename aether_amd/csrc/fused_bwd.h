@@ -1,0 +1,764 @@
+// fused_bwd.h -- parameter gradients of the Aether step for groups of small graphs: the GNN part of the backward
+// (four layers of node-update / edge-MLP / gather backward, locs.py:227-243 differentiated) in ONE launch per step,
+// one workgroup per fused-forward workgroup (same FusedWG descriptors, same local edge order, fused.h).
+//
+// What stays on chip, against the layer-by-layer kernels of backward.h (kb_node / kb_edge / kb_gather + k_outer):
+//   * G = dL/dpre1, h, dL/dpre2 of an edge tile never leave the owning wave: the four GEMMs of the tile
+//     (recompute pre1 / pre2, back through W2 and W_e) chain in registers, and the two edge-level weight-gradient
+//     products of the layer (dW2 += dpre2 (x) h, dW_e += G (x) e_prev; layer 1: dW1 += G (x) features) are
+//     accumulated in the wave's registers over its tiles (the [E,64] row tensors of backward.h: 560 MB per step at
+//     cfg2) -- one partial per workgroup and layer goes to memory, k_fb_reduce adds them in workgroup order;
+//   * the gradient with respect to a message tile (W_e^T G of layer l+1) stays in the registers of the wave that owns
+//     the tile, as the forward keeps the messages;
+//   * sums of G over a node's in-edges (dP_r) and out-edges (dP_s) run on the matrix core against the tile's 0/1
+//     incidence matrices (built from the sender / receiver slots), accumulated over the wave's tiles, added over the
+//     waves in wave order through LDS: fixed order, no atomics, bit-stable;
+//   * node-level work (update MLP backward, dx_{l-1} = dn + W_s^T dP_s + W_r^T dP_r) splits its output rows over the
+//     four waves; its row tensors (2,560 nodes) still go to memory for the node-level weight-gradient products, which
+//     stay with k_outer (they are ~5 % of the bytes the edge-level ones were).
+// Split mode (two workgroups per graph): dP_s of a node needs the G rows of its out-edges in BOTH workgroups.  A
+// workgroup walks its tiles in reverse local order -- the tiles with the partner's senders first -- and every wave
+// publishes its partial sums for the partner's nodes as soon as it is through with them (sc1 stores, drained, one
+// agent-scope add per wave on the workgroup's counter: MI355X_MICROARCH.md, hand-offs measured with sc1 loads, row 3);
+// the partner picks them up after its own edge phase, one tile or more later.
+//
+// 4 waves per workgroup, one per SIMD, up to 512 registers each: the two 64 x 64 accumulators (128 registers), the
+// incidence sums (64) and the carried message gradients (16 per tile) do not fit beside a second wave, and the fp32
+// MFMA shares its SIMD's vector ALUs: a second wave would not overlap with it anyway.
+#pragma once
+#include "common.h"
+#include "fused.h"
+#include "backward.h"
+
+namespace {
+
+constexpr int FB_THREADS = 256;
+constexpr int FB_SA = LDST;                   // staging row stride (floats): 16-byte row writes of a tile are conflict-free
+constexpr int FB_PART = 2 * H * H + 2 * H;    // floats per (workgroup, layer) partial: dW2 | dW_e (dW1) | db2 | db1
+constexpr int FB_MAX_WGS = 1024;              // workgroups whose partials the workspace holds (beyond: backward.h path)
+
+struct FbLds {                                // offsets in floats
+    // Weight images in MFMA-fragment order: [row block mb][k block a][lane 64] x 16 bytes -- what lane (i, q) reads for
+    // (mb, a) is W[16 mb + i][16 a + 4 q .. + 3].  One fragment = 1 KiB contiguous = one LDS-DMA wave instruction with
+    // per-lane source addresses (fb_stage_frags), and the fragment reads are lane-linear: no padding, no conflicts.
+    static constexpr int WE = 0;                                   // W_e   (layer 1: W1, K = 32: 8 fragments)
+    static constexpr int W2 = WE + H * H;                          // W2
+    static constexpr int W2T = W2 + H * H;                         // W2^T
+    static constexpr int WET = W2T + H * H;                        // W_e^T (layer 1: W1^T, 32 rows: 8 fragments)
+    static constexpr int WEND = 2 * 4 * FUSED_MAX_NODES * LDST;    // (the images' region also holds the dumps below)
+    static_assert(WET + H * H <= WEND, "weight images");
+    static constexpr int BIAS = WEND;                              // [64] b2 | [64] b1 (layer 1)
+    static constexpr int PSB = BIAS + 2 * H;                       // [32][LDW]  P_s (visible slots) -> total dP_s
+    static constexpr int PRB = PSB + FUSED_MAX_NODES * LDW;        // [32][LDW]  P_r (own slots)     -> total dP_r
+    static constexpr int DNS = PRB + FUSED_MAX_NODES * LDW;        // [32][LDW]  dn  (own slots)
+    static constexpr int INVD = DNS + FUSED_MAX_NODES * LDW;       // [32]       1 / max(in-degree, 1)
+    static constexpr int STG = INVD + FUSED_MAX_NODES;             // [4 waves][3][16][FB_SA] tile staging
+    static constexpr int STG_SIZE = 4 * 3 * 16 * FB_SA;
+    static constexpr int DXS = STG;                                // [32][LDW]  dx  (own slots)   } node phase only:
+    static constexpr int DPU = DXS + FUSED_MAX_NODES * LDW;        // [32][LDU]  dpre_u            } alias the staging
+    static constexpr int TOTAL = STG + STG_SIZE;
+    // per-wave dumps of the incidence sums alias the (then dead) weight images: [4 waves][32][LDST] each
+    static constexpr int DUMP_S = 0;
+    static constexpr int DUMP_R = 4 * FUSED_MAX_NODES * LDST;
+    static_assert(DPU + FUSED_MAX_NODES * LDU <= TOTAL, "node-phase buffers alias the staging");
+    static_assert(DUMP_R + 4 * FUSED_MAX_NODES * LDST <= WEND, "dumps alias the weight images");
+    static_assert(2 * 2 * H * H <= WEND, "weight-gradient reduction aliases the weight images");
+    static_assert(TOTAL * 4 <= 160 * 1024, "LDS budget");
+};
+
+// Everything layer l of the backward reads and writes: one contiguous record, fetched once at the start of the layer
+// (the kernel-argument segment is memory: pointers indexed by a run-time layer cost a scalar-cache round trip EACH
+// when they are fetched where they are used).
+struct FbLayer {
+    const float* e_prev;       // messages of layer l-1, receiver-sorted rows (layer 1: the edge features [E][FPAD])
+    const float* n;            // n_l = x_{l-1} (res) + mean, saved by the forward
+    const float* ps; const float* pr;     // P_s, P_r of layer l (layers 2-4)
+    const float* msg_w0;       // layer 1: W1 [64][F1]; layers 2-4: [64][192] = W_s | W_r | W_e
+    const float* msg_w2; const float* msg_b2;
+    const float* upd_w0; const float* upd_b0;            // W3 [128][64], b3
+    const float* w4t; const float* w3t; const float* w2t; const float* w0t;     // transposed copies (k_transpose)
+    float* U; float* DPU; float* DPS; float* DPR;        // row tensors of the node-level weight-gradient products
+    float* DXout;              // dL/dx_{l-1} (layers 2-4)
+};
+
+struct FbArgs {
+    // graph view
+    const int32_t* rowptr; const int32_t* send_s; const int32_t* recv_s; const FusedWG* wgdesc;
+    const int32_t* lorder; const int32_t* nrange;
+    FbLayer layer[4];
+    const float* msg_b0_1;     // layer 1 only (layers 2-4: b1 sits in P_r)
+    int f1;
+    const float* dx4;          // in: dL/dx_4 (kb_out)
+    float* DN1;                // dL/dn_1: layer_1.res and the field backward
+    float* DA;                 // [E][FPAD]: dL/d(layer-1 edge features)
+    float* DE;                 // [E][64] scratch: message gradients between layers when they do not fit registers (ROUNDS > 3)
+    float* partial;            // [n_wgs][4 layers][FB_PART]
+    float* xchg;               // split mode: [3 layers][n_wgs][4 waves][32][64] partial dP_s rows
+    int* flags;                // split mode: per workgroup, waves that have published (4 per layer)
+    int* errword;
+    int n_wgs;
+    float* stamps;             // diagnostic build only: [n_wgs][FUSED_STAMPS] microseconds since entry
+};
+
+// acc[mb][nb] += sum_k X[k][4 i' + mb] * Y[k][NB i + nb] over the 16 staged rows k (i' = MFMA row = 4q + r).
+template <int NB>
+__device__ __forceinline__ void fb_outer16(const float* __restrict__ sa, const float* __restrict__ sb,
+                                           f32x4 (&acc)[4][NB], int i, int q) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 av = ld4(sa + (4 * s4 + q) * FB_SA + 4 * i);
+        float bv[NB];
+        if constexpr (NB == 4) {
+            const f32x4 b4 = ld4(sb + (4 * s4 + q) * FB_SA + 4 * i);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bv[nb] = b4[nb];
+        } else {
+            const f32x2 b2 = *reinterpret_cast<const f32x2*>(sb + (4 * s4 + q) * FB_SA + 2 * i);
+            bv[0] = b2[0]; bv[1] = b2[1];
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma16(av[mb], bv[nb], acc[mb][nb]);
+    }
+}
+
+// acc[mb] += W[16 mb + i][k] * act[item][k] with W as a fragment-ordered LDS image of KB k blocks per row block.
+template <int MB, int KB>
+__device__ __forceinline__ void fb_gemm(const float* __restrict__ img, const f32x4 (&bop)[KB], f32x4 (&acc)[MB], int lane) {
+#pragma unroll
+    for (int a = 0; a < KB; ++a) {
+        f32x4 wv[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) wv[mb] = ld4(img + ((mb * KB + a) * 64 + lane) * 4);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(wv[mb][b], bop[a][b], acc[mb]);
+        }
+    }
+}
+
+// LDS-DMA of a [16 MB][16 KB] weight block (row stride src_ld floats, 16-byte aligned rows) into a fragment-ordered
+// image: fragment f = mb * KB + a is one global_load_lds_dwordx4 of the wave that owns it (f mod 4 == wave); no
+// registers, nothing to wait for until the image is read (s_waitcnt vmcnt(0) + barrier by the caller).
+template <int MB, int KB>
+__device__ __forceinline__ void fb_stage_frags(float* img, const float* __restrict__ w, int src_ld, int wave, int lane) {
+    const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int f0 = 0; f0 < MB * KB; f0 += 4) {
+        const int f = f0 + wave;
+        if (f < MB * KB) {
+            const int mb = f / KB, a = f % KB;
+            const float* src = w + (size_t)(16 * mb + i) * src_ld + 16 * a + 4 * q;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(img + f * 256), 16, 0, 0);
+        }
+    }
+}
+
+#ifdef AETHER_FUSED_STAMPS
+#define FB_STAMP(id)                                                                             \
+    do {                                                                                         \
+        if (tid == 0 && blockIdx.x < 4096)                                                       \
+            A.stamps[blockIdx.x * FUSED_STAMPS + (id)] = (float)(wall_clock64() - t_entry) * 0.01f; \
+    } while (0)
+#define FB_WSTAMP(id)                                                                            \
+    do {                                                                                         \
+        if (lane == 0 && blockIdx.x < 4096)                                                      \
+            A.stamps[blockIdx.x * FUSED_STAMPS + 64 + wave * 100 + (id)] = (float)(wall_clock64() - t_entry) * 0.01f; \
+    } while (0)
+#else
+#define FB_STAMP(id)
+#define FB_WSTAMP(id)
+#endif
+
+template <int ROUNDS>
+__global__ void __launch_bounds__(FB_THREADS)
+k_fused_bwd(FbArgs A) {
+    using L = FbLds;
+    constexpr int NWV = 4;
+    constexpr bool DE_REGS = ROUNDS <= 3;     // message gradients carried in registers (else: through the A.DE scratch)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wE = smem + L::WE;
+    float* w2 = smem + L::W2;
+    float* w2t = smem + L::W2T;
+    float* wEt = smem + L::WET;
+    float* bias = smem + L::BIAS;
+    float* psb = smem + L::PSB;
+    float* prb = smem + L::PRB;
+    float* dns = smem + L::DNS;
+    float* invd = smem + L::INVD;
+    float* dxs = smem + L::DXS;
+    float* dpus = smem + L::DPU;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+#ifdef AETHER_FUSED_STAMPS
+    const unsigned long long t_entry = wall_clock64();
+#endif
+    const FusedWG wg = A.wgdesc[blockIdx.x];
+    const int vb = wg.vb, nv = wg.ve - wg.vb;
+    const int nb = wg.nb, n = wg.ne - wg.nb, off = nb - vb;
+    const int eb = A.rowptr[nb], m = A.rowptr[wg.ne] - eb;
+    const int n_tiles = (m + 15) >> 4;
+    const int na = wg.na;
+    const bool split = wg.partner >= 0;
+    const int nbk = n > 16 ? 2 : 1;                      // node tiles of the own range
+    float* sa = smem + L::STG + wave * (3 * 16 * FB_SA);     // dpre2, then G
+    float* sb = sa + 16 * FB_SA;                               // h
+    float* sc = sb + 16 * FB_SA;                               // e_prev (layer 1: the edge features)
+
+    // ---------------------------------------------------------------- per-tile structure (rounds r: tile 4r + wave)
+    int ke[ROUNDS], sl[ROUNDS], rl[ROUNDS];
+    unsigned inc[ROUNDS];                    // bits 0-7: sender incidence (s4 + 4 * node block), 8-15: receiver incidence
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int local = 16 * (NWV * r + wave) + i;
+        const bool ok = local < m;
+        const int k = ok ? eb + A.lorder[eb + local] : eb;
+        ke[r] = ok ? k : -1;
+        sl[r] = m > 0 ? A.send_s[k] - vb : 0;
+        rl[r] = m > 0 ? A.recv_s[k] - nb : 0;
+        unsigned bits = 0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int e_lane = (lane & 48) + 4 * s4 + q;            // lane of this 16-group that holds edge 4 s4 + q
+            const int es = __shfl(sl[r], e_lane), er = __shfl(rl[r], e_lane), ek = __shfl(ke[r], e_lane);
+            if (ek >= 0) {
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    if (es == 16 * b2 + i) bits |= 1u << (s4 + 4 * b2);
+                    if (er == 16 * b2 + i) bits |= 1u << (8 + s4 + 4 * b2);
+                }
+            }
+        }
+        inc[r] = bits;
+    }
+    if (tid < FUSED_MAX_NODES) {
+        float v = 1.0f;
+        if (tid < n) {
+            const int4 nr = *reinterpret_cast<const int4*>(A.nrange + 4 * (int64_t)(nb + tid));
+            const int deg = (nr.y - nr.x) + (nr.w - nr.z);
+            v = 1.0f / (float)(deg > 1 ? deg : 1);
+        }
+        invd[tid] = v;
+    }
+    // dx_4 of the own nodes -> LDS (rows of unused slots zero)
+    for (int idx = tid; idx < FUSED_MAX_NODES * 16; idx += FB_THREADS) {
+        const int s = idx >> 4, c = (idx & 15) * 4;
+        st4(dxs + s * LDW + c, s < n ? ld4(A.dx4 + (int64_t)(nb + s) * H + c) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    __syncthreads();
+
+    FB_STAMP(0);
+    f32x4 de[DE_REGS ? ROUNDS : 1][4];       // dL/d(message tile) carried from layer l+1 to layer l
+    int published = 0;                       // layers whose partial dP_s rows this workgroup's waves have published
+
+    // ================================================================ one layer of the backward
+    auto layer = [&](auto first_tag, const int l) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int NBE = FIRST ? 2 : 4;                       // 16-wide blocks of the edge-side product operand
+        const FbLayer Lp = A.layer[l - 1];
+        // Per-layer copies of the thread coordinates behind an opaque barrier: every address derived from them is
+        // recomputed in this layer instead of being hoisted out of the layer loop and kept (= spilled) for the whole
+        // kernel; a spill reload waits for all global loads in flight (vmcnt counts in order).
+        int tid_o = threadIdx.x;
+        asm volatile("" : "+v"(tid_o));
+        const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int i = lane & 15, q = lane >> 4;
+        float* sa = smem + L::STG + wave * (3 * 16 * FB_SA);
+        float* sb = sa + 16 * FB_SA;
+        float* sc = sb + 16 * FB_SA;
+        // ------------------------------------------------------------ node update backward (locs.py:240-241)
+        // x_l = n + W4 silu(W3 n + b3) + b4:  dpre_u = (W4^T dx) * silu'(pre_u),  dn = dx + W3^T dpre_u
+        {
+            const float* w3 = Lp.upd_w0;
+            const float* b3 = Lp.upd_b0;
+            const float* w4t = Lp.w4t;
+            const float* w3t = Lp.w3t;
+            f32x4 w3f[2][4], w4f[2][4], w3tf[8], b3v[2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int mb = 2 * wave + mm;
+                b3v[mm] = ld4(b3 + 16 * mb + 4 * q);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    w3f[mm][a] = ld4(w3 + (size_t)(16 * mb + i) * H + 16 * a + 4 * q);
+                    w4f[mm][a] = ld4(w4t + (size_t)(16 * mb + i) * H + 16 * a + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) w3tf[a] = ld4(w3t + (size_t)(16 * wave + i) * (2 * H) + 16 * a + 4 * q);
+            FB_STAMP(40 + 4 * (4 - l));
+            // this layer's edge weights -> LDS by LDS-DMA (the images were free since the end of the previous layer);
+            // nothing waits for them until the barrier that ends the node phase
+            if constexpr (FIRST) {
+                // W1 [64][F1] has unaligned rows: through registers, zero padded to K = 32 (fragments [mb 4][a 2])
+#pragma unroll
+                for (int f0 = 0; f0 < 8; f0 += 4) {
+                    const int f = f0 + wave, mb = f >> 1, a = f & 1;
+                    f32x4 v;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int c = 16 * a + 4 * q + b;
+                        v[b] = c < A.f1 ? Lp.msg_w0[(16 * mb + i) * A.f1 + c] : 0.0f;
+                    }
+                    st4(wE + (f * 64 + lane) * 4, v);
+                }
+                fb_stage_frags<2, 4>(wEt, Lp.w0t, H, wave, lane);
+                if (tid < H) bias[H + tid] = A.msg_b0_1[tid];
+            } else {
+                fb_stage_frags<4, 4>(wE, Lp.msg_w0 + 2 * H, 3 * H, wave, lane);
+                fb_stage_frags<4, 4>(wEt, Lp.w0t + 2 * H * H, H, wave, lane);
+                FB_STAMP(41 + 4 * (4 - l));
+                // P_s of the visible nodes, P_r of the own nodes (saved by the forward): 2 x 2 rows of 16 float4 per thread
+                f32x4 pv[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int idx = tid + FB_THREADS * j, sl0 = idx >> 4, c = (idx & 15) * 4;
+                    pv[j][0] = ld4(Lp.ps + (int64_t)(vb + (sl0 < nv ? sl0 : 0)) * H + c);
+                    pv[j][1] = ld4(Lp.pr + (int64_t)(nb + (sl0 < n ? sl0 : 0)) * H + c);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int idx = tid + FB_THREADS * j, sl0 = idx >> 4, c = (idx & 15) * 4;
+                    st4(psb + sl0 * LDW + c, pv[j][0]);
+                    st4(prb + sl0 * LDW + c, pv[j][1]);
+                }
+            }
+            FB_STAMP(42 + 4 * (4 - l));
+            fb_stage_frags<4, 4>(w2, Lp.msg_w2, H, wave, lane);
+            fb_stage_frags<4, 4>(w2t, Lp.w2t, H, wave, lane);
+            if (tid < H) bias[tid] = Lp.msg_b2[tid];
+            FB_STAMP(6 + 8 * (4 - l));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t < nbk) {
+                    const int slot = 16 * t + i;
+                    const int64_t node = nb + (slot < n ? slot : 0);
+                    f32x4 nt[4], dxv[4], pu[2], du[2];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        nt[a] = ld4(Lp.n + node * H + 16 * a + 4 * q);
+                        dxv[a] = ld4(dxs + slot * LDW + 16 * a + 4 * q);
+                    }
+                    f32x4 dn = ld4(dxs + slot * LDW + 16 * wave + 4 * q);      // dx rows 16 * wave .. (stage B)
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) { pu[mm] = b3v[mm]; du[mm] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+#pragma unroll
+                            for (int mm = 0; mm < 2; ++mm) {
+                                pu[mm] = mfma16(w3f[mm][a][b], nt[a][b], pu[mm]);
+                                du[mm] = mfma16(w4f[mm][a][b], dxv[a][b], du[mm]);
+                            }
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        const int mb = 2 * wave + mm;
+                        const f32x4 sg = sigmoid4(pu[mm]);
+                        const f32x4 u = pu[mm] * sg;
+                        const f32x4 dpu = du[mm] * dsilu_from_sigmoid(pu[mm], sg);
+                        if (slot < n) {
+                            st4(Lp.U + node * 2 * H + 16 * mb + 4 * q, u);
+                            st4(Lp.DPU + node * 2 * H + 16 * mb + 4 * q, dpu);
+                        }
+                        st4(dpus + slot * LDU + 16 * mb + 4 * q, dpu);
+                    }
+                    FB_STAMP(7 + 8 * (4 - l));
+                    lds_barrier();                                // dpre_u of this node tile complete
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
+                        const f32x4 bv = ld4(dpus + slot * LDU + 16 * a + 4 * q);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) dn = mfma16(w3tf[a][b], bv[b], dn);
+                    }
+                    st4(dns + slot * LDW + 16 * wave + 4 * q, dn);
+                    if (FIRST && slot < n) st4(A.DN1 + node * H + 16 * wave + 4 * q, dn);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA fragments have landed
+            lds_barrier();         // dn, weights, P rows, bias complete; dxs / dpus dead: staging rows are free
+        }
+        FB_STAMP(1 + 8 * (4 - l));
+
+        // ------------------------------------------------------------ edge tiles, last tile first
+        f32x4 aw2[4][4], awe[4][NBE];          // dW2 += dpre2 (x) h;  dW_e += G (x) e_prev   (dW1 += G (x) features)
+        f32x4 dps[2][4], dpr[2][4];            // sum of G over out-edges (visible slots) / in-edges (own slots)
+        f32x4 db2[4], db1[4];                  // per-lane column sums (edge i of every tile): reduced over lanes at the end
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+            for (int nbx = 0; nbx < 4; ++nbx) aw2[mb][nbx] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nbx = 0; nbx < NBE; ++nbx) awe[mb][nbx] = f32x4{0.f, 0.f, 0.f, 0.f};
+            db2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            db1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int nbx = 0; nbx < 4; ++nbx) { dps[b2][nbx] = f32x4{0.f, 0.f, 0.f, 0.f}; dpr[b2][nbx] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+        // Split mode: the wave's partial dP_s rows (all visible slots; the partner reads its own nodes' rows, which
+        // are final once the wave is through its tiles with partner senders) -> xchg, then one add on the counter.
+        auto publish = [&]() {
+            float* dst = A.xchg + (((size_t)(4 - l) * A.n_wgs + blockIdx.x) * NWV + wave) * (FUSED_MAX_NODES * H);
+            // transpose through the wave's staging rows: sa[node][h] (32 rows x 64 fit the 2 x 16 x FB_SA floats)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int nbx = 0; nbx < 4; ++nbx)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) sa[(16 * b2 + 4 * q + r4) * LDST + 16 * nbx + i] = dps[b2][nbx][r4];
+            __builtin_amdgcn_wave_barrier();
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, FUSED_MAX_NODES * H * 4, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = lane + 64 * j, row = idx >> 4, c = (idx & 15) * 4;
+                const f32x4 v = ld4(sa + row * LDST + c);
+                u32x4 bits;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) bits[r4] = __float_as_uint(v[r4]);
+                __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (row * H + c) * 4, 0, 16);     // aux 16 = sc1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_fetch_add(A.flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_wave_barrier();
+        };
+        static_assert(FUSED_MAX_NODES * LDST <= 3 * 16 * FB_SA, "publish transposes through the wave's staging rows");
+
+        bool need_publish = !FIRST && split;
+#pragma unroll
+        for (int r = ROUNDS - 1; r >= 0; --r) {
+            const int tile = NWV * r + wave;
+            if (need_publish && tile < n_tiles && 16 * (tile + 1) <= na) {         // no partner sender from here on
+                publish();
+                need_publish = false;
+            }
+            if (tile < n_tiles) {
+                FB_WSTAMP(20 * (4 - l) + 4 * r);
+                // Opaque copies: whatever is derived from them (a dozen LDS / global addresses per tile) is recomputed
+                // here instead of being hoisted out of the layer loop for all tiles at once -- hoisted, those values
+                // spill, and every spill reload waits for all global loads in flight (vmcnt counts in order).
+                int ker = ke[r], slr = sl[r], rlr = rl[r];
+                unsigned incr = inc[r];
+                asm volatile("" : "+v"(ker), "+v"(slr), "+v"(rlr), "+v"(incr));
+                const bool ok = ker >= 0;
+                const int64_t kc = ok ? ker : eb;
+                const float vm = ok ? 1.0f : 0.0f;
+                // ---- forward recompute: pre1, h = silu(pre1), pre2.  Operands of the weight-gradient products go to the
+                // wave's staging rows as soon as they exist, so that their registers die with the GEMM that reads them.
+                f32x4 ep[4], p1[4], ds1[4], hh[4], p2[4];
+                if constexpr (FIRST) {
+                    ep[0] = ld4(Lp.e_prev + kc * FPAD + 4 * q) * vm;
+                    ep[1] = ld4(Lp.e_prev + kc * FPAD + 16 + 4 * q) * vm;
+                    st4(sc + i * FB_SA + 4 * q, ep[0]);
+                    st4(sc + i * FB_SA + 16 + 4 * q, ep[1]);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(bias + H + 16 * mb + 4 * q);
+                    f32x4 b2[2] = {ep[0], ep[1]};
+                    fb_gemm<4, 2>(wE, b2, p1, lane);
+                } else {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        ep[mb] = ld4(Lp.e_prev + kc * H + 16 * mb + 4 * q) * vm;
+                        st4(sc + i * FB_SA + 16 * mb + 4 * q, ep[mb]);
+                        p1[mb] = ld4(psb + slr * LDW + 16 * mb + 4 * q) + ld4(prb + rlr * LDW + 16 * mb + 4 * q);
+                    }
+                    fb_gemm<4, 4>(wE, ep, p1, lane);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const f32x4 sg = sigmoid4(p1[mb]);
+                    hh[mb] = p1[mb] * sg;
+                    ds1[mb] = dsilu_from_sigmoid(p1[mb], sg);
+                    st4(sb + i * FB_SA + 16 * mb + 4 * q, hh[mb]);
+                    p2[mb] = ld4(bias + 16 * mb + 4 * q);
+                }
+                fb_gemm<4, 4>(w2, hh, p2, lane);
+                // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
+                f32x4 d2[4], dh[4], g[4];
+                const float sc_deg = invd[rlr] * vm;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    f32x4 dev = ld4(dns + rlr * LDW + 16 * mb + 4 * q) * sc_deg;
+                    if (l < 4) {
+                        if constexpr (DE_REGS) dev += de[r][mb];
+                        else dev += ld4(A.DE + kc * H + 16 * mb + 4 * q) * vm;       // (ROUNDS > 3: [E][64] scratch)
+                    }
+                    d2[mb] = dev * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
+                    dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    db2[mb] += d2[mb];
+                    st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
+                }
+                fb_gemm<4, 4>(w2t, d2, dh, lane);
+                // ---- dW2 += dpre2 (x) h
+                __builtin_amdgcn_wave_barrier();
+                fb_outer16<4>(sa, sb, aw2, i, q);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    g[mb] = dh[mb] * ds1[mb];
+                    st4(sa + i * FB_SA + 16 * mb + 4 * q, g[mb]);
+                    if constexpr (FIRST) db1[mb] += g[mb];
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- dW_e += G (x) e_prev (layer 1: dW1 += G (x) features), incidence sums of G
+                fb_outer16<NBE>(sa, sc, awe, i, q);
+                if constexpr (!FIRST) {
+                    // out[node][h] += sum_edge Inc[node][edge] * G[edge][h]: A = the lane's incidence bits, B = G staged
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const float* grow = sa + (4 * s4 + q) * FB_SA + i;
+                        float gv[4];
+#pragma unroll
+                        for (int nbx = 0; nbx < 4; ++nbx) gv[nbx] = grow[16 * nbx];
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            if (b2 == 0 || nv > 16) {
+                                const float sv = (incr >> (s4 + 4 * b2)) & 1u ? 1.0f : 0.0f;
+#pragma unroll
+                                for (int nbx = 0; nbx < 4; ++nbx) dps[b2][nbx] = mfma16(sv, gv[nbx], dps[b2][nbx]);
+                            }
+                            if (b2 == 0 || n > 16) {
+                                const float rv = (incr >> (8 + s4 + 4 * b2)) & 1u ? 1.0f : 0.0f;
+#pragma unroll
+                                for (int nbx = 0; nbx < 4; ++nbx) dpr[b2][nbx] = mfma16(rv, gv[nbx], dpr[b2][nbx]);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- gradient into this layer's edge input
+                if constexpr (FIRST) {
+                    f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                    fb_gemm<2, 4>(wEt, g, da, lane);
+                    if (ok) { st4(A.DA + kc * FPAD + 4 * q, da[0]); st4(A.DA + kc * FPAD + 16 + 4 * q, da[1]); }
+                } else {
+                    f32x4 dep[4];
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    fb_gemm<4, 4>(wEt, g, dep, lane);
+                    if constexpr (DE_REGS) {
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) de[r][mb] = dep[mb];
+                    } else if (ok) {
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) st4(A.DE + kc * H + 16 * mb + 4 * q, dep[mb]);
+                    }
+                }
+            }
+        }
+        if (need_publish) publish();
+        FB_WSTAMP(20 * (4 - l) + 16);
+
+        // ------------------------------------------------------------ reductions over the workgroup
+        lds_barrier();             // every wave is through its tiles: weight images and P rows are dead
+        FB_STAMP(2 + 8 * (4 - l));
+        if constexpr (!FIRST) {
+            // (1) incidence sums: per-wave dumps -> totals in wave order (+ the partner's four partials)
+            float* dump_s = smem + L::DUMP_S + wave * (FUSED_MAX_NODES * LDST);
+            float* dump_r = smem + L::DUMP_R + wave * (FUSED_MAX_NODES * LDST);
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int nbx = 0; nbx < 4; ++nbx)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        dump_s[(16 * b2 + 4 * q + r4) * LDST + 16 * nbx + i] = dps[b2][nbx][r4];
+                        dump_r[(16 * b2 + 4 * q + r4) * LDST + 16 * nbx + i] = dpr[b2][nbx][r4];
+                    }
+            if (split && tid == 0) {         // the partner's partials of this layer: 4 waves x (layers so far)
+                const int want = NWV * (5 - l);
+                unsigned spins = 0;
+                while (__hip_atomic_load(A.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) {
+                        if (A.errword) __hip_atomic_store(A.errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            lds_barrier();
+            const float* px = A.xchg + ((size_t)(4 - l) * A.n_wgs + (split ? wg.partner : 0)) * NWV * (FUSED_MAX_NODES * H);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, NWV * FUSED_MAX_NODES * H * 4, 0x00020000);
+            for (int idx = tid; idx < FUSED_MAX_NODES * 16; idx += FB_THREADS) {
+                const int s = idx >> 4, c = (idx & 15) * 4;         // own slot s
+                f32x4 ts = f32x4{0.f, 0.f, 0.f, 0.f}, tr = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s < n) {
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w) {
+                        ts += ld4(smem + L::DUMP_S + w * (FUSED_MAX_NODES * LDST) + (off + s) * LDST + c);
+                        tr += ld4(smem + L::DUMP_R + w * (FUSED_MAX_NODES * LDST) + s * LDST + c);
+                    }
+                    if (split) {
+#pragma unroll
+                        for (int w = 0; w < NWV; ++w) {
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                rsrc, ((w * FUSED_MAX_NODES + (off + s)) * H + c) * 4, 0, 16);          // aux 16 = sc1
+                            f32x4 f;
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) f[r4] = __uint_as_float(v[r4]);
+                            ts += f;
+                        }
+                    }
+                    st4(Lp.DPS + (int64_t)(nb + s) * H + c, ts);
+                    st4(Lp.DPR + (int64_t)(nb + s) * H + c, tr);
+                }
+                st4(psb + s * LDW + c, ts);        // totals as B operands of the dx GEMM (own slots)
+                st4(prb + s * LDW + c, tr);
+            }
+            lds_barrier();
+        }
+        FB_STAMP(3 + 8 * (4 - l));
+        // (2) edge-level weight gradients: waves 0, 1 write, waves 2, 3 add, everyone writes the partial out
+        {
+            float* red = smem + (wave & 1) * (2 * H * H);              // [dW2 64 x 64 | dW_e 64 x 64 (dW1: 64 x 32)]
+            auto dump = [&](bool add) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int mrow = 4 * (4 * q + r4) + mb;
+                        f32x4 v = f32x4{aw2[mb][0][r4], aw2[mb][1][r4], aw2[mb][2][r4], aw2[mb][3][r4]};
+                        float* d = red + mrow * H + 4 * i;
+                        if (add) v += ld4(d);
+                        st4(d, v);
+                        if constexpr (FIRST) {
+                            f32x2 v2 = f32x2{awe[mb][0][r4], awe[mb][1][r4]};
+                            f32x2* d2p = reinterpret_cast<f32x2*>(red + H * H + mrow * FPAD + 2 * i);
+                            if (add) v2 += *d2p;
+                            *d2p = v2;
+                        } else {
+                            f32x4 ve = f32x4{awe[mb][0][r4], awe[mb][1][r4], awe[mb][2][r4], awe[mb][3][r4]};
+                            float* de2 = red + H * H + mrow * H + 4 * i;
+                            if (add) ve += ld4(de2);
+                            st4(de2, ve);
+                        }
+                    }
+            };
+            // bias sums: lanes i = 0..15 of a q group hold the 16 edges of a tile position: add them up (DPP row
+            // reduction), then the four waves in order through LDS words behind the matrices
+            float* bred = smem + 2 * (2 * H * H);                     // [4 waves][128]
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    float s2 = db2[mb][r4], s1 = db1[mb][r4];
+#pragma unroll
+                    for (int o = 8; o >= 1; o >>= 1) { s2 += __shfl_xor(s2, o, 16); s1 += __shfl_xor(s1, o, 16); }
+                    if (i == 0) {
+                        bred[wave * 2 * H + 16 * mb + 4 * q + r4] = s2;
+                        bred[wave * 2 * H + H + 16 * mb + 4 * q + r4] = s1;
+                    }
+                }
+            if (wave < 2) dump(false);
+            lds_barrier();
+            if (wave >= 2) dump(true);
+            lds_barrier();
+            float* dst = A.partial + ((size_t)blockIdx.x * 4 + (l - 1)) * FB_PART;
+            for (int f = tid; f < 2 * H * H / 4; f += FB_THREADS)
+                st4(dst + 4 * f, ld4(smem + 4 * f) + ld4(smem + 2 * H * H + 4 * f));
+            if (tid < 2 * H)
+                dst[2 * H * H + tid] = ((bred[tid] + bred[2 * H + tid]) + bred[4 * H + tid]) + bred[6 * H + tid];
+        }
+        static_assert(2 * (2 * H * H) + 4 * 2 * H <= L::WEND + 2 * H, "reduction buffers fit the weight images (+ bias)");
+        FB_STAMP(4 + 8 * (4 - l));
+        // (3) dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed): rows 16 * wave ..
+        if constexpr (!FIRST) {
+            const float* w1t = Lp.w0t;                    // [192][64]: W_s^T | W_r^T | W_e^T
+            f32x4 wsf[4], wrf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                wsf[a] = ld4(w1t + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
+                wrf[a] = ld4(w1t + (size_t)H * H + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t >= nbk) continue;
+                const int slot = 16 * t + i;
+                f32x4 dx = ld4(dns + slot * LDW + 16 * wave + 4 * q);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 bs = ld4(psb + slot * LDW + 16 * a + 4 * q);
+                    const f32x4 br = ld4(prb + slot * LDW + 16 * a + 4 * q);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        dx = mfma16(wsf[a][b], bs[b], dx);
+                        dx = mfma16(wrf[a][b], br[b], dx);
+                    }
+                }
+                st4(dxs + slot * LDW + 16 * wave + 4 * q, dx);
+                if (slot < n) st4(Lp.DXout + (int64_t)(nb + slot) * H + 16 * wave + 4 * q, dx);
+            }
+        }
+        lds_barrier();             // dx_{l-1} complete; reduction buffers consumed: weight images are free again
+        FB_STAMP(5 + 8 * (4 - l));
+    };
+
+#pragma unroll 1
+    for (int l = 4; l >= 2; --l) layer(std::integral_constant<bool, false>{}, l);
+    layer(std::integral_constant<bool, true>{}, 1);
+    (void)published;
+    if (split && tid == 0)         // the partner's counter has been consumed for the last time: re-arm it
+        __hip_atomic_store(A.flags + wg.partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sum of the workgroups' partials in workgroup order: element e of (layer, FB_PART).  1024 threads = 256 elements x 4
+// groups; a group adds its contiguous quarter of the workgroups in order, the four sums are combined in order.
+struct FbReduceArgs {
+    const float* partial; int n_wgs;
+    float* w2[4]; float* b2[4];
+    float* we[4];              // layer 1: dW1 [64][f1]; layers 2-4: into msg_w0 + 2H (row stride 3H)
+    float* b1;                 // layer 1 only
+    int f1;
+};
+__global__ void __launch_bounds__(1024)
+k_fb_reduce(FbReduceArgs R) {
+    const int grp = threadIdx.x >> 8, e = blockIdx.x * 256 + (threadIdx.x & 255);
+    const int l = blockIdx.y;                      // layer index 0..3
+    const bool valid = e < FB_PART;
+    const int per = (R.n_wgs + 3) / 4;
+    const int c0 = grp * per, c1 = c0 + per < R.n_wgs ? c0 + per : R.n_wgs;
+    float s = 0.0f;
+    if (valid) {
+        const float* src = R.partial + (size_t)l * FB_PART + e;
+        int w = c0;
+        for (; w + 8 <= c1; w += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(w + u) * 4 * FB_PART];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; w < c1; ++w) s += src[(size_t)w * 4 * FB_PART];
+    }
+    __shared__ float red[4][256];
+    red[grp][threadIdx.x & 255] = s;
+    __syncthreads();
+    if (grp != 0 || !valid) return;
+    const int t = threadIdx.x & 255;
+    const float tot = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    if (e < H * H) {
+        R.w2[l][e] = tot;
+    } else if (e < 2 * H * H) {
+        const int o = e - H * H;
+        if (l == 0) {
+            const int mrow = o / FPAD, c = o % FPAD;
+            if (o < H * FPAD && c < R.f1) R.we[0][mrow * R.f1 + c] = tot;
+        } else {
+            R.we[l][(o >> 6) * (3 * H) + (o & 63)] = tot;
+        }
+    } else if (e < 2 * H * H + H) {
+        R.b2[l][e - 2 * H * H] = tot;
+    } else if (l == 0) {
+        R.b1[e - 2 * H * H - H] = tot;
+    }
+}
+
+}  // namespace

@@ -122,29 +122,42 @@ class _AetherStep(torch.autograd.Function):
         x, vel, charges, graph, ginfo, ws, n_edges = ctx.saved
         D = module.num_dims
         flat, gstruct, views = module._grad_buffers()
+        plist = module._plist if module._plist is not None else [p for _, p in module.named_parameters()]
+        # aether_backward OVERWRITES its destination.  When some .grad already IS a view of the flat buffer (a
+        # second backward without zero_grad, micro-batch accumulation, the module applied twice in one autograd
+        # graph), the kernels write into a second buffer and the result is added, as torch.autograd would.
+        aliased = module.grad_as_view and any(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                                              for p, v in zip(plist, views))
+        if aliased:
+            dst_flat, dst_struct, dst_views = module._grad_buffers(second=True)
+        else:
+            dst_flat, dst_struct, dst_views = flat, gstruct, views
         g = grad_out.to(torch.float32).contiguous()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        st = lib.aether_backward(C.byref(module._param_struct()), C.byref(gstruct), D, x.shape[0], n_edges,
+        st = lib.aether_backward(C.byref(module._param_struct()), C.byref(dst_struct), D, x.shape[0], n_edges,
                                  x.data_ptr(), vel.data_ptr(), charges.data_ptr(), graph.data_ptr(),
                                  C.byref(ginfo), ws.data_ptr(), ws.numel(), g.data_ptr(), stream)
         _lib.check(st, "aether_backward")
         if module.dp_group is not None:            # one fused all-reduce of the flat buffer (RCCL)
             import torch.distributed as dist
-            dist.all_reduce(flat, group=module.dp_group)
-            flat.div_(dist.get_world_size(module.dp_group))
+            dist.all_reduce(dst_flat, group=module.dp_group)
+            dst_flat.div_(dist.get_world_size(module.dp_group))
         # Hand the gradients over as views of the flat buffer (no 47 small copies): a parameter whose
-        # .grad is unset gets the view itself (like DDP's gradient_as_bucket_view); an existing .grad
-        # is accumulated into, as torch.autograd would.
+        # .grad is unset gets the view itself (like DDP's gradient_as_bucket_view); a .grad that already is
+        # that view is accumulated into in place; any other existing .grad is accumulated by autograd.
         need = ctx.needs_input_grad[_AetherStep.N_FIXED:]
         out = []
-        for p, v, n in zip(module.parameters(), views, need):
+        for p, v, dv, n in zip(plist, views, dst_views, need):
             if not n:
                 out.append(None)
-            elif module.grad_as_view and (p.grad is None or p.grad.data_ptr() == v.data_ptr()):
+            elif module.grad_as_view and p.grad is None and not aliased:
                 p.grad = v
                 out.append(None)
+            elif module.grad_as_view and p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                v.add_(dv)
+                out.append(None)
             else:
-                out.append(v.clone())
+                out.append(dv.clone())
         return (None,) * _AetherStep.N_FIXED + tuple(out)
 
 
@@ -221,6 +234,7 @@ class Aether(nn.Module):
         self._last_ws = None
         self._ws_key = None               # (workspace, shape, graph) of the last completed inference call
         self._gbuf = None
+        self._gbuf2 = None
         self._ws = None
         self._pstruct = None
         self._plist = None
@@ -238,6 +252,7 @@ class Aether(nn.Module):
         self._pstruct = None              # parameter storage may move (.to / .cuda / .float)
         self._plist = None
         self._gbuf = None
+        self._gbuf2 = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -270,14 +285,18 @@ class Aether(nn.Module):
             self._ws_bytes[key] = nbytes
         return nbytes
 
-    def _grad_buffers(self):
-        """Flat fp32 gradient buffer + an AetherParams struct and per-parameter views into it."""
-        if self._gbuf is not None and self._plist is not None and self._gbuf[0].device == self._plist[0].device:
-            return self._gbuf                 # parameter set and device unchanged (both reset _plist / _gbuf)
+    def _grad_buffers(self, second=False):
+        """Flat fp32 gradient buffer + an AetherParams struct and per-parameter views into it.  ``second``: a
+        scratch buffer of the same layout, the destination of a backward whose result has to be ADDED to gradients
+        that already live in the first one."""
+        slot = "_gbuf2" if second else "_gbuf"
+        cur = getattr(self, slot, None)
+        if cur is not None and self._plist is not None and cur[0].device == self._plist[0].device:
+            return cur                        # parameter set and device unchanged (both reset _plist / _gbuf)
         named = list(self.named_parameters())
         total = sum(p.numel() for _, p in named)
         dev = named[0][1].device
-        if self._gbuf is None or self._gbuf[0].device != dev or self._gbuf[0].numel() != total:
+        if cur is None or cur[0].device != dev or cur[0].numel() != total:
             # every tensor starts on a 16-byte boundary (the kernels use 16-byte accesses)
             offs, off = [], 0
             for _, p in named:
@@ -286,8 +305,9 @@ class Aether(nn.Module):
             flat = torch.zeros(off, dtype=torch.float32, device=dev)
             views = [flat[o:o + p.numel()].view_as(p) for o, (_, p) in zip(offs, named)]
             gstruct = _lib.params_struct({n: v for (n, _), v in zip(named, views)})
-            self._gbuf = (flat, gstruct, views)
-        return self._gbuf
+            cur = (flat, gstruct, views)
+            setattr(self, slot, cur)
+        return cur
 
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
@@ -314,6 +334,13 @@ class Aether(nn.Module):
         E = send.numel()
         if recv.numel() != E or edge_attr_orig.shape != (E, 2) or charges.numel() != n_nodes:
             raise ValueError("edge index / edge_attr / charges shapes do not match")
+        if torch.is_grad_enabled() and (x.requires_grad or vel.requires_grad or edge_attr_orig.requires_grad
+                                        or charges.requires_grad):
+            # the reference's forward is differentiable in x / vel (aether.py:169-186); the HIP backward produces
+            # parameter gradients only (the runner detaches its inputs, main.py:243-247): refuse rather than
+            # return a result whose input gradients would silently be missing
+            raise NotImplementedError("aether_amd.Aether: gradients w.r.t. x / vel / edge_attr_orig / charges are not "
+                                      "implemented (parameter gradients only); detach the inputs")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         graph = self.prepare_graph((send, recv), n_nodes)
         if self._plist is None:         # nn.Module.parameters() walks the module tree: 0.15 ms per call

@@ -291,6 +291,10 @@ class DynamicFieldAether(nn.Module):
             raise ValueError("x/vel must be [B * num_nodes, num_dims]")
         if recv.numel() != E or edge_attr_orig.shape != (E, 2) or charges.numel() != n_nodes:
             raise ValueError("edge index / edge_attr / charges shapes do not match")
+        if torch.is_grad_enabled() and (x.requires_grad or vel.requires_grad or edge_attr_orig.requires_grad
+                                        or charges.requires_grad):
+            raise NotImplementedError("aether_amd.DynamicFieldAether: gradients w.r.t. x / vel / edge_attr_orig / charges "
+                                      "are not implemented (parameter gradients only); detach the inputs")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         x, vel, ea, charges = f32(x), f32(vel), f32(edge_attr_orig), f32(charges)
         graph = self._graphs.get(send.contiguous(), recv.contiguous(), n_nodes)

@@ -73,10 +73,10 @@ typedef struct AetherGraphInfo {
 #define AETHER_FLAG_KEEP_INTERMEDIATES 1  /* also write nodeinfo, x0..x4, e1..e4 to the workspace */
 #define AETHER_FLAG_FORCE_STREAMED 2      /* use the layer-by-layer kernels even for small graphs */
 #define AETHER_FLAG_FORCE_FUSED 4         /* fail instead of falling back to the streamed kernels */
-/* The caller passes the workspace of an earlier, COMPLETED aether_forward call with the same n_nodes,
- * n_edges, num_dims and KEEP flag, and nothing else has written to it since.  The fused kernel leaves
- * its inter-workgroup hand-off words re-armed (zero) when it finishes, so the library can skip zeroing
- * them again (one memset node less per step).  Never set it for a fresh or re-purposed buffer. */
+/* Accepted and ignored since 0.4: the fused kernel's inter-workgroup hand-off words now live in the `graph` buffer
+ * (zeroed by aether_graph_build, re-armed by every launch that used them), so no call zeroes anything and a
+ * workspace may be re-purposed freely.  Consequence: two launches that use the SAME graph buffer must not run
+ * concurrently (different streams); build a second graph view for that. */
 #define AETHER_FLAG_WORKSPACE_REUSED 8
 
 /* Library / build identification (host string, static storage). */
@@ -570,6 +570,15 @@ int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_
  * share one block and split its k-groups, partial sums added in wave order; default 4, 1 turns it off).
  */
 int aether_set_option(const char* name, int value);
+
+/*
+ * A kernel cannot return a status.  The one bounded wait in the library -- a split-mode workgroup of the fused
+ * kernel polling for its partner's rows -- sets a word in host-mapped memory when it gives up (partner not
+ * resident within ~seconds); the results of that launch are then invalid.  Every launching entry point checks and
+ * clears the word first (so the NEXT call returns AETHER_EHIP), and this function does so on request, e.g. after
+ * synchronising the stream.  Returns AETHER_OK or AETHER_EHIP (message in aether_last_error).
+ */
+int aether_check_async_error(void);
 
 /*
  * Per-kernel timing for bench.py's roofline line: when enabled, every launch made by
