@@ -805,7 +805,7 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
         R.b1 = Gr.l1_msg_b0;
         R.f1 = F1;
         ProfScope ps(KB_FBRED, st);
-        k_fb_reduce<<<dim3((FB_PART + 255) / 256, 4), dim3(1024), 0, st>>>(R);
+        k_fb_reduce<<<dim3((FB_PART + 63) / 64, 4), dim3(1024), 0, st>>>(R);
     }
     HIP_OK(hipGetLastError());
     return AETHER_OK;

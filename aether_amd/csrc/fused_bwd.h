@@ -276,6 +276,40 @@ k_fused_bwd(FbArgs A) {
             const float* b3 = Lp.upd_b0;
             const float* w4t = Lp.w4t;
             const float* w3t = Lp.w3t;
+            // Issue order = wait order (vmcnt counts in order): LDS-DMA of the edge weights, then the small row loads
+            // whose data is needed first, then the node-phase weight fragments.  One memory round trip for all of it.
+            if constexpr (FIRST) {
+                fb_stage_frags<2, 4>(wEt, Lp.w0t, H, wave, lane);
+            } else {
+                fb_stage_frags<4, 4>(wE, Lp.msg_w0 + 2 * H, 3 * H, wave, lane);
+                fb_stage_frags<4, 4>(wEt, Lp.w0t + 2 * H * H, H, wave, lane);
+            }
+            fb_stage_frags<4, 4>(w2, Lp.msg_w2, H, wave, lane);
+            fb_stage_frags<4, 4>(w2t, Lp.w2t, H, wave, lane);
+            f32x4 pv[2][2], w1v[2];
+            float bv0 = 0.0f, bv1 = 0.0f;
+            if constexpr (FIRST) {
+                // W1 [64][F1] has unaligned rows: through registers, zero padded to K = 32 (fragments [mb 4][a 2])
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int f = 4 * j + wave, mb = f >> 1, a = f & 1;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int c = 16 * a + 4 * q + b;
+                        w1v[j][b] = c < A.f1 ? Lp.msg_w0[(16 * mb + i) * A.f1 + c] : 0.0f;
+                    }
+                }
+                if (tid < H) bv1 = A.msg_b0_1[tid];
+            } else {
+                // P_s of the visible nodes, P_r of the own nodes (saved by the forward): 2 x 2 rows of 16 float4 per thread
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int idx = tid + FB_THREADS * j, sl0 = idx >> 4, c = (idx & 15) * 4;
+                    pv[j][0] = ld4(Lp.ps + (int64_t)(vb + (sl0 < nv ? sl0 : 0)) * H + c);
+                    pv[j][1] = ld4(Lp.pr + (int64_t)(nb + (sl0 < n ? sl0 : 0)) * H + c);
+                }
+            }
+            if (tid < H) bv0 = Lp.msg_b2[tid];
             f32x4 w3f[2][4], w4f[2][4], w3tf[8], b3v[2];
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
@@ -289,36 +323,11 @@ k_fused_bwd(FbArgs A) {
             }
 #pragma unroll
             for (int a = 0; a < 8; ++a) w3tf[a] = ld4(w3t + (size_t)(16 * wave + i) * (2 * H) + 16 * a + 4 * q);
-            FB_STAMP(40 + 4 * (4 - l));
-            // this layer's edge weights -> LDS by LDS-DMA (the images were free since the end of the previous layer);
-            // nothing waits for them until the barrier that ends the node phase
             if constexpr (FIRST) {
-                // W1 [64][F1] has unaligned rows: through registers, zero padded to K = 32 (fragments [mb 4][a 2])
 #pragma unroll
-                for (int f0 = 0; f0 < 8; f0 += 4) {
-                    const int f = f0 + wave, mb = f >> 1, a = f & 1;
-                    f32x4 v;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int c = 16 * a + 4 * q + b;
-                        v[b] = c < A.f1 ? Lp.msg_w0[(16 * mb + i) * A.f1 + c] : 0.0f;
-                    }
-                    st4(wE + (f * 64 + lane) * 4, v);
-                }
-                fb_stage_frags<2, 4>(wEt, Lp.w0t, H, wave, lane);
-                if (tid < H) bias[H + tid] = A.msg_b0_1[tid];
+                for (int j = 0; j < 2; ++j) st4(wE + ((4 * j + wave) * 64 + lane) * 4, w1v[j]);
+                if (tid < H) bias[H + tid] = bv1;
             } else {
-                fb_stage_frags<4, 4>(wE, Lp.msg_w0 + 2 * H, 3 * H, wave, lane);
-                fb_stage_frags<4, 4>(wEt, Lp.w0t + 2 * H * H, H, wave, lane);
-                FB_STAMP(41 + 4 * (4 - l));
-                // P_s of the visible nodes, P_r of the own nodes (saved by the forward): 2 x 2 rows of 16 float4 per thread
-                f32x4 pv[2][2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int idx = tid + FB_THREADS * j, sl0 = idx >> 4, c = (idx & 15) * 4;
-                    pv[j][0] = ld4(Lp.ps + (int64_t)(vb + (sl0 < nv ? sl0 : 0)) * H + c);
-                    pv[j][1] = ld4(Lp.pr + (int64_t)(nb + (sl0 < n ? sl0 : 0)) * H + c);
-                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int idx = tid + FB_THREADS * j, sl0 = idx >> 4, c = (idx & 15) * 4;
@@ -326,10 +335,7 @@ k_fused_bwd(FbArgs A) {
                     st4(prb + sl0 * LDW + c, pv[j][1]);
                 }
             }
-            FB_STAMP(42 + 4 * (4 - l));
-            fb_stage_frags<4, 4>(w2, Lp.msg_w2, H, wave, lane);
-            fb_stage_frags<4, 4>(w2t, Lp.w2t, H, wave, lane);
-            if (tid < H) bias[tid] = Lp.msg_b2[tid];
+            if (tid < H) bias[tid] = bv0;
             FB_STAMP(6 + 8 * (4 - l));
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -431,6 +437,26 @@ k_fused_bwd(FbArgs A) {
         };
         static_assert(FUSED_MAX_NODES * LDST <= 3 * 16 * FB_SA, "publish transposes through the wave's staging rows");
 
+        // e_prev rows of a tile (layer 1: its feature rows), requested one tile ahead: the single wave of a SIMD has
+        // nothing else to hide a memory round trip behind
+        auto load_ep = [&](int rr, f32x4 (&dst)[4]) {
+            const int kr = ke[rr];
+            const int64_t kc = kr >= 0 ? kr : eb;
+            if constexpr (FIRST) {
+                dst[0] = ld4(Lp.e_prev + kc * FPAD + 4 * q);
+                dst[1] = ld4(Lp.e_prev + kc * FPAD + 16 + 4 * q);
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) dst[mb] = ld4(Lp.e_prev + kc * H + 16 * mb + 4 * q);
+            }
+        };
+        f32x4 epn[4];
+        {
+            bool have = false;                                 // the wave's first tile = its highest existing round
+#pragma unroll
+            for (int r = ROUNDS - 1; r >= 0; --r)
+                if (!have && NWV * r + wave < n_tiles) { load_ep(r, epn); have = true; }
+        }
         bool need_publish = !FIRST && split;
 #pragma unroll
         for (int r = ROUNDS - 1; r >= 0; --r) {
@@ -453,9 +479,10 @@ k_fused_bwd(FbArgs A) {
                 // ---- forward recompute: pre1, h = silu(pre1), pre2.  Operands of the weight-gradient products go to the
                 // wave's staging rows as soon as they exist, so that their registers die with the GEMM that reads them.
                 f32x4 ep[4], p1[4], ds1[4], hh[4], p2[4];
+#pragma unroll
+                for (int mb = 0; mb < (FIRST ? 2 : 4); ++mb) ep[mb] = epn[mb] * vm;
+                if (r > 0) load_ep(r > 0 ? r - 1 : 0, epn);      // tile r exists, so does tile r - 1
                 if constexpr (FIRST) {
-                    ep[0] = ld4(Lp.e_prev + kc * FPAD + 4 * q) * vm;
-                    ep[1] = ld4(Lp.e_prev + kc * FPAD + 16 + 4 * q) * vm;
                     st4(sc + i * FB_SA + 4 * q, ep[0]);
                     st4(sc + i * FB_SA + 16 + 4 * q, ep[1]);
 #pragma unroll
@@ -465,12 +492,12 @@ k_fused_bwd(FbArgs A) {
                 } else {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) {
-                        ep[mb] = ld4(Lp.e_prev + kc * H + 16 * mb + 4 * q) * vm;
                         st4(sc + i * FB_SA + 16 * mb + 4 * q, ep[mb]);
                         p1[mb] = ld4(psb + slr * LDW + 16 * mb + 4 * q) + ld4(prb + rlr * LDW + 16 * mb + 4 * q);
                     }
                     fb_gemm<4, 4>(wE, ep, p1, lane);
                 }
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(90);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     const f32x4 sg = sigmoid4(p1[mb]);
@@ -479,7 +506,9 @@ k_fused_bwd(FbArgs A) {
                     st4(sb + i * FB_SA + 16 * mb + 4 * q, hh[mb]);
                     p2[mb] = ld4(bias + 16 * mb + 4 * q);
                 }
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(91);
                 fb_gemm<4, 4>(w2, hh, p2, lane);
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(92);
                 // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
                 f32x4 d2[4], dh[4], g[4];
                 const float sc_deg = invd[rlr] * vm;
@@ -495,10 +524,13 @@ k_fused_bwd(FbArgs A) {
                     db2[mb] += d2[mb];
                     st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
                 }
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(93);
                 fb_gemm<4, 4>(w2t, d2, dh, lane);
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(94);
                 // ---- dW2 += dpre2 (x) h
                 __builtin_amdgcn_wave_barrier();
                 fb_outer16<4>(sa, sb, aw2, i, q);
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(95);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
@@ -508,7 +540,9 @@ k_fused_bwd(FbArgs A) {
                 }
                 __builtin_amdgcn_wave_barrier();
                 // ---- dW_e += G (x) e_prev (layer 1: dW1 += G (x) features), incidence sums of G
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(96);
                 fb_outer16<NBE>(sa, sc, awe, i, q);
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(97);
                 if constexpr (!FIRST) {
                     // out[node][h] += sum_edge Inc[node][edge] * G[edge][h]: A = the lane's incidence bits, B = G staged
 #pragma unroll
@@ -532,6 +566,7 @@ k_fused_bwd(FbArgs A) {
                         }
                     }
                 }
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(98);
                 __builtin_amdgcn_wave_barrier();
                 // ---- gradient into this layer's edge input
                 if constexpr (FIRST) {
@@ -720,10 +755,12 @@ struct FbReduceArgs {
 };
 __global__ void __launch_bounds__(1024)
 k_fb_reduce(FbReduceArgs R) {
-    const int grp = threadIdx.x >> 8, e = blockIdx.x * 256 + (threadIdx.x & 255);
+    // 64 elements x 16 groups per block: a group adds its contiguous sixteenth of the workgroups in order, the sixteen
+    // sums are combined in order -- a fixed tree; short dependent chains and 4 x 130 blocks to fill the chip
+    const int grp = threadIdx.x >> 6, t = threadIdx.x & 63, e = blockIdx.x * 64 + t;
     const int l = blockIdx.y;                      // layer index 0..3
     const bool valid = e < FB_PART;
-    const int per = (R.n_wgs + 3) / 4;
+    const int per = (R.n_wgs + 15) / 16;
     const int c0 = grp * per, c1 = c0 + per < R.n_wgs ? c0 + per : R.n_wgs;
     float s = 0.0f;
     if (valid) {
@@ -738,12 +775,13 @@ k_fb_reduce(FbReduceArgs R) {
         }
         for (; w < c1; ++w) s += src[(size_t)w * 4 * FB_PART];
     }
-    __shared__ float red[4][256];
-    red[grp][threadIdx.x & 255] = s;
+    __shared__ float red[16][64];
+    red[grp][t] = s;
     __syncthreads();
     if (grp != 0 || !valid) return;
-    const int t = threadIdx.x & 255;
-    const float tot = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    float tot = red[0][t];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) tot += red[g][t];
     if (e < H * H) {
         R.w2[l][e] = tot;
     } else if (e < 2 * H * H) {

@@ -45,4 +45,10 @@ for li, l in enumerate((4, 3, 2, 1)):
     for w in range(4):
         row = [med[64 + w * 100 + 20 * li + 4 * r] for r in (2, 1, 0)] + [med[64 + w * 100 + 20 * li + 16]]
         print(f"       wave {w}: tile starts (r=2,1,0) and end: " + " ".join(f"{x:8.2f}" for x in row))
+names = ["tile start", "GEMM1 (W_e e_prev)", "sigmoid, stage h", "GEMM2 (W2 h)", "dpre2, stage", "GEMM3 (W2^T)", "dW2 product",
+         "G, stage", "dW_e product", "incidence sums"]
+for w in range(4):
+    base = 64 + w * 100
+    v = [med[base + 20 * 1 + 4 * 2]] + [med[base + 90 + k] for k in range(9)]
+    print(f"  layer 3, wave {w}, first tile (us): " + " ".join(f"{nm}={b - a:.2f}" for nm, a, b in zip(names[1:], v[:-1], v[1:])))
 print(f"  kernel span: max {st[:, 8 * 3 + 5].max():.2f} us, median {med[8 * 3 + 5]:.2f}")
