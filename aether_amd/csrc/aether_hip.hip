@@ -238,6 +238,7 @@ constexpr int OUTER_MAX_CHUNKS = 256;      // workgroups (= partials) per task
 // Up to this many edges the backward keeps the operands of every layer's weight gradients alive and
 // multiplies all of them in one launch at the end (12 more [E, 64] buffers: 3 KiB per edge).
 int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defer_max_edges", n)
+int g_outer_tiles_per_wave = 0;                 // aether_set_option("outer_tiles_per_wave", n): 16-row tiles per wave of k_outer (0: by task size)
 int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
 int g_linear_kwaves = 4;                        // aether_set_option("linear_kwaves", 1 | 4): waves of a workgroup that split a small layer's k-groups
 int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the filter GEMM
@@ -473,7 +474,10 @@ int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st) 
     size_t next_part = 0;
     for (OuterTask& t : L.tasks) {
         int64_t tiles = (t.rows + 15) / 16;
-        int64_t chunks = (tiles + 3) / 4;               // one row tile per wave until the chunk cap: short MFMA chains
+        // row tiles per wave: 1 for the edge-level products (measured), 4 for node-level ones, whose
+        // 35 KB partial per workgroup otherwise outweighs their operands (29 -> 22 us per step at cfg2)
+        const int tpw = g_outer_tiles_per_wave > 0 ? g_outer_tiles_per_wave : (t.rows > 16384 ? 1 : 4);
+        int64_t chunks = (tiles + 4 * tpw - 1) / (4 * tpw);
         if (chunks < 1) chunks = 1;
         if (chunks > OUTER_MAX_CHUNKS) chunks = OUTER_MAX_CHUNKS;
         t.chunks = (int)chunks;
@@ -836,6 +840,11 @@ int aether_set_option(const char* name, int value) {
     if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces
         if (value < 0) return fail(AETHER_EINVAL, "set_option: outer_defer_max_edges must be >= 0");
         g_outer_defer_max_edges = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "outer_tiles_per_wave")) {
+        if (value < 0 || value > 64) return fail(AETHER_EINVAL, "set_option: outer_tiles_per_wave must be 0..64");
+        g_outer_tiles_per_wave = value;
         return AETHER_OK;
     }
     if (!strcmp(name, "linear_small_wgs")) {

@@ -294,7 +294,7 @@ class Aether(nn.Module):
         if cur is not None and self._plist is not None and cur[0].device == self._plist[0].device:
             return cur                        # parameter set and device unchanged (both reset _plist / _gbuf)
         named = list(self.named_parameters())
-        total = sum(p.numel() for _, p in named)
+        total = sum((p.numel() + 3) // 4 * 4 for _, p in named)       # every tensor padded to 16 bytes (below)
         dev = named[0][1].device
         if cur is None or cur[0].device != dev or cur[0].numel() != total:
             # every tensor starts on a 16-byte boundary (the kernels use 16-byte accesses)

@@ -5,6 +5,11 @@ optimizer step as ~40 separate launches; on the MI355X the step is then bound by
 0.4 ms of kernels at N=20, batch=128).  ``GraphedTrainStep`` captures forward + HIP backward + a capturable fused
 AdamW once (``torch.cuda.CUDAGraph``) on static input buffers and replays it: same arithmetic, one launch per step.
 Shapes and the edge index are fixed at construction (the runner's batches have a fixed shape, main.py:211-212).
+
+Data-parallel (``aether_amd.parallel.attach_data_parallel`` was called on the model): the collective stays outside the
+graphs -- forward + backward replay as one graph, the flat gradient buffer is all-reduced eagerly (RCCL) on the same
+stream, the optimizer replays as a second graph.  Every rank still pays two graph launches + one collective instead of
+~45 eager launches.
 """
 from __future__ import annotations
 
@@ -23,6 +28,13 @@ class GraphedTrainStep:
         self.args = [a.clone() if isinstance(a, torch.Tensor) else a for a in example_args]
         self.target = example_target.clone()
         self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=True)
+        # data-parallel: the step owns the collective from here on (the module's backward no longer issues it)
+        self.dp_group = getattr(model, "dp_group", None)
+        if self.dp_group is not None:
+            if not hasattr(model, "_grad_buffers"):
+                raise ValueError("data-parallel GraphedTrainStep needs a model with one flat gradient buffer (Aether)")
+            model.dp_group = None
+        self.allreduce_events = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                         # warm-up off the capture: lazy initialisation, workspaces
@@ -31,9 +43,18 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self.loss = self._forward_backward()
-            self.optimizer.step()
+        if self.dp_group is None:
+            self.opt_graph = None
+            with torch.cuda.graph(self.graph):
+                self.loss = self._forward_backward()
+                self.optimizer.step()
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._forward_backward()
+            self.flat = model._grad_buffers()[0]          # the .grad tensors are views of it (grad_as_view)
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph):
+                self.optimizer.step()
 
     def _forward_backward(self):
         out = self.model(*self.args)
@@ -41,9 +62,19 @@ class GraphedTrainStep:
         loss.backward()
         return loss
 
+    def _allreduce(self):
+        import torch.distributed as dist
+        flat = getattr(self, "flat", None)
+        if flat is None:
+            flat = self.model._grad_buffers()[0]
+        dist.all_reduce(flat, group=self.dp_group)
+        flat.div_(dist.get_world_size(self.dp_group))
+
     def _eager(self):
         self.optimizer.zero_grad(set_to_none=True)
         loss = self._forward_backward()
+        if self.dp_group is not None:
+            self._allreduce()
         self.optimizer.step()
         return loss
 
@@ -57,4 +88,15 @@ class GraphedTrainStep:
         if target is not None:
             self.target.copy_(target)
         self.graph.replay()
+        if self.dp_group is not None:
+            if self.allreduce_events is not None:
+                self.allreduce_events[0].record()
+            self._allreduce()
+            if self.allreduce_events is not None:
+                self.allreduce_events[1].record()
+            self.opt_graph.replay()
         return self.loss
+
+    def time_allreduce(self, on=True):
+        """Bracket the collective of the following steps with a pair of events (``allreduce_events``)."""
+        self.allreduce_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if on else None)

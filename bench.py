@@ -360,12 +360,14 @@ def main():
                     help="BASELINE.json configuration: cfg1 2-D N=5 B=1, cfg2 (default) 2-D N=20 B=128, cfg3 3-D N=20 B=128, "
                          "cfg5shard 2-D N=1024 B=32 (one GPU's share of config 5, streamed path)")
     args = ap.parse_args()
+    args.big = False
     if args.config is not None:
         args.dims, args.nodes, args.batch = {"cfg1": (2, 5, 1), "cfg2": (2, 20, 128), "cfg3": (3, 20, 128),
                                              "cfg5shard": (2, 1024, 32)}[args.config]
         if args.config == "cfg5shard":                # 33.5 M edges: a step is 25 ms, the CPU legs would take minutes
-            args.no_cpu_baseline, args.no_train, args.no_rollout = True, True, True
+            args.no_cpu_baseline, args.no_rollout = True, True
             args.steps, args.warmup = min(args.steps, 20), min(args.warmup, 3)
+            args.big = True                           # training figure from 3 eager steps (a backward is ~0.1 s here)
     if args.seq2seq:
         return _seq2seq_line(args)
 
@@ -563,38 +565,29 @@ def main():
             loss = torch.nn.functional.mse_loss(o, tgt)
             loss.backward()
             opt.step()
-        tsteps = max(10, args.steps // 4)
-        for _ in range(5):
+        tsteps = 3 if args.big else max(10, args.steps // 4)
+        for _ in range(1 if args.big else 5):
             tstep()
         torch.cuda.synchronize()
         train_launch = "eager"
-        if use_graph and world == 1:
-            # whole training step (forward, HIP backward, AdamW) as one hipGraph replay
+        gstep = None
+        if use_graph and not args.big:
+            # whole training step as hipGraph replays (aether_amd.training.GraphedTrainStep): one graph at N = 1; with
+            # N > 1 forward + backward replay as one graph, the flat gradient buffer is all-reduced eagerly (RCCL),
+            # the fused AdamW replays as a second graph
             try:
-                opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12, capturable=True, fused=True)
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(3):
-                        opt.zero_grad(set_to_none=True)
-                        o = call()
-                        torch.nn.functional.mse_loss(o, tgt).backward()
-                        opt.step()
-                torch.cuda.current_stream().wait_stream(side)
-                tg = torch.cuda.CUDAGraph()
-                opt.zero_grad(set_to_none=True)
-                with torch.cuda.graph(tg):
-                    o = call()
-                    torch.nn.functional.mse_loss(o, tgt).backward()
-                    opt.step()
+                from aether_amd.training import GraphedTrainStep
+                gstep = GraphedTrainStep(model, [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]],
+                                         tgt, lr=5e-4, weight_decay=1e-12)
                 eager_tstep = tstep
-                tstep = tg.replay
+                tstep = gstep.step
                 for _ in range(3):
                     tstep()
                 torch.cuda.synchronize()
-                train_launch = "hipgraph"
+                train_launch = "hipgraph" if world == 1 else "hipgraph (forward + backward) + eager all-reduce + hipgraph (AdamW)"
             except Exception as ex:          # keep the eager figure if capture is not possible
                 print("train-step graph capture failed:", repr(ex), file=sys.stderr)
+                gstep = None
                 torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -611,17 +604,33 @@ def main():
             t = torch.tensor([tdt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tdt = float(t.item())
-        train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps,
+        coll = None
+        if world > 1:
+            # the collective alone: the flat gradient buffer of the model, timed with events on the compute stream
+            flat = model._grad_buffers()[0]
+            grp = gstep.dp_group if gstep is not None else model.dp_group
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for _ in range(3):
+                dist.all_reduce(flat, group=grp)
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(20):
+                dist.all_reduce(flat, group=grp)
+            ev[1].record()
+            torch.cuda.synchronize()
+            coll = {"backend": dist.get_backend(grp), "world_size": dist.get_world_size(grp),
+                    "allreduce_bytes": flat.numel() * 4, "allreduce_us": 1e3 * ev[0].elapsed_time(ev[1]) / 20}
+        train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps, "collective": coll,
                  "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
                  "includes": "forward + HIP backward + " + ("RCCL grad all-reduce + " if world > 1 else "")
                              + "torch AdamW, " + train_launch + " launches"}
         if rank == 0:       # per-kernel breakdown of one training step (rank-local: no collective in here)
-            saved_group, model.dp_group = model.dp_group, None
+            saved_group, model.dp_group = model.dp_group, None       # (GraphedTrainStep already detached it)
             lib = _lib.load()
             nk = lib.aether_profile_kernels()
             lib.aether_profile_enable(1)
-            ks = 10
-            if train_launch == "hipgraph":
+            ks = 2 if args.big else 10
+            if gstep is not None:
                 tstep = eager_tstep
             for _ in range(ks):
                 tstep()
