@@ -58,6 +58,7 @@ FLAG_KEEP_INTERMEDIATES = 1
 FLAG_FORCE_STREAMED = 2
 FLAG_FORCE_FUSED = 4
 FLAG_WORKSPACE_REUSED = 8
+FLAG_WEIGHTS_PREPARED = 16
 
 # name -> (restype, argtypes); every symbol include/aether_hip.h declares
 SIGNATURES = {

@@ -246,7 +246,7 @@ int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_
 
 struct WsLayout {
     // forward (always)
-    size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, part, stamps, flags, velbuf[2], fwd_total;
+    size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, part, stamps, flags, velbuf[2], wimg, fwd_total;
     // saved by the forward under KEEP_INTERMEDIATES for the backward
     size_t n[4], feat;
     // backward temporaries
@@ -273,6 +273,7 @@ struct WsLayout {
         stamps = take((size_t)4096 * FUSED_STAMPS);
         flags = take(2 * nn + 64);              // split-mode hand-off flags, one int per workgroup
         for (auto& v : velbuf) v = take(nn * 4);    // aether_rollout: velocities of the steps, ping-pong
+        wimg = take(FUSED_WIMG_SET);                // split (3 x bf16) images of the edge-MLP weights (k_split_weights)
         fwd_total = off;
         for (auto& v : n) v = take(nn * H);
         feat = take(ee * FPAD);
@@ -334,7 +335,7 @@ int fused_launch(const AetherParams& P, const float* x, const float* vel, const 
 template <int D>
 int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphInfo& info, const float* x,
                const float* vel, const float* charges, const float* ea, const char* graph, char* ws,
-               float* out, bool keep, bool ws_reused, StepExtras step, hipStream_t st) {
+               float* out, bool keep, bool ws_reused, StepExtras step, hipStream_t st, bool weights_prepared = false) {
     GraphLayout G(E, Nn, false);
     WsLayout W(Nn, E, D, keep);
     auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(graph + off); };
@@ -351,12 +352,17 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     // never touched by anything else -- no memset per call, whatever else the caller does with the workspace
     dbg.flags = reinterpret_cast<int*>(const_cast<char*>(graph) + G.hflags);
     dbg.errword = async_error_word();
+    dbg.wimg = wp(W.wimg);
     dbg.step = step;
     const FusedWG* wgd = reinterpret_cast<const FusedWG*>(graph + G.wgdesc);
     const uint32_t* tsel = reinterpret_cast<const uint32_t*>(graph + G.tsel);
     const uint32_t* tdst = reinterpret_cast<const uint32_t*>(graph + G.tdst);
     (void)ws_reused;
     const int tiles = (info.max_group_edges + 15) / 16;
+    if (tiles <= 16 && !weights_prepared) {     // split-GEMM variants: 3 x bf16 images of the eight edge-MLP matrices
+        constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+        k_split_weights<<<dim3(8), dim3(512), 0, st>>>(P, F1, wp(W.wimg));
+    }
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
@@ -1093,13 +1099,14 @@ static int forward_common(const AetherParams* params, int num_dims, int64_t n_no
         return fail(AETHER_EINVAL, "forward: fused path requested but the graph has no groups");
     const bool keep = (flags & AETHER_FLAG_KEEP_INTERMEDIATES) != 0;
     const bool reused = (flags & AETHER_FLAG_WORKSPACE_REUSED) != 0;
+    const bool prepared = (flags & AETHER_FLAG_WEIGHTS_PREPARED) != 0;
     const StepExtras no_extras{nullptr, nullptr, 1.0f, field};
     if (fused) {
         if (num_dims == 2)
             return fused_impl<2>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,
-                                 (const char*)graph, (char*)workspace, out, keep, reused, no_extras, st);
+                                 (const char*)graph, (char*)workspace, out, keep, reused, no_extras, st, prepared);
         return fused_impl<3>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,
-                             (const char*)graph, (char*)workspace, out, keep, reused, no_extras, st);
+                             (const char*)graph, (char*)workspace, out, keep, reused, no_extras, st, prepared);
     }
     if (num_dims == 2)
         return streamed_impl<2>(*params, n_nodes, n_edges, x, vel, charges, edge_attr_orig,
@@ -1173,12 +1180,13 @@ static int rollout_common(const AetherParams* params, const AetherDynFieldParams
         }
         StepExtras ex{charges, reinterpret_cast<float*>(ws + W.velbuf[t & 1]), dt, dyn ? field_buf : nullptr};
         const bool reused = t > 0 || (flags & AETHER_FLAG_WORKSPACE_REUSED);   // the step before re-armed the flags
+        const bool prepared = t > 0 || (flags & AETHER_FLAG_WEIGHTS_PREPARED);  // one weight conversion per rollout
         int rc;
         if (fused)
             rc = num_dims == 2 ? fused_impl<2>(*params, n_nodes, n_edges, *info, x, v, charges, nullptr, (const char*)graph,
-                                               ws, out, false, reused, ex, st)
+                                               ws, out, false, reused, ex, st, prepared)
                                : fused_impl<3>(*params, n_nodes, n_edges, *info, x, v, charges, nullptr, (const char*)graph,
-                                               ws, out, false, reused, ex, st);
+                                               ws, out, false, reused, ex, st, prepared);
         else
             rc = num_dims == 2 ? streamed_impl<2>(*params, n_nodes, n_edges, x, v, charges, nullptr, (const char*)graph, ws,
                                                   out, false, ex, st)

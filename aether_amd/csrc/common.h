@@ -90,6 +90,79 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ w, int ldw,
     }
 }
 
+// ------------------------------------------------------------------ fp32 contraction as six bf16 MFMA terms
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and on the vector ALUs: 32 cycles for 2,048 FLOP,
+// and every VALU instruction next to it costs matrix time.  v_mfma_f32_16x16x32_bf16 does 16,384 FLOP in 16 cycles on
+// the matrix pipe proper.  An fp32 operand x splits exactly into three bf16 pieces, x = hi + mid + lo + r with
+// |r| <= 2^-24 |x| (each piece: round-to-nearest of what the pieces before it left), and
+//     w * x = hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid   + terms <= 2^-22 |w x| relative to each other's sum,
+// each product of two bf16 being exact in fp32 and the MFMA accumulating in fp32.  Measured on the MI355X against an fp64
+// evaluation of the edge MLP (tools/micro/split_tile.hip): 2.3e-7 scale-relative vs 2.9e-7 for the fp32 MFMA chain --
+// the same fp32-level result, for 6 x 16 cycles per 32-deep k block instead of 8 x 32 (1.75 x on the tile's MLP).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16x3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+// The lane's B fragment of one 32-deep k block from two accumulator-layout blocks: element j < 4 is hidden unit
+// 32 kb + 4 q + j, element j >= 4 is 32 kb + 16 + 4 q + (j - 4).  The k order inside a block is thus a permutation
+// of the natural one; weight images (stage_split_*) are written in the same order.
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 h, m, l;
+        split_bf16x3(j < 4 ? v0[j] : v1[j - 4], h, m, l);
+        hi[j] = h; mid[j] = m; lo[j] = l;
+    }
+}
+// Weight image for split GEMMs: [term 3][row block mb][k block kb][lane 64] fragments of 8 bf16 (16 bytes); lane (m, q)
+// of fragment (mb, kb) holds W[16 mb + m][32 kb + 4 q + j] (j < 4) | W[16 mb + m][32 kb + 16 + 4 q + j].
+// `v` = W[row][col .. col + 3] (col a multiple of 4): one half-fragment (8 bytes) per term.
+template <int MBN, int KBN>
+__device__ __forceinline__ void stage_split4(float* img, int row, int col, const f32x4 v) {
+    const int mb = row >> 4, m = row & 15, kb = col >> 5, c5 = col & 31, half = c5 >> 4, qq = (c5 & 15) >> 2;
+    bf16x4 h, md, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 a, b, c;
+        split_bf16x3(v[j], a, b, c);
+        h[j] = a; md[j] = b; l[j] = c;
+    }
+    const int frag = (mb * KBN + kb) * 64 + m + 16 * qq;
+    constexpr int TERM = MBN * KBN * 64;                        // fragments per term
+    *reinterpret_cast<bf16x4*>(img + (frag) * 4 + half * 2) = h;
+    *reinterpret_cast<bf16x4*>(img + (TERM + frag) * 4 + half * 2) = md;
+    *reinterpret_cast<bf16x4*>(img + (2 * TERM + frag) * 4 + half * 2) = l;
+}
+// acc[mb] += W[16 mb + i][k] * act[item][k] over KBN 32-deep k blocks; act = 2 KBN accumulator-layout blocks.
+template <int MBN, int KBN>
+__device__ __forceinline__ void gemm_split(const float* __restrict__ img, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN],
+                                           int lane) {
+    constexpr int TERM = MBN * KBN * 64;
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(img);
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+        bf16x8 xh, xm, xl;
+        split8(act[2 * kb], act[2 * kb + 1], xh, xm, xl);
+#pragma unroll
+        for (int mb = 0; mb < MBN; ++mb) {
+            const int frag = (mb * KBN + kb) * 64 + lane;
+            const bf16x8 wh = w[frag], wm = w[TERM + frag], wl = w[2 * TERM + frag];
+            // small terms first
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[mb], 0, 0, 0);
+        }
+    }
+}
+
 // Cooperative copy of W[rows][cols] (global, row stride src_ld) into LDS [rows][ldw], zero padded.
 __device__ __forceinline__ void stage_weight(float* lds, const float* __restrict__ w, int rows,
                                              int cols, int src_ld, int ldw) {

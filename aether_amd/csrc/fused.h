@@ -27,10 +27,15 @@ constexpr int FUSED_MAX_EDGES = 384;         // 24 tiles (N=20 fully connected: 
 constexpr int FUSED_MAX_TILES = FUSED_MAX_EDGES / 16;
 constexpr int LDU = 2 * H + 8;               // padded LDS row for the 128-wide update hidden
 
+// The edge MLP's two 64 x 64 contractions run as six bf16 MFMA terms on split operands (common.h, gemm_split) wherever
+// the weight images fit (3 x 8 KB each instead of 18 KB of padded fp32): every variant but the 17-24 tile one.
+template <int ROUNDS> constexpr bool fused_split_gemm() { return ROUNDS < 3; }
+constexpr int FUSED_WIMG = 3 * 4 * 2 * 64 * 4;           // floats of a split image of a 64 x 64 matrix (24 KB)
 template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
-    static constexpr int WA = 0;                                   // [64][LDW]  W_e  (layer 1: W1, ld LDF)
-    static constexpr int WB = WA + H * LDW;                        // [64][LDW]  W2
-    static constexpr int BIAS = WB + H * LDW;                      // [128]      b1 | b2
+    static constexpr int WSZ = fused_split_gemm<ROUNDS>() ? FUSED_WIMG : H * LDW;
+    static constexpr int WA = 0;                                   // W_e  (layer 1: W1): [64][LDW] fp32 (ld LDF) | split image
+    static constexpr int WB = WA + WSZ;                            // W2
+    static constexpr int BIAS = WB + WSZ;                          // [128]      b1 | b2
     static constexpr int XBUF = BIAS + 2 * H;                      // [32][LDW]  x_{l-1} / x_l
     static constexpr int NBUF = XBUF + FUSED_MAX_NODES * LDW;      // [32][LDW]  n = x + mean
     static constexpr int PS = NBUF + FUSED_MAX_NODES * LDW;        // [32][LDW]  W_s x
@@ -69,6 +74,36 @@ template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static_assert(TOTAL * 4 <= 160 * 1024, "LDS budget");
 };
 
+// Split (3 x bf16) images of the edge-MLP weights in global memory, in the exact order the kernel keeps them in LDS
+// (stage_split4): per layer l = 1..4 image A (layer 1: W1 padded to K = 32, FUSED_WIMG / 2 floats; layers 2-4: W_e)
+// and image B (W2).  k_split_weights writes them once per weight version; k_fused copies them with LDS-DMA.
+constexpr int FUSED_WIMG_SET = 8 * FUSED_WIMG;           // floats reserved (layer 1's image A uses half of its slot)
+__device__ __host__ constexpr int fused_wimg_offset(int layer, int which) { return ((layer - 1) * 2 + which) * FUSED_WIMG; }
+
+__global__ void __launch_bounds__(512)
+k_split_weights(AetherParams P, int f1, float* __restrict__ wimg) {
+    const int tid = threadIdx.x;
+    const int layer = (int)blockIdx.x / 2 + 1, which = (int)blockIdx.x & 1;
+    float* img = wimg + fused_wimg_offset(layer, which);
+    if (which == 0 && layer == 1) {                       // W1 [64][f1] -> K padded to 32: one float4 per thread
+        const int r = tid >> 3, c0 = (tid & 7) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[b] = c0 + b < f1 ? P.l1_msg_w0[r * f1 + c0 + b] : 0.0f;
+        stage_split4<4, 1>(img, r, c0, v);
+        return;
+    }
+    const float* src;
+    int ld;
+    if (which == 0) { src = P.ln_msg_w0[layer - 2] + 2 * H; ld = 3 * H; }             // W_e = W1[:, 128:192]
+    else { src = layer == 1 ? P.l1_msg_w2 : P.ln_msg_w2[layer - 2]; ld = H; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = tid + 512 * j, rr = idx >> 4, cc = (idx & 15) * 4;
+        stage_split4<4, 2>(img, rr, cc, ld4(src + (size_t)rr * ld + cc));
+    }
+}
+
 // Optional global copies of the intermediates (same layout as the streamed path's workspace), so
 // that the parity tests and (later) the backward can read them.
 struct FusedDebug {
@@ -77,6 +112,7 @@ struct FusedDebug {
     int* flags;             // [workgroups] split mode: layer whose P_s rows this workgroup has published (lives in the
                             // graph buffer: zero when no launch is in flight, every launch re-arms what it consumed)
     int* errword;           // host-mapped word: set when a bounded wait on the partner workgroup gave up
+    const float* wimg;      // split weight images (k_split_weights); used by the split-GEMM variants
     float* stamps;          // [groups][FUSED_STAMPS] diagnostic build only
     StepExtras step;        // rollout: derived edge attributes, next velocity
 };
@@ -294,20 +330,38 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     // ---------------------------------------------------------------- P0: layer-1 weights, loads only
     // (W1 [64][F1] zero padded to [64][LDF], W2, biases); they land in LDS after the prologue, so their
     // latency hides behind the field net.
-    constexpr int P0A = (H * LDF + THREADS - 1) / THREADS;
-    constexpr int P0B = (H * H / 4 + THREADS - 1) / THREADS;
+    constexpr bool SPLITG = fused_split_gemm<ROUNDS>();
+    constexpr int P0A = SPLITG ? 1 : (H * LDF + THREADS - 1) / THREADS;
+    constexpr int P0B = SPLITG ? 1 : (H * H / 4 + THREADS - 1) / THREADS;
     float p0a[P0A];
     f32x4 p0b[P0B];
     float p0bias = 0.0f;
+    // Split-GEMM variants: a layer's two weight images are copied global -> LDS by LDS-DMA, one 1 KiB fragment per wave
+    // instruction (images are lane-linear in both places), no registers, no VALU; `first` skips the unused half of
+    // layer 1's image A.  The caller waits (vmcnt) before the barrier that precedes the first read.
+    auto dma_images = [&](int layer_) {
+        const float* ga = dbg.wimg + fused_wimg_offset(layer_, 0);
+        const float* gb = dbg.wimg + fused_wimg_offset(layer_, 1);
+        const int na_frag = layer_ == 1 ? 12 : 24, total = na_frag + 24;      // 1 KiB fragments: 3 terms x 4 (x 2)
+        for (int f = wave; f < total; f += NW) {
+            const float* src = f < na_frag ? ga + f * 256 : gb + (f - na_frag) * 256;
+            float* dst = f < na_frag ? wA + f * 256 : wB + (f - na_frag) * 256;
+            __builtin_amdgcn_global_load_lds(src + lane * 4, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    if constexpr (SPLITG) {
+        dma_images(1);
+    } else {
 #pragma unroll
-    for (int j = 0; j < P0A; ++j) {
-        const int idx = tid + THREADS * j, r = idx / LDF, c = idx - r * LDF;
-        p0a[j] = (idx < H * LDF && c < F1) ? P.l1_msg_w0[r * F1 + c] : 0.0f;
-    }
+        for (int j = 0; j < P0A; ++j) {
+            const int idx = tid + THREADS * j, r = idx / LDF, c = idx - r * LDF;
+            p0a[j] = (idx < H * LDF && c < F1) ? P.l1_msg_w0[r * F1 + c] : 0.0f;
+        }
 #pragma unroll
-    for (int j = 0; j < P0B; ++j) {
-        const int idx = tid + THREADS * j;
-        if (idx < H * H / 4) p0b[j] = ld4(P.l1_msg_w2 + (size_t)(idx >> 4) * H + (idx & 15) * 4);
+        for (int j = 0; j < P0B; ++j) {
+            const int idx = tid + THREADS * j;
+            if (idx < H * H / 4) p0b[j] = ld4(P.l1_msg_w2 + (size_t)(idx >> 4) * H + (idx & 15) * 4);
+        }
     }
     if (tid < 2 * H) p0bias = tid < H ? P.l1_msg_b0[tid] : P.l1_msg_b2[tid - H];
     FUSED_STAMP(1);
@@ -433,15 +487,19 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 st4(xbuf + (n + (idx >> 4)) * LDW + (idx & 15) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
         }
         // P0, second half: the layer-1 weights go to LDS
+        if constexpr (SPLITG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's LDS-DMA fragments have landed
+        } else {
 #pragma unroll
-        for (int j = 0; j < P0A; ++j) {
-            const int idx = tid + THREADS * j;
-            if (idx < H * LDF) wA[idx] = p0a[j];
-        }
+            for (int j = 0; j < P0A; ++j) {
+                const int idx = tid + THREADS * j;
+                if (idx < H * LDF) wA[idx] = p0a[j];
+            }
 #pragma unroll
-        for (int j = 0; j < P0B; ++j) {
-            const int idx = tid + THREADS * j;
-            if (idx < H * H / 4) st4(wB + (idx >> 4) * LDW + (idx & 15) * 4, p0b[j]);
+            for (int j = 0; j < P0B; ++j) {
+                const int idx = tid + THREADS * j;
+                if (idx < H * H / 4) st4(wB + (idx >> 4) * LDW + (idx & 15) * 4, p0b[j]);
+            }
         }
         if (tid < 2 * H) bias[tid] = p0bias;
         lds_barrier();
@@ -559,7 +617,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // ~130 KB of weights a workgroup needs per layer (all 256 workgroups ask at the same moment)
         // stream in under the tile's MFMAs: next layer's edge weights (W_e = W1[:, 128:192], W2: they
         // go to LDS once every wave has left the edge tiles), then W3 / W4 / next-layer W_s, W_r fragments.
-        constexpr int STG = (H * H / 4 + THREADS - 1) / THREADS;      // float4 per thread per staged matrix
+        constexpr int STG = SPLITG ? 1 : (H * H / 4 + THREADS - 1) / THREADS;      // float4 per thread per staged matrix
         f32x4 w3v[4], w4v[8], stA[STG], stB[STG];
         float b2n = 0.0f;
         // layer 4 has no next edge layer: wsv / wrv carry the out-MLP fragments (out_w0, out_w3) instead
@@ -567,13 +625,15 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // its last tile (a burst of ~20 loads per wave blocks at issue until the L2 returns drain).
         auto issue_loads = [&](int part) {
             if (part == 0 && layer < 4) {
-                const float* w1n = P.ln_msg_w0[layer - 1];
+                if constexpr (!SPLITG) {
+                    const float* w1n = P.ln_msg_w0[layer - 1];
 #pragma unroll
-                for (int j = 0; j < STG; ++j) {
-                    const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
-                    if (idx < H * H / 4) {
-                        stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
-                        stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
+                    for (int j = 0; j < STG; ++j) {
+                        const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+                        if (idx < H * H / 4) {
+                            stA[j] = ld4(w1n + (size_t)rr * (3 * H) + 2 * H + cc);
+                            stB[j] = ld4(P.ln_msg_w2[layer - 1] + (size_t)rr * H + cc);
+                        }
                     }
                 }
                 if (tid < H) b2n = P.ln_msg_b2[layer - 1][tid];
@@ -615,12 +675,14 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[mb] = ld4(bias + 16 * mb + 4 * q);
                 f32x4 bop[2] = {e[r][0], e[r][1]};
-                gemm_tile<4, 2>(wA, LDF, bop, acc, i, q);
+                if constexpr (SPLITG) gemm_split<4, 1>(wA, bop, acc, lane);
+                else gemm_tile<4, 2>(wA, LDF, bop, acc, i, q);
             } else {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     acc[mb] = ld4(prb + rl[r] * LDW + 16 * mb + 4 * q) + ld4(psb + sl[r] * LDW + 16 * mb + 4 * q);
-                gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
+                if constexpr (SPLITG) gemm_split<4, 2>(wA, e[r], acc, lane);
+                else gemm_tile<4, 4>(wA, LDW, e[r], acc, i, q);
             }
         };
         auto receive_partner_rows = [&]() {
@@ -673,7 +735,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             if (last) issue_loads(2);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
-            gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
+            if constexpr (SPLITG) gemm_split<4, 2>(wB, h1, acc2, lane);
+            else gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
             if (last) issue_loads(3);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
@@ -753,13 +816,17 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             st4(nbuf + aslot * LDW + ac4, nv);
             if (keep && aslot < n) st4(dbg.n[layer - 1] + (int64_t)(nb + aslot) * H + ac4, nv);
         }
-        if (layer < 4) {       // next layer's edge weights -> LDS (loads were issued above)
+        if (layer < 4) {       // next layer's edge weights -> LDS
+            if constexpr (SPLITG) {
+                dma_images(layer + 1);       // in flight under the node phase; waited for before its last barrier
+            } else {                         // (loads were issued above)
 #pragma unroll
-            for (int j = 0; j < STG; ++j) {
-                const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
-                if (idx < H * H / 4) {
-                    st4(wA + rr * LDW + cc, stA[j]);
-                    st4(wB + rr * LDW + cc, stB[j]);
+                for (int j = 0; j < STG; ++j) {
+                    const int idx = tid + THREADS * j, rr = idx >> 4, cc = (idx & 15) * 4;
+                    if (idx < H * H / 4) {
+                        st4(wA + rr * LDW + cc, stA[j]);
+                        st4(wB + rr * LDW + cc, stB[j]);
+                    }
                 }
             }
             if (tid < H) bias[H + tid] = b2n;
@@ -852,7 +919,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             // before the barrier, then one lane raises the flag.  The partner picks the rows up after
             // the first GEMM of its next edge phase (receive_partner_rows), as this workgroup does with
             // the partner's: the flag's flight time hides behind those 64 MFMAs.
-            if (wg.partner >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wg.partner >= 0 || SPLITG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // hand-off stores; LDS-DMA images
             lds_barrier();   // P_s / P_r and the staged weights are visible to the next edge tiles
             if (wg.partner >= 0 && tid == 0)
                 __hip_atomic_store(dbg.flags + blockIdx.x, layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

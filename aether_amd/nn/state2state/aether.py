@@ -95,6 +95,10 @@ class _AetherStep(torch.autograd.Function):
             if ws_key is not None and module._ws_key == ws_key:
                 flags |= _lib.FLAG_WORKSPACE_REUSED
             module._ws_key = None
+            wkey = module._weights_key(ws, n_nodes, n_edges)
+            if fused and module._wimg_key == wkey and module._may_reuse_weight_images():
+                flags |= _lib.FLAG_WEIGHTS_PREPARED
+            module._wimg_key = None
         out = torch.empty_like(x)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         st = lib.aether_forward(module._param_struct_ref(), D, n_nodes, n_edges,
@@ -103,6 +107,8 @@ class _AetherStep(torch.autograd.Function):
                                 ws.numel(), out.data_ptr(), flags, stream)
         _lib.check(st, "aether_forward")
         module._ws_key = ws_key
+        if not train:
+            module._wimg_key = wkey
         module._last_ws = ws
         return out, ((x, vel, charges, graph, ginfo, ws, n_edges) if train else None)
 
@@ -232,6 +238,7 @@ class Aether(nn.Module):
         self.dp_group = None              # set by aether_amd.parallel.attach_data_parallel
         self.grad_as_view = True          # .grad tensors alias one flat buffer (see _AetherStep.backward)
         self._last_ws = None
+        self._wimg_key = None             # (workspace, parameter versions) whose split weight images the workspace holds
         self._ws_key = None               # (workspace, shape, graph) of the last completed inference call
         self._gbuf = None
         self._gbuf2 = None
@@ -314,6 +321,20 @@ class Aether(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
+    def _weights_key(self, ws, n_nodes, n_edges):
+        """Identity of the split weight images a call leaves in `ws` (AETHER_FLAG_WEIGHTS_PREPARED): the buffer and the
+        version counters / addresses of all parameters (in-place updates bump the version, re-assignment the address)."""
+        if self._plist is None:
+            self._plist = [p for _, p in self.named_parameters()]
+        return (ws.data_ptr(), int(n_nodes), int(n_edges), tuple(p._version for p in self._plist),
+                tuple(p.data_ptr() for p in self._plist))
+
+    def _may_reuse_weight_images(self):
+        """Eagerly, the version check above is exact.  While a hipGraph is being captured the decision is baked into
+        the graph, so the conversion kernel is only left out in eval mode -- a captured INFERENCE graph, which has to
+        be re-captured when the weights change (as any graph whose kernels read prepared data)."""
+        return not (self.training and torch.cuda.is_current_stream_capturing())
+
     def prepare_graph(self, edges, n_nodes):
         """Build (or fetch) the receiver-sorted view for ``edges = [send, recv]``."""
         send, recv = edges
@@ -380,6 +401,10 @@ class Aether(nn.Module):
         if ws_key is not None and self._ws_key == ws_key:
             flags |= _lib.FLAG_WORKSPACE_REUSED
         self._ws_key = None
+        wkey = self._weights_key(ws, n_nodes, E)
+        if fused and self._wimg_key == wkey and self._may_reuse_weight_images():
+            flags |= _lib.FLAG_WEIGHTS_PREPARED
+        self._wimg_key = None
         traj = torch.empty(int(steps), n_nodes, D, dtype=torch.float32, device=x.device)
         if int(steps) <= 0:
             return traj
@@ -389,6 +414,7 @@ class Aether(nn.Module):
                                 torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(st, "aether_rollout")
         self._ws_key = ws_key
+        self._wimg_key = wkey
         self._last_ws = ws
         return traj
 

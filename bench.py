@@ -410,6 +410,7 @@ def main():
     Nn = B * N
     call = lambda: model(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
 
+    model.eval()                                       # inference figures (the reference's test loop does the same)
     with torch.no_grad():
         out = call()                                   # builds the graph view + workspace
         torch.cuda.synchronize()
@@ -553,6 +554,7 @@ def main():
     # ---- training step: forward + HIP backward + gradient all-reduce (N > 1) + AdamW ----------------
     train = None
     if not args.no_train:
+        model.train()
         if world > 1:
             from aether_amd.parallel import attach_data_parallel
             attach_data_parallel(model)

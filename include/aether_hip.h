@@ -78,6 +78,11 @@ typedef struct AetherGraphInfo {
  * workspace may be re-purposed freely.  Consequence: two launches that use the SAME graph buffer must not run
  * concurrently (different streams); build a second graph view for that. */
 #define AETHER_FLAG_WORKSPACE_REUSED 8
+/* The fused kernel multiplies the edge MLPs as six bf16 matrix-core terms on operands split into three bf16 pieces each
+ * (fp32-equivalent result, see csrc/common.h); the weights' pieces are prepared by a small kernel in front of every call
+ * (workspace region).  Set this flag when `workspace` still holds the pieces written by an earlier call with the SAME
+ * parameter values (inference loops, rollouts): that kernel is then skipped.  Never set it after the weights changed. */
+#define AETHER_FLAG_WEIGHTS_PREPARED 16
 
 /* Library / build identification (host string, static storage). */
 const char* aether_version(void);
