@@ -118,6 +118,9 @@ SIGNATURES = {
     "aether_dyn_decoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64]),
     "aether_dyn_decoder_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64] +
                                 [C.c_void_p] * 9 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aether_dyn_decoder_step_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64] +
+                                        [C.c_void_p] * 11 + [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                             C.c_void_p, C.c_void_p]),
     "aether_dyn_prior_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "aether_dyn_prior_step": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_int64, C.c_int64] + [C.c_void_p] * 9 +
                               [C.c_size_t] + [C.c_void_p] * 4),

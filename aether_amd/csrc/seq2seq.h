@@ -316,7 +316,8 @@ template <int D>
 __global__ void __launch_bounds__(256)
 k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, const int64_t* __restrict__ recv,
                 const float* __restrict__ rel_feat, int polar, float* __restrict__ edge_attr,
-                float* __restrict__ edge_pos, int64_t n_edges) {
+                float* __restrict__ edge_pos, int64_t n_edges, const int64_t* __restrict__ x_send = nullptr,
+                const int64_t* __restrict__ x_recv = nullptr /* rows of x, when they differ from send / recv */) {
     using A = AugDims<D>;
     constexpr int LDR = A::EA + 1;                                   // odd row stride: conflict-free column writes
     __shared__ float rows[256 * LDR];
@@ -325,9 +326,10 @@ k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, c
     const int64_t e = e0 + threadIdx.x;
     if (e < n_edges) {
         const int64_t j = send[e], i = recv[e];
+        const int64_t jx = x_send ? x_send[e] : j, ix = x_recv ? x_recv[e] : i;
         float xj[3 * D], xi[3 * D], o[A::NF];
 #pragma unroll
-        for (int t = 0; t < 3 * D; ++t) { xj[t] = x[j * 3 * D + t]; xi[t] = x[i * 3 * D + t]; }
+        for (int t = 0; t < 3 * D; ++t) { xj[t] = x[jx * 3 * D + t]; xi[t] = x[ix * 3 * D + t]; }
         aug_edge<D>(xj, xi, o);
         float* out = rows + threadIdx.x * LDR;
 #pragma unroll
@@ -395,13 +397,14 @@ k_s2s_select(const float* __restrict__ edge_w, int K, int k, int64_t n_edges, in
 // torch_scatter mean (aether.py:617,635).  One workgroup per node, a thread per 4 columns, fixed order.
 __global__ void __launch_bounds__(128)
 k_s2s_segment_mean(const float* __restrict__ Mx, const int64_t* __restrict__ order, const int64_t* __restrict__ rowptr,
-                   float* __restrict__ agg, int h, float fixed_div /* > 0: sum / fixed_div (Encoder.edge2node) */) {
+                   float* __restrict__ agg, int h, float fixed_div /* > 0: sum / fixed_div (Encoder.edge2node) */,
+                   const float* __restrict__ node_div = nullptr /* per-node divisor (batched scenes) */) {
     const int64_t n = blockIdx.x;
     const int64_t beg = rowptr[n], end = rowptr[n + 1];
     for (int c = threadIdx.x * 4; c < h; c += 128 * 4) {
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int64_t k = beg; k < end; ++k) s += ld4(Mx + (size_t)order[k] * h + c);
-        const float cnt = fixed_div > 0.0f ? fixed_div : (float)(end - beg > 1 ? end - beg : 1);
+        const float cnt = node_div ? node_div[n] : (fixed_div > 0.0f ? fixed_div : (float)(end - beg > 1 ? end - beg : 1));
         st4(agg + (size_t)n * h + c, s / cnt);
     }
 }

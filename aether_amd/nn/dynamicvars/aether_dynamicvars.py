@@ -91,6 +91,17 @@ class AetherDynamicVars(nn.Module):
         """:133-145.  ``uniform``: the U(0,1) draw of gumbel_softmax ([E, K]); drawn on the device when omitted."""
         if not hard_sample:
             raise _lib.AetherHipError("only hard_sample=True (evaluation / prediction) is part of this path")
+        if isinstance(edge_logits, (list, tuple)):                     # B scenes (single_step_forward_batched of the encoder)
+            edges = []
+            for b, lg in enumerate(edge_logits):
+                if lg.nelement() == 0:
+                    edges.append(torch.empty_like(lg).reshape(0, lg.shape[-1]))
+                    continue
+                u = torch.rand(lg.shape, device=lg.device) if uniform is None else uniform[b].reshape(lg.shape).to(lg.device)
+                edges.append(gumbel_softmax_hard(lg, u, self.gumbel_temp).reshape(-1, lg.shape[-1]))
+            predictions, decoder_hidden = self.decoder.forward_batched(inputs, decoder_hidden, edges, node_masks, graph_info,
+                                                                       current_field)
+            return predictions, decoder_hidden, edges
         if edge_logits.nelement() != 0:
             if uniform is None:
                 uniform = torch.rand(edge_logits.shape, device=edge_logits.device)
@@ -103,7 +114,11 @@ class AetherDynamicVars(nn.Module):
     @torch.no_grad()
     def predict_future(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
         """:245-273.  inputs [1, T, Nmax, 4], masks / burn_in_masks [1, T, Nmax], node_inds[0][t], graph_info[0][t]: the
-        present objects and their graph per time step.  ``uniform``: per-step Gumbel draws (list of [E_t, K])."""
+        present objects and their graph per time step.  ``uniform``: per-step Gumbel draws (list of [E_t, K]).
+        With B > 1 scenes (inputs [B, T, Nmax, 4], node_inds[b][t], graph_info[b][t], uniform[t][b]) every time step is
+        ONE batched call per stage (predict_future_batched) -- the reference raises on batch > 1 (:588-591)."""
+        if inputs.size(0) > 1:
+            return self.predict_future_batched(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         n_steps = inputs.size(1) - 1
         prior_state = self.encoder.get_initial_hidden(inputs)
         dec_state = self.decoder.get_initial_hidden(inputs)
@@ -118,6 +133,28 @@ class AetherDynamicVars(nn.Module):
             logits, prior_state = self.encoder.single_step_forward(state, present, node_inds[0][t], graph_info[0][t],
                                                                    prior_state, field)
             last, dec_state, _ = self.single_step_forward(state, present, graph_info[0][t], dec_state, logits, True, field,
+                                                          None if uniform is None else uniform[t])
+            preds.append(last)
+        return torch.stack(preds, dim=1)
+
+    @torch.no_grad()
+    def predict_future_batched(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
+        """``predict_future`` for B scenes at once: per time step one field query, one kNN + prior step, one sampling pass
+        and one decoder step over the present objects of ALL scenes (BASELINE config 4: 64 scenes)."""
+        B, n_steps = inputs.size(0), inputs.size(1) - 1
+        prior_state = self.encoder.get_initial_hidden(inputs)
+        dec_state = self.decoder.get_initial_hidden(inputs)
+        last = inputs[:, 0]
+        preds = []
+        for t in range(n_steps):
+            present = masks[:, t]
+            observed = burn_in_masks[:, t].unsqueeze(-1).type(inputs.dtype)
+            state = observed * inputs[:, t] + (1 - observed) * last
+            field, _ = self.predict_field(state, present)
+            ni_t = [node_inds[b][t] for b in range(B)]
+            gi_t = [graph_info[b][t] for b in range(B)]
+            logits, prior_state = self.encoder.single_step_forward_batched(state, present, ni_t, gi_t, prior_state, field)
+            last, dec_state, _ = self.single_step_forward(state, present, gi_t, dec_state, logits, True, field,
                                                           None if uniform is None else uniform[t])
             preds.append(last)
         return torch.stack(preds, dim=1)

@@ -100,7 +100,12 @@ class Decoder(nn.Module):
             raise _lib.AetherHipError("aether_amd Decoder runs on an MI355X only; got a CPU tensor "
                                       "(there is no CPU fallback)")
         if inputs.size(0) != 1:
-            raise ValueError("Batching during forward not currently supported")       # as the reference's models
+            # the reference's models stop here ("Batching during forward not currently supported",
+            # aether_dynamicvars.py:588-591); several scenes go through forward_batched (one launch sequence for all)
+            if isinstance(edges, (list, tuple)) and isinstance(graph_info, (list, tuple)) and len(graph_info) == inputs.size(0):
+                return self.forward_batched(inputs, hidden, edges, node_masks, graph_info, predicted_field)
+            raise ValueError("Batching during forward not currently supported: pass per-scene lists of edges and "
+                             "graph_info (forward_batched)")
         lib = _lib.load()
         dev = inputs.device
         h, K = self.msg_out_shape, self.edge_types
@@ -139,4 +144,78 @@ class Decoder(nn.Module):
         hidden[0, node_inds] = new_h
         pred_all = torch.zeros_like(inputs)
         pred_all[0, node_inds] = out
+        return pred_all, hidden
+
+    @torch.no_grad()
+    def forward_batched(self, inputs, hidden, edges, node_masks, graph_info, predicted_field):
+        """``forward`` for B scenes in ONE call of the library (true batching; BASELINE config 4 has
+        64 scenes).  inputs [B, Nmax, 4], hidden [B, Nmax, h], node_masks [B, Nmax], predicted_field [B, Nmax, 2];
+        ``edges[b]`` [E_b, K] (or [1, E_b, K]) and ``graph_info[b] = (send, recv, edge2node_inds)`` exactly as the
+        single-scene call takes them for scene b (indices in the numbering of that scene's present objects).  Returns
+        (pred_all [B, Nmax, 4], hidden [B, Nmax, h]); every scene's rows equal its single-scene ``forward``.  Scenes
+        without present objects yield zeros (:841-843); a scene with exactly one raises, as the reference does."""
+        if not inputs.is_cuda:
+            raise _lib.AetherHipError("aether_amd Decoder runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        lib = _lib.load()
+        dev = inputs.device
+        B, Nmax = inputs.size(0), inputs.size(1)
+        h, K = self.msg_out_shape, self.edge_types
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        inputs, hidden, field = f32(inputs), f32(hidden), f32(predicted_field)
+        masks = node_masks.reshape(B, Nmax).to(dev) != 0
+        counts = masks.sum(1)                                            # present objects per scene
+        counts_h = counts.tolist()
+        if any(c == 1 for c in counts_h):
+            raise _lib.AetherHipError("a scene with one present object: the reference fails here as well "
+                                      "(present_agg_msgs is never assigned, aether_dynamicvars.py:843-851)")
+        flat_idx = masks.reshape(-1).nonzero()[:, 0]                     # rows of the [B * Nmax] arrays, scene-major
+        nv = int(flat_idx.numel())
+        pred_all = torch.zeros_like(inputs)
+        if nv == 0:
+            return pred_all, hidden
+        base = torch.cumsum(counts, 0) - counts                          # first concatenated row of every scene
+        send_l, recv_l, ord_l, ssend_l, srecv_l, ew_l, rows_per_node = [], [], [], [], [], [], []
+        e_off = 0
+        for b in range(B):
+            if counts_h[b] == 0:
+                continue
+            s_b, r_b, e2n = (t.to(device=dev, dtype=torch.int64) for t in graph_info[b])
+            E_b = s_b.numel()
+            ew = f32(edges[b]).reshape(-1, K)
+            if r_b.numel() != E_b or ew.shape[0] != E_b or e2n.ndim != 2 or e2n.shape[0] != counts_h[b]:
+                raise ValueError(f"graph_info / edges of scene {b} do not match its present objects")
+            send_l.append(s_b + base[b]); recv_l.append(r_b + base[b])
+            ssend_l.append(s_b + b * Nmax); srecv_l.append(r_b + b * Nmax)        # un-compacted rows, compacted ids (:823)
+            ord_l.append(e2n.reshape(-1) + e_off)
+            rows_per_node.append(torch.full((counts_h[b],), e2n.shape[1], dtype=torch.int64, device=dev))
+            ew_l.append(ew)
+            e_off += E_b
+        send, recv = torch.cat(send_l).contiguous(), torch.cat(recv_l).contiguous()
+        ssend, srecv = torch.cat(ssend_l).contiguous(), torch.cat(srecv_l).contiguous()
+        order = torch.cat(ord_l).contiguous()
+        rowptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.cat(rows_per_node), 0)
+        ew = torch.cat(ew_l).contiguous()
+        E = send.numel()
+        div_node = torch.repeat_interleave((counts - 1).clamp(min=1).to(torch.float32), counts).contiguous()
+        x2, h2, f2 = inputs.reshape(B * Nmax, -1), hidden.reshape(B * Nmax, h), field.reshape(B * Nmax, -1)
+        cur_in, cur_h, cur_f = x2[flat_idx].contiguous(), h2[flat_idx].contiguous(), f2[flat_idx].contiguous()
+        ext_full = torch.cat([x2, f2], -1).contiguous()
+        need = lib.aether_dyn_decoder_workspace_bytes(h, nv, E)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(nv, 4, dtype=torch.float32, device=dev)
+        new_h = torch.empty(nv, h, dtype=torch.float32, device=dev)
+        ps = self._param_struct()
+        st = lib.aether_dyn_decoder_step_batched(
+            C.byref(ps), h, K, 1 if self.skip_first_edge_type else 0, 1 if self.pos_representation == "polar" else 0,
+            nv, E, cur_in.data_ptr(), cur_h.data_ptr(), ew.data_ptr(), cur_f.data_ptr(), ext_full.data_ptr(),
+            ssend.data_ptr(), srecv.data_ptr(), send.data_ptr(), recv.data_ptr(), order.data_ptr(), rowptr.data_ptr(),
+            1.0, div_node.data_ptr(), self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), new_h.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_dyn_decoder_step_batched")
+        hidden = hidden.clone()
+        hidden.reshape(B * Nmax, h)[flat_idx] = new_h
+        pred_all.reshape(B * Nmax, -1)[flat_idx] = out
         return pred_all, hidden

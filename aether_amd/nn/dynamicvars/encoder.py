@@ -145,3 +145,68 @@ class Encoder(nn.Module):
         new_h, new_c = forward_state[0].clone(), forward_state[1].clone()
         new_h[0, slot], new_c[0, slot] = h1, c1
         return logits.unsqueeze(0), (new_h, new_c)
+
+    @torch.no_grad()
+    def single_step_forward_batched(self, inputs, node_masks, node_inds, all_graph_info, forward_state, predicted_field):
+        """``single_step_forward`` for B scenes in one call of the library (the reference refuses batch > 1,
+        aether_dynamicvars.py:588-591).  inputs [B, Nmax, 4], node_masks [B, Nmax], predicted_field [B, Nmax, 2];
+        ``node_inds[b]`` / ``all_graph_info[b]`` as the single-scene call takes them for scene b; forward_state (h, c)
+        each [1, B * Nmax * (Nmax - 1), R] (``get_initial_hidden`` of the batched inputs).  Returns (list of
+        prior_logits [1, E_b, K] per scene, forward_state).  Scenes with fewer than two present objects contribute
+        no edges (:696-697)."""
+        if not inputs.is_cuda:
+            raise _lib.AetherHipError("aether_amd Encoder runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        if self.training:
+            raise _lib.AetherHipError("the prior step uses BatchNorm running statistics: call .eval() first")
+        lib = _lib.load()
+        dev = inputs.device
+        B, Nmax, h, R, K = inputs.size(0), inputs.size(1), self.hidden_size, self.rnn_hidden_size, self.num_edges
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        x, field = f32(inputs), f32(predicted_field)
+        mask = node_masks.reshape(B, Nmax).to(dev) != 0
+        counts = mask.sum(1)
+        counts_h = counts.tolist()
+        # scenes with a single present object have no edges and are left out of the graph (as the single-scene path does)
+        use = mask & (counts >= 2).unsqueeze(1)
+        empty = [torch.empty(1, 0, K, device=dev) for _ in range(B)]
+        if not bool(use.any()):
+            return empty, forward_state
+        send, recv, _ = knn_edges(x, use.to(torch.float32))                # all scenes, concatenated compacted numbering
+        cur_in, cur_f = x[use].contiguous(), field[use].contiguous()
+        n, E = cur_in.shape[0], send.numel()
+        order, rowptr = csr_by_receiver(recv, n)
+        slots, per_scene = [], []
+        for b in range(B):
+            if counts_h[b] < 2:
+                per_scene.append(0)
+                continue
+            gsend, grecv = all_graph_info[b][0].to(dev), all_graph_info[b][1].to(dev)
+            ni = node_inds[b].to(dev)
+            gs, gr = ni[gsend], ni[grecv]
+            slots.append(b * Nmax * (Nmax - 1) + gs * (Nmax - 1) + gr - (gr >= gs).long())
+            per_scene.append(int(gsend.numel()))
+        slot = torch.cat(slots)
+        if slot.numel() != E:
+            raise ValueError("graph_info and the encoder's kNN graphs list a different number of edges")
+        h0, c0 = f32(forward_state[0])[0, slot].contiguous(), f32(forward_state[1])[0, slot].contiguous()
+        ps, n_layers, prior_hidden = self._param_struct()
+        need = lib.aether_dyn_prior_workspace_bytes(h, R, prior_hidden, n, E)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        logits = torch.empty(E, K, dtype=torch.float32, device=dev)
+        h1, c1 = torch.empty_like(h0), torch.empty_like(c0)
+        st = lib.aether_dyn_prior_step(C.byref(ps), h, R, n_layers, prior_hidden, K,
+                                       1 if self.pos_representation == "polar" else 0, n, E, cur_in.data_ptr(),
+                                       cur_f.data_ptr(), h0.data_ptr(), c0.data_ptr(), send.data_ptr(), recv.data_ptr(),
+                                       order.data_ptr(), rowptr.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                       logits.data_ptr(), h1.data_ptr(), c1.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_dyn_prior_step")
+        new_h, new_c = forward_state[0].clone(), forward_state[1].clone()
+        new_h[0, slot], new_c[0, slot] = h1, c1
+        out, off = [], 0
+        for b in range(B):
+            out.append(logits[off:off + per_scene[b]].unsqueeze(0) if per_scene[b] else empty[b])
+            off += per_scene[b]
+        return out, (new_h, new_c)

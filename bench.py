@@ -504,15 +504,32 @@ def main():
                     kernels[lib.aether_profile_kernel_name(k).decode()] = {
                         "launches_per_step": cnt[k] / ksteps, "avg_us": 1e3 * ms[k] / cnt[k]}
             step_flops_alg = float(E) * FLOP_PER_EDGE_STEP[D] + float(Nn) * FLOP_PER_NODE_STEP[D]
+            graph_us = None
             if "k_fused" in kernels:       # one launch does the whole step
                 dom_name, dom, flops = "k_fused", kernels["k_fused"], step_flops_alg
                 executed = None
+                if use_graph:
+                    # the same launch mode as `ms_per_step`: HIP events on the stream around replays of the S-step graph
+                    # (one k_fused launch per step, back to back) -- per launch it includes the gap to the next launch
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                    reps = max(1, min(args.steps, 200) // S)
+                    (group if S > 1 else step)()
+                    torch.cuda.synchronize()
+                    ev[0].record()
+                    for _ in range(reps):
+                        (group if S > 1 else step)()
+                    ev[1].record()
+                    torch.cuda.synchronize()
+                    graph_us = 1e3 * ev[0].elapsed_time(ev[1]) / (reps * S)
             else:
+                # the node-term split leaves this kernel E x (W_e e: 2*64*64 + W2 h: 2*64*64) FLOP; the whole step's
+                # algorithmic rate (reference formulation) is `step_algorithmic_tflops` of the line
                 dom_name, dom = "k_edge_layer", kernels.get("k_edge_layer")
-                flops = float(E) * FLOP_PER_EDGE_LAYER_N
-                executed = float(E) * 2 * (64 * 64 * 2)
+                flops = float(E) * 2 * (64 * 64 * 2)
+                executed = float(E) * 2 * (64 * 64 * 2 + 16 * 64)        # + the per-tile receiver sums on the matrix core
             if dom:
-                achieved = flops / (dom["avg_us"] * 1e-6) / 1e12
+                launch_us = graph_us if graph_us is not None else dom["avg_us"]
+                achieved = flops / (launch_us * 1e-6) / 1e12
                 traffic = None
                 tpath = os.path.join(REPO, "profiles", "traffic.json")
                 if os.path.exists(tpath):
@@ -527,8 +544,21 @@ def main():
                 roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                        "avg_launch_us": dom["avg_us"], "algorithmic_flop_per_launch": flops,
-                        "executed_flop_per_launch": executed}
+                        "avg_launch_us": launch_us,
+                        "launch_mode": ("hipgraph replay (same mode as ms_per_step; includes the gap between launches)"
+                                        if graph_us is not None else "eager, HIP events around each launch"),
+                        "eager_avg_launch_us": dom["avg_us"], "algorithmic_flop_per_launch": flops,
+                        "executed_flop_per_launch": executed,
+                        "source_of_traffic_and_executed": "profiles/traffic.json (rocprofv3 --pmc passes of this command)"
+                                                          if traffic is not None else None}
+                assert roof["frac"] <= 1.0, roof
+                if dom_name == "k_edge_layer":
+                    # HBM side of the streamed edge kernel (SURVEY 8d asks for both fractions): algorithmic bytes per
+                    # edge and layer = read e_{l-1} 256 + write e_l 256 + indices 8 + partial rows 16
+                    bytes_alg = float(E) * 536.0
+                    roof["hbm"] = {"algorithmic_bytes_per_launch": bytes_alg, "achieved_GBps": bytes_alg / (launch_us * 1e-6) / 1e9,
+                                   "peak_GBps": 8000.0, "hbm_frac": bytes_alg / (launch_us * 1e-6) / 8e12,
+                                   "measured_bytes_per_launch": traffic}
 
     # ---- 20-step device rollout (aether_rollout): metric 2's protocol, one launch per step ------------
     roll = None
@@ -656,7 +686,11 @@ def main():
                        else f"edge-messages/sec (forward, {D}-D N={N} batch={B} per GPU)"),
             "value": value, "unit": "edge-messages/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": ("fp32 in, fp32 out, fp32 accumulate; the edge-MLP contractions of the fused kernel run as six bf16 "
+                           "matrix-core terms on operands split exactly into three bf16 pieces (fp32-equivalent: 2.3e-7 vs "
+                           "2.9e-7 for the fp32 MFMA chain against fp64, tools/micro/split_tile.hip)"),
+            "data": "synthetic",
             "config": {"workload": WORKLOAD["name"] if (B, N, D) == (128, 20, 2) else f"D{D}-N{N}-B{B}",
                        "num_dims": D, "nodes_per_graph": N, "graphs_per_gpu": B, "edges_per_gpu": E,
                        "hidden": 64, "launch": (f"hipgraph ({S} steps per replay)" if use_graph else "eager"),

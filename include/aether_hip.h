@@ -515,6 +515,25 @@ int aether_dyn_decoder_step(const AetherDynDecoderParams* params, int hidden, in
                             const float* edge_w, const float* field, const float* edge_state, const int64_t* send,
                             const int64_t* recv, const int64_t* agg_order, const int64_t* agg_rowptr, float agg_div,
                             void* workspace, size_t workspace_bytes, float* outputs, float* hidden_out, void* stream);
+/*
+ * The same step for SEVERAL scenes at once -- what the reference cannot do (its variable-N models raise on batch > 1,
+ * aether_dynamicvars.py:588-591): the present objects of all scenes are concatenated (n_nodes rows), `send` / `recv` /
+ * `agg_order` are in that concatenated numbering (no edge crosses scenes), and the two per-scene quantities of the
+ * single-scene call become arrays:
+ *   agg_div_node : float[n_nodes], the divisor of each object's sums (the reference: its scene's num_vars - 1);
+ *                  NULL = the scalar agg_div for everyone
+ *   state_send, state_recv : int64[e] rows of `edge_state` the edge features read (NULL = send / recv).  The reference
+ *                  indexes its scene's UN-compacted state with compacted indices (:823); with several scenes that is
+ *                  scene_base_of_uncompacted_rows + compacted index within the scene, which differs from `send`.
+ * aether_dyn_decoder_step is this function with both NULL.
+ */
+int aether_dyn_decoder_step_batched(const AetherDynDecoderParams* params, int hidden, int num_edge_types, int skip_first,
+                                    int polar, int64_t n_nodes, int64_t n_edges, const float* inputs,
+                                    const float* hidden_in, const float* edge_w, const float* field,
+                                    const float* edge_state, const int64_t* state_send, const int64_t* state_recv,
+                                    const int64_t* send, const int64_t* recv, const int64_t* agg_order,
+                                    const int64_t* agg_rowptr, float agg_div, const float* agg_div_node, void* workspace,
+                                    size_t workspace_bytes, float* outputs, float* hidden_out, void* stream);
 
 /*
  * Variable-N models, one step of the encoder's prior and the field query: with

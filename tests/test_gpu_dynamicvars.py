@@ -54,6 +54,66 @@ def test_decoder_step_vs_oracle_device_graph(Nmax, p, K, skip, posrep, H):
     assert scale_rel_err(got_p.cpu(), want_p) <= TOL and scale_rel_err(got_h.cpu(), want_h) <= TOL
 
 
+def test_decoder_step_64_scenes_batched_equals_single_scene_oracle():
+    """BASELINE config 4 (inD-like scenes, batch = 64): ONE batched call for 64 scenes of 2..40 present objects against 64
+    single-scene oracle steps (the reference itself refuses batch > 1, aether_dynamicvars.py:588-591).  Includes an empty
+    scene, scenes with interior objects missing (the reference's compacted-index quirk, :823) and kNN graphs with k < 10."""
+    import time
+    B, Nmax, K, H = 64, 40, 4, 256
+    params = {"input_size": 4, "gpu": True, "decoder_hidden": H, "num_edge_types": K, "skip_first": True,
+              "decoder_dropout": 0.0, "pos_representation": "cart"}
+    torch.manual_seed(23)
+    dec = Decoder(params, device="cuda").eval()
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    g = torch.Generator().manual_seed(64)
+    inputs = torch.randn(B, Nmax, 4, generator=g)
+    hidden = torch.randn(B, Nmax, H, generator=g) * 0.3
+    field = torch.randn(B, Nmax, 2, generator=g) * 0.3
+    masks = torch.zeros(B, Nmax)
+    for b in range(B):
+        nv = int(torch.randint(2, Nmax + 1, (1,), generator=g))
+        masks[b, torch.randperm(Nmax, generator=g)[:nv]] = 1.0           # interior objects missing in most scenes
+    masks[5] = 0.0                                                        # an empty scene
+    masks[9] = 0.0
+    masks[9, :3] = 1.0                                                    # three objects: k = 2
+    edges_l, gi_l, want_p, want_h = [], [], [], []
+    for b in range(B):
+        nv = int(masks[b].sum())
+        if nv == 0:
+            edges_l.append(torch.zeros(0, K).cuda()); gi_l.append(None)
+            want_p.append(torch.zeros(1, Nmax, 4)); want_h.append(hidden[b:b + 1])
+            continue
+        send, recv = get_knn_graph_info(inputs[b].cuda(), masks[b].cuda(), nv)
+        k = min(10, nv - 1)
+        e2n = torch.argsort(recv, stable=True).view(-1, k)
+        types = torch.randint(0, K, (send.numel(),), generator=g)
+        e_b = torch.nn.functional.one_hot(types, K).float()
+        p_b, h_b = DO.decoder_step(sd, inputs[b:b + 1], hidden[b:b + 1], e_b.unsqueeze(0), masks[b],
+                                   (send.cpu(), recv.cpu(), e2n.cpu()), field[b:b + 1], True, "cart")
+        edges_l.append(e_b.cuda()); gi_l.append((send, recv, e2n))
+        want_p.append(p_b); want_h.append(h_b)
+    want_p, want_h = torch.cat(want_p), torch.cat(want_h)
+    args = (inputs.cuda(), hidden.cuda(), edges_l, masks.cuda(), gi_l, field.cuda())
+    got_p, got_h = dec(*args)                                             # B > 1 with per-scene lists -> forward_batched
+    assert got_p.shape == (B, Nmax, 4) and got_h.shape == (B, Nmax, H)
+    assert scale_rel_err(got_p.cpu(), want_p) <= TOL and scale_rel_err(got_h.cpu(), want_h) <= TOL
+    assert (got_p.cpu()[masks == 0] == 0).all() and torch.equal(got_h.cpu()[masks == 0], hidden[masks == 0])
+    # one batched call vs 64 single-scene calls of the same module (timing line of DESIGN 4.11 / profiles/)
+    def timed(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+    def singles():
+        for b in range(B):
+            if gi_l[b] is not None:
+                dec(args[0][b:b + 1], args[1][b:b + 1], edges_l[b].unsqueeze(0), args[3][b:b + 1], gi_l[b], args[5][b:b + 1])
+    t_b, t_s = timed(lambda: dec(*args)), timed(singles, 2)
+    print(f"\n[cfg4] decoder step, 64 scenes ({int(masks.sum())} objects): batched {t_b:.2f} ms, 64 single-scene calls {t_s:.2f} ms")
+
+
 def test_decoder_errors():
     params = {"input_size": 4, "gpu": True, "decoder_hidden": 128, "num_edge_types": 2, "skip_first": False,
               "decoder_dropout": 0.0, "pos_representation": "cart"}
@@ -129,6 +189,57 @@ def test_model_vs_oracle_ind_sizes():
     got = model.predict_future(inputs.cuda(), masks.cuda(), [[n.cuda() for n in node_inds]],
                                [[tuple(x.cuda() for x in gi) for gi in graph_info]], burn.cuda(),
                                uniform=[u.cuda() for u in U[:T - 1]])
+    assert scale_rel_err(got.cpu(), want) <= 2 * TOL
+
+
+def test_predict_future_batched_scenes_vs_oracle_per_scene():
+    """B = 6 scenes through ``predict_future`` at once (one field query / kNN + prior step / sampling / decoder step per
+    time step for all scenes) against the ORACLE run scene by scene -- the reference raises on batch > 1
+    (aether_dynamicvars.py:588-591).  inD-like sizes; one scene goes empty at a step, one has two objects."""
+    from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+    import sys, os
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_dynamicvars import MODEL_PARAMS, perturb_bn_
+    params = dict(MODEL_PARAMS, decoder_hidden=256, encoder_hidden=256, num_edge_types=4, pos_representation="polar",
+                  field_hidden=128, encoder_rnn_hidden=64)
+    torch.manual_seed(29)
+    model = AetherDynamicVars(params, device=None).eval()
+    perturb_bn_(model)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    g = torch.Generator().manual_seed(30)
+    B, T, N = 6, 4, 24
+    inputs = torch.randn(B, T, N, 4, generator=g)
+    masks = (torch.rand(B, T, N, generator=g) < 0.7).float()
+    masks[:, :, :3] = 1
+    masks[2, 1] = 0                                           # scene 2 is empty at step 1
+    masks[4] = 0
+    masks[4, :, :2] = 1                                       # scene 4: two objects throughout
+    burn = torch.ones(B, T, N)
+    burn[:, 2:] = 0
+    node_inds, graph_info, U = [], [], [[None] * B for _ in range(T)]
+    for b in range(B):
+        ni_b, gi_b = [], []
+        for step in range(T):
+            nv = int(masks[b, step].sum())
+            if nv >= 2:
+                send, recv = get_knn_graph_info(inputs[b, step].cuda(), masks[b, step].cuda(), nv)
+                e2n = torch.argsort(recv, stable=True).view(-1, min(10, nv - 1))
+                gi_b.append((send.cpu(), recv.cpu(), e2n.cpu()))
+            else:
+                z = torch.zeros(0, dtype=torch.int64)
+                gi_b.append((z, z, torch.zeros(0, 1, dtype=torch.int64)))
+            ni_b.append(masks[b, step].nonzero()[:, -1])
+            U[step][b] = torch.rand(gi_b[-1][0].numel(), 4, generator=g)
+        node_inds.append(ni_b); graph_info.append(gi_b)
+    want = torch.cat([DO.predict_future(sd, inputs[b:b + 1], masks[b:b + 1], node_inds[b], graph_info[b], burn[b:b + 1],
+                                        [U[t][b] for t in range(T - 1)], 0.5, True, "polar") for b in range(B)])
+    cu = lambda t: t.cuda()
+    got = model.predict_future(inputs.cuda(), masks.cuda(), [[cu(n) for n in ni_b] for ni_b in node_inds],
+                               [[tuple(cu(x) for x in gi) for gi in gi_b] for gi_b in graph_info], burn.cuda(),
+                               uniform=[[cu(u) for u in U[t]] for t in range(T - 1)])
+    assert got.shape == want.shape
     assert scale_rel_err(got.cpu(), want) <= 2 * TOL
 
 
