@@ -401,7 +401,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     const unsigned node_grid = (unsigned)((Nn + 15) / 16);
     const uint32_t* gsel = reinterpret_cast<const uint32_t*>(graph + G.gsel);
     if (E > 0) {
-        const size_t lds1 = (size_t)(H * LDF + H * LDW + 2 * H + 4 * 64 * LDF) * 4;
+        const size_t lds1 = (size_t)(SPLIT_WIMG / 2 + SPLIT_WIMG + 2 * H + 4 * 64 * LDF) * 4;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_edge_layer1<D>), lds1)) return AETHER_EHIP;
         const int64_t n_wg1 = ((E + 63) / 64 + 3) / 4;
         unsigned g1 = (unsigned)(n_wg1 < 512 ? n_wg1 : 512);              // 2 workgroups per CU
@@ -423,13 +423,14 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     }
     for (int l = 2; l <= 4; ++l) {
         if (E > 0) {
-            const size_t lds = (size_t)(2 * H * LDW + H + 4 * 16 * LDST) * 4;
-            int64_t wgs = (n_tiles + 3) / 4;
-            unsigned g = (unsigned)(wgs < 1024 ? wgs : 1024);
+            const size_t lds = (size_t)(2 * SPLIT_WIMG + H + EDGE_LN_WAVES * 16 * LDST) * 4;
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_edge_layer), lds)) return AETHER_EHIP;
+            int64_t wgs = (n_tiles + EDGE_LN_WAVES - 1) / EDGE_LN_WAVES;
+            unsigned g = (unsigned)(wgs < 256 ? wgs : 256);                   // one 12-wave workgroup per CU
             ProfScope ps(K_EDGE_LN, st);
             // layer 4's messages are only needed as receiver sums (locs.py:190-193) unless kept
             float* eo = (l == 4 && !keep) ? nullptr : wp(W.e[l - 1]);
-            k_edge_layer<<<dim3(g), dim3(256), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2], P.ln_msg_b2[l - 2],
+            k_edge_layer<<<dim3(g), dim3(64 * EDGE_LN_WAVES), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2], P.ln_msg_b2[l - 2],
                                                          wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), send_s,
                                                          recv_s, gsel, wp(W.part), eo, E);
         }

@@ -99,6 +99,7 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ w, int ldw,
 // each product of two bf16 being exact in fp32 and the MFMA accumulating in fp32.  Measured on the MI355X against an fp64
 // evaluation of the edge MLP (tools/micro/split_tile.hip): 2.3e-7 scale-relative vs 2.9e-7 for the fp32 MFMA chain --
 // the same fp32-level result, for 6 x 16 cycles per 32-deep k block instead of 8 x 32 (1.75 x on the tile's MLP).
+constexpr int SPLIT_WIMG = 3 * 4 * 2 * 64 * 4;          // floats of the split image of a 64 x 64 matrix (3 terms x 8 KB)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 

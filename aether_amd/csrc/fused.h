@@ -30,7 +30,7 @@ constexpr int LDU = 2 * H + 8;               // padded LDS row for the 128-wide 
 // The edge MLP's two 64 x 64 contractions run as six bf16 MFMA terms on split operands (common.h, gemm_split) wherever
 // the weight images fit (3 x 8 KB each instead of 18 KB of padded fp32): every variant but the 17-24 tile one.
 template <int ROUNDS> constexpr bool fused_split_gemm() { return ROUNDS < 3; }
-constexpr int FUSED_WIMG = 3 * 4 * 2 * 64 * 4;           // floats of a split image of a 64 x 64 matrix (24 KB)
+constexpr int FUSED_WIMG = SPLIT_WIMG;                   // floats of a split image of a 64 x 64 matrix (24 KB)
 template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static constexpr int WSZ = fused_split_gemm<ROUNDS>() ? FUSED_WIMG : H * LDW;
     static constexpr int WA = 0;                                   // W_e  (layer 1: W1): [64][LDW] fp32 (ld LDF) | split image

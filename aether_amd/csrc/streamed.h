@@ -158,7 +158,7 @@ __device__ __forceinline__ void tile_receiver_sums(const f32x4 (&e)[4], float* w
 // geometry.py:76-101, followed by [rel_feat[recv] | edge_attr_orig] (aether.py:99,177).
 // Phase B (one wave per 16-edge tile): e1 = SiLU(W2 SiLU(W1 a + b1) + b2), locs.py:206-212.
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
               const float* __restrict__ edge_attr_orig, const int32_t* __restrict__ perm,
               const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
@@ -167,13 +167,22 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
     using NI = NodeInfo<D>;
     constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* w1 = smem;                       // [64][LDF]
-    float* w2 = w1 + H * LDF;               // [64][LDW]
-    float* bias = w2 + H * LDW;             // [128]: b1 | b2
+    float* w1 = smem;                       // split image of W1, K padded to 32 (half an image; common.h gemm_split)
+    float* w2 = w1 + SPLIT_WIMG / 2;        // split image of W2
+    float* bias = w2 + SPLIT_WIMG;          // [128]: b1 | b2
     float* scratch = bias + 2 * H;          // [4 waves][64][LDF]: features of the wave's 64 edges, then
                                             // (once they sit in registers) its 16 tile-staging rows
-    stage_weight(w1, P.l1_msg_w0, H, F1, F1, LDF);
-    stage_weight64<256>(w2, P.l1_msg_w2, H);
+    for (int idx = threadIdx.x; idx < H * FPAD / 4; idx += 256) {
+        const int rr = idx >> 3, c0 = (idx & 7) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[b] = c0 + b < F1 ? P.l1_msg_w0[rr * F1 + c0 + b] : 0.0f;
+        stage_split4<4, 1>(w1, rr, c0, v);
+    }
+    for (int idx = threadIdx.x; idx < H * H / 4; idx += 256) {
+        const int rr = idx >> 4, cc = (idx & 15) * 4;
+        stage_split4<4, 2>(w2, rr, cc, ld4(P.l1_msg_w2 + (size_t)rr * H + cc));
+    }
     if (threadIdx.x < H) {
         bias[threadIdx.x] = P.l1_msg_b0[threadIdx.x];
         bias[H + threadIdx.x] = P.l1_msg_b2[threadIdx.x];
@@ -245,11 +254,11 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
                     acc[mb] = ld4(bias + 16 * mb + 4 * q);
                     acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
                 }
-                gemm_tile<4, 2>(w1, LDF, bop[t], acc, i, q);
+                gemm_split<4, 1>(w1, bop[t], acc, lane);
                 f32x4 h1[4];
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
-                gemm_tile<4, 4>(w2, LDW, h1, acc2, i, q);
+                gemm_split<4, 2>(w2, h1, acc2, lane);
                 f32x4 eo[4];
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
@@ -267,13 +276,17 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
 // ------------------------------------------------------------------ K3: layers 2-4 edge kernel
 // e_l = SiLU(W2 SiLU(W_s x_s + W_r x_r + b1 + W_e e_{l-1}) + b2), locs.py:227-235 with the
 // node terms P_s = W_s x, P_r = W_r x + b1 gathered as the accumulator's initial value.
-// Weights are staged once per workgroup in LDS and their fragments re-read per tile (3 waves per SIMD;
-// keeping them in 128 registers at 2 waves per SIMD was 11 % slower).  Inputs of the next tile (indices two tiles ahead, gathered rows one
+// Both contractions run as six bf16 MFMA terms on 3-way split operands (common.h, gemm_split: fp32-equivalent): with
+// the fp32 MFMA this kernel kept the matrix pipe -- which for fp32 IS the vector ALU -- busy 71 % of the time at
+// 0.32 of the HBM roof (profiles/r02_cfg5shard_pmc_fp32mfma.txt); the bf16 terms run on the matrix pipe proper, beside
+// the SiLU / split VALU work of the SIMD's other wave.  The weights' split images are built once per workgroup in LDS
+// (2 x 24 KB; two workgroups per CU) and their fragments re-read per tile.  Inputs of the next tile (indices two tiles ahead, gathered rows one
 // tile ahead) are in flight while the current tile's 128 MFMAs issue, and the finished tile is
 // stored one iteration late, right after the next loads are issued: LLVM waits vmcnt(0) whenever
 // loads and stores are both pending (they may retire out of order), so a store issued just before
 // the loop-top wait would expose its full write latency on every tile.
-__global__ void __launch_bounds__(256, 3)
+constexpr int EDGE_LN_WAVES = 12;        // waves per workgroup of k_edge_layer: one workgroup per CU, 3 waves per SIMD
+__global__ void __launch_bounds__(64 * EDGE_LN_WAVES)
 k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
              const float* __restrict__ b_msg2, const float* __restrict__ Ps,
              const float* __restrict__ Pr, const float* __restrict__ e_prev,
@@ -282,23 +295,26 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
              float* __restrict__ e_out /* null: the messages themselves are not needed (layer 4) */,
              int64_t n_edges) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* we = smem;                       // [64][LDW]  = W1[:, 128:192]
-    float* w2 = we + H * LDW;               // [64][LDW]
-    float* bias = w2 + H * LDW;             // [64] b2
-    float* wst = bias + H + (threadIdx.x >> 6) * (16 * LDST);     // [4 waves][16][LDST] tile staging
-    stage_weight64<256>(we, w_msg0 + 2 * H, 3 * H);
-    stage_weight64<256>(w2, w_msg2, H);
+    float* we = smem;                       // split image of W_e = W1[:, 128:192]
+    float* w2 = we + SPLIT_WIMG;            // split image of W2
+    float* bias = w2 + SPLIT_WIMG;          // [64] b2
+    float* wst = bias + H + (threadIdx.x >> 6) * (16 * LDST);     // [waves][16][LDST] tile staging
+    for (int idx = threadIdx.x; idx < H * H / 4; idx += 64 * EDGE_LN_WAVES) {
+        const int rr = idx >> 4, cc = (idx & 15) * 4;
+        stage_split4<4, 2>(we, rr, cc, ld4(w_msg0 + (size_t)rr * (3 * H) + 2 * H + cc));
+        stage_split4<4, 2>(w2, rr, cc, ld4(w_msg2 + (size_t)rr * H + cc));
+    }
     if (threadIdx.x < H) bias[threadIdx.x] = b_msg2[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t n_tiles = (n_edges + 15) / 16;
-    const int64_t stride = (int64_t)gridDim.x * 4;
+    const int64_t stride = (int64_t)gridDim.x * EDGE_LN_WAVES;
     f32x4 b2v[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) b2v[mb] = ld4(bias + 16 * mb + 4 * q);
 
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    int64_t tile = (int64_t)blockIdx.x * EDGE_LN_WAVES + wave;
     if (tile >= n_tiles) return;
     auto clampk = [&](int64_t t) { int64_t k = t * 16 + i; return k < n_edges ? k : n_edges - 1; };
     // software pipeline: (s1, r1) = indices of tile+stride; (ps, pr, ev) = rows of the current tile
@@ -340,12 +356,12 @@ k_edge_layer(const float* __restrict__ w_msg0, const float* __restrict__ w_msg2,
         }
         int z = 0;
         asm volatile("" : "+v"(z));      // opaque offset: keeps the fragment reads inside the loop
-        gemm_tile<4, 4>(we + z, LDW, bop, acc, i, q);
+        gemm_split<4, 2>(we + z, bop, acc, lane);
         f32x4 h1[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
         asm volatile("" : "+v"(z));
-        gemm_tile<4, 4>(w2 + z, LDW, h1, acc2, i, q);
+        gemm_split<4, 2>(w2 + z, h1, acc2, lane);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
         ko = k;
