@@ -147,6 +147,7 @@ SIGNATURES = {
     "aether_debug_fetch": (C.c_int64, [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "aether_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "aether_graph_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "aether_check_async_error": (C.c_int, []),
     "aether_profile_enable": (C.c_int, [C.c_int]),
     "aether_profile_kernels": (C.c_int, []),

@@ -187,6 +187,16 @@ __global__ void k_graph_finish(const int64_t* __restrict__ send, const int32_t* 
         for (int64_t n = r + 1; n <= n_nodes; ++n) rowptr[n] = (int32_t)n_edges;
 }
 
+// Does an edge index equal the one a graph view was built from?  (send[perm[k]], recv[perm[k]]) against the sorted copies.
+__global__ void k_graph_match(const int64_t* __restrict__ send, const int64_t* __restrict__ recv, int64_t n_edges,
+                              const int32_t* __restrict__ perm, const int32_t* __restrict__ send_s,
+                              const int32_t* __restrict__ recv_s, int* __restrict__ differs) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_edges) return;
+    const int64_t e = perm[k];
+    if (send[e] != (int64_t)send_s[k] || recv[e] != (int64_t)recv_s[k]) *differs = 1;
+}
+
 // ------------------------------------------------------------------ host-side layouts
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1062,6 +1072,31 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
         }
     }
     return AETHER_OK;
+}
+
+int aether_graph_matches(const int64_t* send, const int64_t* recv, int64_t n_edges, int64_t n_nodes, const void* graph,
+                         void* stream) {
+    if (!graph || n_edges < 0 || n_nodes <= 0) return fail(AETHER_EINVAL, "graph_matches: bad arguments");
+    if (n_edges == 0) return 1;
+    if (!send || !recv) return fail(AETHER_EINVAL, "graph_matches: null edge index");
+    static int* h_flag = nullptr;
+    static int* d_flag = nullptr;
+    if (!h_flag) {
+        void* h = nullptr;
+        HIP_OK(hipHostMalloc(&h, 64, hipHostMallocMapped));
+        void* d = nullptr;
+        HIP_OK(hipHostGetDevicePointer(&d, h, 0));
+        h_flag = (int*)h; d_flag = (int*)d;
+    }
+    GraphLayout G(n_edges, n_nodes, false);
+    const char* g = (const char*)graph;
+    hipStream_t st = (hipStream_t)stream;
+    *(volatile int*)h_flag = 0;
+    k_graph_match<<<dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st>>>(
+        send, recv, n_edges, (const int32_t*)(g + G.perm), (const int32_t*)(g + G.send_s), (const int32_t*)(g + G.recv_s), d_flag);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+    return *(volatile int*)h_flag ? 0 : 1;
 }
 
 int aether_graph_perm(const void* graph, int64_t n_edges, int64_t n_nodes, int32_t* perm_out,

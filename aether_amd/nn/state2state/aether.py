@@ -41,14 +41,20 @@ class GraphCache:
         if hit is not None:
             self._d.move_to_end(key)
             return hit[0]
-        # Same index in new tensors (the runner rebuilds it every batch, main.py:211-212): two
-        # element-wise comparisons on the device are far cheaper than sorting again.
-        for k2, (val, s2, r2) in reversed(list(self._d.items())):
-            if (k2[2], k2[3], k2[6]) == (key[2], key[3], key[6]) and torch.equal(s2, send) and torch.equal(r2, recv):
-                self._d[key] = (val, send, recv)
-                self._trim()
-                return val
+        # Same index in new tensors (the runner rebuilds it every batch, main.py:211-212): one comparison kernel against
+        # the view's own sorted copy + a 4-byte flag (aether_graph_matches, ~20 us) instead of sorting again (two
+        # torch.equal calls cost 0.19 ms: several reductions and a blocking .item() each).
         lib = _lib.load()
+        for k2, (val, s2, r2) in reversed(list(self._d.items())):
+            if (k2[2], k2[3], k2[6]) == (key[2], key[3], key[6]):
+                stream = torch.cuda.current_stream(send.device).cuda_stream
+                same = lib.aether_graph_matches(send.data_ptr(), recv.data_ptr(), send.numel(), n_nodes, val[0].data_ptr(), stream)
+                if same < 0:
+                    _lib.check(same, "aether_graph_matches")
+                if same == 1:
+                    self._d[key] = (val, send, recv)
+                    self._trim()
+                    return val
         E = send.numel()
         nbytes = lib.aether_graph_bytes(E, n_nodes)
         buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=send.device)

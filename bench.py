@@ -535,10 +535,12 @@ def main():
                 if os.path.exists(tpath):
                     try:
                         tj = json.load(open(tpath))
-                        if tj.get("workload") == WORKLOAD["name"] and (B, N, D) == (128, 20, 2):
+                        if tj.get("workload") == WORKLOAD["name"] and (B, N, D) == (128, 20, 2) and dom_name == "k_fused":
                             traffic = tj.get(dom_name + "_hbm_bytes_per_launch")
-                            if executed is None:       # PMC SQ_INSTS_MFMA x 2,048 FLOP, same separate passes
+                            if executed is None:       # PMC SQ_INSTS_MFMA by instruction kind, same separate passes
                                 executed = tj.get(dom_name + "_executed_flop_per_launch")
+                        elif (B, N, D) == (32, 1024, 2) and dom_name == "k_edge_layer":
+                            traffic = tj.get("cfg5shard", {}).get("k_edge_layer_hbm_bytes_per_launch")
                     except Exception:
                         traffic = None
                 roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved,

@@ -101,6 +101,11 @@ const char* aether_last_error(void);
  * temporary host memory.  Returns AETHER_EINDEX if any index is out of range.
  */
 size_t aether_graph_bytes(int64_t n_edges, int64_t n_nodes);
+/* 1 if (send, recv) is element for element the edge index `graph` was built from, 0 if not, < 0 on error.  One small
+ * kernel + a stream synchronisation (a 4-byte flag in host-mapped memory): for callers that rebuild identical index
+ * tensors every batch (experiments/lorentz/main.py:211-212) and want to reuse the view without sorting again. */
+int aether_graph_matches(const int64_t* send, const int64_t* recv, int64_t n_edges, int64_t n_nodes, const void* graph,
+                         void* stream);
 int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges,
                        int64_t n_nodes, void* graph, size_t graph_bytes, AetherGraphInfo* info,
                        void* stream);
