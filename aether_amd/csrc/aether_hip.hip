@@ -327,6 +327,68 @@ struct WsLayout {
 inline int bits_for(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
 
+// Layout of the transposed weight copies the backward kernels read (one region of the workspace), as tasks.
+template <int D>
+BwdWT transposed_weights(const AetherParams& P, float* base, TransposeBatch& TB) {
+    constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+    BwdWT WT;
+    size_t off = 0;
+    TB.n_tasks = 0;
+    auto add = [&](const float* src, int rows, int cols, int src_ld, int col0, int ldd, int cols_pad) {
+        float* dst = base + off;
+        TB.t[TB.n_tasks++] = TransposeTask{src, dst, rows, cols, src_ld, col0, ldd, cols_pad};
+        off += (size_t)cols_pad * ldd;
+        return (const float*)dst;
+    };
+    WT.out_w0t = add(P.out_w0, H, H, H, 0, H, H);
+    WT.out_w3t = add(P.out_w3, H, H, H, 0, H, H);
+    WT.out_w6t = add(P.out_w6, D, H, H, 0, 16, H);
+    for (int l = 1; l <= 4; ++l) {
+        const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
+        const float* w4 = l == 1 ? P.l1_upd_w2 : P.ln_upd_w2[l - 2];
+        const float* w2 = l == 1 ? P.l1_msg_w2 : P.ln_msg_w2[l - 2];
+        WT.upd_w2t[l - 1] = add(w4, H, 2 * H, 2 * H, 0, H, 2 * H);          // [128][64]
+        WT.upd_w0t[l - 1] = add(w3, 2 * H, H, H, 0, 2 * H, H);              // [64][128]
+        WT.msg_w2t[l - 1] = add(w2, H, H, H, 0, H, H);
+        if (l == 1) WT.msg_w0t[0] = add(P.l1_msg_w0, H, F1, F1, 0, H, FPAD); // [32][64]
+        else WT.msg_w0t[l - 1] = add(P.ln_msg_w0[l - 2], H, 3 * H, 3 * H, 0, H, 3 * H);   // [192][64]
+    }
+    return WT;
+}
+
+// Everything derived from the weights alone, in ONE launch in front of the step: the split (3 x bf16) images of the
+// edge-MLP matrices the fused forward copies into LDS (blocks 0-7) and, when the intermediates are kept for a
+// backward, the transposed copies its kernels read (the remaining blocks).
+__global__ void __launch_bounds__(512)
+k_prepare_weights(AetherParams P, int f1, float* __restrict__ wimg, TransposeBatch TB, int split_blocks) {
+    if ((int)blockIdx.x < split_blocks) {
+        split_weights_block(P, f1, wimg, (int)blockIdx.x, threadIdx.x);
+        return;
+    }
+    const int b = (int)blockIdx.x - split_blocks;
+    const TransposeTask T = TB.t[b >> 1];                      // two blocks per task
+    const int total = T.cols_pad * T.ldd;
+    for (int idx = (b & 1) * 512 + threadIdx.x; idx < total; idx += 1024) {
+        const int c = idx / T.ldd, r = idx - c * T.ldd;
+        T.dst[idx] = (c < T.cols && r < T.rows) ? T.src[(size_t)r * T.src_ld + T.col0 + c] : 0.0f;
+    }
+}
+
+template <int D>
+int prepare_weights(const AetherParams& P, char* ws, bool split_images, bool transposes, int64_t Nn, int64_t E, hipStream_t st) {
+    if (!split_images && !transposes) return AETHER_OK;
+    constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
+    WsLayout W(Nn, E, D, transposes);
+    TransposeBatch TB;
+    TB.n_tasks = 0;
+    if (transposes) (void)transposed_weights<D>(P, reinterpret_cast<float*>(ws + W.wt), TB);
+    const int sb = split_images ? 8 : 0;
+    k_prepare_weights<<<dim3((unsigned)(sb + 2 * TB.n_tasks)), dim3(512), 0, st>>>(P, F1, reinterpret_cast<float*>(ws + W.wimg),
+                                                                                    TB, sb);
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
+}
+
 template <int D, int NW, int ROUNDS, bool KEEP>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
                  const float* ea, const int32_t* perm, const int32_t* send_s, const int32_t* recv_s,
@@ -369,10 +431,8 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     const uint32_t* tdst = reinterpret_cast<const uint32_t*>(graph + G.tdst);
     (void)ws_reused;
     const int tiles = (info.max_group_edges + 15) / 16;
-    if (tiles <= 16 && !weights_prepared) {     // split-GEMM variants: 3 x bf16 images of the eight edge-MLP matrices
-        constexpr int F1 = 7 * D + D * (D - 1) / 2 + 2;
-        k_split_weights<<<dim3(8), dim3(512), 0, st>>>(P, F1, wp(W.wimg));
-    }
+    // split-GEMM variants: 3 x bf16 images of the eight edge-MLP matrices; training: the backward's transposed copies
+    if (prepare_weights<D>(P, ws, tiles <= 16 && !weights_prepared, keep, Nn, E, st)) return AETHER_EHIP;
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
@@ -400,6 +460,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int32_t *perm = gp(G.perm), *send_s = gp(G.send_s), *recv_s = gp(G.recv_s), *rowptr = gp(G.rowptr);
     float* nodeinfo = wp(W.nodeinfo);
+    if (prepare_weights<D>(P, ws, false, keep, Nn, E, st)) return AETHER_EHIP;     // the backward's transposed copies
 
     {
         ProfScope ps(K_NODE_PREP, st);
@@ -540,33 +601,8 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     const unsigned egrid = (unsigned)((etile + 3) / 4 < 512 ? (etile + 3) / 4 : 512);    // 2 workgroups per CU
     auto optin = [&](const void* k, size_t lds) -> int { return ensure_dynamic_lds(k, lds); };
     // ---- transposed weight copies (one launch)
-    BwdWT WT;
-    {
-        float* base = wp(W.wt);
-        size_t off = 0;
-        TransposeBatch TB;
-        TB.n_tasks = 0;
-        auto add = [&](const float* src, int rows, int cols, int src_ld, int col0, int ldd, int cols_pad) {
-            float* dst = base + off;
-            TB.t[TB.n_tasks++] = TransposeTask{src, dst, rows, cols, src_ld, col0, ldd, cols_pad};
-            off += (size_t)cols_pad * ldd;
-            return (const float*)dst;
-        };
-        WT.out_w0t = add(P.out_w0, H, H, H, 0, H, H);
-        WT.out_w3t = add(P.out_w3, H, H, H, 0, H, H);
-        WT.out_w6t = add(P.out_w6, D, H, H, 0, 16, H);
-        for (int l = 1; l <= 4; ++l) {
-            const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
-            const float* w4 = l == 1 ? P.l1_upd_w2 : P.ln_upd_w2[l - 2];
-            const float* w2 = l == 1 ? P.l1_msg_w2 : P.ln_msg_w2[l - 2];
-            WT.upd_w2t[l - 1] = add(w4, H, 2 * H, 2 * H, 0, H, 2 * H);          // [128][64]
-            WT.upd_w0t[l - 1] = add(w3, 2 * H, H, H, 0, 2 * H, H);              // [64][128]
-            WT.msg_w2t[l - 1] = add(w2, H, H, H, 0, H, H);
-            if (l == 1) WT.msg_w0t[0] = add(P.l1_msg_w0, H, F1, F1, 0, H, FPAD); // [32][64]
-            else WT.msg_w0t[l - 1] = add(P.ln_msg_w0[l - 2], H, 3 * H, 3 * H, 0, H, 3 * H);   // [192][64]
-        }
-        k_transpose<<<dim3(8, (unsigned)TB.n_tasks), dim3(256), 0, st>>>(TB);
-    }
+    TransposeBatch TB;
+    const BwdWT WT = transposed_weights<D>(P, wp(W.wt), TB);     // written by the forward (prepare_weights)
     // ---- out MLP
     {
         { ProfScope ps(KB_OUT, st);
@@ -700,33 +736,8 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
     OuterList L;
     const unsigned ngrid = (unsigned)((Nn + 15) / 16);
     // ---- transposed weight copies (one launch)
-    BwdWT WT;
-    {
-        float* base = wp(W.wt);
-        size_t off = 0;
-        TransposeBatch TB;
-        TB.n_tasks = 0;
-        auto add = [&](const float* src, int rows, int cols, int src_ld, int col0, int ldd, int cols_pad) {
-            float* dst = base + off;
-            TB.t[TB.n_tasks++] = TransposeTask{src, dst, rows, cols, src_ld, col0, ldd, cols_pad};
-            off += (size_t)cols_pad * ldd;
-            return (const float*)dst;
-        };
-        WT.out_w0t = add(P.out_w0, H, H, H, 0, H, H);
-        WT.out_w3t = add(P.out_w3, H, H, H, 0, H, H);
-        WT.out_w6t = add(P.out_w6, D, H, H, 0, 16, H);
-        for (int l = 1; l <= 4; ++l) {
-            const float* w3 = l == 1 ? P.l1_upd_w0 : P.ln_upd_w0[l - 2];
-            const float* w4 = l == 1 ? P.l1_upd_w2 : P.ln_upd_w2[l - 2];
-            const float* w2 = l == 1 ? P.l1_msg_w2 : P.ln_msg_w2[l - 2];
-            WT.upd_w2t[l - 1] = add(w4, H, 2 * H, 2 * H, 0, H, 2 * H);
-            WT.upd_w0t[l - 1] = add(w3, 2 * H, H, H, 0, 2 * H, H);
-            WT.msg_w2t[l - 1] = add(w2, H, H, H, 0, H, H);
-            if (l == 1) WT.msg_w0t[0] = add(P.l1_msg_w0, H, F1, F1, 0, H, FPAD);
-            else WT.msg_w0t[l - 1] = add(P.ln_msg_w0[l - 2], H, 3 * H, 3 * H, 0, H, 3 * H);
-        }
-        k_transpose<<<dim3(8, (unsigned)TB.n_tasks), dim3(256), 0, st>>>(TB);
-    }
+    TransposeBatch TB;
+    const BwdWT WT = transposed_weights<D>(P, wp(W.wt), TB);     // written by the forward (prepare_weights)
     // ---- out MLP
     { ProfScope ps(KB_OUT, st);
     kb_out<D><<<dim3(ngrid), dim3(64), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),

@@ -76,14 +76,12 @@ template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
 
 // Split (3 x bf16) images of the edge-MLP weights in global memory, in the exact order the kernel keeps them in LDS
 // (stage_split4): per layer l = 1..4 image A (layer 1: W1 padded to K = 32, FUSED_WIMG / 2 floats; layers 2-4: W_e)
-// and image B (W2).  k_split_weights writes them once per weight version; k_fused copies them with LDS-DMA.
+// and image B (W2).  k_prepare_weights (aether_hip.hip) writes them once per weight version; k_fused copies them with LDS-DMA.
 constexpr int FUSED_WIMG_SET = 8 * FUSED_WIMG;           // floats reserved (layer 1's image A uses half of its slot)
 __device__ __host__ constexpr int fused_wimg_offset(int layer, int which) { return ((layer - 1) * 2 + which) * FUSED_WIMG; }
 
-__global__ void __launch_bounds__(512)
-k_split_weights(AetherParams P, int f1, float* __restrict__ wimg) {
-    const int tid = threadIdx.x;
-    const int layer = (int)blockIdx.x / 2 + 1, which = (int)blockIdx.x & 1;
+__device__ __forceinline__ void split_weights_block(const AetherParams& P, int f1, float* __restrict__ wimg, int block, int tid) {
+    const int layer = block / 2 + 1, which = block & 1;
     float* img = wimg + fused_wimg_offset(layer, which);
     if (which == 0 && layer == 1) {                       // W1 [64][f1] -> K padded to 32: one float4 per thread
         const int r = tid >> 3, c0 = (tid & 7) * 4;
