@@ -254,6 +254,30 @@ k_fused_bwd(FbArgs A) {
     f32x4 de[DE_REGS ? ROUNDS : 1][4];       // dL/d(message tile) carried from layer l+1 to layer l
     int published = 0;                       // layers whose partial dP_s rows this workgroup's waves have published
 
+    // Weight fragments of a layer's node update backward (W3, W4^T: rows 32 wave ..; W3^T: rows 16 wave ..).  They depend
+    // on nothing the kernel computes: requested for layer l - 1 as soon as layer l's accumulators have been dumped, they
+    // arrive under the reduction phases instead of costing the next node phase a memory round trip.
+    f32x4 nw3f[2][4], nw4f[2][4], nw3tf[8], nb3v[2];
+    auto issue_node_frags = [&](const int l) {
+        const FbLayer Ln = A.layer[l - 1];
+        int tid_o = threadIdx.x;
+        asm volatile("" : "+v"(tid_o));
+        const int ln = tid_o & 63, wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), ii = ln & 15, qq = ln >> 4;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            const int mb = 2 * wv + mm;
+            nb3v[mm] = ld4(Ln.upd_b0 + 16 * mb + 4 * qq);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                nw3f[mm][a] = ld4(Ln.upd_w0 + (size_t)(16 * mb + ii) * H + 16 * a + 4 * qq);
+                nw4f[mm][a] = ld4(Ln.w4t + (size_t)(16 * mb + ii) * H + 16 * a + 4 * qq);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) nw3tf[a] = ld4(Ln.w3t + (size_t)(16 * wv + ii) * (2 * H) + 16 * a + 4 * qq);
+    };
+    issue_node_frags(4);
+
     // ================================================================ one layer of the backward
     auto layer = [&](auto first_tag, const int l) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -272,10 +296,6 @@ k_fused_bwd(FbArgs A) {
         // ------------------------------------------------------------ node update backward (locs.py:240-241)
         // x_l = n + W4 silu(W3 n + b3) + b4:  dpre_u = (W4^T dx) * silu'(pre_u),  dn = dx + W3^T dpre_u
         {
-            const float* w3 = Lp.upd_w0;
-            const float* b3 = Lp.upd_b0;
-            const float* w4t = Lp.w4t;
-            const float* w3t = Lp.w3t;
             // Issue order = wait order (vmcnt counts in order): LDS-DMA of the edge weights, then the small row loads
             // whose data is needed first, then the node-phase weight fragments.  One memory round trip for all of it.
             if constexpr (FIRST) {
@@ -310,19 +330,7 @@ k_fused_bwd(FbArgs A) {
                 }
             }
             if (tid < H) bv0 = Lp.msg_b2[tid];
-            f32x4 w3f[2][4], w4f[2][4], w3tf[8], b3v[2];
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                const int mb = 2 * wave + mm;
-                b3v[mm] = ld4(b3 + 16 * mb + 4 * q);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    w3f[mm][a] = ld4(w3 + (size_t)(16 * mb + i) * H + 16 * a + 4 * q);
-                    w4f[mm][a] = ld4(w4t + (size_t)(16 * mb + i) * H + 16 * a + 4 * q);
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 8; ++a) w3tf[a] = ld4(w3t + (size_t)(16 * wave + i) * (2 * H) + 16 * a + 4 * q);
+            f32x4 (&w3f)[2][4] = nw3f, (&w4f)[2][4] = nw4f, (&w3tf)[8] = nw3tf, (&b3v)[2] = nb3v;   // requested a phase ago
             if constexpr (FIRST) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) st4(wE + ((4 * j + wave) * 64 + lane) * 4, w1v[j]);
@@ -695,6 +703,7 @@ k_fused_bwd(FbArgs A) {
             if (wave < 2) dump(false);
             lds_barrier();
             if (wave >= 2) dump(true);
+            if (l > 1) issue_node_frags(l - 1);      // the accumulators are dead: their registers take the next fragments
             lds_barrier();
             float* dst = A.partial + ((size_t)blockIdx.x * 4 + (l - 1)) * FB_PART;
             for (int f = tid; f < 2 * H * H / 4; f += FB_THREADS)
