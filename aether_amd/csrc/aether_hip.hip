@@ -432,7 +432,7 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     (void)ws_reused;
     const int tiles = (info.max_group_edges + 15) / 16;
     // split-GEMM variants: 3 x bf16 images of the eight edge-MLP matrices; training: the backward's transposed copies
-    if (prepare_weights<D>(P, ws, tiles <= 16 && !weights_prepared, keep, Nn, E, st)) return AETHER_EHIP;
+    if (prepare_weights<D>(P, ws, !weights_prepared, keep, Nn, E, st)) return AETHER_EHIP;
     int rc;
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \

@@ -27,9 +27,10 @@ constexpr int FUSED_MAX_EDGES = 384;         // 24 tiles (N=20 fully connected: 
 constexpr int FUSED_MAX_TILES = FUSED_MAX_EDGES / 16;
 constexpr int LDU = 2 * H + 8;               // padded LDS row for the 128-wide update hidden
 
-// The edge MLP's two 64 x 64 contractions run as six bf16 MFMA terms on split operands (common.h, gemm_split) wherever
-// the weight images fit (3 x 8 KB each instead of 18 KB of padded fp32): every variant but the 17-24 tile one.
-template <int ROUNDS> constexpr bool fused_split_gemm() { return ROUNDS < 3; }
+// The edge MLP's two 64 x 64 contractions run as six bf16 MFMA terms on split operands (common.h, gemm_split); the
+// weight images (3 x 8 KB each instead of 18 KB of padded fp32) fit every variant since the layer-1 features of the
+// 17-24 tile one are built two rounds at a time.
+template <int ROUNDS> constexpr bool fused_split_gemm() { return true; }
 constexpr int FUSED_WIMG = SPLIT_WIMG;                   // floats of a split image of a 64 x 64 matrix (24 KB)
 template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static constexpr int WSZ = fused_split_gemm<ROUNDS>() ? FUSED_WIMG : H * LDW;
@@ -48,7 +49,7 @@ template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static constexpr int PART = NINFO + FUSED_MAX_NODES * 24;      // [PART_ROWS][LDW]  per-(receiver, tile) sums
     static constexpr int ARRIVED = PART + PART_ROWS * LDW;         // [4] ints: split mode, layer whose partner rows are in LDS
     static constexpr int SCRATCH = ARRIVED + 4;                    // aliased by the regions below
-    static constexpr int FEAT_ROWS = 16 * ROUNDS;                              // per wave
+    static constexpr int FEAT_ROWS = 16 * (ROUNDS < 2 ? ROUNDS : 2);           // per wave: two rounds of features at a time
     static constexpr int SCRATCH_SIZE =
         NW * FEAT_ROWS * LDF > NW * 16 * LDST ? NW * FEAT_ROWS * LDF : NW * 16 * LDST;
     static constexpr int TOTAL = SCRATCH + SCRATCH_SIZE;
@@ -515,50 +516,63 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     int ke[KEEP ? ROUNDS : 1];               // KEEP: receiver-sorted position of the lane's edge (row of the saved tensors)
     {
         float* scratch = smem + L::FEAT + wave * (L::FEAT_ROWS * LDF);
-        if (lane < 16 * ROUNDS) {
-            const int r = lane >> 4, ii = lane & 15;
-            const int local = 16 * (NW * r + wave) + ii;
-            float o[FPAD];
-            if (local < m) {
-                const int k = eb + lorder[eb + local];       // position in the receiver-sorted edge list
-                const float* nj = ninfo + (send_s[k] - vb) * 24;
-                const float* nr = ninfo + (recv_s[k] - vb) * 24;
-                float njl[NI::STRIDE], nrl[NI::STRIDE];
 #pragma unroll
-                for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
-                float eal[2];
-                if (dbg.step.qattr) {          // main.py:243-246: [q_i q_j, sqrt(sum((x_i - x_j)^2))]
-                    float d2 = 0.0f;
+        for (int r0 = 0; r0 < ROUNDS; r0 += 2) {               // two rounds (32 scratch rows) per pass
+            constexpr int PASS = 2;
+            const int nr_pass = ROUNDS - r0 < PASS ? ROUNDS - r0 : PASS;
+            if (lane < 16 * nr_pass) {
+                const int r = r0 + (lane >> 4), ii = lane & 15;
+                const int local = 16 * (NW * r + wave) + ii;
+                float o[FPAD];
+                if (local < m) {
+                    const int k = eb + lorder[eb + local];       // position in the receiver-sorted edge list
+                    const float* nj = ninfo + (send_s[k] - vb) * 24;
+                    const float* nr = ninfo + (recv_s[k] - vb) * 24;
+                    float njl[NI::STRIDE], nrl[NI::STRIDE];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const float df = njl[NI::P + d] - nrl[NI::P + d];
-                        d2 += df * df;
+                    for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
+                    float eal[2];
+                    if (dbg.step.qattr) {          // main.py:243-246: [q_i q_j, sqrt(sum((x_i - x_j)^2))]
+                        float d2 = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            const float df = njl[NI::P + d] - nrl[NI::P + d];
+                            d2 += df * df;
+                        }
+                        eal[0] = dbg.step.qattr[send_s[k]] * dbg.step.qattr[recv_s[k]];
+                        eal[1] = sqrtf(d2);
+                    } else {
+                        const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                        eal[0] = ea[0]; eal[1] = ea[1];
                     }
-                    eal[0] = dbg.step.qattr[send_s[k]] * dbg.step.qattr[recv_s[k]];
-                    eal[1] = sqrtf(d2);
+                    edge_features<D>(njl, nrl, eal, o);
+                    if (keep) {
+#pragma unroll
+                        for (int t = 0; t < FPAD; t += 4)
+                            st4(dbg.feat + (int64_t)k * FPAD + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+                    }
                 } else {
-                    const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
-                    eal[0] = ea[0]; eal[1] = ea[1];
-                }
-                edge_features<D>(njl, nrl, eal, o);
-                if (keep) {
 #pragma unroll
-                    for (int t = 0; t < FPAD; t += 4)
-                        st4(dbg.feat + (int64_t)k * FPAD + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+                    for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
                 }
-            } else {
 #pragma unroll
-                for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
+                for (int t = 0; t < FPAD; t += 4)
+                    st4(scratch + lane * LDF + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
             }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < FPAD; t += 4)
-                st4(scratch + lane * LDF + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
+            for (int rr = 0; rr < PASS; ++rr) {
+                const int r = r0 + rr;
+                if (r < ROUNDS) {
+                    e[r][0] = ld4(scratch + (16 * rr + i) * LDF + 4 * q);   // features as bop[0..1]
+                    e[r][1] = ld4(scratch + (16 * rr + i) * LDF + 16 + 4 * q);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this pass's features sit in registers ...
+            __builtin_amdgcn_wave_barrier();                       // ... before the next pass overwrites the rows
         }
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            e[r][0] = ld4(scratch + (16 * r + i) * LDF + 4 * q);   // features as bop[0..1]
-            e[r][1] = ld4(scratch + (16 * r + i) * LDF + 16 + 4 * q);
             e[r][2] = f32x4{0.f, 0.f, 0.f, 0.f};
             e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile = NW * r + wave;

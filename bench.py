@@ -553,7 +553,12 @@ def main():
                         "executed_flop_per_launch": executed,
                         "source_of_traffic_and_executed": "profiles/traffic.json (rocprofv3 --pmc passes of this command)"
                                                           if traffic is not None else None}
-                assert roof["frac"] <= 1.0, roof
+                if roof["frac"] > 1.0:
+                    # possible off the headline size: `achieved` counts the reference formulation's flops (192 -> 64 first
+                    # layer per edge), the kernel executes ~0.6x of them (node-term split) and runs the 64 x 64
+                    # contractions as bf16 terms on the matrix pipe, whose peak is above the fp32 MFMA peak quoted here
+                    roof["frac_note"] = ("above 1: algorithmic flops of the reference formulation over the fp32 MFMA peak; "
+                                         "the kernel executes fewer flops and uses the bf16 pipe (see dtype_note)")
                 if dom_name == "k_edge_layer":
                     # HBM side of the streamed edge kernel (SURVEY 8d asks for both fractions): algorithmic bytes per
                     # edge and layer = read e_{l-1} 256 + write e_l 256 + indices 8 + partial rows 16
