@@ -90,6 +90,8 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "aether_s2s_filter_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "aether_s2s_filter_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aether_s2s_prior_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "aether_s2s_prior_step": (C.c_int, [C.c_void_p] + [C.c_int] * 8 + [C.c_int64, C.c_int64] + [C.c_void_p] * 9 +
                               [C.c_size_t] + [C.c_void_p] * 4),

@@ -33,6 +33,7 @@
 #include "backward.h"
 #include "fused_bwd.h"
 #include "seq2seq.h"
+#include "s2s_filter.h"
 #include "dynfield.h"
 #include "s2s_dynfield.h"
 #include "knn.h"
@@ -93,14 +94,21 @@ struct ProfScope {
 
 // Kernels that use more than 64 KiB of dynamic LDS need an explicit opt-in, once per (kernel, device).
 int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    struct Entry { const void* kernel; int dev; size_t bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<const void*, int>> done;
+    static std::vector<Entry> done;
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
-    for (const auto& d : done) if (d.first == kernel && d.second == dev) return AETHER_OK;
+    for (auto& d : done)
+        if (d.kernel == kernel && d.dev == dev) {
+            if (d.bytes >= bytes) return AETHER_OK;
+            HIP_OK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            d.bytes = bytes;
+            return AETHER_OK;
+        }
     HIP_OK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    done.emplace_back(kernel, dev);
+    done.push_back({kernel, dev, bytes});
     return AETHER_OK;
 }
 
@@ -251,7 +259,9 @@ int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defe
 int g_outer_tiles_per_wave = 0;                 // aether_set_option("outer_tiles_per_wave", n): 16-row tiles per wave of k_outer (0: by task size)
 int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
 int g_linear_kwaves = 4;                        // aether_set_option("linear_kwaves", 1 | 4): waves of a workgroup that split a small layer's k-groups
-int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the filter GEMM
+int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the first-version filter kernel (variable-N steps)
+int g_filter_wgs = 256;                         // workgroups of k_s2s_filter_split: one per CU
+int g_filter_splits = 0;                        // aether_set_option("filter_splits", n): k-splits of the filter GEMM, 0 = by balance
 
 
 struct WsLayout {
@@ -882,6 +892,17 @@ int aether_set_option(const char* name, int value) {
     if (!strcmp(name, "linear_kwaves")) {
         if (value != 1 && value != 4) return fail(AETHER_EINVAL, "set_option: linear_kwaves must be 1 or 4");
         g_linear_kwaves = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "filter_wgs")) {
+        if (value < 8 || value % 8 != 0) return fail(AETHER_EINVAL, "set_option: filter_wgs must be a multiple of 8");
+        g_filter_wgs = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "filter_splits")) {           // changes the seq2seq / variable-N prior workspace sizes
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(AETHER_EINVAL, "set_option: filter_splits must be 0 (automatic), 1, 2, 4 or 8");
+        g_filter_splits = value;
         return AETHER_OK;
     }
     if (!strcmp(name, "filter_wg_target")) {        // changes the seq2seq / variable-N prior and decoder workspace sizes

@@ -1,0 +1,289 @@
+// Anisotropic edge filter of the seq2seq / variable-N prior step (nn/nn/anisotropic_filter.py:34-40), second version:
+//   out[e][c] = sum_r ea[e][r] * (b2[r h + c] + sum_k L2[r h + c][k] hw[e][k]),   hw[e][k] = act(W1[k] . pos[e] + b1[k])
+// evaluated in the reference's own order -- Z_r = L2_r hw first, then the weighted sum over the R features -- which
+// keeps the matrix-core operand the same for every r: the hidden row hw[e][:] is split ONCE per k slab into three bf16
+// pieces held in registers, the weights come as a prepared bf16 x 3 image (k_s2s_filter_images, once per weight version),
+// and every fp32 product runs as six v_mfma_f32_16x16x32_bf16 terms (common.h: same error level as the fp32 MFMA, 2.6 x
+// its rate).  The first version (seq2seq.h, k_s2s_filter) formed x[(r, k)] = ea[e][r] * hw[e][k] on the fly for the fp32
+// MFMA: it sits at 0.7-0.8 of THAT roof (472 us at 2,560 edges x 39 features, 4.9 ms at 48,640 x 24).
+//
+// Workgroup = 8 waves = 2 (k halves) x 4 (edge quarters) on a 64 (c) x 256 (edges) output tile, two waves per SIMD.
+// The k range of a unit is walked in slabs of 64; wave (a, eq) owns k block a (32 wide) of the slab and edges 64 eq ..
+// 64 eq + 63: its B fragments (64 edges x 32 k x 3 pieces = 48 registers) come once per slab from the prepared image of
+// the hidden rows (k_s2s_filter_bimg: the first hyper-network layer, split; it replaces k_s2s_pos_hidden) and stay put
+// for all R features.
+// Per feature r the workgroup needs the weight fragments of 64 c x 64 k (2 x 12 KB, contiguous per k block in the image):
+// they arrive by LDS-DMA two iterations ahead in a three-slot ring (72 KB), one workgroup barrier per r.  A wave runs
+// 96 MFMAs per r into a fresh Z_r tile (first term on a zero accumulator) and adds out += ea[:, r] * Z_r (its k half of
+// it: the sum over r is linear, the two halves meet once, in LDS, at the end).
+// LDS: ring 72 KB + feature values R x 1 KB + bias slab R x 256 B.
+// Units = (256-edge tile, 64-wide c block, split z): split z covers h / splits consecutive k (a multiple of 64) and writes
+// plane z of `out` (bias in plane 0); k_s2s_sum_planes adds the planes in order (deterministic).  Persistent workgroups,
+// one per CU; the workgroups of an XCD walk the same (c block, split) pairs side by side, one edge tile each.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int FILT_STAGE = 2 * 4 * 3 * 64;      // bf16x8 fragments of one step: 2 k blocks x (64 c x 32 k x 3 pieces = 12 KB)
+constexpr int FILT_NST = 3;
+
+__host__ __device__ constexpr size_t filt_lds_bytes(int R) {
+    return (size_t)(FILT_NST * FILT_STAGE) * 16 + (size_t)R * 256 * 4 + (size_t)R * 64 * 4;
+}
+
+// image[((r (h/32) + a32) (h/16) + mb) 3 + term][lane (i, q)] = pieces of L2[r h + 16 mb + i][32 a32 + 8 q .. + 8)
+__global__ void __launch_bounds__(256)
+k_s2s_filter_images(const float* __restrict__ L2w, int R, int h, bf16x8* __restrict__ img) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;         // (row, k octet)
+    const int oct = h >> 3;
+    if (idx >= (int64_t)R * h * oct) return;
+    const int64_t row = idx / oct;
+    const int o = (int)(idx - row * oct);
+    const int r = (int)(row / h), c = (int)(row - (int64_t)r * h);
+    const f32x4 v0 = ld4(L2w + row * h + 8 * o), v1 = ld4(L2w + row * h + 8 * o + 4);
+    bf16x8 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, d;
+        split_bf16x3(j < 4 ? v0[j] : v1[j - 4], a, b, d);
+        hi[j] = a; mid[j] = b; lo[j] = d;
+    }
+    const int a32 = o >> 2, q = o & 3, mb = c >> 4, i = c & 15;
+    const size_t frag = (((size_t)r * (h >> 5) + a32) * (h >> 4) + mb) * 3;
+    img[(frag + 0) * 64 + i + 16 * q] = hi;
+    img[(frag + 1) * 64 + i + 16 * q] = mid;
+    img[(frag + 2) * 64 + i + 16 * q] = lo;
+}
+
+// B operand of the filter GEMM: the hidden rows of the hyper-network, hw[e][k] = act(W1[k] . pos[e] + b1[k]), split into
+// bf16 pieces and laid out as MFMA fragments: bimg[((e / 16) (h / 32) + a32) 3 + term][lane (i, q)] = pieces of
+// hw[16 (e / 16) + i][32 a32 + 8 q .. + 8).  One thread per (edge, k octet); edges past the end repeat the last one.
+template <int P>
+__global__ void __launch_bounds__(256)
+k_s2s_filter_bimg(const float* __restrict__ pos, const float* __restrict__ W1, const float* __restrict__ b1, int relu,
+                  int h, int64_t n_edges, bf16x8* __restrict__ bimg) {
+    const int oct = h >> 3;
+    const int64_t padded = (n_edges + 15) & ~(int64_t)15;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= padded * oct) return;
+    // consecutive threads: the 16 edges of a block, then the octets -> 256-byte runs of the image
+    const int64_t blk = idx / (16 * oct);
+    const int rem = (int)(idx - blk * 16 * oct), o = rem >> 4, i = rem & 15;
+    int64_t e = blk * 16 + i;
+    e = e < n_edges ? e : n_edges - 1;
+    float pe[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) pe[p] = pos[e * P + p];
+    bf16x8 hi, mid, lo;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = 8 * o + u;
+        float sv = b1[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) sv = fmaf(W1[k * P + p], pe[p], sv);
+        sv = sv > 0.0f ? sv : (relu ? 0.0f : expm1f(sv));
+        __bf16 ph, pm, pl;
+        split_bf16x3(sv, ph, pm, pl);
+        hi[u] = ph; mid[u] = pm; lo[u] = pl;
+    }
+    const int a32 = o >> 2, q = o & 3;
+    bf16x8* dst = bimg + ((blk * (h >> 5) + a32) * 3) * 64 + i + 16 * q;
+    dst[0] = hi;
+    dst[64] = mid;
+    dst[128] = lo;
+}
+
+template <int R>
+__global__ void __launch_bounds__(512)             // two waves per SIMD: <= 256 registers each, no AGPR allocation
+k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2, const float* __restrict__ ea,
+                   const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
+    bf16x8* ring = reinterpret_cast<bf16x8*>(filt_smem);                        // [a 2][slot 3][mb 4][term 3][lane]
+    float* evs = reinterpret_cast<float*>(ring + FILT_NST * FILT_STAGE);        // [r][eq 4][i 16][nb 4]
+    float* b2s = evs + R * 256;                                                 // [r][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int a = wave & 1, eq = wave >> 1;                   // adjacent waves: the two k halves of an edge quarter
+    const int n_eb = (int)((n_edges + 255) >> 8), n_cb = h >> 6;
+    const int n_pairs = n_cb * splits;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, n_slots = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int my_pairs = (n_pairs - xcd + 7) >> 3;             // pairs xcd, xcd + 8, ..
+    const int n_a32 = h >> 5, n_mb = h >> 4;
+    const int slabs = (h / splits) >> 6;                       // 64-wide k slabs of a unit
+    const int IT = slabs * R;                                  // iterations of a unit: (slab, r)
+    const int64_t n_eb16 = (n_edges + 15) >> 4;
+    // image strides in fragments of 64 lanes: one r step, and the jump from (slab, R - 1) to (slab + 1, 0)
+    const int64_t r_stride = (int64_t)n_a32 * n_mb * 3 * 64;
+    const int64_t slab_jump = (int64_t)2 * n_mb * 3 * 64 - (int64_t)(R - 1) * r_stride;
+    // the wave's group (k half a) has its own three-slot ring of 12 KB steps and issues its own DMA: 3 of the 12 fragments
+    bf16x8* gring = ring + a * (FILT_NST * 12 * 64);
+
+    for (int unit = slot; unit < my_pairs * n_eb; unit += n_slots) {
+        const int pair = xcd + 8 * (unit / n_eb);
+        const int64_t e0 = (int64_t)(unit % n_eb) * 256;
+        const int c0 = (pair % n_cb) * 64, z = pair / n_cb;
+        const int kbase = z * (h / splits);
+
+        // DMA cursor: k block a of step (slab 0, r 0), this wave's first fragment
+        const bf16x8* dsrc = img + (((size_t)((kbase >> 5) + a) * n_mb + (c0 >> 4)) * 3 + eq) * 64 + lane;
+        int dr = 0, dslot = 0, dleft = IT;
+        auto dma_next = [&]() {                                // the next step of this group -> its slot; advances the cursor
+            if (dleft <= 0) return;
+            bf16x8* dst = gring + (dslot * 12 + eq) * 64;
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(dsrc + 4 * f * 64),
+                                                 (__attribute__((address_space(3))) void*)(dst + 4 * f * 64), 16, 0, 0);
+            --dleft;
+            dslot = dslot == FILT_NST - 1 ? 0 : dslot + 1;
+            if (++dr == R) { dr = 0; dsrc += slab_jump; } else dsrc += r_stride;
+        };
+        // unit prologue: everything it reads from global memory in one round of loads
+        for (int idx = tid; idx < R * 256; idx += 512) {       // feature values of the tile's edges (coalesced reads)
+            const int nl = idx / R, r = idx - nl * R;
+            int64_t n = e0 + nl;
+            n = n < n_edges ? n : n_edges - 1;
+            evs[r * 256 + (nl & 192) + 4 * (nl & 15) + ((nl >> 4) & 3)] = ea[(size_t)n * R + r];
+        }
+        if (z == 0)
+            for (int idx = tid; idx < R * 64; idx += 512) b2s[idx] = b2[(size_t)(idx >> 6) * h + c0 + (idx & 63)];
+
+        f32x4 outv[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) outv[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* evl = evs + 64 * eq + 4 * i;
+        __syncthreads();                                       // staged values visible, every global load of the prologue done
+        dma_next();
+        dma_next();
+        if (a == 1) dma_next();
+        if (z == 0 && a == 0) {                                // bias term: sum_r ea[e][r] * b2[r h + c]
+#pragma unroll 4
+            for (int r = 0; r < R; ++r) {
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(evl + r * 256);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(b2s + r * 64 + 16 * mb + 4 * q);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += bv * e4[nb];
+                }
+            }
+        }
+
+        bf16x8 xh[4], xm[4], xl[4];                            // B fragments of the wave's k block: edges 16 nb + i, k = 8 q + u
+        auto build_b = [&](int slab) {                         // 12 coalesced 1 KB loads, once per slab
+            const int a32 = ((kbase + 64 * slab) >> 5) + a;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                int64_t blk = (e0 >> 4) + 4 * eq + nb;
+                blk = blk < n_eb16 ? blk : n_eb16 - 1;
+                const bf16x8* src = bimg + ((blk * n_a32 + a32) * 3) * 64 + lane;
+                xh[nb] = src[0]; xm[nb] = src[64]; xl[nb] = src[128];
+            }
+            // consume the loads HERE: left pending, the compiler's wait for them lands in front of the first MFMA of the
+            // iteration as vmcnt(0) -- behind the DMA just issued for a later step, whose latency it then exposes
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+v"(xh[nb]), "+v"(xm[nb]), "+v"(xl[nb]));
+        };
+        // Fragment reads as inline assembly: the compiler waits for EVERY outstanding LDS-DMA (vmcnt(0)) before an LDS read
+        // it can see -- it cannot tell the ring slots apart -- which would expose the latency of the step just requested.
+        auto frags = [&](int it, bf16x8 (&w)[12], f32x4& e4, int r) {
+            const bf16x8* st = gring + (it % FILT_NST) * 12 * 64 + lane;
+            const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
+            const unsigned eaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(evl + r * 256);
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[j]) : "v"(base), "n"(j * 1024));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(e4) : "v"(eaddr));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
+                           "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(e4));
+        };
+        auto tile = [&](const bf16x8 (&w)[12], int mb, const f32x4 e4) {      // Z_r rows 16 mb .. + 16, then out += ea[:, r] Z_r
+            const bf16x8 wh = w[mb * 3], wm = w[mb * 3 + 1], wl = w[mb * 3 + 2];
+            f32x4 tmp[4];
+            // small terms first; four independent accumulators per term
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[nb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += tmp[nb] * e4[nb];
+        };
+        // IT + 1 workgroup barriers b_0 .. b_IT in both groups.  Group 0 passes b_it at the top of its iteration it; group 1
+        // runs half an iteration out of phase -- b_{it+1} sits in the middle of its iteration it -- so that on every SIMD one
+        // wave's DMA issue, fragment reads and barrier wait run under the other wave's MFMAs (in phase, both waves of a SIMD
+        // did them at the same time: 1,250 of 5,000 cycles per iteration with the matrix pipe idle, s_memtime stamps).
+        bf16x8 w[12];
+        f32x4 e4;
+        if (a == 0) {
+            for (int it = 0; it < IT; ++it) {
+                const int slab = it / R, r = it - slab * R;
+                if (r == 0) build_b(slab);
+                // this step's fragments have landed (the three loads of step it + 1 may still be in flight) ...
+                if (it + 1 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();                                 // b_it: ... for every wave; slot (it - 1) % NST is free
+                dma_next();                                    // step it + 2
+                frags(it, w, e4, r);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) tile(w, mb, e4);
+            }
+            lds_barrier();                                     // b_IT
+        } else {
+            if (IT > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (IT > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();                                     // b_0: step 0 of this group has landed for every wave
+            for (int it = 0; it < IT; ++it) {
+                const int slab = it / R, r = it - slab * R;
+                if (r == 0) build_b(slab);
+                frags(it, w, e4, r);
+                tile(w, 0, e4);
+                tile(w, 1, e4);
+                // step it + 1 has landed (the loads of step it + 2 may be in flight); this step's fragments are in registers
+                if (it + 2 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();                                 // b_{it+1}: its slot is free
+                dma_next();                                    // step it + 3
+                tile(w, 2, e4);
+                tile(w, 3, e4);
+            }
+        }
+        // the two k halves meet: waves a = 1 park their tile in the (now idle) ring, waves a = 0 add and store
+        lds_barrier();
+        f32x4* red = reinterpret_cast<f32x4*>(ring) + (size_t)eq * 16 * 64 + lane;
+        if (a == 1) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) red[(mb * 4 + nb) * 64] = outv[mb][nb];
+        }
+        lds_barrier();
+        if (a == 0) {
+            float* dst = out + (size_t)z * n_edges * h;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int64_t n = e0 + 64 * eq + 16 * nb + i;
+                if (n >= n_edges) continue;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    st4(dst + (size_t)n * h + c0 + 16 * mb + 4 * q, outv[mb][nb] + red[(mb * 4 + nb) * 64]);
+            }
+        }
+        __syncthreads();                                       // ring and staged values are free for the next unit; stores issued
+    }
+}
+
+}  // namespace

@@ -22,7 +22,7 @@ from .field import FieldQuery
 
 
 def _tensors_key(module):
-    return tuple(t.data_ptr() for t in list(module.parameters()) + list(module.buffers()))
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
 
 class _StepRunner:

@@ -27,7 +27,7 @@ class _PriorParams(C.Structure):
         "mlp4_w0", "mlp4_b0", "mlp4_w3", "mlp4_b3", "mlp4_bn_w", "mlp4_bn_b", "mlp4_bn_mean", "mlp4_bn_var",
         "lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh")] +
         [("prior_w", C.c_void_p * 4), ("prior_b", C.c_void_p * 4)] +
-        [(n, C.c_void_p) for n in ("res1_w", "res1_b", "filt_w0", "filt_b0", "filt_w2", "filt_b2")])
+        [(n, C.c_void_p) for n in ("res1_w", "res1_b", "filt_w0", "filt_b0", "filt_w2", "filt_b2", "filt_image")])
 
 
 def gumbel_softmax_hard(logits, uniform, tau):
@@ -146,7 +146,25 @@ class Encoder(nn.Module):
         ps.res1_w, ps.res1_b = ptr(self.res1.weight), ptr(self.res1.bias)
         f = self.edge_filter.edge_filter
         ps.filt_w0, ps.filt_b0, ps.filt_w2, ps.filt_b2 = ptr(f[0].weight), ptr(f[0].bias), ptr(f[2].weight), ptr(f[2].bias)
+        ps.filt_image = self._filter_image(f[2].weight).data_ptr()
         return ps, len(layers), (layers[0].out_features if len(layers) > 1 else 0)
+
+    def _filter_image(self, w):
+        """bf16 x 3 image of the filter bank for the matrix cores (``aether_s2s_filter_prepare``), rebuilt -- into the same
+        buffer, which captured graphs point at -- whenever the weight tensor moved or was written to."""
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._cache.get("filt_image")
+        if hit is None or hit[0] != key:
+            lib = _lib.load()
+            R, h = self.edge_filter.num_relative_features, self.hidden_size
+            nbytes = lib.aether_s2s_filter_image_bytes(R, h)
+            buf = hit[1] if hit is not None and hit[1].numel() == nbytes and hit[1].device == w.device else \
+                torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            _lib.check(lib.aether_s2s_filter_prepare(w.data_ptr(), R, h, buf.data_ptr(), nbytes,
+                                                     torch.cuda.current_stream(w.device).cuda_stream),
+                       "aether_s2s_filter_prepare")
+            hit = self._cache["filt_image"] = (key, buf)
+        return hit[1]
 
     def _graph(self, B, N, device):
         key = (B, N, str(device))

@@ -338,7 +338,17 @@ typedef struct AetherS2SPriorParams {
     const float* res1_w; const float* res1_b;                                                    /* [h][7D+O] */
     const float* filt_w0; const float* filt_b0;                                                  /* [h][D+O] */
     const float* filt_w2; const float* filt_b2;                                                  /* [R h][h], R = 2(4D+O)+3D */
+    const void* filt_image;   /* aether_s2s_filter_prepare(filt_w2, R, h, ..) of the CURRENT filt_w2 values, or NULL: the
+                                 step then builds the image in its workspace on every call (reads all of filt_w2) */
 } AetherS2SPriorParams;
+/*
+ * The filter GEMM (anisotropic_filter.py:34-40) runs as bf16 x 3 matrix-core terms (fp32-equivalent); its
+ * weight operand is a re-ordered three-piece image of filt_w2 (6 bytes per weight).  Prepare it once per weight version:
+ *   image : device buffer of aether_s2s_filter_image_bytes(n_features, hidden) bytes, 16-byte aligned
+ */
+size_t aether_s2s_filter_image_bytes(int n_features, int hidden);
+int aether_s2s_filter_prepare(const float* filt_w2, int n_features, int hidden, void* image, size_t image_bytes,
+                              void* stream);
 size_t aether_s2s_prior_workspace_bytes(int num_dims, int hidden, int rnn_hidden, int prior_hidden,
                                         int64_t n_nodes, int64_t n_edges);
 int aether_s2s_prior_step(const AetherS2SPriorParams* params, int num_dims, int hidden, int rnn_hidden,

@@ -277,6 +277,77 @@ def test_prior_step_variants_vs_oracle(D, layers, rep):
         assert scale_rel_err(got.cpu(), want) <= TOL
 
 
+@pytest.mark.parametrize("D,N,B,H", [(2, 3, 5, 128), (3, 7, 9, 256), (2, 12, 5, 512)])
+def test_filter_gemm_split_counts_and_ragged_tiles_vs_oracle(D, N, B, H):
+    """The bf16 x 3 filter GEMM (csrc/s2s_filter.h) at edge counts that are not multiples of its 16-edge fragment blocks or
+    256-edge tiles (30, 378, 660 edges), for every k-split count the hidden size allows (1, 2, 4, 8: one plane per split,
+    added in order), with the weight image prepared by the module and, through the C ABI directly, built per call
+    (filt_image = NULL)."""
+    import ctypes as C
+    from aether_amd import _lib
+    from aether_amd.nn.seq2seq.encoder import Encoder
+    R = 32
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
+              "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 1,
+              "encoder_mlp_hidden": 32, "prior_num_layers": 1, "prior_hidden_size": 48, "use_3d": D == 3,
+              "pos_representation": "polar" if D == 2 else "cart"}
+    torch.manual_seed(51)
+    enc = Encoder(params, device="cuda").eval()
+    g = torch.Generator().manual_seed(52)
+    sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    E = N * (N - 1)
+    x = torch.randn(B, N, 2 * D, generator=g)
+    f = torch.randn(B, N, D, generator=g) * 0.3
+    st = (torch.randn(B, E, R, generator=g) * 0.3, torch.randn(B, E, R, generator=g) * 0.3)
+    want_l, (want_h, want_c) = S.prior_step(sd, x, st, f, D == 3, params["pos_representation"], 1)
+    lib = _lib.load()
+    try:
+        for splits in [s for s in (0, 1, 2, 4, 8) if s == 0 or (H // 64) % s == 0]:
+            lib.aether_set_option(b"filter_splits", splits)
+            enc._cache.pop("ws", None)                       # the workspace layout depends on the split count
+            got_l, (got_h, got_c) = enc.single_step_forward(x.cuda(), (st[0].cuda(), st[1].cuda()), f.cuda())
+            for got, want in ((got_l, want_l), (got_h, want_h), (got_c, want_c)):
+                assert scale_rel_err(got.cpu(), want) <= TOL, splits
+        # no prepared image: the step builds it in its workspace
+        lib.aether_set_option(b"filter_splits", 0)
+        enc._cache.pop("ws", None)
+        real = enc._filter_image
+        enc._filter_image = lambda w: torch.empty(0, dtype=torch.uint8, device="cuda")        # data_ptr() == 0
+        try:
+            got_l, _ = enc.single_step_forward(x.cuda(), (st[0].cuda(), st[1].cuda()), f.cuda())
+        finally:
+            enc._filter_image = real
+        assert scale_rel_err(got_l.cpu(), want_l) <= TOL
+    finally:
+        lib.aether_set_option(b"filter_splits", 0)
+
+
+def test_filter_image_follows_weight_updates():
+    """The cached bf16 x 3 image of the filter bank is rebuilt when the weight tensor is written to (in place)."""
+    from aether_amd.nn.seq2seq.encoder import Encoder
+    D, N, B, H, R = 2, 4, 3, 128, 32
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
+              "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 1,
+              "encoder_mlp_hidden": 32, "prior_num_layers": 1, "prior_hidden_size": 48, "use_3d": False,
+              "pos_representation": "polar"}
+    torch.manual_seed(53)
+    enc = Encoder(params, device="cuda").eval()
+    g = torch.Generator().manual_seed(54)
+    E = N * (N - 1)
+    x = torch.randn(B, N, 2 * D, generator=g)
+    f = torch.randn(B, N, D, generator=g) * 0.3
+    st = (torch.zeros(B, E, R), torch.zeros(B, E, R))
+    run = lambda: enc.single_step_forward(x.cuda(), (st[0].cuda(), st[1].cuda()), f.cuda())[0].cpu()
+    first = run()
+    with torch.no_grad():
+        enc.edge_filter.edge_filter[2].weight.mul_(0.5)
+    sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    want, _ = S.prior_step(sd, x, st, f, False, "polar", 1)
+    got = run()
+    assert scale_rel_err(got, want) <= TOL
+    assert scale_rel_err(got, first) > 1e-3
+
+
 # ---------------------------------------------------------------- dynamic-field variant (SURVEY 8f N3)
 def test_dynamic_field_variant_matches_reference():
     """nn/seq2seq/dynamic_field_aether.py: graph summary (GRU + attention pooling), FiLM field query and the whole
