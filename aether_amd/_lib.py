@@ -90,6 +90,13 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "aether_s2s_plan_bytes": (C.c_size_t, [C.c_int] * 4),
+    "aether_s2s_plan_build": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aether_s2s_step_workspace_bytes": (C.c_size_t, [C.c_int] * 6 + [C.c_int64, C.c_int64]),
+    "aether_s2s_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_float, C.c_int64, C.c_int64] + [C.c_void_p] * 10 +
+                        [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
+    "aether_s2s_rollout": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_float, C.c_int64, C.c_int64] + [C.c_void_p] * 4 +
+                           [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3),
     "aether_s2s_filter_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "aether_s2s_filter_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aether_s2s_prior_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]),

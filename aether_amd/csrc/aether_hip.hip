@@ -34,6 +34,7 @@
 #include "fused_bwd.h"
 #include "seq2seq.h"
 #include "s2s_filter.h"
+#include "s2s_step.h"
 #include "dynfield.h"
 #include "s2s_dynfield.h"
 #include "knn.h"
@@ -862,6 +863,7 @@ const char* aether_version(void) { return "aether_hip 0.4 (gfx950; state2state f
 const char* aether_last_error(void) { return g_err; }
 
 #include "host_seq2seq.inc"
+#include "host_s2s_step.inc"
 #include "host_dynamicvars.inc"
 #include "host_sim.inc"
 

@@ -227,18 +227,33 @@ k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2,
         // did them at the same time: 1,250 of 5,000 cycles per iteration with the matrix pipe idle, s_memtime stamps).
         bf16x8 w[12];
         f32x4 e4;
+#ifdef AETHER_FILTER_STAMPS
+        unsigned long long T_[6] = {0, 0, 0, 0, 0, 0}, t_[6];
+#define FSTAMP(k) t_[k] = __builtin_amdgcn_s_memtime()
+#define FACC() do { for (int k_ = 0; k_ < 5; ++k_) T_[k_] += t_[k_ + 1] - t_[k_]; } while (0)
+#else
+#define FSTAMP(k)
+#define FACC()
+#endif
         if (a == 0) {
             for (int it = 0; it < IT; ++it) {
                 const int slab = it / R, r = it - slab * R;
+                FSTAMP(0);
                 if (r == 0) build_b(slab);
                 // this step's fragments have landed (the three loads of step it + 1 may still be in flight) ...
                 if (it + 1 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                FSTAMP(1);
                 lds_barrier();                                 // b_it: ... for every wave; slot (it - 1) % NST is free
+                FSTAMP(2);
                 dma_next();                                    // step it + 2
+                FSTAMP(3);
                 frags(it, w, e4, r);
+                FSTAMP(4);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) tile(w, mb, e4);
+                FSTAMP(5);
+                FACC();
             }
             lds_barrier();                                     // b_IT
         } else {
@@ -248,19 +263,33 @@ k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2,
             lds_barrier();                                     // b_0: step 0 of this group has landed for every wave
             for (int it = 0; it < IT; ++it) {
                 const int slab = it / R, r = it - slab * R;
+                FSTAMP(0);
                 if (r == 0) build_b(slab);
                 frags(it, w, e4, r);
+                FSTAMP(1);
                 tile(w, 0, e4);
                 tile(w, 1, e4);
                 // step it + 1 has landed (the loads of step it + 2 may be in flight); this step's fragments are in registers
                 if (it + 2 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                FSTAMP(2);
                 lds_barrier();                                 // b_{it+1}: its slot is free
+                FSTAMP(3);
                 dma_next();                                    // step it + 3
+                FSTAMP(4);
                 tile(w, 2, e4);
                 tile(w, 3, e4);
+                FSTAMP(5);
+                FACC();
             }
         }
+#ifdef AETHER_FILTER_STAMPS
+        if (blockIdx.x == 0 && lane == 0 && unit == slot)
+            printf("wave %d (a=%d) IT %d per iteration: %s %.0f | %s %.0f | %s %.0f | %s %.0f | %s %.0f\n", wave, a, IT,
+                   a == 0 ? "build_b+vmcnt" : "build_b+reads", (double)T_[0] / IT, a == 0 ? "barrier" : "tiles01+vmcnt", (double)T_[1] / IT,
+                   a == 0 ? "dma" : "barrier", (double)T_[2] / IT, a == 0 ? "reads" : "dma", (double)T_[3] / IT,
+                   a == 0 ? "tiles0-3" : "tiles23", (double)T_[4] / IT);
+#endif
         // the two k halves meet: waves a = 1 park their tile in the (now idle) ring, waves a = 0 add and store
         lds_barrier();
         f32x4* red = reinterpret_cast<f32x4*>(ring) + (size_t)eq * 16 * 64 + lane;

@@ -1,0 +1,414 @@
+// One autoregressive step of the seq2seq Aether in ~33 launches instead of ~75: field query -> prior
+// step -> hard Gumbel sample -> decoder step (nn/seq2seq/aether.py:176-185, :384-410, :590-654), on prepared weights
+// (host_s2s_step.inc: aether_s2s_plan_build).  What changes against the per-module entry points (host_seq2seq.inc):
+//   * dense layers that share nothing but the launch go into ONE launch (k_s2s_linear_jobs: a table of up to eight
+//     independent GEMM jobs, workgroups numbered through the table): the four first-layer products of the hidden-state
+//     messages, the two edge types of every message layer, the sender / receiver halves of mlp4, and the four gate
+//     pre-activations -- the latter as K-concatenated products [W_in | W_present | W_hidden] . [rel | agg_p | agg_h] on
+//     one wide activation row instead of three accumulating launches each;
+//   * the local frames are built once per step (the decoder's AugmentedLocalizer sees the same [inputs | field] as the
+//     prior's), by one node kernel (extend + canonicalise + padded copies) and one edge kernel;
+//   * padded weights, BatchNorm affines and the filter image come from the plan; the scatter targets are cleared by
+//     kernels that run anyway; partial planes of the filter GEMM are added while the in-edge sums are taken.
+#pragma once
+#include "seq2seq.h"
+
+namespace {
+
+constexpr int S2S_MAX_JOBS = 8;
+
+// Y[n][m] = act(sum_k W[m][k] X[n][k] + b[m] [+ G1[i1[n]][m] + G2[i2[n]][m]]) [affine] [* scale[n]] [+ Y]
+struct S2SJob {
+    const float* W; const float* bias; const float* X; float* Y;
+    const float* scale; const float* post_scale; const float* post_shift;
+    const float* g1; const float* g2;            // epilogue gathers: rows g1[i1[n]], g2[i2[n]] (stride M) added before act
+    const int64_t* i1; const int64_t* i2;
+    const int64_t* xidx; const int64_t* yidx; const int* n_dev;
+    int64_t N;
+    int M, K, ldw, ldx, ldy, sstride, act, accumulate;
+    int wg0, gx;                                 // first workgroup of the job, workgroups along n
+};
+struct S2SJobs { int n; S2SJob j[S2S_MAX_JOBS]; };
+
+// The body of k_s2s_linear (seq2seq.h) with the activation, the row stride of X and the job chosen at run time.
+template <int MT, int NT, int PF, int KW>
+__global__ void __launch_bounds__(256)
+k_s2s_linear_jobs(const S2SJobs jobs) {
+    int ji = 0;
+#pragma unroll
+    for (int t = 1; t < S2S_MAX_JOBS; ++t)
+        if (t < jobs.n && (int)blockIdx.x >= jobs.j[t].wg0) ji = t;
+    const S2SJob& J = jobs.j[ji];
+    const int local = (int)blockIdx.x - J.wg0, bx = local % J.gx, by = local / J.gx;
+    int64_t N = J.N;
+    if (J.n_dev != nullptr) N = *J.n_dev;
+    const int M = J.M, K = J.K, ldw = J.ldw, ldx = J.ldx, ldy = J.ldy;
+    const float* __restrict__ W = J.W;
+    const float* __restrict__ X = J.X;
+    float* __restrict__ Y = J.Y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = KW == 1 ? by * (32 * MT) + 16 * MT * (wave >> 1) : by * (16 * MT);
+    const int64_t n0 = KW == 1 ? (int64_t)bx * (32 * NT) + 16 * NT * (wave & 1) : (int64_t)bx * (16 * NT);
+    if (m0 >= M || n0 >= N) return;                    // the same for every wave of the workgroup when KW > 1
+    const float* wrow[MT];
+    const float* xrow[NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = m0 + 16 * t + i;
+        wrow[t] = W + (size_t)(m < M ? m : M - 1) * ldw + 4 * q;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t n = n0 + 16 * t + i;
+        n = n < N ? n : N - 1;
+        if (J.xidx != nullptr) n = J.xidx[n];
+        xrow[t] = X + (size_t)n * ldx + 4 * q;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) {
+        f32x4 b4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * mb + 4 * q + r;
+            b4[r] = (J.bias != nullptr && m < M && (KW == 1 || wave == 0)) ? J.bias[m] : 0.0f;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = b4;
+    }
+    const int steps = KW == 1 ? K >> 4 : ((K >> 4) - wave + KW - 1) / KW;
+    auto kg = [&](int a) { return KW == 1 ? a : wave + KW * a; };
+    if (steps > 0) {
+        f32x4 wq[PF][MT], xq[PF][NT];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int a = kg(p < steps ? p : steps - 1);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * a);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xq[p][t] = ld4(xrow[t] + 16 * a);
+        }
+        for (int a0 = 0; a0 < steps; a0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                if (a0 + p < steps) {
+                    f32x4 wv[MT], xv[NT];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) wv[t] = wq[p][t];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) xv[t] = xq[p][t];
+                    const int an = kg(a0 + p + PF < steps ? a0 + p + PF : steps - 1);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * an);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) xq[p][t] = ld4(xrow[t] + 16 * an);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = mfma16(wv[mb][b], xv[nb][b], acc[mb][nb]);
+                }
+            }
+        }
+    }
+    if constexpr (KW > 1) {
+        __shared__ f32x4 red[KW - 1][MT * NT][64];
+        if (wave != 0) {
+#pragma unroll
+            for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) red[wave - 1][mb * NT + nb][lane] = acc[mb][nb];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 0; w < KW - 1; ++w)
+#pragma unroll
+            for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) acc[mb][nb] += red[w][mb * NT + nb][lane];
+    }
+    const int act = J.act;
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        int64_t n = n0 + 16 * nb + i;
+        if (n >= N) continue;
+        const int64_t nsrc = n;
+        if (J.yidx != nullptr) n = J.yidx[n];
+        const float* g1 = J.g1 != nullptr ? J.g1 + (size_t)J.i1[nsrc] * M : nullptr;
+        const float* g2 = J.g2 != nullptr ? J.g2 + (size_t)J.i2[nsrc] * M : nullptr;
+#pragma unroll
+        for (int mb = 0; mb < MT; ++mb) {
+            const int m = m0 + 16 * mb + 4 * q;
+            f32x4 v = acc[mb][nb];
+            if (g1 != nullptr && m + 3 < M) v += ld4(g1 + m) + ld4(g2 + m);
+            if (act == 1) v = silu4(v);
+            else if (act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            } else if (act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            } else if (act == 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);
+            }
+            if (J.post_scale != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < M) v[r] = v[r] * J.post_scale[m + r] + J.post_shift[m + r];
+            }
+            if (J.scale != nullptr) v = v * J.scale[(size_t)n * J.sstride];
+            if (m + 3 < M) {
+                if (J.accumulate) v += ld4(Y + (size_t)n * ldy + m);
+                st4(Y + (size_t)n * ldy + m, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < M) Y[(size_t)n * ldy + m + r] = v[r] + (J.accumulate ? Y[(size_t)n * ldy + m + r] : 0.0f);
+            }
+        }
+    }
+}
+
+// Node side of the local frames in one launch (k_s2s_extend + k_s2s_aug_nodes + two k_s2s_pad_rows): per node
+// ext = [inputs | field], rel_feat (7D + O columns), Rinv, and zero-padded copies of rel_feat at the row strides the
+// dense layers read (the prior's res1 and the first columns of the decoder's wide gate row).  Also clears the per-type
+// edge counters of the step.
+template <int D>
+__global__ void __launch_bounds__(256)
+k_s2s_node_prep(const float* __restrict__ inputs, const float* __restrict__ field, float* __restrict__ ext,
+                float* __restrict__ rel_feat, float* __restrict__ Rinv, float* __restrict__ relp, int ldp,
+                float* __restrict__ wide, int ldwide, int* __restrict__ counts, int64_t n_nodes) {
+    using A = AugDims<D>;
+    constexpr int RFp = (A::RF + 15) / 16 * 16;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 8 && counts != nullptr) counts[threadIdx.x] = 0;
+    if (n >= n_nodes) return;
+    float xi[3 * D];
+#pragma unroll
+    for (int t = 0; t < 2 * D; ++t) xi[t] = inputs[n * 2 * D + t];
+#pragma unroll
+    for (int t = 0; t < D; ++t) xi[2 * D + t] = field[n * D + t];
+#pragma unroll
+    for (int t = 0; t < 3 * D; ++t) ext[n * 3 * D + t] = xi[t];
+    float row[RFp];
+    float R[D][D];
+    if constexpr (D == 2) {
+        const float ang = atan2f(xi[3], xi[2]);
+        const float c = cosf(ang), s = sinf(ang);
+        R[0][0] = c; R[0][1] = -s; R[1][0] = s; R[1][1] = c;
+        row[0] = 0.f; row[1] = 0.f; row[2] = sqrtf(xi[2] * xi[2] + xi[3] * xi[3]); row[3] = 0.f;
+        row[4] = c * xi[4] + s * xi[5]; row[5] = -s * xi[4] + c * xi[5];
+    } else {
+        float rho, th, ph;
+        spherical3(xi + 3, rho, th, ph);
+        rot3(th, ph, R);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            row[a] = 0.f;
+            row[3 + a] = R[0][a] * xi[3] + R[1][a] * xi[4] + R[2][a] * xi[5];
+            row[6 + a] = R[0][a] * xi[6] + R[1][a] * xi[7] + R[2][a] * xi[8];
+        }
+    }
+    float origin[3 * D];
+#pragma unroll
+    for (int t = 0; t < 3 * D; ++t) origin[t] = t == D ? 1.0f : 0.0f;
+    aug_edge<D>(origin, xi, row + 3 * D);
+#pragma unroll
+    for (int t = A::RF; t < RFp; ++t) row[t] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < A::RF; ++t) rel_feat[n * A::RF + t] = row[t];
+#pragma unroll
+    for (int t = 0; t < RFp; ++t) relp[n * ldp + t] = row[t];
+    if (wide != nullptr) {
+#pragma unroll
+        for (int t = 0; t < RFp; ++t) wide[n * ldwide + t] = row[t];
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) Rinv[n * D * D + a * D + b] = R[a][b];
+}
+
+// k_s2s_aug_edges plus a zero-padded copy of the rows (stride EAp, the decoder's present-message layer).
+template <int D>
+__global__ void __launch_bounds__(256)
+k_s2s_edge_prep(const float* __restrict__ x, const int64_t* __restrict__ send, const int64_t* __restrict__ recv,
+                const float* __restrict__ rel_feat, int polar, float* __restrict__ edge_attr, float* __restrict__ eap,
+                float* __restrict__ edge_pos, int64_t n_edges) {
+    using A = AugDims<D>;
+    constexpr int EAp = (A::EA + 15) / 16 * 16;
+    constexpr int LDR = A::EA + 1;
+    __shared__ float rows[256 * LDR];
+    __shared__ float prow[256 * (A::EP + 1)];
+    const int64_t e0 = (int64_t)blockIdx.x * 256;
+    const int64_t e = e0 + threadIdx.x;
+    if (e < n_edges) {
+        const int64_t j = send[e], i = recv[e];
+        float xj[3 * D], xi[3 * D], o[A::NF];
+#pragma unroll
+        for (int t = 0; t < 3 * D; ++t) { xj[t] = x[j * 3 * D + t]; xi[t] = x[i * 3 * D + t]; }
+        aug_edge<D>(xj, xi, o);
+        float* out = rows + threadIdx.x * LDR;
+#pragma unroll
+        for (int t = 0; t < A::NF; ++t) out[t] = o[t];
+#pragma unroll
+        for (int t = 0; t < A::RF; ++t) out[A::NF + t] = rel_feat[i * A::RF + t];
+        const int p0 = polar ? (D == 2 ? 2 : 3) : 0;
+#pragma unroll
+        for (int t = 0; t < A::EP; ++t) prow[threadIdx.x * (A::EP + 1) + t] = o[p0 + t];
+    }
+    __syncthreads();
+    const int64_t left = n_edges - e0;
+    const int cnt = (int)(left < 256 ? left : 256);
+    for (int idx = threadIdx.x; idx < cnt * A::EA; idx += 256) {
+        const int r = idx / A::EA, c = idx - r * A::EA;
+        edge_attr[e0 * A::EA + idx] = rows[r * LDR + c];
+    }
+    for (int idx = threadIdx.x; idx < cnt * EAp; idx += 256) {
+        const int r = idx / EAp, c = idx - r * EAp;
+        eap[e0 * EAp + idx] = c < A::EA ? rows[r * LDR + c] : 0.0f;
+    }
+    for (int idx = threadIdx.x; idx < cnt * A::EP; idx += 256) {
+        const int r = idx / A::EP, c = idx - r * A::EP;
+        edge_pos[e0 * A::EP + idx] = prow[r * (A::EP + 1) + c];
+    }
+}
+
+// eaf[e][:] = sum_z planes[z][e][:] for the node's in-edges (every edge has one receiver: each row is produced once) and
+// X0[n][:] = sum over the in-edges / fixed_div: k_s2s_sum_planes + k_s2s_segment_mean of the prior step in one pass.
+__global__ void __launch_bounds__(128)
+k_s2s_planes_segsum(const float* __restrict__ planes, int n_planes, int64_t plane_stride, const int64_t* __restrict__ order,
+                    const int64_t* __restrict__ rowptr, float* __restrict__ eaf, float* __restrict__ X0, int h,
+                    float fixed_div) {
+    const int64_t n = blockIdx.x;
+    const int64_t beg = rowptr[n], end = rowptr[n + 1];
+    for (int c = threadIdx.x * 4; c < h; c += 128 * 4) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t k = beg; k < end; ++k) {
+            const int64_t e = order[k];
+            f32x4 v = ld4(planes + (size_t)e * h + c);
+            for (int z = 1; z < n_planes; ++z) v += ld4(planes + (size_t)z * plane_stride + (size_t)e * h + c);
+            if (n_planes > 1 || eaf != planes) st4(eaf + (size_t)e * h + c, v);
+            s += v;
+        }
+        st4(X0 + (size_t)n * h + c, s / fixed_div);
+    }
+}
+
+// Hard Gumbel sample (k_s2s_gumbel_hard) + the per-type edge lists of the decoder (k_s2s_select for every type) + the
+// cleared message rows of the edge, in one launch.  counts must be zero (k_s2s_node_prep clears them).
+__global__ void __launch_bounds__(256)
+k_s2s_gumbel_select(const float* __restrict__ logits, const float* __restrict__ uniform, float tau, int K, int k0,
+                    float* __restrict__ edges, int64_t* __restrict__ lists /* [K][n_edges] */, int* __restrict__ counts,
+                    int64_t n_edges) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e < n_edges) {
+        float y[4], mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float g = -logf(1e-10f - logf(uniform[e * K + k] + 1e-10f));
+            y[k] = (logits[e * K + k] + g) / tau;
+            mx = fmaxf(mx, y[k]);
+        }
+        float sum = 0.0f;
+        for (int k = 0; k < K; ++k) { y[k] = expf(y[k] - mx); sum += y[k]; }
+        int best = 0;
+        for (int k = 0; k < K; ++k) { y[k] = y[k] / sum; if (y[k] > y[best]) best = k; }
+        for (int k = 0; k < K; ++k) {
+            w[k] = ((k == best ? 1.0f : 0.0f) - y[k]) + y[k];
+            edges[e * K + k] = w[k];
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    for (int k = k0; k < K; ++k) {
+        const bool on = e < n_edges && w[k] != 0.0f;
+        const unsigned long long mask = __ballot(on);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(counts + k, __popcll(mask));
+        base = __shfl(base, 0);
+        if (on) lists[(size_t)k * n_edges + base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+    }
+}
+
+// The per-type lists alone (edge weights given, e.g. teacher-forced burn-in with supplied samples)
+__global__ void __launch_bounds__(256)
+k_s2s_select_all(const float* __restrict__ edge_w, int K, int k0, int64_t* __restrict__ lists, int* __restrict__ counts,
+                 int64_t n_edges) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    for (int k = k0; k < K; ++k) {
+        const bool on = e < n_edges && edge_w[e * K + k] != 0.0f;
+        const unsigned long long mask = __ballot(on);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(counts + k, __popcll(mask));
+        base = __shfl(base, 0);
+        if (on) lists[(size_t)k * n_edges + base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+    }
+}
+
+// T[k][e][:] = tanh(A_k[recv[e]][:] + S_k[send[e]][:]) for every type k whose weight on edge e is not zero (rows by edge
+// id: the second message layer gathers them through the type's list), and M1[e][:] = M2[e][:] = 0: k_s2s_pair_tanh of
+// all types and the two clears of the scatter targets in one launch.  A, S: [K][n_nodes][h]; T: [K][n_edges][h].
+__global__ void __launch_bounds__(256)
+k_s2s_pair_tanh_all(const float* __restrict__ A, const float* __restrict__ S, int64_t n_nodes,
+                    const int64_t* __restrict__ send, const int64_t* __restrict__ recv, const float* __restrict__ edge_w,
+                    int K, int k0, float* __restrict__ T, float* __restrict__ M1, float* __restrict__ M2, int h,
+                    int64_t n_edges) {
+    const int q4 = h >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_edges * q4) return;
+    const int64_t e = idx / q4;
+    const int c = (int)(idx - e * q4) * 4;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    st4(M1 + (size_t)e * h + c, zero);
+    st4(M2 + (size_t)e * h + c, zero);
+    const int64_t r = recv[e], s = send[e];
+    for (int k = k0; k < K; ++k) {
+        if (edge_w[e * K + k] == 0.0f) continue;
+        const f32x4 v = ld4(A + ((size_t)k * n_nodes + r) * h + c) + ld4(S + ((size_t)k * n_nodes + s) * h + c);
+        st4(T + ((size_t)k * n_edges + e) * h + c, f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])});
+    }
+}
+
+// Both in-edge means of the decoder in one launch: blockIdx.y = 0: M1 -> out0, 1: M2 -> out1 (row stride ldo each).
+__global__ void __launch_bounds__(128)
+k_s2s_segment_mean2(const float* __restrict__ M1, const float* __restrict__ M2, const int64_t* __restrict__ order,
+                    const int64_t* __restrict__ rowptr, float* __restrict__ out0, float* __restrict__ out1, int ldo, int h) {
+    const int64_t n = blockIdx.x;
+    const float* Mx = blockIdx.y == 0 ? M1 : M2;
+    float* out = blockIdx.y == 0 ? out0 : out1;
+    const int64_t beg = rowptr[n], end = rowptr[n + 1];
+    for (int c = threadIdx.x * 4; c < h; c += 128 * 4) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t k = beg; k < end; ++k) s += ld4(Mx + (size_t)order[k] * h + c);
+        const float cnt = (float)(end - beg > 1 ? end - beg : 1);
+        st4(out + (size_t)n * ldo + c, s / cnt);
+    }
+}
+
+// Plan helpers: dst[r][0 .. ld) = [a[r][0..ca) zero-padded to cap | b[r][0..cb) | c[r][0..cc)] (nullptr parts are skipped)
+__global__ void __launch_bounds__(256)
+k_s2s_concat_rows(const float* __restrict__ a, int ca, int cap, const float* __restrict__ b, int cb,
+                  const float* __restrict__ c, int cc, float* __restrict__ dst, int ld, int64_t rows) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * ld) return;
+    const int64_t r = idx / ld;
+    const int col = (int)(idx - r * ld);
+    float v = 0.0f;
+    if (col < cap) v = col < ca ? a[r * ca + col] : 0.0f;
+    else if (col < cap + cb) v = b != nullptr ? b[r * cb + (col - cap)] : 0.0f;
+    else if (col < cap + cb + cc) v = c != nullptr ? c[r * cc + (col - cap - cb)] : 0.0f;
+    dst[idx] = v;
+}
+// dst = a + b
+__global__ void __launch_bounds__(256)
+k_s2s_add_vec(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst, int n) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) dst[idx] = a[idx] + b[idx];
+}
+
+}  // namespace

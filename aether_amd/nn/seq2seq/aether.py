@@ -10,6 +10,7 @@ Mirrors the parts of ``nn.seq2seq.aether.Aether`` (aether.py:14-191) that run on
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
@@ -26,8 +27,8 @@ def _tensors_key(module):
 
 
 class _StepRunner:
-    """One autoregressive step -- field query -> prior step -> hard Gumbel sample -> decoder step -- captured once in
-    a hipGraph (``torch.cuda.CUDAGraph``: every launch of the step is stream-ordered and free of host
+    """One autoregressive step -- field query -> prior step -> hard Gumbel sample -> decoder step (``aether_s2s_step``,
+    one C call) -- captured once in a hipGraph (``torch.cuda.CUDAGraph``: every launch of the step is stream-ordered and free of host
     synchronisation) and replayed per time step on static state buffers.  The reference's configurations have
     5 objects per graph: the step is ~80 short kernels; a replay issues them with one launch.  Results are
     bit-identical to the eager step (same kernels).  Opt-in (``graph=True``): on the MI355X box the step is bound
@@ -57,10 +58,8 @@ class _StepRunner:
 
     def _step(self):
         m = self.model
-        field = self.field_fn(self.x)
-        logits, (h1, c1) = m.encoder.single_step_forward(self.x, (self.ph, self.pc), field)
-        edges = gumbel_softmax_hard(logits, self.u, m.gumbel_temp)
-        pred, dh = m.decoder(self.x, self.dh, edges, field)
+        field = None if self.field_fn is None else self.field_fn(self.x)         # None: the built-in field query
+        pred, dh, (h1, c1), edges = m._fused_step(self.x, self.dh, (self.ph, self.pc), self.u, field)
         self.x.copy_(pred); self.dh.copy_(dh); self.ph.copy_(h1); self.pc.copy_(c1)
         self.edges = edges
 
@@ -78,12 +77,128 @@ class _StepRunner:
 
 
 class _StepLoop:
-    """Mixin of the two seq2seq models: the burn-in / prediction loops on a cached ``_StepRunner``."""
+    """Mixin of the two seq2seq models: the fused autoregressive step (``aether_s2s_step`` / ``aether_s2s_rollout`` on a
+    cached plan of prepared weights) and the burn-in / prediction loops on a cached ``_StepRunner``."""
+
+    def _step_sizes(self):
+        enc, dec = self.encoder, self.decoder
+        return (self.num_dims, enc.hidden_size, dec.msg_out_shape, enc.rnn_hidden_size, self.num_edge_types)
+
+    def _plan(self, device):
+        """Prepared weights of the fused step (``aether_s2s_plan_build``), rebuilt -- into the same buffer, which captured
+        graphs point at -- whenever an encoder / decoder tensor moved or was written to."""
+        enc, dec = self.encoder, self.decoder
+        tensors = list(enc.parameters()) + list(enc.buffers()) + list(dec.parameters())
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self.__dict__.get("_plan_cache")
+        if hit is None or hit[0] != key:
+            lib = _lib.load()
+            D, he, hd, _, K = self._step_sizes()
+            nbytes = lib.aether_s2s_plan_bytes(D, he, hd, K)
+            if nbytes == 0:
+                raise _lib.AetherHipError("fused seq2seq step: encoder_hidden must be a multiple of 128, decoder_hidden of 32")
+            buf = hit[1] if hit is not None and hit[1].numel() == nbytes and hit[1].device == torch.device(device) else \
+                torch.empty(nbytes, dtype=torch.uint8, device=device)
+            pe, _, _ = enc._param_struct(with_image=False)
+            pd = dec._param_struct()
+            _lib.check(lib.aether_s2s_plan_build(C.byref(pe), C.byref(pd), D, he, hd, K, buf.data_ptr(), nbytes,
+                                                 torch.cuda.current_stream(device).cuda_stream), "aether_s2s_plan_build")
+            hit = self.__dict__["_plan_cache"] = (key, buf)
+        return hit[1]
+
+    def _step_common(self, B, N, device):
+        """(plan, workspace, graph arrays, parameter structs, scalar arguments) of the fused step for B graphs of N objects."""
+        if self.encoder.training:
+            raise _lib.AetherHipError("the prior step uses BatchNorm running statistics: call .eval() first")
+        lib = _lib.load()
+        enc, dec = self.encoder, self.decoder
+        D, he, hd, R, K = self._step_sizes()
+        E1 = enc.recv_edges.shape[0]
+        plan = self._plan(device)
+        pe, n_layers, prior_hidden = enc._param_struct(with_image=False)
+        pd = dec._param_struct()
+        need = lib.aether_s2s_step_workspace_bytes(D, he, hd, R, prior_hidden, K, B * N, B * E1)
+        ws = self.__dict__.get("_step_ws")
+        if ws is None or ws.numel() < need or ws.device != torch.device(device):
+            ws = self.__dict__["_step_ws"] = torch.empty(need, dtype=torch.uint8, device=device)
+        fq = getattr(self, "_fq", None)
+        pf = None
+        if fq is not None:
+            fn, ce = fq[0].field_net, fq[0].coordinate_embedding
+            from .field import _S2SFieldParams
+            pf = _S2SFieldParams(*[t.data_ptr() for t in (ce.B, fn[0].weight, fn[0].bias, fn[2].weight, fn[2].bias,
+                                                          fn[4].weight, fn[4].bias)])
+        scal = (D, he, hd, R, n_layers, prior_hidden, K, 1 if dec.skip_first_edge_type else 0,
+                1 if enc.pos_representation == "polar" else 0, N, float(self.gumbel_temp), B * N, B * E1)
+        return lib, plan, ws, enc._graph(B, N, device), (pf, pe, pd), scal
+
+    @torch.no_grad()
+    def _fused_step(self, x, decoder_hidden, prior_hidden, uniform, field=None):
+        """One autoregressive step: x [B, N, 2D], decoder_hidden [B, N, hd], prior_hidden (h, c) [B, E, rnn], uniform
+        [B, E, K]; ``field`` [B, N, D] replaces the built-in field query -> (predictions, decoder_hidden, (h, c), edges)."""
+        if not x.is_cuda:
+            raise _lib.AetherHipError("aether_amd seq2seq models run on an MI355X only; got a CPU tensor (there is no CPU fallback)")
+        B, N, _ = x.shape
+        dev = x.device
+        lib, plan, ws, (send, recv, order, rowptr), (pf, pe, pd), scal = self._step_common(B, N, dev)
+        D, he, hd, R, K = self._step_sizes()
+        E1 = self.encoder.recv_edges.shape[0]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        xf, dhf, h0, c0, uf = f32(x), f32(decoder_hidden), f32(prior_hidden[0]), f32(prior_hidden[1]), f32(uniform)
+        if xf.shape != (B, N, 2 * D) or dhf.shape != (B, N, hd) or h0.shape != (B, E1, R) or c0.shape != h0.shape or \
+                uf.numel() != B * E1 * K:
+            raise ValueError("fused step: input shapes do not match the model")
+        ff = None if field is None else f32(field)
+        if ff is None and pf is None:
+            raise _lib.AetherHipError("this model has no built-in field query: pass the field")
+        out = torch.empty_like(xf)
+        dh_out = torch.empty_like(dhf)
+        h1, c1 = torch.empty_like(h0), torch.empty_like(c0)
+        edges = torch.empty(B, E1, K, dtype=torch.float32, device=dev)
+        st = lib.aether_s2s_step(None if pf is None else C.byref(pf), C.byref(pe), C.byref(pd), plan.data_ptr(), *scal,
+                                 send.data_ptr(), recv.data_ptr(), order.data_ptr(), rowptr.data_ptr(), xf.data_ptr(),
+                                 None if ff is None else ff.data_ptr(), dhf.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                 uf.data_ptr(), ws.data_ptr(), ws.numel(), out.data_ptr(), dh_out.data_ptr(), h1.data_ptr(),
+                                 c1.data_ptr(), edges.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_s2s_step")
+        return out, dh_out, (h1, c1), edges
+
+    @torch.no_grad()
+    def _fused_rollout(self, burn_in, x_last, decoder_hidden, prior_hidden, steps, uniform, return_edges):
+        """``aether_s2s_rollout``: burn_in [B, T0, N, 2D] (or None) teacher-forced, then ``steps`` autoregressive steps from
+        x_last [B, N, 2D]; uniform [T0 + steps, B, E, K] -> (predictions [B, steps, N, 2D], edges or None, final state)."""
+        B, N, _ = x_last.shape
+        dev = x_last.device
+        lib, plan, ws, (send, recv, order, rowptr), (pf, pe, pd), scal = self._step_common(B, N, dev)
+        if pf is None:
+            raise _lib.AetherHipError("this model has no built-in field query: step it with _fused_step")
+        D, he, hd, R, K = self._step_sizes()
+        E1 = self.encoder.recv_edges.shape[0]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        T0 = 0 if burn_in is None else burn_in.shape[1]
+        bi = None if T0 == 0 else f32(burn_in.transpose(0, 1))                       # [T0, B, N, 2D]
+        xl = f32(x_last)
+        dh = f32(decoder_hidden).clone()
+        h, c = f32(prior_hidden[0]).clone(), f32(prior_hidden[1]).clone()
+        if uniform is None:
+            uniform = torch.rand(T0 + steps, B, E1, K, device=dev)
+        uf = f32(uniform.reshape(T0 + steps, B, E1, K))
+        preds = torch.empty(steps, B, N, 2 * D, dtype=torch.float32, device=dev)
+        edges = torch.empty(steps, B, E1, K, dtype=torch.float32, device=dev) if return_edges else None
+        st = lib.aether_s2s_rollout(C.byref(pf), C.byref(pe), C.byref(pd), plan.data_ptr(), *scal, send.data_ptr(),
+                                    recv.data_ptr(), order.data_ptr(), rowptr.data_ptr(), T0,
+                                    None if bi is None else bi.data_ptr(), int(steps), xl.data_ptr(), dh.data_ptr(),
+                                    h.data_ptr(), c.data_ptr(), uf.data_ptr(), ws.data_ptr(), ws.numel(), preds.data_ptr(),
+                                    None if edges is None else edges.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_s2s_rollout")
+        return (preds.transpose(0, 1).contiguous(), None if edges is None else edges.transpose(0, 1).contiguous(),
+                (dh, (h, c)))
 
     def _graph_keepalive(self):
         """Workspaces and index tensors the captured launches point at (a module may later replace its cached
         workspace by a larger one; the graph must keep the one it was captured with alive)."""
         keep = [list(m._cache.values()) for m in (self.encoder, self.decoder)]
+        keep += [self.__dict__.get("_plan_cache"), self.__dict__.get("_step_ws")]
         fq = getattr(self, "_fq", None)
         if fq is not None:
             keep.append(fq[0]._ws)
@@ -276,33 +391,24 @@ class Aether(_StepLoop, _EvalLoss, nn.Module):
 
     @torch.no_grad()
     def predict_future(self, inputs, prediction_steps, return_edges=False, uniform=None, graph=False):
-        """aether.py:155-191.  inputs [B, T, N, 2D] (burn-in observations).  The burn-in half takes its prior logits
-        and LSTM state from the full-sequence encoder, as the reference does; with ``graph=True`` it chains the
-        captured single step instead (the encoder's prior path is causal -- forward LSTM from the zero state,
-        BatchNorm in eval mode -- so both give the same logits and state to rounding; both are pinned against the
-        reference's own ``predict_future``).  ``uniform`` [T - 1 + steps, B, E, K].
-        ``graph``: replay the step from a captured hipGraph (``_StepRunner``) instead of launching it kernel by kernel."""
+        """aether.py:155-191.  inputs [B, T, N, 2D] (burn-in observations); ``uniform`` [T - 1 + steps, B, E, K].
+        ``graph``: replay the step from a captured hipGraph (``_StepRunner``) instead of launching it kernel by kernel;
+        both ways run the same fused step (``aether_s2s_step``) and give identical results."""
         B, T, N, _ = inputs.shape
         E = N * (N - 1)
         decoder_hidden = self.decoder.get_initial_hidden(inputs)
         R = self.encoder.rnn_hidden_size
         prior_hidden = (torch.zeros(B, E, R, device=inputs.device), torch.zeros(B, E, R, device=inputs.device))
         if graph:
-            preds, edges, _ = self._graphed(lambda x: self.predict_field(x)[0], inputs[:, :T - 1].float(),
-                                            inputs[:, T - 1].float(), decoder_hidden, prior_hidden,
-                                            int(prediction_steps), uniform, return_edges)
+            preds, edges, _ = self._graphed(None, inputs[:, :T - 1].float(), inputs[:, T - 1].float(), decoder_hidden,
+                                            prior_hidden, int(prediction_steps), uniform, return_edges)
             return (preds, edges) if return_edges else preds
-        if T > 1:
-            # burn-in as the reference runs it (aether.py:161-173): field and prior logits of the whole observed
-            # sequence at once (the per-step features batch over T - 1 time steps), then the decoder step by step
-            field_all, _ = self.predict_field(inputs[:, :-1].transpose(2, 1).contiguous())       # [B, N, T - 1, D]
-            prior_logits, _, prior_hidden = self.encoder(inputs[:, :-1], field_all)
-            for step in range(T - 1):
-                _, decoder_hidden, _ = self.single_step_forward(
-                    inputs[:, step], decoder_hidden, prior_logits[:, step].contiguous(), True,
-                    field_all[:, :, step].contiguous(), None if uniform is None else uniform[step])
-        return self.predict_from_state(inputs[:, T - 1], decoder_hidden, prior_hidden, prediction_steps,
-                                       None if uniform is None else uniform[T - 1:], return_edges, graph=False)
+        # burn-in and prediction loop on the device (aether_s2s_rollout).  The reference takes the burn-in's prior logits
+        # from the full-sequence encoder (aether.py:161-173); its prior path is causal (forward LSTM from the zero state,
+        # BatchNorm in eval mode), so chaining the single step gives the same logits and state to rounding.
+        preds, edges, _ = self._fused_rollout(inputs[:, :T - 1].float() if T > 1 else None, inputs[:, T - 1].float(),
+                                              decoder_hidden, prior_hidden, int(prediction_steps), uniform, return_edges)
+        return (preds, edges) if return_edges else preds
 
     @torch.no_grad()
     def predict_from_state(self, predictions, decoder_hidden, prior_hidden, prediction_steps, uniform=None,
@@ -311,9 +417,19 @@ class Aether(_StepLoop, _EvalLoss, nn.Module):
         leaves behind: last observed state ``predictions`` [B, N, 2D], ``decoder_hidden`` [B, N, h],
         ``prior_hidden`` = (h, c) each [B, E, rnn].  ``uniform`` [steps, B, E, K] fixes the Gumbel draws."""
         if graph:
-            preds, edges, _ = self._graphed(lambda x: self.predict_field(x)[0], None, predictions.float(),
-                                            decoder_hidden, prior_hidden, int(prediction_steps), uniform, return_edges)
+            preds, edges, _ = self._graphed(None, None, predictions.float(), decoder_hidden, prior_hidden,
+                                            int(prediction_steps), uniform, return_edges)
             return (preds, edges) if return_edges else preds
+        # the whole loop on the device (aether_s2s_rollout): one C call, the fused step per time step
+        preds, edges, _ = self._fused_rollout(None, predictions, decoder_hidden, prior_hidden, int(prediction_steps),
+                                              uniform, return_edges)
+        return (preds, edges) if return_edges else preds
+
+    @torch.no_grad()
+    def predict_from_state_stepwise(self, predictions, decoder_hidden, prior_hidden, prediction_steps, uniform=None,
+                                    return_edges=False):
+        """The same loop through the four per-module entry points (``predict_field`` -> ``Encoder.single_step_forward`` ->
+        ``single_step_forward``), as the reference writes it (aether.py:175-185); kept as the cross-check of the fused path."""
         all_predictions, all_edges = [], []
         for step in range(int(prediction_steps)):
             current_field, _ = self.predict_field(predictions)

@@ -294,25 +294,27 @@ class DynamicFieldAether(_StepLoop, _EvalLoss, nn.Module):
                                             inputs[:, T - 1].float(), decoder_hidden, prior_hidden,
                                             int(prediction_steps), uniform, return_edges, extra_key=(mod.data_ptr(),))
             return (preds, edges) if return_edges else preds
+        # The fused step (aether_s2s_step) with the FiLM field handed in; the burn-in chains it on the observations (the
+        # reference takes the burn-in's prior logits from the full-sequence encoder, :221-222: its prior path is causal, so
+        # both give the same logits and state to rounding).
         all_predictions, all_edges = [], []
-        if T > 1:
-            prior_logits, _, prior_hidden = self.encoder(inputs[:, :-1], predicted_field)        # :221-222
+        E1 = self.encoder.recv_edges.shape[0]
+        K = self.num_edge_types
+        if uniform is None:
+            uniform = torch.rand(T - 1 + int(prediction_steps), B, E1, K, device=inputs.device)
+        uniform = uniform.reshape(T - 1 + int(prediction_steps), B, E1, K)
         for step in range(T - 1):
-            current_inputs = inputs[:, step]
             field = predicted_field[:, :, step].contiguous()
-            predictions, decoder_hidden, edges = self.single_step_forward(
-                current_inputs, decoder_hidden, prior_logits[:, step].contiguous(), True, field, None,
-                None if uniform is None else uniform[step])
+            predictions, decoder_hidden, prior_hidden, edges = self._fused_step(
+                inputs[:, step], decoder_hidden, prior_hidden, uniform[step], field)
             if return_everything:
                 all_edges.append(edges)
                 all_predictions.append(predictions)
         predictions = inputs[:, T - 1]
         for step in range(int(prediction_steps)):
             current_field, _ = self.predict_field(predictions, gr_summary)
-            current_edge_logits, prior_hidden = self.encoder.single_step_forward(predictions, prior_hidden, current_field)
-            predictions, decoder_hidden, edges = self.single_step_forward(
-                predictions, decoder_hidden, current_edge_logits, True, current_field, None,
-                None if uniform is None else uniform[T - 1 + step])
+            predictions, decoder_hidden, prior_hidden, edges = self._fused_step(
+                predictions, decoder_hidden, prior_hidden, uniform[T - 1 + step], current_field)
             all_predictions.append(predictions)
             all_edges.append(edges)
         predictions = torch.stack(all_predictions, dim=1)

@@ -127,7 +127,7 @@ class Encoder(nn.Module):
             self.to(device)
 
     # -- plumbing ----------------------------------------------------------------------
-    def _param_struct(self):
+    def _param_struct(self, with_image=True):
         ps = _PriorParams()
         ptr = lambda t: t.data_ptr()
         for name in ("mlp3", "mlp4"):
@@ -146,7 +146,7 @@ class Encoder(nn.Module):
         ps.res1_w, ps.res1_b = ptr(self.res1.weight), ptr(self.res1.bias)
         f = self.edge_filter.edge_filter
         ps.filt_w0, ps.filt_b0, ps.filt_w2, ps.filt_b2 = ptr(f[0].weight), ptr(f[0].bias), ptr(f[2].weight), ptr(f[2].bias)
-        ps.filt_image = self._filter_image(f[2].weight).data_ptr()
+        ps.filt_image = self._filter_image(f[2].weight).data_ptr() if with_image else None   # (the fused step's plan has its own)
         return ps, len(layers), (layers[0].out_features if len(layers) > 1 else 0)
 
     def _filter_image(self, w):

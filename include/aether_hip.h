@@ -381,6 +381,47 @@ int aether_s2s_mlp_head(const float* const* w, const float* const* b, int layers
                         int out_size, int64_t n_rows, const float* x, float* scratch, float* out, void* stream);
 
 /*
+ * The whole autoregressive step in one call: field query -> prior step -> hard Gumbel sample -> decoder
+ * step, nn/seq2seq/aether.py:176-185 (= predict_field :86-90, Encoder.single_step_forward :384-410, gumbel_softmax
+ * :92-98, RecurrentDecoder.forward :590-654), ~33 launches instead of the ~75 of the four entry points above: dense
+ * layers that are independent of each other share a launch, the gate pre-activations are K-concatenated products, the
+ * local frames are built once for prior and decoder, and everything derived from the weights alone comes from a PLAN:
+ *   aether_s2s_plan_build : filter image, padded input layers, BatchNorm affines, concatenated gate weights / summed gate
+ *                           biases -> plan (device, 256-byte aligned, aether_s2s_plan_bytes); rebuild after the weights change
+ *   aether_s2s_step       : inputs [n_nodes][2D], decoder_hidden_in [n_nodes][hd], h0 / c0 [n_edges][rnn], uniform
+ *                           [n_edges][K] (the U(0,1) draw of gumbel_softmax) -> outputs, decoder_hidden_out, h1, c1 and,
+ *                           when edges_out is not NULL, the sampled edge types [n_edges][K].  ext_field != NULL replaces the
+ *                           built-in field query by a given field [n_nodes][D] (the dynamic-field model); field params may
+ *                           then be NULL.  Graph arrays as for aether_s2s_prior_step.
+ *   aether_s2s_rollout    : the loop of predict_future (:166-185) on the device: burn_in_steps teacher-forced steps on
+ *                           burn_in [burn_in_steps][n_nodes][2D] (predictions discarded), then `steps` autoregressive steps
+ *                           from `inputs`; predictions [steps][n_nodes][2D], edges_out [steps][n_edges][K] or NULL; uniform
+ *                           [burn_in_steps + steps][n_edges][K]; decoder_state [n_nodes][hd], h, c are read at entry and hold the final
+ *                           state at exit.
+ * Results equal the four separate calls up to the rounding of re-associated sums (gate biases are added once, as a sum).
+ */
+size_t aether_s2s_plan_bytes(int num_dims, int encoder_hidden, int decoder_hidden, int num_edge_types);
+int aether_s2s_plan_build(const AetherS2SPriorParams* prior, const AetherS2SDecoderParams* decoder, int num_dims,
+                          int encoder_hidden, int decoder_hidden, int num_edge_types, void* plan, size_t plan_bytes,
+                          void* stream);
+size_t aether_s2s_step_workspace_bytes(int num_dims, int encoder_hidden, int decoder_hidden, int rnn_hidden, int prior_hidden,
+                                       int num_edge_types, int64_t n_nodes, int64_t n_edges);
+int aether_s2s_step(const AetherS2SFieldParams* field, const AetherS2SPriorParams* prior, const AetherS2SDecoderParams* decoder,
+                    const void* plan, int num_dims, int encoder_hidden, int decoder_hidden, int rnn_hidden, int prior_layers,
+                    int prior_hidden, int num_edge_types, int skip_first, int polar, int num_vars, float tau, int64_t n_nodes,
+                    int64_t n_edges, const int64_t* send, const int64_t* recv, const int64_t* order, const int64_t* rowptr,
+                    const float* inputs, const float* ext_field, const float* decoder_hidden_in, const float* h0,
+                    const float* c0, const float* uniform, void* workspace, size_t workspace_bytes, float* outputs,
+                    float* decoder_hidden_out, float* h1, float* c1, float* edges_out, void* stream);
+int aether_s2s_rollout(const AetherS2SFieldParams* field, const AetherS2SPriorParams* prior, const AetherS2SDecoderParams* decoder,
+                       const void* plan, int num_dims, int encoder_hidden, int decoder_hidden, int rnn_hidden, int prior_layers,
+                       int prior_hidden, int num_edge_types, int skip_first, int polar, int num_vars, float tau, int64_t n_nodes,
+                       int64_t n_edges, const int64_t* send, const int64_t* recv, const int64_t* order, const int64_t* rowptr,
+                       int burn_in_steps, const float* burn_in, int steps, const float* inputs, float* decoder_state, float* h,
+                       float* c, const float* uniform, void* workspace, size_t workspace_bytes, float* predictions,
+                       float* edges_out, void* stream);
+
+/*
  * seq2seq dynamic-field variant: nn/seq2seq/dynamic_field_aether.py, the model
  * scripts/gravitational_field_3d_aether.sh trains (use_charges is never set by a runner: False).
  *

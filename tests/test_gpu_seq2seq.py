@@ -348,6 +348,79 @@ def test_filter_image_follows_weight_updates():
     assert scale_rel_err(got, first) > 1e-3
 
 
+def _s2s_model(D, N, K, skip_first, he=128, hd=64, R=32, layers=2, seed=61):
+    from aether_amd.nn.seq2seq.aether import Aether
+    params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": hd, "num_edge_types": K,
+              "skip_first": skip_first, "decoder_dropout": 0.0, "use_3d": D == 3, "encoder_dropout": 0.0,
+              "encoder_hidden": he, "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 1,
+              "encoder_mlp_hidden": 32, "prior_num_layers": layers, "prior_hidden_size": 48,
+              "pos_representation": "polar" if D == 2 else "cart", "gumbel_temp": 0.5, "rff_std": 1.0}
+    torch.manual_seed(seed)
+    return Aether(params, device="cuda").eval()
+
+
+@pytest.mark.parametrize("D,N,B,K,skip_first,layers", [(2, 5, 7, 2, False, 3), (3, 4, 5, 3, True, 1), (2, 20, 3, 2, False, 2)])
+def test_fused_step_equals_the_four_entry_points(D, N, B, K, skip_first, layers):
+    """aether_s2s_step (one call, shared launches, prepared weights) against predict_field -> Encoder.single_step_forward
+    -> gumbel -> RecurrentDecoder.forward on the same inputs: same edge samples, outputs to fp32 rounding."""
+    m = _s2s_model(D, N, K, skip_first, layers=layers)
+    g = torch.Generator().manual_seed(62)
+    E = N * (N - 1)
+    R, hd = m.encoder.rnn_hidden_size, m.decoder.msg_out_shape
+    x = torch.randn(B, N, 2 * D, generator=g).cuda()
+    dh = (torch.randn(B, N, hd, generator=g) * 0.3).cuda()
+    st = ((torch.randn(B, E, R, generator=g) * 0.3).cuda(), (torch.randn(B, E, R, generator=g) * 0.3).cuda())
+    u = torch.rand(B, E, K, generator=g).cuda()
+    field, _ = m.predict_field(x)
+    logits, (h1, c1) = m.encoder.single_step_forward(x, st, field)
+    want_x, want_dh, want_e = m.single_step_forward(x, dh, logits, True, field, uniform=u)
+    got_x, got_dh, (got_h, got_c), got_e = m._fused_step(x, dh, st, u)
+    assert torch.equal(got_e, want_e)
+    for got, want in ((got_x, want_x), (got_dh, want_dh), (got_h, h1), (got_c, c1)):
+        assert scale_rel_err(got.cpu(), want.cpu()) <= 2e-6
+    # a given field instead of the built-in query (the dynamic-field model's use)
+    got_x2, _, _, _ = m._fused_step(x, dh, st, u, field=field)
+    assert scale_rel_err(got_x2.cpu(), want_x.cpu()) <= 2e-6
+
+
+def test_device_rollout_equals_stepwise_loop_and_follows_weight_updates():
+    """aether_s2s_rollout (burn-in + prediction loop in the library) against the loop of per-module calls; the plan of
+    prepared weights is rebuilt when a parameter is written to."""
+    D, N, B, K = 2, 5, 6, 2
+    m = _s2s_model(D, N, K, False, layers=3)
+    g = torch.Generator().manual_seed(63)
+    E, T0, steps = N * (N - 1), 4, 6
+    R, hd = m.encoder.rnn_hidden_size, m.decoder.msg_out_shape
+    x0 = torch.randn(B, N, 2 * D, generator=g).cuda()
+    dh = (torch.randn(B, N, hd, generator=g) * 0.3).cuda()
+    st = ((torch.randn(B, E, R, generator=g) * 0.3).cuda(), (torch.randn(B, E, R, generator=g) * 0.3).cuda())
+    u = torch.rand(steps, B, E, K, generator=g).cuda()
+    for rnd in range(2):
+        want, want_e = m.predict_from_state_stepwise(x0, dh, st, steps, uniform=u, return_edges=True)
+        got, got_e = m.predict_from_state(x0, dh, st, steps, uniform=u, return_edges=True)
+        same = (got_e == want_e).all(dim=-1).all(dim=-1)                       # [B, steps]: a flipped sample changes the trajectory
+        assert same.float().mean() > 0.95
+        ok = same.cumprod(dim=1).bool()                                         # compare up to the first flip of each graph
+        err = ((got - want).abs().amax(dim=(-1, -2)) / want.abs().amax().clamp_min(1.0))[ok]
+        assert float(err.max()) <= 2e-5
+        with torch.no_grad():                                                   # second round: changed weights
+            m.decoder.out_mlp[0].weight.mul_(0.7)
+            m.encoder.res1.weight.add_(0.01)
+    # teacher-forced burn-in inside the library equals chaining the step
+    burn = torch.randn(B, T0, N, 2 * D, generator=g).cuda()
+    ub = torch.rand(T0 + steps, B, E, K, generator=g).cuda()
+    preds, _, (dh_end, _) = m._fused_rollout(burn, x0, dh, st, steps, ub, False)
+    d, s2, xx = dh, st, None
+    for t in range(T0):
+        _, d, s2, _ = m._fused_step(burn[:, t], d, s2, ub[t])
+    xx = x0
+    outs = []
+    for t in range(steps):
+        xx, d, s2, _ = m._fused_step(xx, d, s2, ub[T0 + t])
+        outs.append(xx)
+    assert torch.equal(preds, torch.stack(outs, 1)) and torch.equal(dh_end, d)
+
+
 # ---------------------------------------------------------------- dynamic-field variant (SURVEY 8f N3)
 def test_dynamic_field_variant_matches_reference():
     """nn/seq2seq/dynamic_field_aether.py: graph summary (GRU + attention pooling), FiLM field query and the whole

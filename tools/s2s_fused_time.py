@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Time the fused autoregressive step of the seq2seq model (aether_s2s_step / aether_s2s_rollout) against the loop of the four
+per-module entry points: eager C call per step, device-side rollout, and hipGraph replay of the captured step."""
+import os, sys, time, argparse
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aether_amd.nn.seq2seq.aether import Aether
+ap = argparse.ArgumentParser()
+ap.add_argument("--dims", type=int, default=3)
+ap.add_argument("--nodes", type=int, default=5)
+ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--decoder-hidden", type=int, default=256)
+ap.add_argument("--steps", type=int, default=20)
+a = ap.parse_args()
+D, N, B, H, R = a.dims, a.nodes, a.batch, 512, 128
+params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": a.decoder_hidden, "num_edge_types": 2,
+          "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3, "encoder_dropout": 0.0, "encoder_hidden": H,
+          "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 256,
+          "prior_num_layers": 3, "prior_hidden_size": 256, "pos_representation": "polar" if D == 2 else "cart",
+          "gumbel_temp": 0.5, "rff_std": 1.0}
+torch.manual_seed(0)
+m = Aether(params, device="cuda").eval()
+E, T = N * (N - 1), a.steps
+x = torch.randn(B, N, 2 * D, device="cuda")
+dh = torch.zeros(B, N, a.decoder_hidden, device="cuda")
+ps = (torch.zeros(B, E, R, device="cuda"), torch.zeros(B, E, R, device="cuda"))
+U = torch.rand(T, B, E, 2, device="cuda")
+def timed(fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+t_old = timed(lambda: m.predict_from_state_stepwise(x, dh, ps, T, uniform=U)) / T
+t_step = timed(lambda: m._fused_step(x, dh, ps, U[0]), reps=20)
+t_roll = timed(lambda: m.predict_from_state(x, dh, ps, T, uniform=U)) / T
+t_graph = timed(lambda: m.predict_from_state(x, dh, ps, T, uniform=U, graph=True)) / T
+edges = B * E
+print("D=%d N=%d B=%d hd=%d: per step: four entry points %.3f ms | fused step (one C call) %.3f ms | device rollout %.3f ms | "
+      "hipGraph replay %.3f ms = %.2f M edge-steps/s" % (D, N, B, a.decoder_hidden, t_old, t_step, t_roll, t_graph,
+                                                        edges / min(t_roll, t_graph) / 1e3))
