@@ -1,4 +1,4 @@
-// One autoregressive step of the seq2seq Aether in ~33 launches instead of ~75: field query -> prior
+// One autoregressive step of the seq2seq Aether in ~31 launches instead of ~75: field query -> prior
 // step -> hard Gumbel sample -> decoder step (nn/seq2seq/aether.py:176-185, :384-410, :590-654), on prepared weights
 // (host_s2s_step.inc: aether_s2s_plan_build).  What changes against the per-module entry points (host_seq2seq.inc):
 //   * dense layers that share nothing but the launch go into ONE launch (k_s2s_linear_jobs: a table of up to eight
@@ -24,8 +24,9 @@ struct S2SJob {
     const float* g1; const float* g2;            // epilogue gathers: rows g1[i1[n]], g2[i2[n]] (stride M) added before act
     const int64_t* i1; const int64_t* i2;
     const int64_t* xidx; const int64_t* yidx; const int* n_dev;
+    const float* W2; const float* X2;            // second K segment: + sum_k W2[m][k] X2[n][k], k < K2 (K-concatenated product)
     int64_t N;
-    int M, K, ldw, ldx, ldy, sstride, act, accumulate;
+    int M, K, ldw, ldx, ldy, sstride, act, accumulate, K2, ldw2, ldx2;
     int wg0, gx;                                 // first workgroup of the job, workgroups along n
 };
 struct S2SJobs { int n; S2SJob j[S2S_MAX_JOBS]; };
@@ -53,10 +54,14 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
     if (m0 >= M || n0 >= N) return;                    // the same for every wave of the workgroup when KW > 1
     const float* wrow[MT];
     const float* xrow[NT];
+    const float* wrow2[MT];
+    const float* xrow2[NT];
+    const int k1g = K >> 4, k2g = J.W2 != nullptr ? J.K2 >> 4 : 0;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = m0 + 16 * t + i;
         wrow[t] = W + (size_t)(m < M ? m : M - 1) * ldw + 4 * q;
+        wrow2[t] = k2g ? J.W2 + (size_t)(m < M ? m : M - 1) * J.ldw2 + 4 * q - 16 * k1g : wrow[t];
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -64,7 +69,10 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
         n = n < N ? n : N - 1;
         if (J.xidx != nullptr) n = J.xidx[n];
         xrow[t] = X + (size_t)n * ldx + 4 * q;
+        xrow2[t] = k2g ? J.X2 + (size_t)n * J.ldx2 + 4 * q - 16 * k1g : xrow[t];
     }
+    auto ldw_ = [&](int t, int a) { return ld4((a < k1g ? wrow[t] : wrow2[t]) + 16 * a); };
+    auto ldx_ = [&](int t, int a) { return ld4((a < k1g ? xrow[t] : xrow2[t]) + 16 * a); };
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb) {
@@ -77,7 +85,8 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = b4;
     }
-    const int steps = KW == 1 ? K >> 4 : ((K >> 4) - wave + KW - 1) / KW;
+    const int kgroups = k1g + k2g;
+    const int steps = KW == 1 ? kgroups : (kgroups - wave + KW - 1) / KW;
     auto kg = [&](int a) { return KW == 1 ? a : wave + KW * a; };
     if (steps > 0) {
         f32x4 wq[PF][MT], xq[PF][NT];
@@ -85,9 +94,9 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
         for (int p = 0; p < PF; ++p) {
             const int a = kg(p < steps ? p : steps - 1);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * a);
+            for (int t = 0; t < MT; ++t) wq[p][t] = ldw_(t, a);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) xq[p][t] = ld4(xrow[t] + 16 * a);
+            for (int t = 0; t < NT; ++t) xq[p][t] = ldx_(t, a);
         }
         for (int a0 = 0; a0 < steps; a0 += PF) {
 #pragma unroll
@@ -100,9 +109,9 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
                     for (int t = 0; t < NT; ++t) xv[t] = xq[p][t];
                     const int an = kg(a0 + p + PF < steps ? a0 + p + PF : steps - 1);
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) wq[p][t] = ld4(wrow[t] + 16 * an);
+                    for (int t = 0; t < MT; ++t) wq[p][t] = ldw_(t, an);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) xq[p][t] = ld4(xrow[t] + 16 * an);
+                    for (int t = 0; t < NT; ++t) xq[p][t] = ldx_(t, an);
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -173,25 +182,53 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
     }
 }
 
-// Node side of the local frames in one launch (k_s2s_extend + k_s2s_aug_nodes + two k_s2s_pad_rows): per node
-// ext = [inputs | field], rel_feat (7D + O columns), Rinv, and zero-padded copies of rel_feat at the row strides the
-// dense layers read (the prior's res1 and the first columns of the decoder's wide gate row).  Also clears the per-type
-// edge counters of the step.
+// Node side of the local frames in one launch (last field layer + k_s2s_extend + k_s2s_aug_nodes + two k_s2s_pad_rows):
+// a wave per node.  With fh2 != nullptr the wave first finishes the field query, field[n] = W4 fh2[n] + b4 (D rows of he
+// weights: 64 lanes x he / 64 products each, butterfly sum); then lane 0 builds ext = [inputs | field], rel_feat (7D + O
+// columns), Rinv and the zero-padded copies of rel_feat at the row strides the dense layers read (the prior's res1 and the
+// first columns of the decoder's wide gate row).  Also clears the per-type edge counters of the step.
 template <int D>
 __global__ void __launch_bounds__(256)
-k_s2s_node_prep(const float* __restrict__ inputs, const float* __restrict__ field, float* __restrict__ ext,
-                float* __restrict__ rel_feat, float* __restrict__ Rinv, float* __restrict__ relp, int ldp,
-                float* __restrict__ wide, int ldwide, int* __restrict__ counts, int64_t n_nodes) {
+k_s2s_node_prep(const float* __restrict__ inputs, const float* __restrict__ field_in, const float* __restrict__ fh2,
+                const float* __restrict__ w4, const float* __restrict__ b4, int he, float* __restrict__ field_out,
+                float* __restrict__ ext, float* __restrict__ rel_feat, float* __restrict__ Rinv, float* __restrict__ relp,
+                int ldp, float* __restrict__ wide, int ldwide, int* __restrict__ counts, int64_t n_nodes) {
     using A = AugDims<D>;
     constexpr int RFp = (A::RF + 15) / 16 * 16;
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x < 8 && counts != nullptr) counts[threadIdx.x] = 0;
     if (n >= n_nodes) return;
     float xi[3 * D];
+    if (fh2 != nullptr) {
+        float part[D];
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) part[dd] = 0.0f;
+        for (int k = 4 * lane; k < he; k += 256) {
+            const f32x4 xv = ld4(fh2 + (size_t)n * he + k);
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const f32x4 wv = ld4(w4 + (size_t)dd * he + k);
+                part[dd] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) part[dd] += __shfl_xor(part[dd], off);
+            xi[2 * D + dd] = part[dd] + b4[dd];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < D; ++t) xi[2 * D + t] = field_in[n * D + t];
+    }
+    if (lane != 0) return;
 #pragma unroll
     for (int t = 0; t < 2 * D; ++t) xi[t] = inputs[n * 2 * D + t];
+    if (field_out != nullptr) {
 #pragma unroll
-    for (int t = 0; t < D; ++t) xi[2 * D + t] = field[n * D + t];
+        for (int t = 0; t < D; ++t) field_out[n * D + t] = xi[2 * D + t];
+    }
 #pragma unroll
     for (int t = 0; t < 3 * D; ++t) ext[n * 3 * D + t] = xi[t];
     float row[RFp];
@@ -231,6 +268,45 @@ k_s2s_node_prep(const float* __restrict__ inputs, const float* __restrict__ fiel
     for (int a = 0; a < D; ++a)
 #pragma unroll
         for (int b = 0; b < D; ++b) Rinv[n * D * D + a * D + b] = R[a][b];
+}
+
+// Last layer of the decoder's output MLP + Globalizer + residual in one launch (aether.py:649-652): a wave per node,
+// pred = W6 o2[n] + b6 (2D rows of hd weights, butterfly sums), outputs = inputs + [R pred_pos | R pred_vel].
+template <int D>
+__global__ void __launch_bounds__(256)
+k_s2s_out_globalize(const float* __restrict__ o2, const float* __restrict__ w6, const float* __restrict__ b6, int hd,
+                    const float* __restrict__ inputs, const float* __restrict__ Rinv, float* __restrict__ out,
+                    int64_t n_nodes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_nodes) return;
+    float pred[2 * D];
+#pragma unroll
+    for (int t = 0; t < 2 * D; ++t) pred[t] = 0.0f;
+    for (int k = 4 * lane; k < hd; k += 256) {
+        const f32x4 xv = ld4(o2 + (size_t)n * hd + k);
+#pragma unroll
+        for (int t = 0; t < 2 * D; ++t) {
+            const f32x4 wv = ld4(w6 + (size_t)t * hd + k);
+            pred[t] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * D; ++t) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) pred[t] += __shfl_xor(pred[t], off);
+        pred[t] += b6[t];
+    }
+    if (lane != 0) return;
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk)
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int b = 0; b < D; ++b) s += Rinv[n * D * D + a * D + b] * pred[chunk * D + b];
+            out[n * 2 * D + chunk * D + a] = inputs[n * 2 * D + chunk * D + a] + s;
+        }
 }
 
 // k_s2s_aug_edges plus a zero-padded copy of the rows (stride EAp, the decoder's present-message layer).
@@ -280,6 +356,7 @@ k_s2s_edge_prep(const float* __restrict__ x, const int64_t* __restrict__ send, c
 
 // eaf[e][:] = sum_z planes[z][e][:] for the node's in-edges (every edge has one receiver: each row is produced once) and
 // X0[n][:] = sum over the in-edges / fixed_div: k_s2s_sum_planes + k_s2s_segment_mean of the prior step in one pass.
+// (Folding the small res1 layer in as well was measured: 12.6 -> 39.8 us, its strided weight reads serialise.)
 __global__ void __launch_bounds__(128)
 k_s2s_planes_segsum(const float* __restrict__ planes, int n_planes, int64_t plane_stride, const int64_t* __restrict__ order,
                     const int64_t* __restrict__ rowptr, float* __restrict__ eaf, float* __restrict__ X0, int h,
@@ -299,8 +376,9 @@ k_s2s_planes_segsum(const float* __restrict__ planes, int n_planes, int64_t plan
     }
 }
 
-// Hard Gumbel sample (k_s2s_gumbel_hard) + the per-type edge lists of the decoder (k_s2s_select for every type) + the
-// cleared message rows of the edge, in one launch.  counts must be zero (k_s2s_node_prep clears them).
+// Hard Gumbel sample (k_s2s_gumbel_hard) + the per-type edge lists of the decoder (k_s2s_select for every type) in one
+// launch.  counts must be zero (k_s2s_node_prep clears them).  (Computing the last prior layer here, an edge per thread,
+// was measured: 4.9 + 8 -> 34.5 us.)
 __global__ void __launch_bounds__(256)
 k_s2s_gumbel_select(const float* __restrict__ logits, const float* __restrict__ uniform, float tau, int K, int k0,
                     float* __restrict__ edges, int64_t* __restrict__ lists /* [K][n_edges] */, int* __restrict__ counts,
