@@ -7,15 +7,18 @@
 // its rate).  The first version (seq2seq.h, k_s2s_filter) formed x[(r, k)] = ea[e][r] * hw[e][k] on the fly for the fp32
 // MFMA: it sits at 0.7-0.8 of THAT roof (472 us at 2,560 edges x 39 features, 4.9 ms at 48,640 x 24).
 //
-// Workgroup = 8 waves = 2 (k halves) x 4 (edge quarters) on a 64 (c) x 256 (edges) output tile, two waves per SIMD.
-// The k range of a unit is walked in slabs of 64; wave (a, eq) owns k block a (32 wide) of the slab and edges 64 eq ..
-// 64 eq + 63: its B fragments (64 edges x 32 k x 3 pieces = 48 registers) come once per slab from the prepared image of
-// the hidden rows (k_s2s_filter_bimg: the first hyper-network layer, split; it replaces k_s2s_pos_hidden) and stay put
-// for all R features.
-// Per feature r the workgroup needs the weight fragments of 64 c x 64 k (2 x 12 KB, contiguous per k block in the image):
-// they arrive by LDS-DMA two iterations ahead in a three-slot ring (72 KB), one workgroup barrier per r.  A wave runs
-// 96 MFMAs per r into a fresh Z_r tile (first term on a zero accumulator) and adds out += ea[:, r] * Z_r (its k half of
-// it: the sum over r is linear, the two halves meet once, in LDS, at the end).
+// Workgroup = 8 waves = 2 (c halves) x 4 (edge quarters) on a 64 (c) x 256 (edges) output tile, two waves per SIMD.  The
+// k range of a unit is walked in slabs of 64; a wave owns 32 c x 64 edges and holds the B fragments of its edges for BOTH
+// 32-wide k blocks of the slab (64 edges x 64 k x 3 pieces = 96 registers), loaded once per slab from the prepared image
+// of the hidden rows (k_s2s_filter_bimg: the first hyper-network layer, split; it replaces k_s2s_pos_hidden), so Z_r
+// accumulates over the whole slab before it is weighted.  Per feature r the workgroup needs the weight fragments of
+// 64 c x 64 k (24 KB, contiguous in the image): they arrive by LDS-DMA two iterations ahead in a three-slot ring (72 KB),
+// one workgroup barrier per r.  A wave runs 96 MFMAs per r (first term of each tile on a zero accumulator) and adds
+// out += ea[:, r] * Z_r (32 FMAs per lane).  Measured at 48,640 edges x 24 features (612 GFLOP): 2.47 ms = 248 TFLOP/s
+// fp32-equivalent (1.49 PFLOP/s of bf16 MFMA work, 0.59 of that pipe's peak; the fp32-MFMA version took 4.9 ms).  With
+// the DMA, the fragment reads, the barrier and the weighting removed one by one the loop runs at the pipe's peak (1.46 ms):
+// each of them adds its full cost whichever wave of the SIMD issues it -- a half-iteration phase shift between the two
+// waves of a SIMD, a k-half-per-wave layout and a two-slot ring were all measured within 5 % of this version.
 // LDS: ring 72 KB + feature values R x 1 KB + bias slab R x 256 B.
 // Units = (256-edge tile, 64-wide c block, split z): split z covers h / splits consecutive k (a multiple of 64) and writes
 // plane z of `out` (bias in plane 0); k_s2s_sum_planes adds the planes in order (deterministic).  Persistent workgroups,
@@ -25,7 +28,7 @@
 
 namespace {
 
-constexpr int FILT_STAGE = 2 * 4 * 3 * 64;      // bf16x8 fragments of one step: 2 k blocks x (64 c x 32 k x 3 pieces = 12 KB)
+constexpr int FILT_STAGE = 2 * 4 * 3 * 64;      // bf16x8 fragments of one step: 2 k blocks x 4 row blocks x 3 pieces (24 KB)
 constexpr int FILT_NST = 3;
 
 __host__ __device__ constexpr size_t filt_lds_bytes(int R) {
@@ -99,12 +102,12 @@ __global__ void __launch_bounds__(512)             // two waves per SIMD: <= 256
 k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2, const float* __restrict__ ea,
                    const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
-    bf16x8* ring = reinterpret_cast<bf16x8*>(filt_smem);                        // [a 2][slot 3][mb 4][term 3][lane]
+    bf16x8* ring = reinterpret_cast<bf16x8*>(filt_smem);                        // [slot 3][kb 2][mb 4][term 3][lane]
     float* evs = reinterpret_cast<float*>(ring + FILT_NST * FILT_STAGE);        // [r][eq 4][i 16][nb 4]
     float* b2s = evs + R * 256;                                                 // [r][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int a = wave & 1, eq = wave >> 1;                   // adjacent waves: the two k halves of an edge quarter
+    const int chalf = wave >> 2, eq = wave & 3;
     const int n_eb = (int)((n_edges + 255) >> 8), n_cb = h >> 6;
     const int n_pairs = n_cb * splits;
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, n_slots = ((int)gridDim.x + 7 - xcd) >> 3;
@@ -113,11 +116,10 @@ k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2,
     const int slabs = (h / splits) >> 6;                       // 64-wide k slabs of a unit
     const int IT = slabs * R;                                  // iterations of a unit: (slab, r)
     const int64_t n_eb16 = (n_edges + 15) >> 4;
-    // image strides in fragments of 64 lanes: one r step, and the jump from (slab, R - 1) to (slab + 1, 0)
-    const int64_t r_stride = (int64_t)n_a32 * n_mb * 3 * 64;
-    const int64_t slab_jump = (int64_t)2 * n_mb * 3 * 64 - (int64_t)(R - 1) * r_stride;
-    // the wave's group (k half a) has its own three-slot ring of 12 KB steps and issues its own DMA: 3 of the 12 fragments
-    bf16x8* gring = ring + a * (FILT_NST * 12 * 64);
+    // image strides in fragments of 64 lanes: k block to k block, one r step, and the jump from (slab, R - 1) to (slab + 1, 0)
+    const int64_t kb_stride = (int64_t)n_mb * 3 * 64;
+    const int64_t r_stride = (int64_t)n_a32 * kb_stride;
+    const int64_t slab_jump = 2 * kb_stride - (int64_t)(R - 1) * r_stride;
 
     for (int unit = slot; unit < my_pairs * n_eb; unit += n_slots) {
         const int pair = xcd + 8 * (unit / n_eb);
@@ -125,16 +127,19 @@ k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2,
         const int c0 = (pair % n_cb) * 64, z = pair / n_cb;
         const int kbase = z * (h / splits);
 
-        // DMA cursor: k block a of step (slab 0, r 0), this wave's first fragment
-        const bf16x8* dsrc = img + (((size_t)((kbase >> 5) + a) * n_mb + (c0 >> 4)) * 3 + eq) * 64 + lane;
+        // DMA cursor: step (slab 0, r 0); the wave moves fragments wave, wave + 8, wave + 16 of the step's 24
+        // (fragment f = 12 kb + 3 mb + term sits at kb * kb_stride + (3 mb + term) * 64 of the image)
+        const bf16x8* dsrc = img + ((size_t)(kbase >> 5) * n_mb + (c0 >> 4)) * 3 * 64 + lane;
         int dr = 0, dslot = 0, dleft = IT;
-        auto dma_next = [&]() {                                // the next step of this group -> its slot; advances the cursor
+        auto dma_next = [&]() {                                // the next step -> its slot; advances the cursor
             if (dleft <= 0) return;
-            bf16x8* dst = gring + (dslot * 12 + eq) * 64;
+            bf16x8* dst = ring + dslot * FILT_STAGE;
 #pragma unroll
-            for (int f = 0; f < 3; ++f)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(dsrc + 4 * f * 64),
-                                                 (__attribute__((address_space(3))) void*)(dst + 4 * f * 64), 16, 0, 0);
+            for (int f = 0; f < 3; ++f) {
+                const int fr = wave + 8 * f, kb = fr >= 12 ? 1 : 0, rest = fr - 12 * kb;
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(dsrc + kb * kb_stride + rest * 64),
+                                                 (__attribute__((address_space(3))) void*)(dst + fr * 64), 16, 0, 0);
+            }
             --dleft;
             dslot = dslot == FILT_NST - 1 ? 0 : dslot + 1;
             if (++dr == R) { dr = 0; dsrc += slab_jump; } else dsrc += r_stride;
@@ -149,167 +154,110 @@ k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2,
         if (z == 0)
             for (int idx = tid; idx < R * 64; idx += 512) b2s[idx] = b2[(size_t)(idx >> 6) * h + c0 + (idx & 63)];
 
-        f32x4 outv[4][4];
+        f32x4 outv[2][4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) outv[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* evl = evs + 64 * eq + 4 * i;
         __syncthreads();                                       // staged values visible, every global load of the prologue done
         dma_next();
         dma_next();
-        if (a == 1) dma_next();
-        if (z == 0 && a == 0) {                                // bias term: sum_r ea[e][r] * b2[r h + c]
+        if (z == 0) {                                          // bias term: sum_r ea[e][r] * b2[r h + c]
 #pragma unroll 4
             for (int r = 0; r < R; ++r) {
                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(evl + r * 256);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(b2s + r * 64 + 16 * mb + 4 * q);
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(b2s + r * 64 + 32 * chalf + 16 * mb + 4 * q);
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += bv * e4[nb];
                 }
             }
         }
 
-        bf16x8 xh[4], xm[4], xl[4];                            // B fragments of the wave's k block: edges 16 nb + i, k = 8 q + u
-        auto build_b = [&](int slab) {                         // 12 coalesced 1 KB loads, once per slab
-            const int a32 = ((kbase + 64 * slab) >> 5) + a;
+        bf16x8 xh[2][4], xm[2][4], xl[2][4];                   // B fragments [k block][nb]: edges 16 nb + i, k = 32 kb + 8 q + u
+        auto build_b = [&](int slab) {                         // 24 coalesced 1 KB loads, once per slab
+            const int a32 = (kbase + 64 * slab) >> 5;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 int64_t blk = (e0 >> 4) + 4 * eq + nb;
                 blk = blk < n_eb16 ? blk : n_eb16 - 1;
-                const bf16x8* src = bimg + ((blk * n_a32 + a32) * 3) * 64 + lane;
-                xh[nb] = src[0]; xm[nb] = src[64]; xl[nb] = src[128];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8* src = bimg + ((blk * n_a32 + a32 + kb) * 3) * 64 + lane;
+                    xh[kb][nb] = src[0]; xm[kb][nb] = src[64]; xl[kb][nb] = src[128];
+                }
             }
             // consume the loads HERE: left pending, the compiler's wait for them lands in front of the first MFMA of the
             // iteration as vmcnt(0) -- behind the DMA just issued for a later step, whose latency it then exposes
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+v"(xh[nb]), "+v"(xm[nb]), "+v"(xl[nb]));
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+v"(xh[kb][nb]), "+v"(xm[kb][nb]), "+v"(xl[kb][nb]));
         };
-        // Fragment reads as inline assembly: the compiler waits for EVERY outstanding LDS-DMA (vmcnt(0)) before an LDS read
-        // it can see -- it cannot tell the ring slots apart -- which would expose the latency of the step just requested.
-        auto frags = [&](int it, bf16x8 (&w)[12], f32x4& e4, int r) {
-            const bf16x8* st = gring + (it % FILT_NST) * 12 * 64 + lane;
-            const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
-            const unsigned eaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(evl + r * 256);
-#pragma unroll
-            for (int j = 0; j < 12; ++j)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[j]) : "v"(base), "n"(j * 1024));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(e4) : "v"(eaddr));
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
-                           "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(e4));
-        };
-        auto tile = [&](const bf16x8 (&w)[12], int mb, const f32x4 e4) {      // Z_r rows 16 mb .. + 16, then out += ea[:, r] Z_r
-            const bf16x8 wh = w[mb * 3], wm = w[mb * 3 + 1], wl = w[mb * 3 + 2];
-            f32x4 tmp[4];
-            // small terms first; four independent accumulators per term
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[nb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[nb], tmp[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[nb], tmp[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[nb], tmp[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[nb], tmp[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[nb], tmp[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += tmp[nb] * e4[nb];
-        };
-        // IT + 1 workgroup barriers b_0 .. b_IT in both groups.  Group 0 passes b_it at the top of its iteration it; group 1
-        // runs half an iteration out of phase -- b_{it+1} sits in the middle of its iteration it -- so that on every SIMD one
-        // wave's DMA issue, fragment reads and barrier wait run under the other wave's MFMAs (in phase, both waves of a SIMD
-        // did them at the same time: 1,250 of 5,000 cycles per iteration with the matrix pipe idle, s_memtime stamps).
-        bf16x8 w[12];
-        f32x4 e4;
-#ifdef AETHER_FILTER_STAMPS
-        unsigned long long T_[6] = {0, 0, 0, 0, 0, 0}, t_[6];
-#define FSTAMP(k) t_[k] = __builtin_amdgcn_s_memtime()
-#define FACC() do { for (int k_ = 0; k_ < 5; ++k_) T_[k_] += t_[k_ + 1] - t_[k_]; } while (0)
-#else
-#define FSTAMP(k)
-#define FACC()
-#endif
-        if (a == 0) {
-            for (int it = 0; it < IT; ++it) {
-                const int slab = it / R, r = it - slab * R;
-                FSTAMP(0);
-                if (r == 0) build_b(slab);
-                // this step's fragments have landed (the three loads of step it + 1 may still be in flight) ...
-                if (it + 1 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                FSTAMP(1);
-                lds_barrier();                                 // b_it: ... for every wave; slot (it - 1) % NST is free
-                FSTAMP(2);
-                dma_next();                                    // step it + 2
-                FSTAMP(3);
-                frags(it, w, e4, r);
-                FSTAMP(4);
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) tile(w, mb, e4);
-                FSTAMP(5);
-                FACC();
-            }
-            lds_barrier();                                     // b_IT
-        } else {
-            if (IT > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (IT > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        for (int it = 0; it < IT; ++it) {
+            const int slab = it / R, r = it - slab * R;
+            if (r == 0) build_b(slab);
+            // this step's fragments have landed (the three loads of step it + 1 may still be in flight) ...
+            if (it + 1 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();                                     // b_0: step 0 of this group has landed for every wave
-            for (int it = 0; it < IT; ++it) {
-                const int slab = it / R, r = it - slab * R;
-                FSTAMP(0);
-                if (r == 0) build_b(slab);
-                frags(it, w, e4, r);
-                FSTAMP(1);
-                tile(w, 0, e4);
-                tile(w, 1, e4);
-                // step it + 1 has landed (the loads of step it + 2 may be in flight); this step's fragments are in registers
-                if (it + 2 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                FSTAMP(2);
-                lds_barrier();                                 // b_{it+1}: its slot is free
-                FSTAMP(3);
-                dma_next();                                    // step it + 3
-                FSTAMP(4);
-                tile(w, 2, e4);
-                tile(w, 3, e4);
-                FSTAMP(5);
-                FACC();
+            lds_barrier();                                     // ... for every wave; slot (it - 1) % NST is free
+            dma_next();                                        // step it + 2
+            // Fragment reads as inline assembly: the compiler waits for EVERY outstanding LDS-DMA (vmcnt(0)) before an LDS
+            // read it can see -- it cannot tell the ring slots apart -- which would expose the latency of the step just
+            // requested.  [kb][mb][term] of this wave's c half: fragment 12 kb + 3 (2 chalf + mb) + term
+            bf16x8 w[2][2][3];
+            f32x4 e4;
+            {
+                const bf16x8* st = ring + (it % FILT_NST) * FILT_STAGE + (6 * chalf) * 64 + lane;
+                const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
+                const unsigned eaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(evl + r * 256);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[kb][mb][t]) : "v"(base), "n"((12 * kb + 3 * mb + t) * 1024));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(e4) : "v"(eaddr));
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(w[0][0][0]), "+v"(w[0][0][1]), "+v"(w[0][0][2]), "+v"(w[0][1][0]), "+v"(w[0][1][1]),
+                               "+v"(w[0][1][2]), "+v"(w[1][0][0]), "+v"(w[1][0][1]), "+v"(w[1][0][2]), "+v"(w[1][1][0]),
+                               "+v"(w[1][1][1]), "+v"(w[1][1][2]), "+v"(e4));
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {                   // Z_r rows 16 mb .. + 16 of this wave over the slab's 64 k
+                f32x4 tmp[4];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8 wh = w[kb][mb][0], wm = w[kb][mb][1], wl = w[kb][mb][2];
+                    // small terms first; four independent accumulators per term
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[kb][nb], kb == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : tmp[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[kb][nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[kb][nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[kb][nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[kb][nb], tmp[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[kb][nb], tmp[nb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += tmp[nb] * e4[nb];       // out += ea[:, r] * Z_r
             }
         }
-#ifdef AETHER_FILTER_STAMPS
-        if (blockIdx.x == 0 && lane == 0 && unit == slot)
-            printf("wave %d (a=%d) IT %d per iteration: %s %.0f | %s %.0f | %s %.0f | %s %.0f | %s %.0f\n", wave, a, IT,
-                   a == 0 ? "build_b+vmcnt" : "build_b+reads", (double)T_[0] / IT, a == 0 ? "barrier" : "tiles01+vmcnt", (double)T_[1] / IT,
-                   a == 0 ? "dma" : "barrier", (double)T_[2] / IT, a == 0 ? "reads" : "dma", (double)T_[3] / IT,
-                   a == 0 ? "tiles0-3" : "tiles23", (double)T_[4] / IT);
-#endif
-        // the two k halves meet: waves a = 1 park their tile in the (now idle) ring, waves a = 0 add and store
-        lds_barrier();
-        f32x4* red = reinterpret_cast<f32x4*>(ring) + (size_t)eq * 16 * 64 + lane;
-        if (a == 1) {
+        float* dst = out + (size_t)z * n_edges * h;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+        for (int nb = 0; nb < 4; ++nb) {
+            const int64_t n = e0 + 64 * eq + 16 * nb + i;
+            if (n >= n_edges) continue;
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) red[(mb * 4 + nb) * 64] = outv[mb][nb];
-        }
-        lds_barrier();
-        if (a == 0) {
-            float* dst = out + (size_t)z * n_edges * h;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int64_t n = e0 + 64 * eq + 16 * nb + i;
-                if (n >= n_edges) continue;
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-                    st4(dst + (size_t)n * h + c0 + 16 * mb + 4 * q, outv[mb][nb] + red[(mb * 4 + nb) * 64]);
-            }
+            for (int mb = 0; mb < 2; ++mb) st4(dst + (size_t)n * h + c0 + 32 * chalf + 16 * mb + 4 * q, outv[mb][nb]);
         }
         __syncthreads();                                       // ring and staged values are free for the next unit; stores issued
     }
