@@ -32,7 +32,7 @@ struct S2SJob {
 struct S2SJobs { int n; S2SJob j[S2S_MAX_JOBS]; };
 
 // The body of k_s2s_linear (seq2seq.h) with the activation, the row stride of X and the job chosen at run time.
-template <int MT, int NT, int PF, int KW>
+template <int MT, int NT, int PF, int KW, bool TWO>
 __global__ void __launch_bounds__(256)
 k_s2s_linear_jobs(const S2SJobs jobs) {
     int ji = 0;
@@ -56,7 +56,7 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
     const float* xrow[NT];
     const float* wrow2[MT];
     const float* xrow2[NT];
-    const int k1g = K >> 4, k2g = J.W2 != nullptr ? J.K2 >> 4 : 0;
+    const int k1g = K >> 4, k2g = (TWO && J.W2 != nullptr) ? J.K2 >> 4 : 0;      // TWO = false: no job of the launch has a second segment
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = m0 + 16 * t + i;
@@ -71,8 +71,8 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
         xrow[t] = X + (size_t)n * ldx + 4 * q;
         xrow2[t] = k2g ? J.X2 + (size_t)n * J.ldx2 + 4 * q - 16 * k1g : xrow[t];
     }
-    auto ldw_ = [&](int t, int a) { return ld4((a < k1g ? wrow[t] : wrow2[t]) + 16 * a); };
-    auto ldx_ = [&](int t, int a) { return ld4((a < k1g ? xrow[t] : xrow2[t]) + 16 * a); };
+    auto ldw_ = [&](int t, int a) { return ld4((!TWO || a < k1g ? wrow[t] : wrow2[t]) + 16 * a); };
+    auto ldx_ = [&](int t, int a) { return ld4((!TWO || a < k1g ? xrow[t] : xrow2[t]) + 16 * a); };
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb) {
