@@ -76,6 +76,43 @@ class _StepRunner:
         self.graph.replay()
 
 
+class _RolloutRunner:
+    """The whole loop of ``predict_future`` -- burn-in and prediction steps, ``aether_s2s_rollout`` -- captured once in a
+    hipGraph on static buffers: one graph launch per rollout (T0 + steps steps of 31 kernels each).  Results are
+    bit-identical to the eager call (same kernels)."""
+
+    def __init__(self, model, B, N, T0, steps, device):
+        D, E, K = model.num_dims, N * (N - 1), model.num_edge_types
+        R, h = model.encoder.rnn_hidden_size, model.decoder.msg_out_shape
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
+        self.burn = z(B, T0, N, 2 * D) if T0 > 0 else None
+        self.x, self.dh, self.ph, self.pc = z(B, N, 2 * D), z(B, N, h), z(B, E, R), z(B, E, R)
+        self.u = torch.full((T0 + steps, B, E, K), 0.5, dtype=torch.float32, device=device)
+        self.model, self.steps = model, steps
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):                              # warm-up: plan, workspaces, lazy initialisation
+            self._run()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+        self.keep = model._graph_keepalive()
+
+    def _run(self):
+        return self.model._fused_rollout(self.burn, self.x, self.dh, (self.ph, self.pc), self.steps, self.u, True)
+
+    def __call__(self, burn_in, x_last, decoder_hidden, prior_hidden, uniform):
+        if self.burn is not None:
+            self.burn.copy_(burn_in)
+        self.x.copy_(x_last); self.dh.copy_(decoder_hidden)
+        self.ph.copy_(prior_hidden[0]); self.pc.copy_(prior_hidden[1])
+        self.u.copy_(uniform.reshape(self.u.shape))
+        self.graph.replay()
+        preds, edges, (dh, (h, c)) = self.out
+        return preds.clone(), edges.clone(), (dh.clone(), (h.clone(), c.clone()))
+
+
 class _StepLoop:
     """Mixin of the two seq2seq models: the fused autoregressive step (``aether_s2s_step`` / ``aether_s2s_rollout`` on a
     cached plan of prepared weights) and the burn-in / prediction loops on a cached ``_StepRunner``."""
@@ -211,6 +248,22 @@ class _StepLoop:
             hit.clear()                                            # parameters moved or shapes changed: drop old graphs
             hit[key] = _StepRunner(self, field_fn, B, N, device)
         return hit[key]
+
+    def _graphed_rollout(self, burn_in, x_last, decoder_hidden, prior_hidden, steps, uniform, return_edges):
+        """One hipGraph launch for the whole loop (``_RolloutRunner``); arguments as ``_fused_rollout``."""
+        B, N = x_last.shape[0], x_last.shape[1]
+        dev = x_last.device
+        T0 = 0 if burn_in is None else burn_in.shape[1]
+        E, K = N * (N - 1), self.num_edge_types
+        if uniform is None:
+            uniform = torch.rand(T0 + steps, B, E, K, device=dev)
+        key = ("rollout", B, N, T0, int(steps), str(dev), _tensors_key(self))
+        hit = self.__dict__.setdefault("_runners", {})
+        if key not in hit:
+            hit.clear()                                            # parameters moved or shapes changed: drop old graphs
+            hit[key] = _RolloutRunner(self, B, N, T0, int(steps), dev)
+        preds, edges, state = hit[key](burn_in, x_last, decoder_hidden, prior_hidden, uniform)
+        return preds, (edges if return_edges else None), state
 
     def _graphed(self, field_fn, burn_in, x_last, decoder_hidden, prior_hidden, steps, uniform, return_edges,
                  extra_key=()):
@@ -392,16 +445,16 @@ class Aether(_StepLoop, _EvalLoss, nn.Module):
     @torch.no_grad()
     def predict_future(self, inputs, prediction_steps, return_edges=False, uniform=None, graph=False):
         """aether.py:155-191.  inputs [B, T, N, 2D] (burn-in observations); ``uniform`` [T - 1 + steps, B, E, K].
-        ``graph``: replay the step from a captured hipGraph (``_StepRunner``) instead of launching it kernel by kernel;
-        both ways run the same fused step (``aether_s2s_step``) and give identical results."""
+        ``graph``: replay the whole loop from ONE captured hipGraph (``_RolloutRunner``: a single graph launch per rollout)
+        instead of launching it kernel by kernel; both ways run the same fused step and give identical results."""
         B, T, N, _ = inputs.shape
         E = N * (N - 1)
         decoder_hidden = self.decoder.get_initial_hidden(inputs)
         R = self.encoder.rnn_hidden_size
         prior_hidden = (torch.zeros(B, E, R, device=inputs.device), torch.zeros(B, E, R, device=inputs.device))
         if graph:
-            preds, edges, _ = self._graphed(None, inputs[:, :T - 1].float(), inputs[:, T - 1].float(), decoder_hidden,
-                                            prior_hidden, int(prediction_steps), uniform, return_edges)
+            preds, edges, _ = self._graphed_rollout(inputs[:, :T - 1].float() if T > 1 else None, inputs[:, T - 1].float(),
+                                                    decoder_hidden, prior_hidden, int(prediction_steps), uniform, return_edges)
             return (preds, edges) if return_edges else preds
         # burn-in and prediction loop on the device (aether_s2s_rollout).  The reference takes the burn-in's prior logits
         # from the full-sequence encoder (aether.py:161-173); its prior path is causal (forward LSTM from the zero state,
@@ -417,8 +470,8 @@ class Aether(_StepLoop, _EvalLoss, nn.Module):
         leaves behind: last observed state ``predictions`` [B, N, 2D], ``decoder_hidden`` [B, N, h],
         ``prior_hidden`` = (h, c) each [B, E, rnn].  ``uniform`` [steps, B, E, K] fixes the Gumbel draws."""
         if graph:
-            preds, edges, _ = self._graphed(None, None, predictions.float(), decoder_hidden, prior_hidden,
-                                            int(prediction_steps), uniform, return_edges)
+            preds, edges, _ = self._graphed_rollout(None, predictions.float(), decoder_hidden, prior_hidden,
+                                                    int(prediction_steps), uniform, return_edges)
             return (preds, edges) if return_edges else preds
         # the whole loop on the device (aether_s2s_rollout): one C call, the fused step per time step
         preds, edges, _ = self._fused_rollout(None, predictions, decoder_hidden, prior_hidden, int(prediction_steps),
