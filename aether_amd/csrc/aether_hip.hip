@@ -261,6 +261,8 @@ int g_outer_tiles_per_wave = 0;                 // aether_set_option("outer_tile
 int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
 int g_linear_kwaves = 4;                        // aether_set_option("linear_kwaves", 1 | 4): waves of a workgroup that split a small layer's k-groups
 int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the first-version filter kernel (variable-N steps)
+int g_dyn_filter_v1 = 0;                        // aether_set_option("dyn_filter_v1", 0 auto | 1 always | 2 never): first-version filter kernel in the variable-N steps
+int g_dyn_filter_v1_edges = 0;                  // auto: below this many edges (measured: no size where the first version wins)
 int g_filter_wgs = 256;                         // workgroups of k_s2s_filter_split: one per CU
 int g_filter_splits = 0;                        // aether_set_option("filter_splits", n): k-splits of the filter GEMM, 0 = by balance
 
@@ -896,6 +898,12 @@ int aether_set_option(const char* name, int value) {
         g_linear_kwaves = value;
         return AETHER_OK;
     }
+    if (!strcmp(name, "dyn_filter_v1")) {
+        if (value < 0 || value > 2) return fail(AETHER_EINVAL, "set_option: dyn_filter_v1 must be 0, 1 or 2");
+        g_dyn_filter_v1 = value;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "dyn_filter_v1_edges")) { g_dyn_filter_v1_edges = value; return AETHER_OK; }
     if (!strcmp(name, "filter_wgs")) {
         if (value < 8 || value % 8 != 0) return fail(AETHER_EINVAL, "set_option: filter_wgs must be a multiple of 8");
         g_filter_wgs = value;

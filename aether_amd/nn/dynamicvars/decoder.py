@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
-from ..seq2seq.encoder import _AnisotropicEdgeFilter
+from ..seq2seq.encoder import _AnisotropicEdgeFilter, filter_image
 
 
 class _DynDecoderParams(C.Structure):
@@ -25,7 +25,7 @@ class _DynDecoderParams(C.Structure):
                                            "input_i_b", "input_n_w", "input_n_b", "present_r_w", "present_r_b",
                                            "present_i_w", "present_i_b", "present_n_w", "present_n_b", "out1_w", "out1_b",
                                            "out2_w", "out2_b", "out3_w", "out3_b")] +
-                [(n, C.c_void_p * 4) for n in ("filt_w0", "filt_b0", "filt_w2", "filt_b2")])
+                [(n, C.c_void_p * 4) for n in ("filt_w0", "filt_b0", "filt_w2", "filt_b2", "filt_image")])
 
 
 class Decoder(nn.Module):
@@ -79,6 +79,8 @@ class Decoder(nn.Module):
             ps.msg_fc2_w[k], ps.msg_fc2_b[k] = ptr(self.msg_fc2[k].weight), ptr(self.msg_fc2[k].bias)
             f = self.edge_filter[k].edge_filter
             ps.filt_w0[k], ps.filt_b0[k], ps.filt_w2[k], ps.filt_b2[k] = ptr(f[0].weight), ptr(f[0].bias), ptr(f[2].weight), ptr(f[2].bias)
+            ps.filt_image[k] = filter_image(self.__dict__.setdefault("_img_cache", {}), f"filt{k}", f[2].weight, 15,
+                                            f[2].weight.shape[1]).data_ptr()
         ps.hidden_r_w, ps.hidden_i_w, ps.hidden_h_w = ptr(self.hidden_r.weight), ptr(self.hidden_i.weight), ptr(self.hidden_h.weight)
         for g in ("r", "i", "n"):
             for kind in ("input", "present"):

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ...knn import csr_by_receiver, knn_edges
-from ..seq2seq.encoder import _AnisotropicEdgeFilter, _RefNRIMLP, _mlp_out
+from ..seq2seq.encoder import _AnisotropicEdgeFilter, _RefNRIMLP, _mlp_out, filter_image
 
 
 class _DynPriorParams(C.Structure):
@@ -27,7 +27,7 @@ class _DynPriorParams(C.Structure):
                  for t in ("w0", "b0", "w3", "b3", "bn_w", "bn_b", "bn_mean", "bn_var")] +
                 [(n, C.c_void_p) for n in ("lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh")] +
                 [("prior_w", C.c_void_p * 4), ("prior_b", C.c_void_p * 4)] +
-                [(n, C.c_void_p) for n in ("filt_w0", "filt_b0", "filt_w2", "filt_b2")])
+                [(n, C.c_void_p) for n in ("filt_w0", "filt_b0", "filt_w2", "filt_b2", "filt_image")])
 
 
 class Encoder(nn.Module):
@@ -95,6 +95,8 @@ class Encoder(nn.Module):
             ps.prior_w[l], ps.prior_b[l] = ptr(lin.weight), ptr(lin.bias)
         f = self.edge_filter.edge_filter
         ps.filt_w0, ps.filt_b0, ps.filt_w2, ps.filt_b2 = ptr(f[0].weight), ptr(f[0].bias), ptr(f[2].weight), ptr(f[2].bias)
+        ps.filt_image = filter_image(self.__dict__.setdefault("_img_cache", {}), "filt", f[2].weight, 15,
+                                     f[2].weight.shape[1]).data_ptr()
         return ps, len(layers), (layers[0].out_features if len(layers) > 1 else 0)
 
     @torch.no_grad()

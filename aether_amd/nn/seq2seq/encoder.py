@@ -43,6 +43,24 @@ def gumbel_softmax_hard(logits, uniform, tau):
     return out.view(logits.shape)
 
 
+def filter_image(cache, name, w, n_features, hidden):
+    """bf16 x 3 image of a filter bank ``w`` [n_features * hidden, hidden] for the matrix cores
+    (``aether_s2s_filter_prepare``), kept in ``cache[name]`` and rebuilt -- into the same buffer, which captured graphs
+    point at -- whenever the weight tensor moved or was written to."""
+    key = (w.data_ptr(), w._version, str(w.device))
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        lib = _lib.load()
+        nbytes = lib.aether_s2s_filter_image_bytes(n_features, hidden)
+        buf = hit[1] if hit is not None and hit[1].numel() == nbytes and hit[1].device == w.device else \
+            torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _lib.check(lib.aether_s2s_filter_prepare(w.data_ptr(), n_features, hidden, buf.data_ptr(), nbytes,
+                                                 torch.cuda.current_stream(w.device).cuda_stream),
+                   "aether_s2s_filter_prepare")
+        hit = cache[name] = (key, buf)
+    return hit[1]
+
+
 class _RefNRIMLP(nn.Module):
     """Parameter holder of ``RefNRIMLP`` (nn/utils/model_utils.py:15-43), same creation / init order."""
 
@@ -150,21 +168,7 @@ class Encoder(nn.Module):
         return ps, len(layers), (layers[0].out_features if len(layers) > 1 else 0)
 
     def _filter_image(self, w):
-        """bf16 x 3 image of the filter bank for the matrix cores (``aether_s2s_filter_prepare``), rebuilt -- into the same
-        buffer, which captured graphs point at -- whenever the weight tensor moved or was written to."""
-        key = (w.data_ptr(), w._version, str(w.device))
-        hit = self._cache.get("filt_image")
-        if hit is None or hit[0] != key:
-            lib = _lib.load()
-            R, h = self.edge_filter.num_relative_features, self.hidden_size
-            nbytes = lib.aether_s2s_filter_image_bytes(R, h)
-            buf = hit[1] if hit is not None and hit[1].numel() == nbytes and hit[1].device == w.device else \
-                torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-            _lib.check(lib.aether_s2s_filter_prepare(w.data_ptr(), R, h, buf.data_ptr(), nbytes,
-                                                     torch.cuda.current_stream(w.device).cuda_stream),
-                       "aether_s2s_filter_prepare")
-            hit = self._cache["filt_image"] = (key, buf)
-        return hit[1]
+        return filter_image(self._cache, "filt_image", w, self.edge_filter.num_relative_features, self.hidden_size)
 
     def _graph(self, B, N, device):
         key = (B, N, str(device))

@@ -564,6 +564,7 @@ typedef struct AetherDynDecoderParams {
     const float* out3_w; const float* out3_b;                /* out_fc3: [4][h] */
     const float* filt_w0[4]; const float* filt_b0[4];        /* edge_filter.k.edge_filter.0: [h][3], [h] */
     const float* filt_w2[4]; const float* filt_b2[4];        /* edge_filter.k.edge_filter.2: [15 h][h], [15 h] */
+    const void* filt_image[4];   /* aether_s2s_filter_prepare(filt_w2[k], 15, h, ..) of the current values, or NULL (built per call) */
 } AetherDynDecoderParams;
 size_t aether_dyn_decoder_workspace_bytes(int hidden, int64_t n_nodes, int64_t n_edges);
 int aether_dyn_decoder_step(const AetherDynDecoderParams* params, int hidden, int num_edge_types, int skip_first,
@@ -620,6 +621,7 @@ typedef struct AetherDynPriorParams {
     const float* prior_w[4]; const float* prior_b[4];                                            /* prior_fc_out */
     const float* filt_w0; const float* filt_b0;                                                  /* [h][3] */
     const float* filt_w2; const float* filt_b2;                                                  /* [15 h][h] */
+    const void* filt_image;   /* aether_s2s_filter_prepare(filt_w2, 15, h, ..) of the current values, or NULL (built per call) */
 } AetherDynPriorParams;
 size_t aether_dyn_prior_workspace_bytes(int hidden, int rnn_hidden, int prior_hidden, int64_t n_nodes, int64_t n_edges);
 int aether_dyn_prior_step(const AetherDynPriorParams* params, int hidden, int rnn_hidden, int prior_layers,
