@@ -25,6 +25,7 @@ struct S2SJob {
     const int64_t* i1; const int64_t* i2;
     const int64_t* xidx; const int64_t* yidx; const int* n_dev;
     const float* W2; const float* X2;            // second K segment: + sum_k W2[m][k] X2[n][k], k < K2 (K-concatenated product)
+    const void* Wimg; const void* W2img;         // bf16 x 3 images of W / W2 (k_s2s_gemm_image), or NULL: fp32 MFMA only
     int64_t N;
     int M, K, ldw, ldx, ldy, sstride, act, accumulate, K2, ldw2, ldx2;
     int wg0, gx;                                 // first workgroup of the job, workgroups along n
@@ -178,6 +179,189 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
                 for (int r = 0; r < 4; ++r)
                     if (m + r < M) Y[(size_t)n * ldy + m + r] = v[r] + (J.accumulate ? Y[(size_t)n * ldy + m + r] : 0.0f);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Large dense layers (>= 16 K rows) on the bf16 pipe: the job-table GEMM as six bf16 MFMA terms on 3-way split operands
+// (common.h: fp32-equivalent).  Weights come as prepared images (the plan), the activation rows are split in registers.
+//   image of W [M][K] (row stride ldw): [k block K/32][row block M/16][piece 3][lane (i, q)] = W[16 mb + i][32 a + 8 q .. + 8)
+__global__ void __launch_bounds__(256)
+k_s2s_gemm_image(const float* __restrict__ W, int M, int K, int ldw, bf16x8* __restrict__ img) {
+    const int oct = K >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;         // (row, k octet)
+    if (idx >= (int64_t)M * oct) return;
+    const int m = (int)(idx / oct), o = (int)(idx - (int64_t)m * oct);
+    const f32x4 v0 = ld4(W + (size_t)m * ldw + 8 * o), v1 = ld4(W + (size_t)m * ldw + 8 * o + 4);
+    bf16x8 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, d;
+        split_bf16x3(j < 4 ? v0[j] : v1[j - 4], a, b, d);
+        hi[j] = a; mid[j] = b; lo[j] = d;
+    }
+    const int a32 = o >> 2, q = o & 3, mb = m >> 4, i = m & 15;
+    const size_t frag = ((size_t)a32 * (M >> 4) + mb) * 3;
+    img[(frag + 0) * 64 + i + 16 * q] = hi;
+    img[(frag + 1) * 64 + i + 16 * q] = mid;
+    img[(frag + 2) * 64 + i + 16 * q] = lo;
+}
+
+// Workgroup = 4 waves on a 128 (m) x 128 (rows n) tile; a wave owns 128 m x 32 rows (8 x 2 accumulator blocks).  Per
+// 32-wide k step the 24 KB of weight fragments (128 m x 32 k x 3 pieces, contiguous in the image) arrive by LDS-DMA two
+// steps ahead in a three-slot ring (one barrier per step); the wave's two row blocks of X (lane: row i, eight consecutive k)
+// are requested one step ahead (inline-asm loads, so that the manual vmcnt accounting below is exact: X first, then the
+// DMA of step s + 2), split into three bf16 pieces in registers (16 values per lane) and feed 8 x 2 x 6 = 96 MFMAs.
+// Epilogue and job table as k_s2s_linear_jobs.  Needs M % 128 == 0, K % 32 == 0 (both segments).
+constexpr int GS_STAGE = 8 * 3 * 64;             // bf16x8 fragments per k step (24 KB)
+constexpr int GS_NST = 3;
+__global__ void __launch_bounds__(256, 2)
+k_s2s_gemm_split(const S2SJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
+    bf16x8* ring = reinterpret_cast<bf16x8*>(gs_smem);
+    int ji = 0;
+#pragma unroll
+    for (int t = 1; t < S2S_MAX_JOBS; ++t)
+        if (t < jobs.n && (int)blockIdx.x >= jobs.j[t].wg0) ji = t;
+    const S2SJob& J = jobs.j[ji];
+    const int local = (int)blockIdx.x - J.wg0, bx = local % J.gx, by = local / J.gx;
+    int64_t N = J.N;
+    if (J.n_dev != nullptr) N = *J.n_dev;
+    const int M = J.M, ldy = J.ldy;
+    float* __restrict__ Y = J.Y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = by * 128;
+    const int64_t n0 = (int64_t)bx * 128 + 32 * wave;
+    if ((int64_t)bx * 128 >= N) return;                      // the whole workgroup
+    const int s1 = J.K >> 5, s2 = J.W2img != nullptr ? J.K2 >> 5 : 0, S = s1 + s2;
+    const int n_mb = M >> 4;
+    const bf16x8* img1 = reinterpret_cast<const bf16x8*>(J.Wimg);
+    const bf16x8* img2 = reinterpret_cast<const bf16x8*>(J.W2img);
+    // rows of X for the wave's two blocks (clamped; gathered through xidx)
+    const float* xr1[2];
+    const float* xr2[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int64_t n = n0 + 16 * nb + i;
+        n = n < N ? n : N - 1;
+        if (J.xidx != nullptr) n = J.xidx[n];
+        xr1[nb] = J.X + (size_t)n * J.ldx + 8 * q;
+        xr2[nb] = s2 ? J.X2 + (size_t)n * J.ldx2 + 8 * q : xr1[nb];
+    }
+    auto dma = [&](int s) {                                   // weight fragments of step s -> slot s % NST
+        const bf16x8* src = (s < s1 ? img1 + ((size_t)s * n_mb + (m0 >> 4)) * 3 * 64
+                                    : img2 + ((size_t)(s - s1) * n_mb + (m0 >> 4)) * 3 * 64) + lane;
+        bf16x8* dst = ring + (s % GS_NST) * GS_STAGE;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const int fr = wave + 4 * f;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + fr * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + fr * 64), 16, 0, 0);
+        }
+    };
+    f32x4 xa[2][2];                                           // the next step's X values: [nb][half]
+    auto xload = [&](int s) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float* p = s < s1 ? xr1[nb] + 32 * s : xr2[nb] + 32 * (s - s1);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xa[nb][0]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xa[nb][1]) : "v"(p));
+        }
+    };
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (J.bias != nullptr) b4 = ld4(J.bias + m0 + 16 * mb + 4 * q);
+        acc[mb][0] = b4; acc[mb][1] = b4;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // bias / index loads done: the counts below are exact
+    xload(0);
+    dma(0);
+    if (S > 1) dma(1);
+    for (int s = 0; s < S; ++s) {
+        // X of this step and the fragments of this step have landed; the six loads of step s + 1 may be in flight
+        if (s + 1 < S) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bf16x8 xh[2], xm[2], xl[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            asm volatile("" : "+v"(xa[nb][0]), "+v"(xa[nb][1]));
+            split8(xa[nb][0], xa[nb][1], xh[nb], xm[nb], xl[nb]);   // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
+        }
+        lds_barrier();                                        // fragments visible to every wave; slot (s - 1) % NST is free
+        if (s + 1 < S) xload(s + 1);                          // X first, then the DMA (see the vmcnt above)
+        if (s + 2 < S) dma(s + 2);
+        else if (s + 1 < S) asm volatile("" ::: "memory");
+        const bf16x8* st = ring + (s % GS_NST) * GS_STAGE + lane;
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
+        // fragments of row block mb + 1 are requested before the MFMAs of row block mb (LDS returns in order: lgkmcnt(3)
+        // leaves exactly the newer three outstanding)
+        bf16x8 w[2][3];
+#define GS_READ(buf, mb)                                                                                          \
+        do {                                                                                                      \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[buf][0]) : "v"(base), "n"(((mb) * 3 + 0) * 1024)); \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[buf][1]) : "v"(base), "n"(((mb) * 3 + 1) * 1024)); \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[buf][2]) : "v"(base), "n"(((mb) * 3 + 2) * 1024)); \
+        } while (0)
+        GS_READ(0, 0);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const int cur = mb & 1;
+            if (mb < 7) {
+                if (cur == 0) GS_READ(1, mb + 1); else GS_READ(0, mb + 1);
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w[cur][0]), "+v"(w[cur][1]), "+v"(w[cur][2]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[cur][0]), "+v"(w[cur][1]), "+v"(w[cur][2]));
+            }
+            const bf16x8 wh = w[cur][0], wm = w[cur][1], wl = w[cur][2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[nb], acc[mb][nb], 0, 0, 0);
+        }
+#undef GS_READ
+    }
+    const int act = J.act;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int64_t n = n0 + 16 * nb + i;
+        if (n >= N) continue;
+        const int64_t nsrc = n;
+        if (J.yidx != nullptr) n = J.yidx[n];
+        const float* g1 = J.g1 != nullptr ? J.g1 + (size_t)J.i1[nsrc] * M : nullptr;
+        const float* g2 = J.g2 != nullptr ? J.g2 + (size_t)J.i2[nsrc] * M : nullptr;
+        const float sc = J.scale != nullptr ? J.scale[(size_t)n * J.sstride] : 1.0f;
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const int m = m0 + 16 * mb + 4 * q;
+            f32x4 v = acc[mb][nb];
+            if (g1 != nullptr) v += ld4(g1 + m) + ld4(g2 + m);
+            if (act == 1) v = silu4(v);
+            else if (act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            } else if (act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            } else if (act == 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);
+            }
+            if (J.post_scale != nullptr) v = v * ld4(J.post_scale + m) + ld4(J.post_shift + m);
+            v = v * sc;
+            if (J.accumulate) v += ld4(Y + (size_t)n * ldy + m);
+            st4(Y + (size_t)n * ldy + m, v);
         }
     }
 }

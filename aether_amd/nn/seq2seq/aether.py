@@ -131,14 +131,14 @@ class _StepLoop:
         if hit is None or hit[0] != key:
             lib = _lib.load()
             D, he, hd, R, K = self._step_sizes()
-            nbytes = lib.aether_s2s_plan_bytes(D, he, hd, R, K)
+            pe, n_layers, prior_hidden = enc._param_struct(with_image=False)
+            nbytes = lib.aether_s2s_plan_bytes(D, he, hd, R, n_layers, prior_hidden, K)
             if nbytes == 0:
                 raise _lib.AetherHipError("fused seq2seq step: encoder_hidden must be a multiple of 128, decoder_hidden of 32")
             buf = hit[1] if hit is not None and hit[1].numel() == nbytes and hit[1].device == torch.device(device) else \
                 torch.empty(nbytes, dtype=torch.uint8, device=device)
-            pe, _, _ = enc._param_struct(with_image=False)
             pd = dec._param_struct()
-            _lib.check(lib.aether_s2s_plan_build(C.byref(pe), C.byref(pd), D, he, hd, R, K, buf.data_ptr(), nbytes,
+            _lib.check(lib.aether_s2s_plan_build(C.byref(pe), C.byref(pd), D, he, hd, R, n_layers, prior_hidden, K, buf.data_ptr(), nbytes,
                                                  torch.cuda.current_stream(device).cuda_stream), "aether_s2s_plan_build")
             hit = self.__dict__["_plan_cache"] = (key, buf)
         return hit[1]
