@@ -213,24 +213,26 @@ k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2,
                 const bf16x8* st = ring + (it % FILT_NST) * FILT_STAGE + (6 * chalf) * 64 + lane;
                 const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
                 const unsigned eaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(evl + r * 256);
+                // issue order = consumption order (e4, then (mb, kb) groups of three); LDS returns in order, so
+                // lgkmcnt(9 - 3 g) in front of group g leaves exactly the later groups outstanding
+                asm volatile("ds_read_b128 %0, %1" : "=v"(e4) : "v"(eaddr));
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
+                    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int t = 0; t < 3; ++t)
                             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[kb][mb][t]) : "v"(base), "n"((12 * kb + 3 * mb + t) * 1024));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(e4) : "v"(eaddr));
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(w[0][0][0]), "+v"(w[0][0][1]), "+v"(w[0][0][2]), "+v"(w[0][1][0]), "+v"(w[0][1][1]),
-                               "+v"(w[0][1][2]), "+v"(w[1][0][0]), "+v"(w[1][0][1]), "+v"(w[1][0][2]), "+v"(w[1][1][0]),
-                               "+v"(w[1][1][1]), "+v"(w[1][1][2]), "+v"(e4));
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {                   // Z_r rows 16 mb .. + 16 of this wave over the slab's 64 k
                 f32x4 tmp[4];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
+                    if (mb == 0 && kb == 0) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(w[0][0][0]), "+v"(w[0][0][1]), "+v"(w[0][0][2]), "+v"(e4));
+                    else if (mb == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(w[1][0][0]), "+v"(w[1][0][1]), "+v"(w[1][0][2]));
+                    else if (kb == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w[0][1][0]), "+v"(w[0][1][1]), "+v"(w[0][1][2]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[1][1][0]), "+v"(w[1][1][1]), "+v"(w[1][1][2]));
                     const bf16x8 wh = w[kb][mb][0], wm = w[kb][mb][1], wl = w[kb][mb][2];
                     // small terms first; four independent accumulators per term
 #pragma unroll
