@@ -10,6 +10,7 @@ raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -73,6 +74,11 @@ class GraphCache:
             self._d.popitem(last=False)
 
 
+class _WsToken:
+    """Held by the autograd node of a training forward: while it is alive that forward's workspace is still needed."""
+    __slots__ = ("__weakref__",)
+
+
 class _AetherStep(torch.autograd.Function):
     """aether_forward / aether_backward behind torch.autograd (parameters only get gradients:
     the runner detaches positions and edge attributes, experiments/lorentz/main.py:243-247)."""
@@ -90,8 +96,27 @@ class _AetherStep(torch.autograd.Function):
         keep = bool(flags & _lib.FLAG_KEEP_INTERMEDIATES)
         ws_bytes = module._workspace_bytes(n_nodes, n_edges, keep)
         ws_key = None
-        if train:        # the backward reads this forward's intermediates: one workspace per call
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        if train:
+            # The backward reads this forward's intermediates: one workspace per forward that is still waiting for its
+            # backward.  The usual loop (forward, backward, step) gets the module's cached buffer back every time -- a
+            # fresh torch.empty per call kept TWO of them alive across steps (this one and the previous step's, still
+            # referenced), which at the 33.5 M-edge shard of config 5 (~120 GB each) pushed the caching allocator into
+            # freeing and re-allocating device memory every step (0.44 s of a 0.55 s step).  Under hipGraph capture the
+            # buffer comes from the graph's pool as before.
+            # "Still waiting": the autograd node that saved the buffer is alive (a token it holds; after backward() without
+            # retain_graph the node and the token are gone).
+            tw, tok = module._train_ws, module._train_ws_token
+            busy = tok is not None and tok() is not None
+            capturing = torch.cuda.is_current_stream_capturing()
+            if tw is not None and not busy and tw.numel() >= ws_bytes and tw.device == x.device and not capturing:
+                ws = tw
+            else:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+                if not capturing:
+                    module._train_ws = ws
+            token = _WsToken() if not capturing else None
+            if token is not None:
+                module._train_ws_token = weakref.ref(token)
         else:
             ws = module._workspace(ws_bytes, x.device)
             # same buffer, same layout as the last completed inference call: the fused kernel left its
@@ -116,7 +141,7 @@ class _AetherStep(torch.autograd.Function):
         if not train:
             module._wimg_key = wkey
         module._last_ws = ws
-        return out, ((x, vel, charges, graph, ginfo, ws, n_edges) if train else None)
+        return out, ((x, vel, charges, graph, ginfo, ws, n_edges, token) if train else None)
 
     @staticmethod
     def forward(ctx, module, x, vel, edge_attr, charges, graph, n_edges, *params):
@@ -131,7 +156,7 @@ class _AetherStep(torch.autograd.Function):
     def backward(ctx, grad_out):
         lib = _lib.load()
         module = ctx.module
-        x, vel, charges, graph, ginfo, ws, n_edges = ctx.saved
+        x, vel, charges, graph, ginfo, ws, n_edges, _token = ctx.saved
         D = module.num_dims
         flat, gstruct, views = module._grad_buffers()
         plist = module._plist if module._plist is not None else [p for _, p in module.named_parameters()]
@@ -244,6 +269,7 @@ class Aether(nn.Module):
         self.dp_group = None              # set by aether_amd.parallel.attach_data_parallel
         self.grad_as_view = True          # .grad tensors alias one flat buffer (see _AetherStep.backward)
         self._last_ws = None
+        self._train_ws, self._train_ws_token = None, None
         self._wimg_key = None             # (workspace, parameter versions) whose split weight images the workspace holds
         self._ws_key = None               # (workspace, shape, graph) of the last completed inference call
         self._gbuf = None
