@@ -210,12 +210,12 @@ k_s2s_gemm_image(const float* __restrict__ W, int M, int K, int ldw, bf16x8* __r
 
 // Workgroup = 4 waves on a 128 (m) x 128 (rows n) tile; a wave owns 128 m x 32 rows (8 x 2 accumulator blocks).  Per
 // 32-wide k step the 24 KB of weight fragments (128 m x 32 k x 3 pieces, contiguous in the image) arrive by LDS-DMA two
-// steps ahead in a three-slot ring (one barrier per step); the wave's two row blocks of X (lane: row i, eight consecutive k)
-// are requested one step ahead (inline-asm loads, so that the manual vmcnt accounting below is exact: X first, then the
-// DMA of step s + 2), split into three bf16 pieces in registers (16 values per lane) and feed 8 x 2 x 6 = 96 MFMAs.
+// steps ahead in a three-slot ring (one barrier per step); the wave's row blocks of X (lane: row i, eight consecutive k)
+// are requested one step ahead, split into three bf16 pieces in registers (8 NB values per lane) and feed 8 x NB x 6 MFMAs.
 // Epilogue and job table as k_s2s_linear_jobs.  Needs M % 128 == 0, K % 32 == 0 (both segments).
 constexpr int GS_STAGE = 8 * 3 * 64;             // bf16x8 fragments per k step (24 KB)
 constexpr int GS_NST = 3;
+template <int NB>          // row blocks of 16 per wave: 2 (128-row tiles) from 16 K rows on, 1 (64-row tiles) for 2 K - 16 K rows
 __global__ void __launch_bounds__(256, 2)
 k_s2s_gemm_split(const S2SJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
@@ -233,17 +233,17 @@ k_s2s_gemm_split(const S2SJobs jobs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m0 = by * 128;
-    const int64_t n0 = (int64_t)bx * 128 + 32 * wave;
-    if ((int64_t)bx * 128 >= N) return;                      // the whole workgroup
+    const int64_t n0 = (int64_t)bx * (64 * NB) + 16 * NB * wave;
+    if ((int64_t)bx * (64 * NB) >= N) return;                // the whole workgroup
     const int s1 = J.K >> 5, s2 = J.W2img != nullptr ? J.K2 >> 5 : 0, S = s1 + s2;
     const int n_mb = M >> 4;
     const bf16x8* img1 = reinterpret_cast<const bf16x8*>(J.Wimg);
     const bf16x8* img2 = reinterpret_cast<const bf16x8*>(J.W2img);
     // rows of X for the wave's two blocks (clamped; gathered through xidx)
-    const float* xr1[2];
-    const float* xr2[2];
+    const float* xr1[NB];
+    const float* xr2[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         int64_t n = n0 + 16 * nb + i;
         n = n < N ? n : N - 1;
         if (J.xidx != nullptr) n = J.xidx[n];
@@ -261,36 +261,38 @@ k_s2s_gemm_split(const S2SJobs jobs) {
                                              (__attribute__((address_space(3))) void*)(dst + fr * 64), 16, 0, 0);
         }
     };
-    f32x4 xa[2][2];                                           // the next step's X values: [nb][half]
+    f32x4 xa[NB][2];                                          // the next step's X values: [nb][half]
+    // (Plain loads: as inline assembly their destination registers are loop-carried values the compiler knows nothing
+    // asynchronous about -- it copied them at the back edge before the data had arrived.  The price: its wait in front of
+    // the split is vmcnt(0), which also drains the DMA of step s + 1.)
     auto xload = [&](int s) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             const float* p = s < s1 ? xr1[nb] + 32 * s : xr2[nb] + 32 * (s - s1);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xa[nb][0]) : "v"(p));
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xa[nb][1]) : "v"(p));
+            xa[nb][0] = ld4(p);
+            xa[nb][1] = ld4(p + 4);
         }
     };
-    f32x4 acc[8][2];
+    f32x4 acc[8][NB];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (J.bias != nullptr) b4 = ld4(J.bias + m0 + 16 * mb + 4 * q);
-        acc[mb][0] = b4; acc[mb][1] = b4;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = b4;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // bias / index loads done: the counts below are exact
     xload(0);
     dma(0);
     if (S > 1) dma(1);
     for (int s = 0; s < S; ++s) {
-        // X of this step and the fragments of this step have landed; the six loads of step s + 1 may be in flight
+        // X of this step and the fragments of this step have landed; the six DMA loads of step s + 1 may be in flight
         if (s + 1 < S) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bf16x8 xh[2], xm[2], xl[2];
+        bf16x8 xh[NB], xm[NB], xl[NB];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            asm volatile("" : "+v"(xa[nb][0]), "+v"(xa[nb][1]));
+        for (int nb = 0; nb < NB; ++nb)
             split8(xa[nb][0], xa[nb][1], xh[nb], xm[nb], xl[nb]);   // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
-        }
         lds_barrier();                                        // fragments visible to every wave; slot (s - 1) % NST is free
         if (s + 1 < S) xload(s + 1);                          // X first, then the DMA (see the vmcnt above)
         if (s + 2 < S) dma(s + 2);
@@ -318,23 +320,23 @@ k_s2s_gemm_split(const S2SJobs jobs) {
             }
             const bf16x8 wh = w[cur][0], wm = w[cur][1], wl = w[cur][2];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[nb], acc[mb][nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[nb], acc[mb][nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[nb], acc[mb][nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[nb], acc[mb][nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[nb], acc[mb][nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[nb], acc[mb][nb], 0, 0, 0);
         }
 #undef GS_READ
     }
     const int act = J.act;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         int64_t n = n0 + 16 * nb + i;
         if (n >= N) continue;
         const int64_t nsrc = n;

@@ -383,18 +383,18 @@ def test_fused_step_equals_the_four_entry_points(D, N, B, K, skip_first, layers)
     assert scale_rel_err(got_x2.cpu(), want_x.cpu()) <= 2e-6
 
 
-@pytest.mark.parametrize("D", [2, 3])
-def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D):
+@pytest.mark.parametrize("D,he,hd", [(2, 128, 128), (3, 128, 128), (2, 512, 256)])
+def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he, hd):
     """From 16 K rows on the edge-level layers of the fused step run as six bf16 MFMA terms on prepared weight images
     (k_s2s_gemm_split); aether_set_option("gemm_split", 0) sends them through the fp32-MFMA job kernel instead: same edge
     samples, outputs equal to fp32 rounding (16,720 edges, ragged last tile, per-type row lists, two-segment LSTM product,
-    gather epilogue)."""
+    gather epilogue; 64-row tiles at hidden 128, 128-row tiles for the 512-wide layers)."""
     from aether_amd import _lib
     from aether_amd.nn.seq2seq.aether import Aether
     N, B, K = 20, 44, 2
-    params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": 128, "num_edge_types": K,
+    params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": hd, "num_edge_types": K,
               "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3, "encoder_dropout": 0.0,
-              "encoder_hidden": 128, "encoder_rnn_hidden": 32, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 1,
+              "encoder_hidden": he, "encoder_rnn_hidden": 32, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 1,
               "encoder_mlp_hidden": 32, "prior_num_layers": 3, "prior_hidden_size": 128,
               "pos_representation": "polar" if D == 2 else "cart", "gumbel_temp": 0.5, "rff_std": 1.0}
     torch.manual_seed(71)
@@ -402,7 +402,7 @@ def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D):
     g = torch.Generator().manual_seed(72)
     E = N * (N - 1)
     x = torch.randn(B, N, 2 * D, generator=g).cuda()
-    dh = (torch.randn(B, N, 128, generator=g) * 0.3).cuda()
+    dh = (torch.randn(B, N, hd, generator=g) * 0.3).cuda()
     st = ((torch.randn(B, E, 32, generator=g) * 0.3).cuda(), (torch.randn(B, E, 32, generator=g) * 0.3).cuda())
     u = torch.rand(B, E, K, generator=g).cuda()
     lib = _lib.load()
@@ -415,10 +415,14 @@ def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D):
         lib.aether_set_option(b"gemm_split", 1)
     assert (got_e == want_e).all(dim=-1).float().mean() > 0.9999          # a sample may sit on the rounding of its logits
     same = (got_e == want_e).all(dim=-1).all(dim=-1)                      # graphs without a flipped sample
-    for got, want in ((got_h, want_h), (got_c, want_c)):
-        assert scale_rel_err(got.cpu(), want.cpu()) <= 2e-6
+    for got, want in ((got_h, want_h), (got_c, want_c)):                  # two fp32-level evaluations of K = 512 chains
+        assert scale_rel_err(got.cpu(), want.cpu()) <= TOL
     for got, want in ((got_x, want_x), (got_dh, want_dh)):
-        assert scale_rel_err(got[same].cpu(), want[same].cpu()) <= 2e-6
+        assert scale_rel_err(got[same].cpu(), want[same].cpu()) <= TOL
+    # the split path is bit-stable run to run (an inline-asm prefetch of X once raced with a register copy at the loop's
+    # back edge: results changed from run to run)
+    again = m._fused_step(x, dh, st, u)
+    assert torch.equal(again[0], got_x) and torch.equal(again[2][0], got_h) and torch.equal(again[3], got_e)
 
 
 def test_device_rollout_equals_stepwise_loop_and_follows_weight_updates():
