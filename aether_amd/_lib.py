@@ -91,7 +91,7 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "aether_s2s_plan_bytes": (C.c_size_t, [C.c_int] * 7),
-    "aether_s2s_plan_build": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aether_s2s_plan_build": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "aether_s2s_step_workspace_bytes": (C.c_size_t, [C.c_int] * 6 + [C.c_int64, C.c_int64]),
     "aether_s2s_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_float, C.c_int64, C.c_int64] + [C.c_void_p] * 10 +
                         [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),

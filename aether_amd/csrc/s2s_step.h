@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int S2S_MAX_JOBS = 8;
+constexpr int S2S_RFG = 32;            // columns of the decoder's wide gate row that hold rel_feat (7D + O <= 24, zero padded)
 
 // Y[n][m] = act(sum_k W[m][k] X[n][k] + b[m] [+ G1[i1[n]][m] + G2[i2[n]][m]]) [affine] [* scale[n]] [+ Y]
 struct S2SJob {
@@ -446,9 +447,9 @@ k_s2s_node_prep(const float* __restrict__ inputs, const float* __restrict__ fiel
     for (int t = 0; t < A::RF; ++t) rel_feat[n * A::RF + t] = row[t];
 #pragma unroll
     for (int t = 0; t < RFp; ++t) relp[n * ldp + t] = row[t];
-    if (wide != nullptr) {
+    if (wide != nullptr) {                            // S2S_RFG columns: a whole 32-wide k block for the split GEMM
 #pragma unroll
-        for (int t = 0; t < RFp; ++t) wide[n * ldwide + t] = row[t];
+        for (int t = 0; t < S2S_RFG; ++t) wide[n * ldwide + t] = t < RFp ? row[t < RFp ? t : 0] : 0.0f;
     }
 #pragma unroll
     for (int a = 0; a < D; ++a)

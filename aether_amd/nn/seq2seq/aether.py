@@ -125,7 +125,10 @@ class _StepLoop:
         """Prepared weights of the fused step (``aether_s2s_plan_build``), rebuilt -- into the same buffer, which captured
         graphs point at -- whenever an encoder / decoder tensor moved or was written to."""
         enc, dec = self.encoder, self.decoder
+        fq = getattr(self, "_fq", None)
         tensors = list(enc.parameters()) + list(enc.buffers()) + list(dec.parameters())
+        if fq is not None:
+            tensors += list(fq[0].field_net.parameters())
         key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
         hit = self.__dict__.get("_plan_cache")
         if hit is None or hit[0] != key:
@@ -138,10 +141,22 @@ class _StepLoop:
             buf = hit[1] if hit is not None and hit[1].numel() == nbytes and hit[1].device == torch.device(device) else \
                 torch.empty(nbytes, dtype=torch.uint8, device=device)
             pd = dec._param_struct()
-            _lib.check(lib.aether_s2s_plan_build(C.byref(pe), C.byref(pd), D, he, hd, R, n_layers, prior_hidden, K, buf.data_ptr(), nbytes,
+            pf = self._field_struct()
+            _lib.check(lib.aether_s2s_plan_build(None if pf is None else C.byref(pf), C.byref(pe), C.byref(pd), D, he, hd, R, n_layers,
+                                                 prior_hidden, K, buf.data_ptr(), nbytes,
                                                  torch.cuda.current_stream(device).cuda_stream), "aether_s2s_plan_build")
             hit = self.__dict__["_plan_cache"] = (key, buf)
         return hit[1]
+
+    def _field_struct(self):
+        """Parameter struct of the built-in field query, or None (the dynamic-field model hands its field in)."""
+        fq = getattr(self, "_fq", None)
+        if fq is None:
+            return None
+        fn, ce = fq[0].field_net, fq[0].coordinate_embedding
+        from .field import _S2SFieldParams
+        return _S2SFieldParams(*[t.data_ptr() for t in (ce.B, fn[0].weight, fn[0].bias, fn[2].weight, fn[2].bias,
+                                                        fn[4].weight, fn[4].bias)])
 
     def _step_common(self, B, N, device):
         """(plan, workspace, graph arrays, parameter structs, scalar arguments) of the fused step for B graphs of N objects."""
@@ -158,13 +173,7 @@ class _StepLoop:
         ws = self.__dict__.get("_step_ws")
         if ws is None or ws.numel() < need or ws.device != torch.device(device):
             ws = self.__dict__["_step_ws"] = torch.empty(need, dtype=torch.uint8, device=device)
-        fq = getattr(self, "_fq", None)
-        pf = None
-        if fq is not None:
-            fn, ce = fq[0].field_net, fq[0].coordinate_embedding
-            from .field import _S2SFieldParams
-            pf = _S2SFieldParams(*[t.data_ptr() for t in (ce.B, fn[0].weight, fn[0].bias, fn[2].weight, fn[2].bias,
-                                                          fn[4].weight, fn[4].bias)])
+        pf = self._field_struct()
         scal = (D, he, hd, R, n_layers, prior_hidden, K, 1 if dec.skip_first_edge_type else 0,
                 1 if enc.pos_representation == "polar" else 0, N, float(self.gumbel_temp), B * N, B * E1)
         return lib, plan, ws, enc._graph(B, N, device), (pf, pe, pd), scal

@@ -387,7 +387,8 @@ int aether_s2s_mlp_head(const float* const* w, const float* const* b, int layers
  * layers that are independent of each other share a launch, the gate pre-activations are K-concatenated products, the
  * local frames are built once for prior and decoder, and everything derived from the weights alone comes from a PLAN:
  *   aether_s2s_plan_build : filter image, padded input layers, BatchNorm affines, concatenated gate weights / summed gate
- *                           biases, summed LSTM biases, bf16 x 3 images of the edge-level layers (used from 16 K rows on) -> plan (device, 256-byte aligned, aether_s2s_plan_bytes); rebuild after the weights change
+ *                           biases, summed LSTM biases, bf16 x 3 images of the dense layers (used from 2 K rows on; `field` may be
+ *                           NULL when every step will be given ext_field, otherwise pass the field net the steps will use) -> plan (device, 256-byte aligned, aether_s2s_plan_bytes); rebuild after the weights change
  *   aether_s2s_step       : inputs [n_nodes][2D], decoder_hidden_in [n_nodes][hd], h0 / c0 [n_edges][rnn], uniform
  *                           [n_edges][K] (the U(0,1) draw of gumbel_softmax) -> outputs, decoder_hidden_out, h1, c1 and,
  *                           when edges_out is not NULL, the sampled edge types [n_edges][K].  ext_field != NULL replaces the
@@ -402,9 +403,10 @@ int aether_s2s_mlp_head(const float* const* w, const float* const* b, int layers
  */
 size_t aether_s2s_plan_bytes(int num_dims, int encoder_hidden, int decoder_hidden, int rnn_hidden, int prior_layers,
                              int prior_hidden, int num_edge_types);
-int aether_s2s_plan_build(const AetherS2SPriorParams* prior, const AetherS2SDecoderParams* decoder, int num_dims,
-                          int encoder_hidden, int decoder_hidden, int rnn_hidden, int prior_layers, int prior_hidden,
-                          int num_edge_types, void* plan, size_t plan_bytes, void* stream);
+int aether_s2s_plan_build(const AetherS2SFieldParams* field, const AetherS2SPriorParams* prior,
+                          const AetherS2SDecoderParams* decoder, int num_dims, int encoder_hidden, int decoder_hidden,
+                          int rnn_hidden, int prior_layers, int prior_hidden, int num_edge_types, void* plan,
+                          size_t plan_bytes, void* stream);
 size_t aether_s2s_step_workspace_bytes(int num_dims, int encoder_hidden, int decoder_hidden, int rnn_hidden, int prior_hidden,
                                        int num_edge_types, int64_t n_nodes, int64_t n_edges);
 int aether_s2s_step(const AetherS2SFieldParams* field, const AetherS2SPriorParams* prior, const AetherS2SDecoderParams* decoder,

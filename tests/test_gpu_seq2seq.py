@@ -383,15 +383,17 @@ def test_fused_step_equals_the_four_entry_points(D, N, B, K, skip_first, layers)
     assert scale_rel_err(got_x2.cpu(), want_x.cpu()) <= 2e-6
 
 
-@pytest.mark.parametrize("D,he,hd", [(2, 128, 128), (3, 128, 128), (2, 512, 256)])
-def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he, hd):
+@pytest.mark.parametrize("D,he,hd,B", [(2, 128, 128, 44), (3, 128, 128, 44), (2, 512, 256, 44), (2, 512, 256, 110)])
+def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he, hd, B):
     """From 16 K rows on the edge-level layers of the fused step run as six bf16 MFMA terms on prepared weight images
     (k_s2s_gemm_split); aether_set_option("gemm_split", 0) sends them through the fp32-MFMA job kernel instead: same edge
     samples, outputs equal to fp32 rounding (16,720 edges, ragged last tile, per-type row lists, two-segment LSTM product,
-    gather epilogue; 64-row tiles at hidden 128, 128-row tiles for the 512-wide layers)."""
+    gather epilogue; 64-row tiles at hidden 128, 128-row tiles for the 512-wide layers; with 110 graphs = 2,200 nodes the
+    node-level layers -- field net, mlp3, mlp4 halves, message first layers, K-concatenated gates, output MLP -- take the
+    split path too)."""
     from aether_amd import _lib
     from aether_amd.nn.seq2seq.aether import Aether
-    N, B, K = 20, 44, 2
+    N, K = 20, 2
     params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": hd, "num_edge_types": K,
               "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3, "encoder_dropout": 0.0,
               "encoder_hidden": he, "encoder_rnn_hidden": 32, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 1,
