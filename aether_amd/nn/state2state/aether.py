@@ -198,6 +198,54 @@ class _AetherStep(torch.autograd.Function):
         return (None,) * _AetherStep.N_FIXED + tuple(out)
 
 
+def _pad_blocks(name, shape, H):
+    """Where a parameter of a model with hidden_size H < 64 lives inside the same-named parameter of the 64-wide model the
+    kernels are built for: a list of (source slices, destination slices).  Hidden vectors sit at the start of their
+    64-wide (update MLP: 128-wide) counterparts; the first message layer of layers 2-4 reads [x_send | x_recv | e], three
+    H-wide column blocks that go to the starts of the three 64-wide blocks.  Everything else in the wide parameters stays
+    zero, which makes the padded channels exactly zero through SiLU, the mean and the residuals: the wide model computes
+    the narrow one."""
+    full = tuple(slice(0, n) for n in shape)
+    if name.startswith("field_net."):
+        return [(full, full)]
+    if name.endswith("message_fn.0.weight") and not name.startswith("gnn.layer_1."):
+        return [((slice(0, H), slice(b * H, (b + 1) * H)), (slice(0, H), slice(64 * b, 64 * b + H))) for b in range(3)]
+    return [(full, full)]                  # top / top-left aligned
+
+
+class _PaddedStep(torch.autograd.Function):
+    """forward / backward of a model with hidden_size < 64 through its zero-padded 64-wide engine (same kernels): the
+    engine's autograd node is recorded in an inner graph, its parameter gradients are cut back to the narrow shapes."""
+
+    N_FIXED = 7
+
+    @staticmethod
+    def forward(ctx, outer, x, send, recv, vel, edge_attr, charges, *params):
+        eng = outer._engine
+        with torch.enable_grad():
+            out = eng(None, x, [send, recv], vel, edge_attr, charges)
+        ctx.outer, ctx.inner_out = outer, out
+        return out.detach()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        outer = ctx.outer
+        eng = outer._engine
+        eparams = [p for _, p in eng.named_parameters()]
+        grads = torch.autograd.grad(ctx.inner_out, eparams, grad_out.contiguous(), allow_unused=True)
+        need = ctx.needs_input_grad[_PaddedStep.N_FIXED:]
+        out = []
+        for (name, p), g, n in zip(outer.named_parameters(), grads, need):
+            if not n or g is None:
+                out.append(None)
+                continue
+            d = torch.empty_like(p)
+            for ss, ds in _pad_blocks(name, p.shape, outer.hidden_size):
+                d[ss] = g[ds]
+            out.append(d)
+        return (None,) * _PaddedStep.N_FIXED + tuple(out)
+
+
 class _FieldNetwork(nn.Module):
     """Parameter holder with the reference's names (aether.py:108-121)."""
 
@@ -253,16 +301,20 @@ class Aether(nn.Module):
 
     def __init__(self, input_size, hidden_size, dropout_prob, num_dims, device="cuda"):
         super().__init__()
-        if hidden_size != 64:
-            raise ValueError("the HIP kernels are built for hidden_size=64 "
-                             "(experiments/lorentz/main.py:42-43)")
+        if not (1 <= hidden_size <= 64):
+            raise ValueError("hidden_size must be at most 64: the HIP kernels are built 64 wide (narrower models run "
+                             "zero-padded on them, exactly; wider ones are not supported) -- experiments/lorentz/main.py:42-43")
         if num_dims not in (2, 3) or input_size != 2 * num_dims:
             raise ValueError("num_dims must be 2 or 3 and input_size == 2*num_dims")
+        if hidden_size == 3 * num_dims:
+            raise ValueError("hidden_size == 3 * num_dims is not supported (the reference then builds layer_1 without its "
+                             "res Linear, locs.py:214-218)")
         if dropout_prob != 0.0:
             raise ValueError("dropout_prob must be 0.0 (the runner's value, main.py:143)")
         self.gnn = _GNN(input_size, hidden_size, dropout_prob, num_dims,
                         additional_features=num_dims)
         self.num_dims = num_dims
+        self.hidden_size = hidden_size
         self.field_net = _FieldNetwork(num_dims, 32, 16)
         self._graphs = GraphCache()
         self.flags = 0                    # _lib.FLAG_* bits passed to aether_forward
@@ -279,6 +331,19 @@ class Aether(nn.Module):
         self._plist = None
         self._ws_bytes = {}
         self.to(device)
+        if hidden_size != 64:
+            # the 64-wide engine: same class, its parameters are the zero-padded images of this model's (kept out of
+            # state_dict / parameters(); its random initialisation is discarded and must not consume this model's RNG stream)
+            import contextlib, io
+            with torch.random.fork_rng(devices=[]), contextlib.redirect_stdout(io.StringIO()):
+                eng = Aether(input_size, 64, dropout_prob, num_dims, device=device)
+            eng.grad_as_view = False
+            eng.requires_grad_(True)
+            with torch.no_grad():
+                for p_ in eng.parameters():
+                    p_.zero_()
+            self.__dict__["_engine"] = eng
+            self.__dict__["_engine_key"] = None
         self.params = self.__str__()
 
     def __str__(self):
@@ -292,7 +357,27 @@ class Aether(nn.Module):
         self._plist = None
         self._gbuf = None
         self._gbuf2 = None
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            eng._apply(fn, *a, **k)
+            self.__dict__["_engine_key"] = None
         return super()._apply(fn, *a, **k)
+
+    def _sync_engine(self):
+        """Copy this model's parameters into their places in the 64-wide engine when any of them changed."""
+        eng = self._engine
+        if self._plist is None:
+            self._plist = [p for _, p in self.named_parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in self._plist)
+        if self._engine_key != key:
+            with torch.no_grad():
+                for (name, p), (_, ep) in zip(self.named_parameters(), eng.named_parameters()):
+                    for ss, ds in _pad_blocks(name, p.shape, self.hidden_size):
+                        ep[ds].copy_(p[ss])
+            self.__dict__["_engine_key"] = key
+        eng.flags = self.flags
+        eng.train(self.training)
+        return eng
 
     def load_state_dict(self, *a, **k):
         self._pstruct = None
@@ -395,6 +480,15 @@ class Aether(nn.Module):
             raise NotImplementedError("aether_amd.Aether: gradients w.r.t. x / vel / edge_attr_orig / charges are not "
                                       "implemented (parameter gradients only); detach the inputs")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        if self.hidden_size != 64:      # narrow model: the zero-padded 64-wide engine computes it (same kernels)
+            eng = self._sync_engine()
+            if not (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)):
+                with torch.no_grad():
+                    return eng(h, x, edges, vel, edge_attr_orig, charges)
+            if self.dp_group is not None:
+                raise NotImplementedError("data-parallel training of a hidden_size < 64 model is not wired (the engine's "
+                                          "padded gradient buffer would be the one to all-reduce)")
+            return _PaddedStep.apply(self, f32(x), send, recv, f32(vel), f32(edge_attr_orig), f32(charges), *self._plist)
         graph = self.prepare_graph((send, recv), n_nodes)
         if self._plist is None:         # nn.Module.parameters() walks the module tree: 0.15 ms per call
             self._plist = [p for _, p in self.named_parameters()]
@@ -414,6 +508,8 @@ class Aether(nn.Module):
         if not x.is_cuda:
             raise _lib.AetherHipError("aether_amd.Aether runs on an MI355X only; got a CPU tensor "
                                       "(there is no CPU fallback)")
+        if self.hidden_size != 64:
+            return self._sync_engine().rollout(x, vel, edges, charges, steps, dt)
         lib = _lib.load()
         send, recv = edges
         if send.dtype != torch.int64 or recv.dtype != torch.int64:

@@ -28,6 +28,7 @@ class GraphedTrainStep:
         self.args = [a.clone() if isinstance(a, torch.Tensor) else a for a in example_args]
         self.target = example_target.clone()
         self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=True)
+        self._params = [p for p in model.parameters()]
         # data-parallel: the step owns the collective from here on (the module's backward no longer issues it)
         self.dp_group = getattr(model, "dp_group", None)
         if self.dp_group is not None:
@@ -95,6 +96,9 @@ class GraphedTrainStep:
             if self.allreduce_events is not None:
                 self.allreduce_events[1].record()
             self.opt_graph.replay()
+        # A replay rewrites the parameters without touching their version counters, which the modules use to decide whether
+        # data derived from the weights (split weight images, the padded engine of a narrow model) is still current.
+        torch.autograd.graph.increment_version(self._params)
         return self.loss
 
     def time_allreduce(self, on=True):

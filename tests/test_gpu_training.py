@@ -71,7 +71,7 @@ def test_drop_in_error_behaviour():
     bad[1][3] = inp["x"].shape[0]                       # receiver out of range
     with pytest.raises(_lib.AetherHipError, match="outside"):
         m(*args(edges=bad))
-    for ctor in (lambda: Aether(4, 32, 0.0, 2), lambda: Aether(4, 64, 0.1, 2), lambda: Aether(4, 64, 0.0, 4)):
+    for ctor in (lambda: Aether(4, 128, 0.0, 2), lambda: Aether(4, 64, 0.1, 2), lambda: Aether(4, 64, 0.0, 4)):
         with pytest.raises(ValueError):
             ctor()
     # C ABI: a workspace that is too small is refused, nothing is launched
@@ -128,3 +128,38 @@ def test_graphed_train_step_matches_eager():
     for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
         assert scale_rel_err(p.detach().cpu(), q.detach().cpu()) <= 1e-5, k
     assert all(l == l and abs(l) < 1e30 for l in losses)
+
+
+def test_eval_after_graph_replays_sees_the_updated_weights():
+    """A hipGraph replay rewrites the parameters without bumping their version counters; the module decides by those
+    counters whether the split weight images in its workspace are current.  GraphedTrainStep bumps them after a replay:
+    an inference call between / after replayed training steps must use the new weights."""
+    from aether_amd.training import GraphedTrainStep
+    from oracle import aether_oracle as O
+    D = 2
+    torch.manual_seed(5)
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    host = make_batch(16, 20, D, seed=9)
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in host.items()}
+    inp["edges"] = [e.cuda() for e in host["edges"]]
+    call = lambda: m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+    m.eval()
+    with torch.no_grad():
+        call()                                              # leaves prepared images + their key behind
+    m.train()
+    step = GraphedTrainStep(m, [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]], inp["target"],
+                            lr=1e-3, weight_decay=1e-12, warmup=1)
+    for _ in range(2):
+        m.eval()
+        with torch.no_grad():
+            call()
+        m.train()
+        for _ in range(3):
+            step.step()
+        m.eval()
+        with torch.no_grad():
+            got = call().cpu()
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            want = O.aether_forward(sd, host["x"], host["vel"], host["edges"], host["edge_attr"], host["charges"])
+        assert scale_rel_err(got, want) <= 1e-5

@@ -61,9 +61,28 @@ def test_state_dict_surface_and_default_init(D):
 
 def test_ctor_rejects_unsupported():
     with pytest.raises(ValueError):
-        Aether(4, 32, 0.0, 2, device="cpu")
+        Aether(4, 128, 0.0, 2, device="cpu")             # wider than the kernels
+    with pytest.raises(ValueError):
+        Aether(4, 6, 0.0, 2, device="cpu")               # hidden_size == 3 D: the reference drops layer_1.res there
     with pytest.raises(ValueError):
         Aether(4, 64, 0.1, 2, device="cpu")
+
+
+def test_narrow_hidden_size_keeps_the_reference_parameter_shapes():
+    """hidden_size < 64 (--nf of experiments/lorentz/main.py:42-43): parameters and state_dict have the narrow model's own
+    shapes (the 64-wide engine it runs on is not part of them), and constructing it leaves the RNG stream where the
+    reference's constructor would."""
+    torch.manual_seed(3)
+    m = Aether(4, 32, 0.0, 2, device="cpu")
+    after = torch.rand(1)
+    sd = m.state_dict()
+    assert sd["gnn.layer_2.message_fn.0.weight"].shape == (32, 96)
+    assert sd["gnn.layer_1.update_fn.0.weight"].shape == (64, 32) and sd["gnn.out_mlp.6.weight"].shape == (2, 32)
+    assert not any("engine" in k for k in sd) and len(sd) == 47
+    torch.manual_seed(3)
+    from aether_amd.nn.state2state.aether import _GNN, _FieldNetwork
+    _GNN(4, 32, 0.0, 2, additional_features=2); _FieldNetwork(2, 32, 16)
+    assert torch.equal(after, torch.rand(1))
 
 
 def test_cpu_tensor_fails_loudly():
