@@ -427,6 +427,30 @@ def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he
     assert torch.equal(again[0], got_x) and torch.equal(again[2][0], got_h) and torch.equal(again[3], got_e)
 
 
+@pytest.mark.parametrize("B", [6, 44])
+def test_fused_step_with_an_empty_edge_type(B):
+    """Every edge sampled as type 0 (uniform draws that make its Gumbel noise win): the other type's row list is empty,
+    its jobs in the shared launches have nothing to do -- in the fp32 job kernel (B = 6) and in the split GEMM (B = 44:
+    16,720 edges) -- and the step still equals the four entry points."""
+    D, N, K = 2, 20, 2
+    m = _s2s_model(D, N, K, False, he=128, hd=128, R=32, layers=2)
+    g = torch.Generator().manual_seed(81)
+    E = N * (N - 1)
+    x = torch.randn(B, N, 2 * D, generator=g).cuda()
+    dh = (torch.randn(B, N, 128, generator=g) * 0.3).cuda()
+    st = ((torch.randn(B, E, 32, generator=g) * 0.3).cuda(), (torch.randn(B, E, 32, generator=g) * 0.3).cuda())
+    u = torch.empty(B, E, K)
+    u[..., 0], u[..., 1] = 1.0 - 1e-7, 1e-7
+    u = u.cuda()
+    field, _ = m.predict_field(x)
+    logits, (h1, c1) = m.encoder.single_step_forward(x, st, field)
+    want_x, want_dh, want_e = m.single_step_forward(x, dh, logits, True, field, uniform=u)
+    assert float(want_e[..., 1].abs().max()) == 0.0                      # the premise: nobody picked type 1
+    got_x, got_dh, _, got_e = m._fused_step(x, dh, st, u)
+    assert torch.equal(got_e, want_e)
+    assert scale_rel_err(got_x.cpu(), want_x.cpu()) <= TOL and scale_rel_err(got_dh.cpu(), want_dh.cpu()) <= TOL
+
+
 def test_device_rollout_equals_stepwise_loop_and_follows_weight_updates():
     """aether_s2s_rollout (burn-in + prediction loop in the library) against the loop of per-module calls; the plan of
     prepared weights is rebuilt when a parameter is written to."""
