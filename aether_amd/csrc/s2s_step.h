@@ -503,7 +503,7 @@ k_s2s_edge_prep(const float* __restrict__ x, const int64_t* __restrict__ send, c
                 const float* __restrict__ rel_feat, int polar, float* __restrict__ edge_attr, float* __restrict__ eap,
                 float* __restrict__ edge_pos, int64_t n_edges) {
     using A = AugDims<D>;
-    constexpr int EAp = (A::EA + 15) / 16 * 16;
+    constexpr int EAp = (A::EA + 31) / 32 * 32;
     constexpr int LDR = A::EA + 1;
     __shared__ float rows[256 * LDR];
     __shared__ float prow[256 * (A::EP + 1)];
