@@ -14,11 +14,9 @@
 // accumulates over the whole slab before it is weighted.  Per feature r the workgroup needs the weight fragments of
 // 64 c x 64 k (24 KB, contiguous in the image): they arrive by LDS-DMA two iterations ahead in a three-slot ring (72 KB),
 // one workgroup barrier per r.  A wave runs 96 MFMAs per r (first term of each tile on a zero accumulator) and adds
-// out += ea[:, r] * Z_r (32 FMAs per lane).  Measured at 48,640 edges x 24 features (612 GFLOP): 2.47 ms = 248 TFLOP/s
-// fp32-equivalent (1.49 PFLOP/s of bf16 MFMA work, 0.59 of that pipe's peak; the fp32-MFMA version took 4.9 ms).  With
-// the DMA, the fragment reads, the barrier and the weighting removed one by one the loop runs at the pipe's peak (1.46 ms):
-// each of them adds its full cost whichever wave of the SIMD issues it -- a half-iteration phase shift between the two
-// waves of a SIMD, a k-half-per-wave layout and a two-slot ring were all measured within 5 % of this version.
+// out += ea[:, r] * Z_r (32 FMAs per lane).  Measured at 48,640 edges x 24 features (612 GFLOP): 2.45 ms = 250 TFLOP/s
+// fp32-equivalent, 1.5 PFLOP/s of bf16 MFMA work; the fp32-MFMA version took 4.9 ms.  PMC: the matrix pipe is busy 0.69 of
+// the cycles at the 2.08 GHz the chip holds under this load (DESIGN.md 4.8a has the split of the other 31 %).
 // LDS: ring 72 KB + feature values R x 1 KB + bias slab R x 256 B.
 // Units = (256-edge tile, 64-wide c block, split z): split z covers h / splits consecutive k (a multiple of 64) and writes
 // plane z of `out` (bias in plane 0); k_s2s_sum_planes adds the planes in order (deterministic).  Persistent workgroups,
