@@ -599,22 +599,6 @@ k_s2s_gumbel_select(const float* __restrict__ logits, const float* __restrict__ 
     }
 }
 
-// The per-type lists alone (edge weights given, e.g. teacher-forced burn-in with supplied samples)
-__global__ void __launch_bounds__(256)
-k_s2s_select_all(const float* __restrict__ edge_w, int K, int k0, int64_t* __restrict__ lists, int* __restrict__ counts,
-                 int64_t n_edges) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    for (int k = k0; k < K; ++k) {
-        const bool on = e < n_edges && edge_w[e * K + k] != 0.0f;
-        const unsigned long long mask = __ballot(on);
-        int base = 0;
-        if (lane == 0 && mask) base = atomicAdd(counts + k, __popcll(mask));
-        base = __shfl(base, 0);
-        if (on) lists[(size_t)k * n_edges + base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
-    }
-}
-
 // T[k][e][:] = tanh(A_k[recv[e]][:] + S_k[send[e]][:]) for every type k whose weight on edge e is not zero (rows by edge
 // id: the second message layer gathers them through the type's list), and M1[e][:] = M2[e][:] = 0: k_s2s_pair_tanh of
 // all types and the two clears of the scatter targets in one launch.  A, S: [K][n_nodes][h]; T: [K][n_edges][h].
