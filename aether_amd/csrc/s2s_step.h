@@ -599,6 +599,29 @@ k_s2s_gumbel_select(const float* __restrict__ logits, const float* __restrict__ 
     }
 }
 
+// The variable-N decoder's version (weights given, not sampled): k_s2s_select of every type and the weights divided by
+// the number of active types (k_s2s_scale) in one launch.  lists: type k at lists + k * list_stride; counts must be zero.
+__global__ void __launch_bounds__(256)
+k_s2s_select_all(const float* __restrict__ edge_w, int K, int k0, float norm, float* __restrict__ ewn,
+                 int64_t* __restrict__ lists, size_t list_stride, int* __restrict__ counts, int64_t n_edges) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e < n_edges)
+        for (int k = 0; k < K; ++k) {
+            w[k] = edge_w[e * K + k];
+            ewn[e * K + k] = w[k] * norm;
+        }
+    const int lane = threadIdx.x & 63;
+    for (int k = k0; k < K; ++k) {
+        const bool on = e < n_edges && w[k] != 0.0f;
+        const unsigned long long mask = __ballot(on);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(counts + k, __popcll(mask));
+        base = __shfl(base, 0);
+        if (on) lists[(size_t)k * list_stride + base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+    }
+}
+
 // T[k][e][:] = tanh(A_k[recv[e]][:] + S_k[send[e]][:]) for every type k whose weight on edge e is not zero (rows by edge
 // id: the second message layer gathers them through the type's list), and M1[e][:] = M2[e][:] = 0: k_s2s_pair_tanh of
 // all types and the two clears of the scatter targets in one launch.  A, S: [K][n_nodes][h]; T: [K][n_edges][h].
