@@ -117,6 +117,9 @@ class _AetherStep(torch.autograd.Function):
             token = _WsToken() if not capturing else None
             if token is not None:
                 module._train_ws_token = weakref.ref(token)
+            # An optimizer step follows a training forward, and not every optimizer bumps the parameters' version
+            # counters (torch's fused AdamW does not): the inference workspace's weight images are stale from here on.
+            module._wimg_key = None
         else:
             ws = module._workspace(ws_bytes, x.device)
             # same buffer, same layout as the last completed inference call: the fused kernel left its
@@ -243,6 +246,13 @@ class _PaddedStep(torch.autograd.Function):
             for ss, ds in _pad_blocks(name, p.shape, outer.hidden_size):
                 d[ss] = g[ds]
             out.append(d)
+        if outer.dp_group is not None:             # data-parallel: one all-reduce of the narrow gradients, flat
+            import torch.distributed as dist
+            have = [g for g in out if g is not None]
+            flat = torch.cat([g.reshape(-1) for g in have])
+            dist.all_reduce(flat, group=outer.dp_group)
+            flat.div_(dist.get_world_size(outer.dp_group))
+            torch._foreach_copy_(have, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in have]), have)])
         return (None,) * _PaddedStep.N_FIXED + tuple(out)
 
 
@@ -369,12 +379,16 @@ class Aether(nn.Module):
         if self._plist is None:
             self._plist = [p for _, p in self.named_parameters()]
         key = tuple((p.data_ptr(), p._version) for p in self._plist)
-        if self._engine_key != key:
+        # Training: always (an optimizer step lies between two training forwards and torch's fused AdamW leaves the version
+        # counters alone; inside a captured training step the copies have to be part of the graph), and the call after a
+        # training forward as well.
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
+        if self._engine_key != key or train:
             with torch.no_grad():
                 for (name, p), (_, ep) in zip(self.named_parameters(), eng.named_parameters()):
                     for ss, ds in _pad_blocks(name, p.shape, self.hidden_size):
                         ep[ds].copy_(p[ss])
-            self.__dict__["_engine_key"] = key
+            self.__dict__["_engine_key"] = None if train else key
         eng.flags = self.flags
         eng.train(self.training)
         return eng
@@ -485,9 +499,6 @@ class Aether(nn.Module):
             if not (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)):
                 with torch.no_grad():
                     return eng(h, x, edges, vel, edge_attr_orig, charges)
-            if self.dp_group is not None:
-                raise NotImplementedError("data-parallel training of a hidden_size < 64 model is not wired (the engine's "
-                                          "padded gradient buffer would be the one to all-reduce)")
             return _PaddedStep.apply(self, f32(x), send, recv, f32(vel), f32(edge_attr_orig), f32(charges), *self._plist)
         graph = self.prepare_graph((send, recv), n_nodes)
         if self._plist is None:         # nn.Module.parameters() walks the module tree: 0.15 ms per call

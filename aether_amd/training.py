@@ -52,7 +52,9 @@ class GraphedTrainStep:
         else:
             with torch.cuda.graph(self.graph):
                 self.loss = self._forward_backward()
-            self.flat = model._grad_buffers()[0]          # the .grad tensors are views of it (grad_as_view)
+            # the .grad tensors are views of one flat buffer (grad_as_view); a narrow model (hidden_size < 64) hands out
+            # ordinary gradients cut from its padded engine's: those are flattened around the collective
+            self.flat = model._grad_buffers()[0] if self._grads_are_views() else None
             self.opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.opt_graph):
                 self.optimizer.step()
@@ -63,13 +65,24 @@ class GraphedTrainStep:
         loss.backward()
         return loss
 
+    def _grads_are_views(self):
+        return getattr(self.model, "hidden_size", 64) == 64
+
     def _allreduce(self):
         import torch.distributed as dist
+        world = dist.get_world_size(self.dp_group)
+        if not self._grads_are_views():
+            grads = [p.grad for p in self._params if p.grad is not None]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat, group=self.dp_group)
+            flat.div_(world)
+            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+            return
         flat = getattr(self, "flat", None)
         if flat is None:
             flat = self.model._grad_buffers()[0]
         dist.all_reduce(flat, group=self.dp_group)
-        flat.div_(dist.get_world_size(self.dp_group))
+        flat.div_(world)
 
     def _eager(self):
         self.optimizer.zero_grad(set_to_none=True)

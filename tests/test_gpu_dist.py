@@ -40,6 +40,8 @@ def _worker(rank, world, port, q, variant):
         from aether_amd.nn.state2state.dynamic_field_aether import DynamicFieldAether
         torch.manual_seed(100 + 7 * rank)
         m = DynamicFieldAether(2 * D, 64, 0.0, D, device=dev)
+    elif variant == "narrow":                            # hidden_size 32: the zero-padded 64-wide engine
+        m = Aether(2 * D, 32, 0.0, D, device=dev)
     else:
         m = Aether(2 * D, 64, 0.0, D, device=dev)
         if rank == 0:
@@ -66,7 +68,7 @@ def _worker(rank, world, port, q, variant):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("variant", ["aether", "dynamic_field"])
+@pytest.mark.parametrize("variant", ["aether", "dynamic_field", "narrow"])
 def test_two_ranks_on_one_gpu_match_single_process_gradients(variant):
     from aether_amd.nn.state2state.aether import Aether
     from aether_amd.synthetic import make_batch
@@ -88,6 +90,11 @@ def test_two_ranks_on_one_gpu_match_single_process_gradients(variant):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in res[0][5].items()})      # rank 0's broadcast weights
         assert all((res[0][5][k] == res[1][5][k]).all() for k in res[0][5])
         extra = (N,)
+    elif variant == "narrow":
+        m = Aether(2 * D, 32, 0.0, D, device="cuda")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in res[0][5].items()})
+        assert all((res[0][5][k] == res[1][5][k]).all() for k in res[0][5])
+        extra = ()
     else:
         m = Aether(2 * D, 64, 0.0, D, device="cuda")
         m.load_state_dict(load_state_dict(D))
@@ -106,7 +113,7 @@ def test_two_ranks_on_one_gpu_match_single_process_gradients(variant):
         assert (res[0][2][k] == res[1][2][k]).all(), k                                      # replicas stay in sync
 
 
-def _worker_graphed(rank, world, port, q):
+def _worker_graphed(rank, world, port, q, hidden=64):
     """Three data-parallel steps through GraphedTrainStep (two graphs around an eager collective) and through the
     eager module path; both from the same start."""
     sys.path.insert(0, REPO)
@@ -132,14 +139,15 @@ def _worker_graphed(rank, world, port, q):
     res = {}
     for mode in ("eager", "graphed"):
         torch.manual_seed(100 + rank)
-        m = Aether(2 * D, 64, 0.0, D, device=dev)
-        if rank == 0:
+        m = Aether(2 * D, hidden, 0.0, D, device=dev)
+        if rank == 0 and hidden == 64:
             m.load_state_dict(load_state_dict(D))
         attach_data_parallel(m)
+        start = {k: t.detach().clone() for k, t in m.state_dict().items()}
         if mode == "graphed":
             step = GraphedTrainStep(m, [h, x, edges, v, ea, q_], tgt, warmup=1)
-            # the warm-up steps moved the weights: restart both modes from rank 0's reference weights
-            m.load_state_dict(load_state_dict(D))
+            # the warm-up steps moved the weights: restart both modes from rank 0's weights
+            m.load_state_dict(start)
             for st in step.optimizer.state.values():
                 for val in st.values():
                     if torch.is_tensor(val):
@@ -162,14 +170,15 @@ def _worker_graphed(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_graphed_data_parallel_step_keeps_replicas_identical():
+@pytest.mark.parametrize("hidden", [64, 32])
+def test_graphed_data_parallel_step_keeps_replicas_identical(hidden):
     """GraphedTrainStep under attach_data_parallel: forward + backward graph, eager all-reduce of the flat gradient
     buffer, optimizer graph.  Replicas bit-identical after three steps; same trajectory as the eager module path."""
     from conftest import scale_rel_err
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_graphed, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_graphed, args=(r, 2, port, q, hidden)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])

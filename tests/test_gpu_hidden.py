@@ -83,3 +83,39 @@ def test_narrow_model_follows_its_parameters_rollout_and_captured_training():
         got = call().cpu()
         want = O.aether_forward(sd1, host["x"], host["vel"], host["edges"], host["edge_attr"], host["charges"])
     assert scale_rel_err(got, want) <= TOL
+
+
+def test_narrow_model_captured_training_follows_the_eager_loop():
+    """Three AdamW steps of a hidden_size = 32 model through GraphedTrainStep and through the eager module: the padded
+    engine has to be re-synchronised inside the graph on every replay (fused AdamW does not bump version counters)."""
+    from aether_amd.training import GraphedTrainStep
+    D, H = 2, 32
+    inp = _dev(make_batch(8, 20, D, seed=6))
+    args = [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]]
+    res = {}
+    for mode in ("eager", "graphed"):
+        torch.manual_seed(12)
+        m = Aether(2 * D, H, 0.0, D, device="cuda")
+        start = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        if mode == "graphed":
+            step = GraphedTrainStep(m, args, inp["target"], lr=5e-4, weight_decay=1e-12, warmup=1)
+            m.load_state_dict(start)
+            for st in step.optimizer.state.values():
+                for val in st.values():
+                    if torch.is_tensor(val):
+                        val.zero_()
+            losses = [float(step.step().item()) for _ in range(3)]
+        else:
+            opt = torch.optim.AdamW(m.parameters(), lr=5e-4, weight_decay=1e-12)
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                loss = torch.nn.functional.mse_loss(m(*args), inp["target"])
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.item()))
+        res[mode] = (losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    for a, b in zip(res["graphed"][0], res["eager"][0]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    for k in res["eager"][1]:
+        assert scale_rel_err(res["graphed"][1][k], res["eager"][1][k]) <= 1e-4, k

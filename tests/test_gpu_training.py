@@ -163,3 +163,38 @@ def test_eval_after_graph_replays_sees_the_updated_weights():
         with torch.no_grad():
             want = O.aether_forward(sd, host["x"], host["vel"], host["edges"], host["edge_attr"], host["charges"])
         assert scale_rel_err(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("H", [64, 32])
+def test_eval_after_a_fused_optimizer_step_sees_the_updated_weights(H):
+    """torch's fused AdamW writes the parameters without bumping their version counters (the module's cue that weight
+    images / the narrow model's padded engine are stale): a training forward marks them stale itself.  Eager loop,
+    inference calls in between; the second training step must also run on the updated weights."""
+    D = 2
+    torch.manual_seed(5)
+    m = Aether(2 * D, H, 0.0, D, device="cuda")
+    host = make_batch(16, 20, D, seed=9)
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in host.items()}
+    inp["edges"] = [e.cuda() for e in host["edges"]]
+    call = lambda: m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+    oracle = lambda sd: O.aether_forward(sd, host["x"], host["vel"], host["edges"], host["edge_attr"], host["charges"])
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=1e-12, fused=True)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt_o = torch.optim.AdamW(list(sd.values()), lr=1e-2, weight_decay=1e-12)
+    with torch.no_grad():
+        before = call().cpu()
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.mse_loss(call(), inp["target"]).backward()
+        opt.step()
+        opt_o.zero_grad()
+        torch.nn.functional.mse_loss(oracle(sd), host["target"]).backward()
+        opt_o.step()
+        with torch.no_grad():
+            got = call().cpu()
+            want = oracle({k: v.detach().cpu() for k, v in m.state_dict().items()})
+        assert scale_rel_err(got, want) <= 1e-5
+        assert scale_rel_err(before, want) > 1e-4                    # the step did move the output
+    # two steps on stale weights would have ended elsewhere: the oracle's own two AdamW steps agree
+    for k, v in m.state_dict().items():
+        assert scale_rel_err(v.detach().cpu(), sd[k].detach()) <= 2e-3, k
