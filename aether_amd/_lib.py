@@ -49,6 +49,12 @@ def params_struct(tensors: dict) -> AetherParams:
     return p
 
 
+class AetherAdamWTensor(C.Structure):
+    """include/aether_hip.h: one parameter tensor of aether_adamw_step."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_int64)]
+
+
 class AetherGraphInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("n_groups", C.c_int32),
                 ("max_group_nodes", C.c_int32), ("max_group_edges", C.c_int32), ("reserved", C.c_int32)]
@@ -156,6 +162,11 @@ SIGNATURES = {
     "aether_debug_fetch": (C.c_int64, [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "aether_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "aether_mse_scratch_bytes": (C.c_size_t, []),
+    "aether_mse_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p]),
+    "aether_adamw_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_void_p]),
     "aether_graph_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "aether_check_async_error": (C.c_int, []),
     "aether_profile_enable": (C.c_int, [C.c_int]),

@@ -39,6 +39,7 @@
 #include "s2s_dynfield.h"
 #include "knn.h"
 #include "sim.h"
+#include "train_step.h"
 
 #include <mutex>
 #include <utility>
@@ -561,8 +562,11 @@ struct OuterList {
 
 // Multiplies every task of the list (all of them 64 x 64 or smaller: OuterList::add): one k_outer and
 // one k_outer_reduce launch per OUTER_MAX_TASKS tasks; then empties the list.
-int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st) {
-    if (L.tasks.empty()) return AETHER_OK;
+int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st, const FbReduceArgs* fb = nullptr) {
+    if (L.tasks.empty()) {
+        if (fb != nullptr) k_fb_reduce<<<dim3(FB_REDUCE_GX, 4), dim3(1024), 0, st>>>(*fb);
+        return AETHER_OK;
+    }
     size_t next_part = 0;
     for (OuterTask& t : L.tasks) {
         int64_t tiles = (t.rows + 15) / 16;
@@ -589,7 +593,13 @@ int run_outer(OuterList& L, float* partial, size_t partial_cap, hipStream_t st) 
         }
         const size_t lds = (size_t)4 * 16 * (64 + 16 + 64 + 16) * sizeof(float);
         k_outer<4, 4><<<dim3((unsigned)max_chunks, (unsigned)b.n_tasks), dim3(256), lds, st>>>(b, partial);
-        k_outer_reduce<<<dim3((unsigned)(64 * 64 / 256 + 1), (unsigned)b.n_tasks), dim3(1024), 0, st>>>(b, partial);
+        const bool last = k0 + OUTER_MAX_TASKS >= L.tasks.size();
+        if (fb != nullptr && last) {         // the fused backward's edge-level partials ride along (one launch less)
+            const int outer_blocks = OUTER_REDUCE_GX * b.n_tasks;
+            k_reduce_both<<<dim3((unsigned)(outer_blocks + FB_REDUCE_GX * 4)), dim3(1024), 0, st>>>(b, partial, *fb, outer_blocks);
+        } else {
+            k_outer_reduce<<<dim3((unsigned)OUTER_REDUCE_GX, (unsigned)b.n_tasks), dim3(1024), 0, st>>>(b, partial);
+        }
     }
     L.tasks.clear();
     return AETHER_OK;
@@ -837,8 +847,8 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
         L.add(wp(W.DPH1), 32, 32, wp(W.Z), 32, FIN, Nn, Gr.field_w0, FIN, Gr.field_b0);
         L.add(wp(W.ONEHOT), 16, 3, wp(W.DZE), 16, 16, Nn, Gr.field_emb, 16, nullptr);
     }
-    if (run_outer(L, wp(W.partial), W.partial_cap, st)) return AETHER_EHIP;
-    // ---- edge-level weight gradients: the workgroups' partials, added in workgroup order
+    // ---- edge-level weight gradients: the workgroups' partials, added in workgroup order -- in the launch that adds up
+    // the node-level products' partials
     {
         FbReduceArgs R;
         R.partial = wp(W.fpart);
@@ -850,8 +860,7 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
         }
         R.b1 = Gr.l1_msg_b0;
         R.f1 = F1;
-        ProfScope ps(KB_FBRED, st);
-        k_fb_reduce<<<dim3((FB_PART + 63) / 64, 4), dim3(1024), 0, st>>>(R);
+        if (run_outer(L, wp(W.partial), W.partial_cap, st, &R)) return AETHER_EHIP;
     }
     HIP_OK(hipGetLastError());
     return AETHER_OK;
@@ -869,6 +878,7 @@ const char* aether_last_error(void) { return g_err; }
 #include "host_s2s_step.inc"
 #include "host_dynamicvars.inc"
 #include "host_sim.inc"
+#include "host_train.inc"
 
 int aether_set_option(const char* name, int value) {
     if (!name) return fail(AETHER_EINVAL, "set_option: null name");

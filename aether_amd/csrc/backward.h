@@ -197,17 +197,17 @@ k_outer(OuterBatch batch, float* __restrict__ partial) {
 // grid = (1 + 16MB*16NB/256, n_tasks), 1024 threads: 256 elements x 4 chunk groups.  Each group adds
 // its contiguous quarter of the chunks in order; the four group sums are combined in order through
 // LDS: a fixed summation tree, hence deterministic.  The last block of a task reduces the bias row.
-__global__ void __launch_bounds__(1024)
-k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
-    const OuterTask T = batch.t[blockIdx.y];
+__device__ __forceinline__ void outer_reduce_body(const OuterBatch& batch, const float* __restrict__ partial, int bx,
+                                                  int by) {
+    const OuterTask T = batch.t[by];
     const int MBn = (T.M + 15) >> 4, NBn = (T.N + 15) >> 4;
     const int ldp = NBn > 4 ? 128 : 64, mpad = MBn > 4 ? 128 : 64;
     const int nblk = mpad * ldp / 256;
-    if ((int)blockIdx.x > nblk) return;
-    const bool is_bias = (int)blockIdx.x == nblk;
+    if (bx > nblk) return;
+    const bool is_bias = bx == nblk;
     if (is_bias && T.bias == nullptr) return;
     const int grp = threadIdx.x >> 8, e = threadIdx.x & 255;
-    const int off = is_bias ? 8192 + e : (int)blockIdx.x * 256 + e;
+    const int off = is_bias ? 8192 + e : bx * 256 + e;
     const int m = is_bias ? e : off / ldp, n = is_bias ? 0 : off % ldp;
     const bool valid = is_bias ? e < T.M : (m < T.M && n < T.N);
     const int per = (T.chunks + 3) / 4;
@@ -233,6 +233,10 @@ k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
         if (is_bias) T.bias[e] = tot;
         else T.C[(size_t)m * T.ldc + n] = tot;
     }
+}
+__global__ void __launch_bounds__(1024)
+k_outer_reduce(OuterBatch batch, const float* __restrict__ partial) {
+    outer_reduce_body(batch, partial, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------ transposed weight copies

@@ -762,12 +762,10 @@ struct FbReduceArgs {
     float* b1;                 // layer 1 only
     int f1;
 };
-__global__ void __launch_bounds__(1024)
-k_fb_reduce(FbReduceArgs R) {
+__device__ __forceinline__ void fb_reduce_body(const FbReduceArgs& R, int bx, int l /* layer index 0..3 */) {
     // 64 elements x 16 groups per block: a group adds its contiguous sixteenth of the workgroups in order, the sixteen
     // sums are combined in order -- a fixed tree; short dependent chains and 4 x 130 blocks to fill the chip
-    const int grp = threadIdx.x >> 6, t = threadIdx.x & 63, e = blockIdx.x * 64 + t;
-    const int l = blockIdx.y;                      // layer index 0..3
+    const int grp = threadIdx.x >> 6, t = threadIdx.x & 63, e = bx * 64 + t;
     const bool valid = e < FB_PART;
     const int per = (R.n_wgs + 15) / 16;
     const int c0 = grp * per, c1 = c0 + per < R.n_wgs ? c0 + per : R.n_wgs;
@@ -805,6 +803,23 @@ k_fb_reduce(FbReduceArgs R) {
         R.b2[l][e - 2 * H * H] = tot;
     } else if (l == 0) {
         R.b1[e - 2 * H * H - H] = tot;
+    }
+}
+constexpr int FB_REDUCE_GX = (FB_PART + 63) / 64;
+__global__ void __launch_bounds__(1024)
+k_fb_reduce(FbReduceArgs R) { fb_reduce_body(R, (int)blockIdx.x, (int)blockIdx.y); }
+
+// k_outer_reduce (the node-level products' partials, backward.h) and k_fb_reduce in one launch: they write different
+// gradient tensors and neither reads what the other writes.  Blocks [0, outer_blocks): (bx, task) of k_outer_reduce.
+constexpr int OUTER_REDUCE_GX = 64 * 64 / 256 + 1;
+__global__ void __launch_bounds__(1024)
+k_reduce_both(OuterBatch batch, const float* __restrict__ partial, FbReduceArgs R, int outer_blocks) {
+    const int b = (int)blockIdx.x;
+    if (b < outer_blocks) {
+        outer_reduce_body(batch, partial, b % OUTER_REDUCE_GX, b / OUTER_REDUCE_GX);
+    } else {
+        const int c = b - outer_blocks;
+        fb_reduce_body(R, c % FB_REDUCE_GX, c / FB_REDUCE_GX);
     }
 }
 

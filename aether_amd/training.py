@@ -17,17 +17,27 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, example_args, example_target, lr=5e-4, weight_decay=1e-12, loss_fn=None, warmup=3):
+    def __init__(self, model, example_args, example_target, lr=5e-4, weight_decay=1e-12, loss_fn=None, warmup=3,
+                 optimizer="aether"):
         """``example_args``: the positional arguments of ``model.forward`` for one batch (tensors are cloned into static
-        buffers; the edge index list and non-tensors are kept as they are), ``example_target``: the batch's target."""
+        buffers; the edge index list and non-tensors are kept as they are), ``example_target``: the batch's target.
+        ``loss_fn`` None: the runner's ``nn.MSELoss`` (main.py:86), loss and the seed of the backward in one launch
+        (``aether_amd.optim.mse_loss_grad``); any callable ``loss_fn(out, target)`` goes through autograd instead.
+        ``optimizer``: "aether" (``aether_amd.optim.FusedAdamW``, one launch) or "torch" (capturable fused AdamW)."""
         dev = example_target.device
         if dev.type != "cuda":
             raise ValueError("GraphedTrainStep needs CUDA/HIP tensors")
         self.model = model
-        self.loss_fn = loss_fn or torch.nn.functional.mse_loss
+        self.loss_fn = loss_fn
         self.args = [a.clone() if isinstance(a, torch.Tensor) else a for a in example_args]
         self.target = example_target.clone()
-        self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=True)
+        if optimizer == "aether":
+            from .optim import FusedAdamW
+            self.optimizer = FusedAdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+        elif optimizer == "torch":
+            self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=True)
+        else:
+            raise ValueError('optimizer: "aether" or "torch"')
         self._params = [p for p in model.parameters()]
         # data-parallel: the step owns the collective from here on (the module's backward no longer issues it)
         self.dp_group = getattr(model, "dp_group", None)
@@ -61,6 +71,11 @@ class GraphedTrainStep:
 
     def _forward_backward(self):
         out = self.model(*self.args)
+        if self.loss_fn is None:
+            from .optim import mse_loss_grad
+            loss, grad = mse_loss_grad(out, self.target)
+            out.backward(grad)
+            return loss
         loss = self.loss_fn(out, self.target)
         loss.backward()
         return loss
@@ -101,6 +116,8 @@ class GraphedTrainStep:
                     dst.copy_(src)
         if target is not None:
             self.target.copy_(target)
+        if hasattr(self.optimizer, "sync_lr"):
+            self.optimizer.sync_lr()                  # a scheduler's new learning rate -> the device scalar the graph reads
         self.graph.replay()
         if self.dp_group is not None:
             if self.allreduce_events is not None:

@@ -651,7 +651,7 @@ def main():
         if use_graph and not args.big:
             # whole training step as hipGraph replays (aether_amd.training.GraphedTrainStep): one graph at N = 1; with
             # N > 1 forward + backward replay as one graph, the flat gradient buffer is all-reduced eagerly (RCCL),
-            # the fused AdamW replays as a second graph
+            # AdamW (one launch, aether_amd.optim.FusedAdamW) replays as a second graph
             try:
                 from aether_amd.training import GraphedTrainStep
                 gstep = GraphedTrainStep(model, [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]],
@@ -699,8 +699,9 @@ def main():
                     "allreduce_bytes": flat.numel() * 4, "allreduce_us": 1e3 * ev[0].elapsed_time(ev[1]) / 20}
         train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps, "collective": coll,
                  "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
-                 "includes": "forward + HIP backward + " + ("RCCL grad all-reduce + " if world > 1 else "")
-                             + "torch AdamW, " + train_launch + " launches"}
+                 "includes": ("forward + MSE loss + HIP backward + " if gstep is not None else "forward + torch MSE loss + HIP backward + ")
+                             + ("RCCL grad all-reduce + " if world > 1 else "")
+                             + ("AdamW (aether_adamw_step), " if gstep is not None else "torch AdamW, ") + train_launch + " launches"}
         if rank == 0:       # per-kernel breakdown of one training step (rank-local: no collective in here)
             saved_group, model.dp_group = model.dp_group, None       # (GraphedTrainStep already detached it)
             lib = _lib.load()

@@ -643,6 +643,31 @@ int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_
                      void* workspace, size_t workspace_bytes, float* field, void* stream);
 
 /*
+ * The rest of the runner's training step (experiments/lorentz/main.py:86,164,289-292): nn.MSELoss with the seed of its
+ * backward, and optim.AdamW over every parameter tensor -- one launch each (torch: 4 + 3).
+ *
+ * aether_mse_loss_grad: *loss = mean((pred - target)^2), dpred[i] = 2 (pred[i] - target[i]) / n.  scratch: at least
+ *   aether_mse_scratch_bytes() bytes of device memory, ZERO before the first call (the kernel re-arms it), not shared by
+ *   launches that may run concurrently.  Partial sums are added in a fixed order (bit-stable).
+ * aether_adamw_step: torch.optim.AdamW(betas, eps, weight_decay; amsgrad = maximize = False) for n_tensors fp32
+ *   tensors (64 per launch).  `step` (device float: steps taken so far, incremented by the launch), `lr` (device float) and `counter`
+ *   (device int, zero before the first call) live in device memory, so a captured launch follows the step counter and a
+ *   learning-rate schedule.  fp32 arithmetic; the bias corrections 1 - beta^t as -expm1(t log beta), betas in (0, 1).
+ */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} AetherAdamWTensor;
+size_t aether_mse_scratch_bytes(void);
+int aether_mse_loss_grad(const float* pred, const float* target, int64_t n, float* loss, float* dpred, void* scratch,
+                         size_t scratch_bytes, void* stream);
+int aether_adamw_step(const AetherAdamWTensor* tensors, int n_tensors, float* step, const float* lr, int* counter,
+                      double beta1, double beta2, double eps, double weight_decay, void* stream);
+
+/*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
  * there are fewer groups than half the CUs; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and

@@ -198,3 +198,92 @@ def test_eval_after_a_fused_optimizer_step_sees_the_updated_weights(H):
     # two steps on stale weights would have ended elsewhere: the oracle's own two AdamW steps agree
     for k, v in m.state_dict().items():
         assert scale_rel_err(v.detach().cpu(), sd[k].detach()) <= 2e-3, k
+
+
+@pytest.mark.parametrize("n", [1, 7, 5120, 300001])
+def test_mse_loss_grad_matches_torch(n):
+    """aether_mse_loss_grad (nn.MSELoss + the seed of its backward, main.py:86,289-290) vs torch autograd in fp64."""
+    from aether_amd.optim import mse_loss_grad
+    g = torch.Generator().manual_seed(n)
+    pred = torch.randn(n, generator=g).cuda().view(-1, 1) if n > 1 else torch.randn(1, generator=g).cuda()
+    tgt = torch.randn(pred.shape, generator=g).cuda()
+    loss, grad = mse_loss_grad(pred, tgt)
+    loss2, grad2 = mse_loss_grad(pred, tgt)                       # the scratch counter re-armed itself; fixed-order sum
+    assert torch.equal(loss, loss2) and torch.equal(grad, grad2)
+    p64 = pred.double().requires_grad_(True)
+    want = torch.nn.functional.mse_loss(p64, tgt.double())
+    want.backward()
+    assert abs(float(loss) - float(want.detach())) <= 2e-6 * abs(float(want.detach()))
+    assert scale_rel_err(grad.cpu(), p64.grad.float().cpu()) <= 1e-6
+
+
+def test_fused_adamw_tracks_torch_adamw():
+    """aether_adamw_step vs torch.optim.AdamW over 70 tensors (two launches per step) of ragged sizes, 12 steps, with a
+    learning-rate change on the way; the shared step counter sits under torch's state key."""
+    from aether_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 192), (64,), (3, 16), (1,), (1025,), (128, 64)] + [(5, k + 1) for k in range(64)]
+    mine = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    kw = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    opt_m, opt_r = FusedAdamW(mine, **kw), torch.optim.AdamW(ref, **kw)
+    for it in range(12):
+        if it == 6:
+            for o in (opt_m, opt_r):
+                o.param_groups[0]["lr"] = 1e-3
+        for a, b in zip(mine, ref):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (it % 3 - 1))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        opt_m.step()
+        opt_r.step()
+    assert opt_m.steps_taken() == 12 and float(opt_m.state[mine[3]]["step"]) == 12.0
+    for a, b in zip(mine, ref):
+        assert scale_rel_err(a.detach().cpu(), b.detach().cpu()) <= 2e-6, tuple(a.shape)
+        assert scale_rel_err(opt_m.state[a]["exp_avg_sq"].cpu(), opt_r.state[b]["exp_avg_sq"].cpu()) <= 2e-6
+    # state_dict round trip keeps counting from 12
+    opt_2 = FusedAdamW(mine, **kw)
+    opt_2.load_state_dict(opt_m.state_dict())
+    for a, b in zip(mine, ref):
+        gr = torch.randn(a.shape, generator=g).cuda()
+        a.grad, b.grad = gr.clone(), gr.clone()
+    opt_2.param_groups[0]["lr"] = 1e-3
+    opt_2.step()
+    opt_r.step()
+    assert opt_2.steps_taken() == 13
+    for a, b in zip(mine, ref):
+        assert scale_rel_err(a.detach().cpu(), b.detach().cpu()) <= 2e-6
+
+
+def test_graphed_step_with_library_loss_and_optimizer_matches_the_torch_ones():
+    """GraphedTrainStep(optimizer="aether", MSE in one launch) vs GraphedTrainStep(optimizer="torch", autograd MSE): same
+    trajectory over 5 replays; a learning rate set between replays reaches the captured optimizer launch (lr = 0 stops
+    the weights)."""
+    from aether_amd.training import GraphedTrainStep
+    D = 2
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in make_batch(16, 20, D, seed=4).items()}
+    inp["edges"] = [e.cuda() for e in inp["edges"]]
+    args = [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]]
+    res = {}
+    for kind in ("aether", "torch"):
+        torch.manual_seed(21)
+        m = Aether(2 * D, 64, 0.0, D, device="cuda")
+        start = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        step = GraphedTrainStep(m, args, inp["target"], lr=1e-3, weight_decay=1e-12, warmup=1, optimizer=kind,
+                                loss_fn=None if kind == "aether" else torch.nn.functional.mse_loss)
+        m.load_state_dict(start)
+        for st in step.optimizer.state.values():
+            for val in st.values():
+                if torch.is_tensor(val):
+                    val.zero_()
+        losses = [float(step.step().item()) for _ in range(5)]
+        res[kind] = (losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+        if kind == "aether":
+            assert step.optimizer.steps_taken() == 5
+            step.optimizer.param_groups[0]["lr"] = 0.0
+            step.step()
+            assert step.optimizer.steps_taken() == 6
+            assert all(torch.equal(v.detach().cpu(), res[kind][1][k]) for k, v in m.state_dict().items())
+    for a, b in zip(res["aether"][0], res["torch"][0]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    for k in res["torch"][1]:
+        assert scale_rel_err(res["aether"][1][k], res["torch"][1][k]) <= 1e-4, k
