@@ -37,4 +37,21 @@ with torch.no_grad():
             bad += int(not torch.equal(out, r0))
 torch.cuda.synchronize()
 print(f"20000 inference launches, 1000 compared: mismatches {bad}")
-sys.exit(1 if (bad or bad_o or bad_g) else 0)
+# the captured training step (library loss + AdamW, aether_amd.training.GraphedTrainStep): two runs from the same start
+from aether_amd.training import GraphedTrainStep
+finals = []
+for run in range(2):
+    torch.manual_seed(1)
+    m2 = Aether(4, 64, 0.0, D, device="cuda")
+    start = {k: v.detach().clone() for k, v in m2.state_dict().items()}
+    gs = GraphedTrainStep(m2, [a["h"], a["x"], a["edges"], a["vel"], a["edge_attr"], a["charges"]], a["target"], warmup=1)
+    m2.load_state_dict(start)
+    gs.optimizer.reset_state()
+    for _ in range(400):
+        gs.step()
+    torch.cuda.synchronize()
+    finals.append((float(gs.loss), torch.cat([p.detach().reshape(-1) for p in m2.parameters()]).clone(), gs.optimizer.steps_taken()))
+same = torch.equal(finals[0][1], finals[1][1]) and finals[0][0] == finals[1][0]
+print(f"2 x 400 captured training steps from the same start: final loss {finals[0][0]:.6g} / {finals[1][0]:.6g}, "
+      f"optimizer steps {finals[0][2]} / {finals[1][2]}, weights bit-identical: {same}")
+sys.exit(1 if (bad or bad_o or bad_g or not same) else 0)
