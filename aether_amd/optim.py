@@ -56,6 +56,12 @@ class FusedAdamW(torch.optim.Optimizer):
         self._tables = {}
 
     def _group_state(self, gi, group):
+        hit = self._tables.get(gi)
+        # same gradient tensor objects (kept alive here, so identity is exact) and parameter addresses as last time: the
+        # table stands (a module with one flat gradient buffer hands out the same views every step)
+        if hit is not None and all(p.grad is g and p.data_ptr() == d
+                                   for p, g, d in zip(group["params"], hit["grads_all"], hit["ptrs_all"])):
+            return hit
         params = [p for p in group["params"] if p.grad is not None]
         if not params:
             return None
@@ -77,7 +83,8 @@ class FusedAdamW(torch.optim.Optimizer):
         for p in params:
             self.state[p]["step"] = shared
         key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr()) for p in params) + (shared.data_ptr(),)
-        hit = self._tables.get(gi)
+        if hit is not None and hit["key"] == key:
+            hit["grads_all"], hit["ptrs_all"] = [p.grad for p in group["params"]], [p.data_ptr() for p in group["params"]]
         if hit is None or hit["key"] != key:
             arr = (_lib.AetherAdamWTensor * len(params))()
             for a, p in zip(arr, params):
@@ -87,6 +94,7 @@ class FusedAdamW(torch.optim.Optimizer):
             old = hit or {}
             hit = self._tables[gi] = dict(
                 key=key, arr=arr, n=len(params), step=shared,
+                grads_all=[p.grad for p in group["params"]], ptrs_all=[p.data_ptr() for p in group["params"]],
                 lr=old.get("lr", torch.full((), float(group["lr"]), dtype=torch.float32, device=dev)),
                 lr_host=old.get("lr_host", float(group["lr"])),
                 counter=old.get("counter", torch.zeros((), dtype=torch.int32, device=dev)))

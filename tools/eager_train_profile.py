@@ -24,10 +24,28 @@ for _ in range(100):
     step()
 torch.cuda.synchronize()
 print("eager training step: %.3f ms" % (1e3 * (time.perf_counter() - t0) / 100))
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(50):
-    step()
+# the same loop with the library's loss and optimizer (aether_amd.optim: one launch each)
+from aether_amd.optim import FusedAdamW, mse_loss_grad
+opt2 = FusedAdamW(m.parameters(), lr=5e-4, weight_decay=1e-12)
+def step2():
+    opt2.zero_grad()
+    out = m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+    loss, grad = mse_loss_grad(out, inp["target"])
+    out.backward(grad)
+    opt2.step()
+for _ in range(10):
+    step2()
 torch.cuda.synchronize()
-pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+t0 = time.perf_counter()
+for _ in range(100):
+    step2()
+torch.cuda.synchronize()
+print("eager training step, aether_amd.optim loss + AdamW: %.3f ms" % (1e3 * (time.perf_counter() - t0) / 100))
+for fn in (step, step2):
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50):
+        fn()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
