@@ -700,7 +700,7 @@ def main():
         train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps, "collective": coll,
                  "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
                  "includes": ("forward + MSE loss + HIP backward + " if gstep is not None else "forward + torch MSE loss + HIP backward + ")
-                             + ("RCCL grad all-reduce + " if world > 1 else "")
+                             + ((("RCCL" if coll["backend"] == "nccl" else coll["backend"]) + " grad all-reduce + ") if world > 1 else "")
                              + ("AdamW (aether_adamw_step), " if gstep is not None else "torch AdamW, ") + train_launch + " launches"}
         if rank == 0:       # per-kernel breakdown of one training step (rank-local: no collective in here)
             saved_group, model.dp_group = model.dp_group, None       # (GraphedTrainStep already detached it)
