@@ -65,6 +65,7 @@ FLAG_FORCE_STREAMED = 2
 FLAG_FORCE_FUSED = 4
 FLAG_WORKSPACE_REUSED = 8
 FLAG_WEIGHTS_PREPARED = 16
+FLAG_BACKWARD_ONLY = 32
 
 # name -> (restype, argtypes); every symbol include/aether_hip.h declares
 SIGNATURES = {

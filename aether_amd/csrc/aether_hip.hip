@@ -431,6 +431,7 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
     dbg.nodeinfo = wp(W.nodeinfo);
     for (int k = 0; k < 5; ++k) dbg.x[k] = wp(W.x[k]);
     for (int k = 0; k < 4; ++k) dbg.e[k] = wp(W.e[k]);
+    if (step.skip_e4) dbg.e[3] = nullptr;       // training: the backward never reads the last layer's messages
     for (int k = 0; k < 4; ++k) dbg.n[k] = wp(W.n[k]);
     for (int k = 0; k < 3; ++k) { dbg.ps[k] = wp(W.ps[k]); dbg.pr[k] = wp(W.pr[k]); }
     dbg.feat = wp(W.feat);
@@ -515,7 +516,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
             unsigned g = (unsigned)(wgs < 256 ? wgs : 256);                   // one 12-wave workgroup per CU
             ProfScope ps(K_EDGE_LN, st);
             // layer 4's messages are only needed as receiver sums (locs.py:190-193) unless kept
-            float* eo = (l == 4 && !keep) ? nullptr : wp(W.e[l - 1]);
+            float* eo = (l == 4 && (!keep || step.skip_e4)) ? nullptr : wp(W.e[l - 1]);
             k_edge_layer<<<dim3(g), dim3(64 * EDGE_LN_WAVES), lds, st>>>(P.ln_msg_w0[l - 2], P.ln_msg_w2[l - 2], P.ln_msg_b2[l - 2],
                                                          wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), send_s,
                                                          recv_s, gsel, wp(W.part), eo, E);
@@ -1190,7 +1191,7 @@ static int forward_common(const AetherParams* params, int num_dims, int64_t n_no
     const bool keep = (flags & AETHER_FLAG_KEEP_INTERMEDIATES) != 0;
     const bool reused = (flags & AETHER_FLAG_WORKSPACE_REUSED) != 0;
     const bool prepared = (flags & AETHER_FLAG_WEIGHTS_PREPARED) != 0;
-    const StepExtras no_extras{nullptr, nullptr, 1.0f, field};
+    const StepExtras no_extras{nullptr, nullptr, 1.0f, field, (flags & AETHER_FLAG_BACKWARD_ONLY) != 0};
     if (fused) {
         if (num_dims == 2)
             return fused_impl<2>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,

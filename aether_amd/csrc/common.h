@@ -196,7 +196,7 @@ __device__ __forceinline__ void stage_weight64(float* lds, const float* __restri
 // experiments/lorentz/main.py:243-246) instead of reading it; `vel_out` != nullptr also writes the
 // next velocity (x_next - x) / dt next to the output; `ext_field` != nullptr replaces the built-in field net
 // by a precomputed per-node field [n_nodes][D] (the dynamic-field variant, aether_dynamic_field).
-struct StepExtras { const float* qattr; float* vel_out; float dt; const float* ext_field; };
+struct StepExtras { const float* qattr; float* vel_out; float dt; const float* ext_field; bool skip_e4 = false; };
 
 template <int D> struct NodeInfo {
     // [p(D) v(D) f(D) R(D*D row-major) cv(D) cf(D)], padded to a multiple of 4 floats

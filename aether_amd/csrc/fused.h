@@ -753,7 +753,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
             if constexpr (KEEP) {
-                if (ke[r] >= 0) {
+                if (ke[r] >= 0 && dbg.e[layer - 1] != nullptr) {          // (layer 4 under AETHER_FLAG_BACKWARD_ONLY: not kept)
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
                         st4(dbg.e[layer - 1] + (int64_t)ke[r] * H + 16 * mb + 4 * q, e[r][mb]);

@@ -92,7 +92,10 @@ class _AetherStep(torch.autograd.Function):
         graph, ginfo = graph
         D = module.num_dims
         n_nodes = x.shape[0]
-        flags = module.flags | (_lib.FLAG_KEEP_INTERMEDIATES if train else 0)
+        flags = module.flags
+        if train and not (flags & _lib.FLAG_KEEP_INTERMEDIATES):
+            # training: keep what the backward reads, not the last layer's messages (only aether_debug_fetch reads them)
+            flags |= _lib.FLAG_KEEP_INTERMEDIATES | _lib.FLAG_BACKWARD_ONLY
         keep = bool(flags & _lib.FLAG_KEEP_INTERMEDIATES)
         ws_bytes = module._workspace_bytes(n_nodes, n_edges, keep)
         ws_key = None

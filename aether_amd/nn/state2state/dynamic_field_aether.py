@@ -222,7 +222,7 @@ class DynamicFieldAether(nn.Module):
         ws_key = None
         if train:                           # the backward reads this forward's intermediates: one workspace per call
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-            flags |= _lib.FLAG_KEEP_INTERMEDIATES
+            flags |= _lib.FLAG_KEEP_INTERMEDIATES | (0 if self.flags & _lib.FLAG_KEEP_INTERMEDIATES else _lib.FLAG_BACKWARD_ONLY)
         else:
             if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
                 self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)

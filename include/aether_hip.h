@@ -83,6 +83,9 @@ typedef struct AetherGraphInfo {
  * (workspace region).  Set this flag when `workspace` still holds the pieces written by an earlier call with the SAME
  * parameter values (inference loops, rollouts): that kernel is then skipped.  Never set it after the weights changed. */
 #define AETHER_FLAG_WEIGHTS_PREPARED 16
+/* With AETHER_FLAG_KEEP_INTERMEDIATES: keep only what aether_backward reads -- the last layer's messages e4 (12 MB at
+ * N=20, batch=128; 8.6 GB for a 33.5 M-edge shard) are then not written (aether_debug_fetch("e4") is undefined). */
+#define AETHER_FLAG_BACKWARD_ONLY 32
 
 /* Library / build identification (host string, static storage). */
 const char* aether_version(void);
