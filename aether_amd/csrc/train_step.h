@@ -27,6 +27,10 @@ k_mse_loss_grad(const float* __restrict__ pred, const float* __restrict__ target
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
+    if (gridDim.x == 1) {                      // small inputs: no round trips through memory
+        if (threadIdx.x == 0) *loss = red[0] * inv;
+        return;
+    }
     int* counter = reinterpret_cast<int*>(scratch + 256);
     if (threadIdx.x == 0) {
         __hip_atomic_store(scratch + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
