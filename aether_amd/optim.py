@@ -130,12 +130,11 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        capturing = torch.cuda.is_current_stream_capturing()
         for gi, group in enumerate(self.param_groups):
-            hit = self._group_state(gi, group)
+            hit = self._group_state(gi, group)          # (raises for CPU tensors before anything touches the device)
             if hit is None:
                 continue
-            if not capturing and hit["lr_host"] != float(group["lr"]):
+            if hit["lr_host"] != float(group["lr"]) and not torch.cuda.is_current_stream_capturing():
                 hit["lr"].fill_(float(group["lr"]))
                 hit["lr_host"] = float(group["lr"])
             b1, b2 = group["betas"]

@@ -92,6 +92,22 @@ def test_cpu_tensor_fails_loudly():
         m(torch.zeros(3, 1), torch.zeros(3, 2), e, torch.ones(3, 2), torch.zeros(6, 2), torch.ones(3, 1))
 
 
+def test_loss_and_optimizer_fail_loudly_on_the_cpu():
+    """aether_amd.optim has no CPU path either: CPU tensors raise instead of computing something."""
+    from aether_amd.optim import FusedAdamW, mse_loss_grad
+    with pytest.raises(_lib.AetherHipError):
+        mse_loss_grad(torch.zeros(4, 2), torch.zeros(4, 2))
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    opt = FusedAdamW([p], lr=1e-3)
+    with pytest.raises(_lib.AetherHipError):
+        opt.step()
+    assert torch.equal(p.detach(), torch.zeros(8))
+    with pytest.raises(ValueError):
+        FusedAdamW([p], lr=1e-3, betas=(1.0, 0.999))
+    assert ctypes.sizeof(_lib.AetherAdamWTensor) == 40          # include/aether_hip.h: four pointers and an int64
+
+
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports what include/aether_hip.h declares."""
     hdr = open(os.path.join(REPO, "include", "aether_hip.h")).read()
