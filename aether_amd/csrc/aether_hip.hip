@@ -788,6 +788,8 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
             Y.upd_w0 = k == 0 ? P.l1_upd_w0 : P.ln_upd_w0[k - 1];
             Y.upd_b0 = k == 0 ? P.l1_upd_b0 : P.ln_upd_b0[k - 1];
             Y.w4t = WT.upd_w2t[k]; Y.w3t = WT.upd_w0t[k]; Y.w2t = WT.msg_w2t[k]; Y.w0t = WT.msg_w0t[k];
+            Y.img_e = wp(W.wimg) + fused_wimg_offset(k + 1, 0);      // written by the forward of this step (prepare_weights)
+            Y.img_2 = wp(W.wimg) + fused_wimg_offset(k + 1, 1);
             Y.U = wp(W.Ul[k]); Y.DPU = wp(W.DPUl[k]); Y.DPS = wp(W.DPSl[k]); Y.DPR = wp(W.DPRl[k]);
             Y.DXout = k == 0 ? nullptr : wp(W.DXl[k]);         // layer k + 1 produces dL/dx_k
         }

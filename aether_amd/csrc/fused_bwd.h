@@ -41,12 +41,14 @@ struct FbLds {                                // offsets in floats
     // Weight images in MFMA-fragment order: [row block mb][k block a][lane 64] x 16 bytes -- what lane (i, q) reads for
     // (mb, a) is W[16 mb + i][16 a + 4 q .. + 3].  One fragment = 1 KiB contiguous = one LDS-DMA wave instruction with
     // per-lane source addresses (fb_stage_frags), and the fragment reads are lane-linear: no padding, no conflicts.
-    static constexpr int WE = 0;                                   // W_e   (layer 1: W1, K = 32: 8 fragments)
-    static constexpr int W2 = WE + H * H;                          // W2
-    static constexpr int W2T = W2 + H * H;                         // W2^T
+    // W_e and W2 -- the two recompute GEMMs of a tile -- are the forward's split (3 x bf16) images, copied as they lie
+    // in the workspace (k_prepare_weights; common.h gemm_split): 24 KB each instead of 16.
+    static constexpr int WE = 0;                                   // W_e   split image (layer 1: W1, K = 32: half of it)
+    static constexpr int W2 = WE + SPLIT_WIMG;                     // W2    split image
+    static constexpr int W2T = W2 + SPLIT_WIMG;                    // W2^T  fp32 fragments
     static constexpr int WET = W2T + H * H;                        // W_e^T (layer 1: W1^T, 32 rows: 8 fragments)
-    static constexpr int WEND = 2 * 4 * FUSED_MAX_NODES * LDST;    // (the images' region also holds the dumps below)
-    static_assert(WET + H * H <= WEND, "weight images");
+    static constexpr int WEND = WET + H * H;                       // (the images' region also holds the dumps below)
+    static_assert(2 * 4 * FUSED_MAX_NODES * LDST <= WEND, "per-wave dumps alias the weight images");
     static constexpr int BIAS = WEND;                              // [64] b2 | [64] b1 (layer 1)
     static constexpr int PSB = BIAS + 2 * H;                       // [32][LDW]  P_s (visible slots) -> total dP_s
     static constexpr int PRB = PSB + FUSED_MAX_NODES * LDW;        // [32][LDW]  P_r (own slots)     -> total dP_r
@@ -77,6 +79,7 @@ struct FbLayer {
     const float* msg_w2; const float* msg_b2;
     const float* upd_w0; const float* upd_b0;            // W3 [128][64], b3
     const float* w4t; const float* w3t; const float* w2t; const float* w0t;     // transposed copies (k_transpose)
+    const float* img_e; const float* img_2;  // the forward's split images of W_e (layer 1: W1) and W2 (fused.h, fused_wimg_offset)
     float* U; float* DPU; float* DPS; float* DPR;        // row tensors of the node-level weight-gradient products
     float* DXout;              // dL/dx_{l-1} (layers 2-4)
 };
@@ -153,6 +156,17 @@ __device__ __forceinline__ void fb_stage_frags(float* img, const float* __restri
             const float* src = w + (size_t)(16 * mb + i) * src_ld + 16 * a + 4 * q;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(img + f * 256), 16, 0, 0);
         }
+    }
+}
+
+// LDS-DMA of a prepared image that already lies in fragment order: NFRAG contiguous 1 KiB fragments, one wave instruction each.
+template <int NFRAG>
+__device__ __forceinline__ void fb_stage_image(float* img, const float* __restrict__ src, int wave, int lane) {
+#pragma unroll
+    for (int f0 = 0; f0 < NFRAG; f0 += 4) {
+        const int f = f0 + wave;
+        if (NFRAG % 4 == 0 || f < NFRAG)
+            __builtin_amdgcn_global_load_lds(src + f * 256 + lane * 4, (__attribute__((address_space(3))) void*)(img + f * 256), 16, 0, 0);
     }
 }
 
@@ -299,26 +313,17 @@ k_fused_bwd(FbArgs A) {
             // Issue order = wait order (vmcnt counts in order): LDS-DMA of the edge weights, then the small row loads
             // whose data is needed first, then the node-phase weight fragments.  One memory round trip for all of it.
             if constexpr (FIRST) {
+                fb_stage_image<12>(wE, Lp.img_e, wave, lane);              // W1 padded to K = 32: 3 terms x 4 fragments
                 fb_stage_frags<2, 4>(wEt, Lp.w0t, H, wave, lane);
             } else {
-                fb_stage_frags<4, 4>(wE, Lp.msg_w0 + 2 * H, 3 * H, wave, lane);
+                fb_stage_image<24>(wE, Lp.img_e, wave, lane);
                 fb_stage_frags<4, 4>(wEt, Lp.w0t + 2 * H * H, H, wave, lane);
             }
-            fb_stage_frags<4, 4>(w2, Lp.msg_w2, H, wave, lane);
+            fb_stage_image<24>(w2, Lp.img_2, wave, lane);
             fb_stage_frags<4, 4>(w2t, Lp.w2t, H, wave, lane);
-            f32x4 pv[2][2], w1v[2];
+            f32x4 pv[2][2];
             float bv0 = 0.0f, bv1 = 0.0f;
             if constexpr (FIRST) {
-                // W1 [64][F1] has unaligned rows: through registers, zero padded to K = 32 (fragments [mb 4][a 2])
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int f = 4 * j + wave, mb = f >> 1, a = f & 1;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int c = 16 * a + 4 * q + b;
-                        w1v[j][b] = c < A.f1 ? Lp.msg_w0[(16 * mb + i) * A.f1 + c] : 0.0f;
-                    }
-                }
                 if (tid < H) bv1 = A.msg_b0_1[tid];
             } else {
                 // P_s of the visible nodes, P_r of the own nodes (saved by the forward): 2 x 2 rows of 16 float4 per thread
@@ -332,8 +337,6 @@ k_fused_bwd(FbArgs A) {
             if (tid < H) bv0 = Lp.msg_b2[tid];
             f32x4 (&w3f)[2][4] = nw3f, (&w4f)[2][4] = nw4f, (&w3tf)[8] = nw3tf, (&b3v)[2] = nb3v;   // requested a phase ago
             if constexpr (FIRST) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) st4(wE + ((4 * j + wave) * 64 + lane) * 4, w1v[j]);
                 if (tid < H) bias[H + tid] = bv1;
             } else {
 #pragma unroll
@@ -496,14 +499,14 @@ k_fused_bwd(FbArgs A) {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(bias + H + 16 * mb + 4 * q);
                     f32x4 b2[2] = {ep[0], ep[1]};
-                    fb_gemm<4, 2>(wE, b2, p1, lane);
+                    gemm_split<4, 1>(wE, b2, p1, lane);
                 } else {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) {
                         st4(sc + i * FB_SA + 16 * mb + 4 * q, ep[mb]);
                         p1[mb] = ld4(psb + slr * LDW + 16 * mb + 4 * q) + ld4(prb + rlr * LDW + 16 * mb + 4 * q);
                     }
-                    fb_gemm<4, 4>(wE, ep, p1, lane);
+                    gemm_split<4, 2>(wE, ep, p1, lane);
                 }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(90);
 #pragma unroll
@@ -515,7 +518,7 @@ k_fused_bwd(FbArgs A) {
                     p2[mb] = ld4(bias + 16 * mb + 4 * q);
                 }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(91);
-                fb_gemm<4, 4>(w2, hh, p2, lane);
+                gemm_split<4, 2>(w2, hh, p2, lane);
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(92);
                 // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
                 f32x4 d2[4], dh[4], g[4];
