@@ -631,7 +631,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     // ---- out MLP
     {
         { ProfScope ps(KB_OUT, st);
-        kb_out<D><<<dim3(ngrid), dim3(64), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
+        kb_out<D><<<dim3(ngrid), dim3(256), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
                                                    wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
         L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
         L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
@@ -765,7 +765,7 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
     const BwdWT WT = transposed_weights<D>(P, wp(W.wt), TB);     // written by the forward (prepare_weights)
     // ---- out MLP
     { ProfScope ps(KB_OUT, st);
-    kb_out<D><<<dim3(ngrid), dim3(64), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
+    kb_out<D><<<dim3(ngrid), dim3(256), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
                                                wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
     L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
     L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
