@@ -19,7 +19,7 @@ from . import _lib
 MAX_K = 16
 
 
-def _run(x, masks, k):
+def _run(x, masks, k, n_present=None):
     if not (x.is_cuda and masks.is_cuda):
         raise _lib.AetherHipError("aether_amd.knn runs on an MI355X only; got a CPU tensor (there is no CPU fallback)")
     lib = _lib.load()
@@ -52,18 +52,24 @@ def _run(x, masks, k):
                               scene_edges.data_ptr(), scene_nodes.data_ptr(), totals.data_ptr(), ws.data_ptr(),
                               ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(st, "aether_knn_edges")
-    E = int(totals[0].item())                                        # the reference's boolean-mask filter syncs here too
+    if n_present is not None and S == 1:
+        # one scene whose number of present objects the caller knows: every one of them has min(k, n - 1) neighbours
+        n_present = int(n_present)
+        E = n_present * min(k, max(n_present - 1, 0))
+    else:
+        E = int(totals[0].item())                                    # the reference's boolean-mask filter syncs here too
     return send[:E], recv[:E], scene_edges, scene_nodes
 
 
 @torch.no_grad()
-def knn_edges(x, masks, k=10):
+def knn_edges(x, masks, k=10, n_present=None):
     """x [..., T, N, D >= 2], masks [..., T, N] -> (send_index [E], recv_index [E], num_edges_per_batch):
     aether_dynamicvars.py:559-586.  ``num_edges_per_batch`` sums the edges over the last scene axis, as the
-    reference does (``.sum([-1, -2, -3])`` of [..., T, N, k])."""
+    reference does (``.sum([-1, -2, -3])`` of [..., T, N, k]).  ``n_present`` (one scene only): the number of non-zero
+    mask entries, when the caller knows it on the host -- the edge count then needs no device round trip."""
     if x.ndim < 3:
         raise ValueError("x must be [..., T, N, D]")
-    send, recv, scene_edges, _ = _run(x, masks, k)
+    send, recv, scene_edges, _ = _run(x, masks, k, n_present)
     return send, recv, scene_edges.reshape(x.shape[:-2]).sum(-1)
 
 
@@ -85,5 +91,7 @@ def csr_by_receiver(recv, n_nodes):
     ``aether_s2s_prior_step`` take in place of the reference's ``edge2node_inds``."""
     order = torch.argsort(recv, stable=True).contiguous()
     rowptr = torch.zeros(int(n_nodes) + 1, dtype=torch.int64, device=recv.device)
-    rowptr[1:] = torch.cumsum(torch.bincount(recv, minlength=int(n_nodes)), 0)
+    # in-degrees without torch.bincount (which reads back the largest index: a device round trip per call)
+    counts = torch.zeros(int(n_nodes), dtype=torch.int64, device=recv.device).scatter_add_(0, recv, torch.ones_like(recv))
+    rowptr[1:] = torch.cumsum(counts, 0)
     return order, rowptr

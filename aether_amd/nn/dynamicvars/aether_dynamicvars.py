@@ -52,8 +52,9 @@ class AetherDynamicVars(nn.Module):
         self.load_state_dict(torch.load(path))
 
     @torch.no_grad()
-    def predict_field(self, x, masks=None):
-        """:64-79.  x [..., Nmax, 4] -> (field [..., Nmax, 2], zero where masks is 0; coords of the present objects)."""
+    def predict_field(self, x, masks=None, n_present=None):
+        """:64-79.  x [..., Nmax, 4] -> (field [..., Nmax, 2], zero where masks is 0; coords of the present objects).
+        ``n_present``: the number of non-zero mask entries when the caller knows it on the host (no device round trip)."""
         if not x.is_cuda:
             raise _lib.AetherHipError("aether_amd AetherDynamicVars runs on an MI355X only; got a CPU tensor "
                                       "(there is no CPU fallback)")
@@ -62,7 +63,12 @@ class AetherDynamicVars(nn.Module):
             masks = torch.ones_like(x[..., 0], dtype=torch.bool)
         m = masks.to(x.device).bool()
         predicted_field = torch.zeros_like(x[..., :2], dtype=torch.float32)
-        xs = x[m].detach().to(torch.float32).contiguous()
+        idx = None
+        if n_present is None:
+            xs = x[m].detach().to(torch.float32).contiguous()
+        else:
+            idx = torch.nonzero_static(m.reshape(-1), size=int(n_present))[:, 0]
+            xs = x.detach().reshape(-1, x.shape[-1]).index_select(0, idx).to(torch.float32)
         coords = torch.cat([xs[..., :2], nn.functional.normalize(xs[..., 2:], dim=-1)], -1)
         n = xs.shape[0]
         if n == 0:
@@ -82,12 +88,15 @@ class AetherDynamicVars(nn.Module):
         st = lib.aether_dyn_field(C.byref(ps), h, n, xs.data_ptr(), self._ws.data_ptr(), self._ws.numel(), out.data_ptr(),
                                   torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(st, "aether_dyn_field")
-        predicted_field[m] = out
+        if idx is None:
+            predicted_field[m] = out
+        else:
+            predicted_field.view(-1, 2).index_copy_(0, idx, out)
         return predicted_field, coords
 
     @torch.no_grad()
     def single_step_forward(self, inputs, node_masks, graph_info, decoder_hidden, edge_logits, hard_sample, current_field,
-                            uniform=None):
+                            uniform=None, n_present=None):
         """:133-145.  ``uniform``: the U(0,1) draw of gumbel_softmax ([E, K]); drawn on the device when omitted."""
         if not hard_sample:
             raise _lib.AetherHipError("only hard_sample=True (evaluation / prediction) is part of this path")
@@ -108,7 +117,8 @@ class AetherDynamicVars(nn.Module):
             edges = gumbel_softmax_hard(edge_logits, uniform.reshape(edge_logits.shape).to(edge_logits.device), self.gumbel_temp)
         else:
             edges = torch.empty_like(edge_logits)
-        predictions, decoder_hidden = self.decoder(inputs, decoder_hidden, edges, node_masks, graph_info, current_field)
+        predictions, decoder_hidden = self.decoder(inputs, decoder_hidden, edges, node_masks, graph_info, current_field,
+                                                   n_present=n_present)
         return predictions, decoder_hidden, edges
 
     @torch.no_grad()
@@ -129,11 +139,14 @@ class AetherDynamicVars(nn.Module):
             observed = burn_in_masks[:, t].unsqueeze(-1).type(inputs.dtype)
             # observed objects are fed their ground truth, the others the model's own last prediction (:264)
             state = observed * inputs[:, t] + (1 - observed) * last
-            field, _ = self.predict_field(state, present)
+            # the data set hands over the present objects of every step (node_inds, built from the masks): their number
+            # is known on the host, which spares the three stages their device round trips (mask -> index list)
+            n_t = int(node_inds[0][t].numel())
+            field, _ = self.predict_field(state, present, n_present=n_t)
             logits, prior_state = self.encoder.single_step_forward(state, present, node_inds[0][t], graph_info[0][t],
-                                                                   prior_state, field)
+                                                                   prior_state, field, n_present=n_t)
             last, dec_state, _ = self.single_step_forward(state, present, graph_info[0][t], dec_state, logits, True, field,
-                                                          None if uniform is None else uniform[t])
+                                                          None if uniform is None else uniform[t], n_present=n_t)
             preds.append(last)
         return torch.stack(preds, dim=1)
 

@@ -79,28 +79,43 @@ class Encoder(nn.Module):
         return (torch.zeros(1, batch, self.rnn_hidden_size, device=inputs.device),
                 torch.zeros(1, batch, self.rnn_hidden_size, device=inputs.device))
 
+    def _apply(self, fn, *args, **kwargs):                 # .to() / .cuda(): the cached pointer struct is stale
+        self.__dict__.pop("_plist", None)
+        self.__dict__.pop("_pstruct", None)
+        return super()._apply(fn, *args, **kwargs)
+
     def _param_struct(self):
-        ps = _DynPriorParams()
-        ptr = lambda t: t.data_ptr()
-        for name in ("mlp1", "mlp3", "mlp4"):
-            m = getattr(self, name)
-            for tag, t in (("w0", m.model[0].weight), ("b0", m.model[0].bias), ("w3", m.model[3].weight), ("b3", m.model[3].bias),
-                           ("bn_w", m.bn.weight), ("bn_b", m.bn.bias), ("bn_mean", m.bn.running_mean), ("bn_var", m.bn.running_var)):
-                setattr(ps, f"{name}_{tag}", ptr(t))
-        rnn = self.forward_rnn
-        ps.lstm_w_ih, ps.lstm_w_hh, ps.lstm_b_ih, ps.lstm_b_hh = ptr(rnn.weight_ih_l0), ptr(rnn.weight_hh_l0), ptr(rnn.bias_ih_l0), ptr(rnn.bias_hh_l0)
-        layers = [self.prior_fc_out] if isinstance(self.prior_fc_out, nn.Linear) else \
-            [m for m in self.prior_fc_out if isinstance(m, nn.Linear)]
-        for l, lin in enumerate(layers):
-            ps.prior_w[l], ps.prior_b[l] = ptr(lin.weight), ptr(lin.bias)
-        f = self.edge_filter.edge_filter
-        ps.filt_w0, ps.filt_b0, ps.filt_w2, ps.filt_b2 = ptr(f[0].weight), ptr(f[0].bias), ptr(f[2].weight), ptr(f[2].bias)
-        ps.filt_image = filter_image(self.__dict__.setdefault("_img_cache", {}), "filt", f[2].weight, 15,
-                                     f[2].weight.shape[1]).data_ptr()
-        return ps, len(layers), (layers[0].out_features if len(layers) > 1 else 0)
+        """Pointer struct of parameters and BatchNorm buffers, rebuilt only when one of them moved."""
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters()) + list(self.buffers())
+        key = tuple(p.data_ptr() for p in plist)
+        hit = self.__dict__.get("_pstruct")
+        if hit is None or hit[0] != key:
+            ps = _DynPriorParams()
+            ptr = lambda t: t.data_ptr()
+            for name in ("mlp1", "mlp3", "mlp4"):
+                m = getattr(self, name)
+                for tag, t in (("w0", m.model[0].weight), ("b0", m.model[0].bias), ("w3", m.model[3].weight), ("b3", m.model[3].bias),
+                               ("bn_w", m.bn.weight), ("bn_b", m.bn.bias), ("bn_mean", m.bn.running_mean), ("bn_var", m.bn.running_var)):
+                    setattr(ps, f"{name}_{tag}", ptr(t))
+            rnn = self.forward_rnn
+            ps.lstm_w_ih, ps.lstm_w_hh, ps.lstm_b_ih, ps.lstm_b_hh = ptr(rnn.weight_ih_l0), ptr(rnn.weight_hh_l0), ptr(rnn.bias_ih_l0), ptr(rnn.bias_hh_l0)
+            layers = [self.prior_fc_out] if isinstance(self.prior_fc_out, nn.Linear) else \
+                [m for m in self.prior_fc_out if isinstance(m, nn.Linear)]
+            for l, lin in enumerate(layers):
+                ps.prior_w[l], ps.prior_b[l] = ptr(lin.weight), ptr(lin.bias)
+            f = self.edge_filter.edge_filter
+            ps.filt_w0, ps.filt_b0, ps.filt_w2, ps.filt_b2 = ptr(f[0].weight), ptr(f[0].bias), ptr(f[2].weight), ptr(f[2].bias)
+            hit = self.__dict__["_pstruct"] = (key, ps, f[2].weight, len(layers), (layers[0].out_features if len(layers) > 1 else 0))
+        ps, w = hit[1], hit[2]
+        # the filter image follows in-place updates by itself (version counter)
+        ps.filt_image = filter_image(self.__dict__.setdefault("_img_cache", {}), "filt", w, 15, w.shape[1]).data_ptr()
+        return ps, hit[3], hit[4]
 
     @torch.no_grad()
-    def single_step_forward(self, inputs, node_masks, node_inds, all_graph_info, forward_state, predicted_field):
+    def single_step_forward(self, inputs, node_masks, node_inds, all_graph_info, forward_state, predicted_field,
+                            n_present=None):
         """aether_dynamicvars.py:672-699.  inputs [1, Nmax, 4], node_masks [1, Nmax], node_inds: the present objects,
         all_graph_info = (send, recv, ...) in their numbering, forward_state (h, c) each [1, Nmax (Nmax - 1), R],
         predicted_field [1, Nmax, 2] -> (prior_logits [1, E, K], forward_state)."""
@@ -118,9 +133,16 @@ class Encoder(nn.Module):
         x, field = f32(inputs), f32(predicted_field)
         mask = node_masks.reshape(-1).to(dev)
         # the encoder's own kNN graph of the present objects, from the current inputs (:528)
-        send, recv, _ = knn_edges(x, mask.reshape(1, -1).to(torch.float32))
-        keep = mask.bool()
-        cur_in, cur_f = x[0, keep].contiguous(), field[0, keep].contiguous()
+        if n_present is None:
+            send, recv, _ = knn_edges(x, mask.reshape(1, -1).to(torch.float32))
+            keep = mask.bool()
+            cur_in, cur_f = x[0, keep].contiguous(), field[0, keep].contiguous()
+        else:
+            # predict_future's own calls: the number of present objects is known on the host (len(node_inds)), so the rows
+            # of the mask's non-zero entries can be gathered without a device round trip
+            send, recv, _ = knn_edges(x, mask.reshape(1, -1).to(torch.float32), n_present=n_present)
+            idx = torch.nonzero_static(mask, size=int(n_present))[:, 0]
+            cur_in, cur_f = x[0].index_select(0, idx), field[0].index_select(0, idx)
         n, E = cur_in.shape[0], send.numel()
         order, rowptr = csr_by_receiver(recv, n)
         # LSTM state rows of the caller's edges: one slot per fully connected pair (:680-686)
