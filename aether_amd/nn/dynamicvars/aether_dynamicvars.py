@@ -101,13 +101,17 @@ class AetherDynamicVars(nn.Module):
         if not hard_sample:
             raise _lib.AetherHipError("only hard_sample=True (evaluation / prediction) is part of this path")
         if isinstance(edge_logits, (list, tuple)):                     # B scenes (single_step_forward_batched of the encoder)
-            edges = []
-            for b, lg in enumerate(edge_logits):
-                if lg.nelement() == 0:
-                    edges.append(torch.empty_like(lg).reshape(0, lg.shape[-1]))
-                    continue
-                u = torch.rand(lg.shape, device=lg.device) if uniform is None else uniform[b].reshape(lg.shape).to(lg.device)
-                edges.append(gumbel_softmax_hard(lg, u, self.gumbel_temp).reshape(-1, lg.shape[-1]))
+            # one sampling pass over the edges of all scenes (torch.rand fills a tensor in index order: the draws of scene b
+            # differ from those of B separate calls, as any batched sampler's do; pass `uniform` to fix them)
+            K = edge_logits[0].shape[-1]
+            sizes = [lg.nelement() // K for lg in edge_logits]
+            lg_all = torch.cat([lg.reshape(-1, K) for lg in edge_logits])
+            if uniform is None:
+                u_all = torch.rand(lg_all.shape, device=lg_all.device)
+            else:
+                u_all = torch.cat([uniform[b].reshape(-1, K).to(lg_all.device) for b in range(len(edge_logits))])
+            edges = list(gumbel_softmax_hard(lg_all, u_all, self.gumbel_temp).reshape(-1, K).split(sizes)) if lg_all.numel() \
+                else [lg.reshape(0, K) for lg in edge_logits]
             predictions, decoder_hidden = self.decoder.forward_batched(inputs, decoder_hidden, edges, node_masks, graph_info,
                                                                        current_field)
             return predictions, decoder_hidden, edges

@@ -196,30 +196,32 @@ class Decoder(nn.Module):
         if nv == 0:
             return pred_all, hidden
         base = torch.cumsum(counts, 0) - counts                          # first concatenated row of every scene
-        send_l, recv_l, ord_l, ssend_l, srecv_l, ew_l, rows_per_node = [], [], [], [], [], [], []
-        e_off = 0
-        for b in range(B):
-            if counts_h[b] == 0:
-                continue
-            s_b, r_b, e2n = (t.to(device=dev, dtype=torch.int64) for t in graph_info[b])
-            E_b = s_b.numel()
-            ew = f32(edges[b]).reshape(-1, K)
-            if r_b.numel() != E_b or ew.shape[0] != E_b or e2n.ndim != 2 or e2n.shape[0] != counts_h[b]:
+        # The scenes' index lists are concatenated and shifted with a handful of launches, whatever B is (a loop of eight
+        # small tensor operations per scene made the 64-scene step host-bound: 3.9 ms for 0.7 ms of kernels).
+        present = [b for b in range(B) if counts_h[b] > 0]
+        gi = [tuple(t.to(device=dev, dtype=torch.int64) for t in graph_info[b]) for b in present]
+        ews = [f32(edges[b]).reshape(-1, K) for b in present]
+        E_l = [g[0].numel() for g in gi]
+        for b, g, ew_b, E_b in zip(present, gi, ews, E_l):
+            if g[1].numel() != E_b or ew_b.shape[0] != E_b or g[2].ndim != 2 or g[2].shape[0] != counts_h[b]:
                 raise ValueError(f"graph_info / edges of scene {b} do not match its present objects")
-            send_l.append(s_b + base[b]); recv_l.append(r_b + base[b])
-            ssend_l.append(s_b + b * Nmax); srecv_l.append(r_b + b * Nmax)        # un-compacted rows, compacted ids (:823)
-            ord_l.append(e2n.reshape(-1) + e_off)
-            rows_per_node.append(torch.full((counts_h[b],), e2n.shape[1], dtype=torch.int64, device=dev))
-            ew_l.append(ew)
-            e_off += E_b
-        send, recv = torch.cat(send_l).contiguous(), torch.cat(recv_l).contiguous()
-        ssend, srecv = torch.cat(ssend_l).contiguous(), torch.cat(srecv_l).contiguous()
-        order = torch.cat(ord_l).contiguous()
+        E = sum(E_l)
+        L_l = [g[2].numel() for g in gi]
+        e_off = [sum(E_l[:j]) for j in range(len(present))]
+        meta = torch.tensor([E_l, present, [b * Nmax for b in present], L_l, e_off, [g[2].shape[1] for g in gi],
+                             [counts_h[b] for b in present]], dtype=torch.int64, device=dev)
+        scene_e = torch.repeat_interleave(torch.arange(len(present), device=dev), meta[0], output_size=E)
+        S_all, R_all = torch.cat([g[0] for g in gi]), torch.cat([g[1] for g in gi])
+        off_c, off_u = base[meta[1]][scene_e], meta[2][scene_e]
+        send, recv = (S_all + off_c).contiguous(), (R_all + off_c).contiguous()
+        ssend, srecv = (S_all + off_u).contiguous(), (R_all + off_u).contiguous()        # un-compacted rows, compacted ids (:823)
+        order = (torch.cat([g[2].reshape(-1) for g in gi])
+                 + torch.repeat_interleave(meta[4], meta[3], output_size=sum(L_l))).contiguous()
         rowptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
-        rowptr[1:] = torch.cumsum(torch.cat(rows_per_node), 0)
-        ew = torch.cat(ew_l).contiguous()
+        rowptr[1:] = torch.cumsum(torch.repeat_interleave(meta[5], meta[6], output_size=nv), 0)
+        ew = torch.cat(ews).contiguous()
         E = send.numel()
-        div_node = torch.repeat_interleave((counts - 1).clamp(min=1).to(torch.float32), counts).contiguous()
+        div_node = torch.repeat_interleave((counts - 1).clamp(min=1).to(torch.float32), counts, output_size=nv).contiguous()
         x2, h2, f2 = inputs.reshape(B * Nmax, -1), hidden.reshape(B * Nmax, h), field.reshape(B * Nmax, -1)
         cur_in, cur_h, cur_f = x2[flat_idx].contiguous(), h2[flat_idx].contiguous(), f2[flat_idx].contiguous()
         ext_full = torch.cat([x2, f2], -1).contiguous()

@@ -200,17 +200,23 @@ class Encoder(nn.Module):
         cur_in, cur_f = x[use].contiguous(), field[use].contiguous()
         n, E = cur_in.shape[0], send.numel()
         order, rowptr = csr_by_receiver(recv, n)
-        slots, per_scene = [], []
-        for b in range(B):
-            if counts_h[b] < 2:
-                per_scene.append(0)
-                continue
-            gsend, grecv = all_graph_info[b][0].to(dev), all_graph_info[b][1].to(dev)
-            ni = node_inds[b].to(dev)
-            gs, gr = ni[gsend], ni[grecv]
-            slots.append(b * Nmax * (Nmax - 1) + gs * (Nmax - 1) + gr - (gr >= gs).long())
-            per_scene.append(int(gsend.numel()))
-        slot = torch.cat(slots)
+        # LSTM state slots of all scenes' edges with a handful of launches, whatever B is (:680-686 per scene)
+        used = [b for b in range(B) if counts_h[b] >= 2]
+        gs_l = [all_graph_info[b][0].to(device=dev, dtype=torch.int64) for b in used]
+        gr_l = [all_graph_info[b][1].to(device=dev, dtype=torch.int64) for b in used]
+        ni_l = [node_inds[b].to(device=dev, dtype=torch.int64) for b in used]
+        E_l = [g.numel() for g in gs_l]
+        per_scene = [0] * B
+        for b, E_b in zip(used, E_l):
+            per_scene[b] = E_b
+        n_l = [t.numel() for t in ni_l]
+        meta = torch.tensor([E_l, [sum(n_l[:j]) for j in range(len(used))], [b * Nmax * (Nmax - 1) for b in used]],
+                            dtype=torch.int64, device=dev)
+        scene_e = torch.repeat_interleave(torch.arange(len(used), device=dev), meta[0], output_size=sum(E_l))
+        ni_all = torch.cat(ni_l)
+        ni_off = meta[1][scene_e]
+        gs, gr = ni_all[torch.cat(gs_l) + ni_off], ni_all[torch.cat(gr_l) + ni_off]
+        slot = meta[2][scene_e] + gs * (Nmax - 1) + gr - (gr >= gs).long()
         if slot.numel() != E:
             raise ValueError("graph_info and the encoder's kNN graphs list a different number of edges")
         h0, c0 = f32(forward_state[0])[0, slot].contiguous(), f32(forward_state[1])[0, slot].contiguous()
@@ -229,8 +235,6 @@ class Encoder(nn.Module):
         _lib.check(st, "aether_dyn_prior_step")
         new_h, new_c = forward_state[0].clone(), forward_state[1].clone()
         new_h[0, slot], new_c[0, slot] = h1, c1
-        out, off = [], 0
-        for b in range(B):
-            out.append(logits[off:off + per_scene[b]].unsqueeze(0) if per_scene[b] else empty[b])
-            off += per_scene[b]
+        parts = logits.split(per_scene)
+        out = [parts[b].unsqueeze(0) if per_scene[b] else empty[b] for b in range(B)]
         return out, (new_h, new_c)
