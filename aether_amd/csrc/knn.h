@@ -122,7 +122,8 @@ k_knn_scan(const int64_t* __restrict__ scene_nodes, const int64_t* __restrict__ 
     __syncthreads();
     if (tid == 0) {
         int64_t rn = 0, re = 0;
-        for (int t = 0; t < 1024; ++t) {
+        const int active = (int)((n_scenes + chunk - 1) / (chunk > 0 ? chunk : 1));     // threads that own scenes (one scene: 1, not 1,024 serial steps)
+        for (int t = 0; t < (active < 1024 ? active : 1024); ++t) {
             const int64_t vn = pn[t], ve = pe[t];
             pn[t] = rn; pe[t] = re; rn += vn; re += ve;
         }
