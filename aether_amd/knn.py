@@ -10,7 +10,6 @@ receiver-sorted order the library's kernels consume.  No CPU fallback.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 
