@@ -126,6 +126,19 @@ class AetherDynamicVars(nn.Module):
         return predictions, decoder_hidden, edges
 
     @torch.no_grad()
+    def _step_core(self, state, present, node_inds_t, gsend, grecv, e2n, prior_h, prior_c, dec_state, uniform_t):
+        """One step of ``predict_future`` for one scene: (prediction [1, Nmax, 4], prior state h, c, decoder state).  The
+        number of present objects is ``node_inds_t.numel()`` (host-known): no stage reads a count back from the device."""
+        n_t = int(node_inds_t.numel())
+        gi = (gsend, grecv, e2n)
+        field, _ = self.predict_field(state, present, n_present=n_t)
+        logits, (new_h, new_c) = self.encoder.single_step_forward(state, present, node_inds_t, gi, (prior_h, prior_c), field,
+                                                                   n_present=n_t)
+        last, new_dec, _ = self.single_step_forward(state, present, gi, dec_state, logits, True, field, uniform_t,
+                                                    n_present=n_t)
+        return last, new_h, new_c, new_dec
+
+    @torch.no_grad()
     def predict_future(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
         """:245-273.  inputs [1, T, Nmax, 4], masks / burn_in_masks [1, T, Nmax], node_inds[0][t], graph_info[0][t]: the
         present objects and their graph per time step.  ``uniform``: per-step Gumbel draws (list of [E_t, K]).
@@ -138,6 +151,7 @@ class AetherDynamicVars(nn.Module):
         dec_state = self.decoder.get_initial_hidden(inputs)
         last = inputs[:, 0]
         preds = []
+        dev = inputs.device
         for t in range(n_steps):
             present = masks[:, t]
             observed = burn_in_masks[:, t].unsqueeze(-1).type(inputs.dtype)
@@ -145,12 +159,22 @@ class AetherDynamicVars(nn.Module):
             state = observed * inputs[:, t] + (1 - observed) * last
             # the data set hands over the present objects of every step (node_inds, built from the masks): their number
             # is known on the host, which spares the three stages their device round trips (mask -> index list)
-            n_t = int(node_inds[0][t].numel())
-            field, _ = self.predict_field(state, present, n_present=n_t)
-            logits, prior_state = self.encoder.single_step_forward(state, present, node_inds[0][t], graph_info[0][t],
-                                                                   prior_state, field, n_present=n_t)
-            last, dec_state, _ = self.single_step_forward(state, present, graph_info[0][t], dec_state, logits, True, field,
-                                                          None if uniform is None else uniform[t], n_present=n_t)
+            ni_t = node_inds[0][t]
+            n_t = int(ni_t.numel())
+            if n_t >= 2:
+                gs, gr, e2n = (g.to(dev) for g in graph_info[0][t])
+                u_t = uniform[t] if uniform is not None else torch.rand(gs.numel(), self.num_edge_types, device=dev)
+                args = (state.to(torch.float32), present.to(dev).to(torch.float32), ni_t.to(dev), gs, gr, e2n,
+                        prior_state[0], prior_state[1], dec_state.to(torch.float32),
+                        u_t.to(dev).reshape(gs.numel(), self.num_edge_types).to(torch.float32))
+                last, new_h, new_c, dec_state = self._step_core(*args)
+                prior_state = (new_h, new_c)
+            else:                                                  # nobody or one object: the stages' own early exits
+                field, _ = self.predict_field(state, present, n_present=n_t)
+                logits, prior_state = self.encoder.single_step_forward(state, present, ni_t, graph_info[0][t], prior_state,
+                                                                       field, n_present=n_t)
+                last, dec_state, _ = self.single_step_forward(state, present, graph_info[0][t], dec_state, logits, True, field,
+                                                              None if uniform is None else uniform[t], n_present=n_t)
             preds.append(last)
         return torch.stack(preds, dim=1)
 

@@ -273,3 +273,4 @@ def test_decoder_and_encoder_two_objects():
     gl, (gh0, gc0) = enc.single_step_forward(inputs.cuda(), masks.cuda(), node_inds.cuda(), (send, recv, e2n),
                                              (st[0].cuda(), st[1].cuda()), field.cuda())
     assert scale_rel_err(gl.cpu(), wl) <= TOL and scale_rel_err(gh0.cpu(), wh0) <= TOL and scale_rel_err(gc0.cpu(), wc0) <= TOL
+
