@@ -61,9 +61,9 @@ k_s2s_filter_images(const float* __restrict__ L2w, int R, int h, bf16x8* __restr
 // bf16 pieces and laid out as MFMA fragments: bimg[((e / 16) (h / 32) + a32) 3 + term][lane (i, q)] = pieces of
 // hw[16 (e / 16) + i][32 a32 + 8 q .. + 8).  One thread per (edge, k octet); edges past the end repeat the last one.
 template <int P>
-__global__ void __launch_bounds__(256)
-k_s2s_filter_bimg(const float* __restrict__ pos, const float* __restrict__ W1, const float* __restrict__ b1, int relu,
-                  int h, int64_t n_edges, bf16x8* __restrict__ bimg) {
+__device__ __forceinline__ void filter_bimg_body(const float* __restrict__ pos, const float* __restrict__ W1,
+                                                 const float* __restrict__ b1, int relu, int h, int64_t n_edges,
+                                                 bf16x8* __restrict__ bimg) {
     const int oct = h >> 3;
     const int64_t padded = (n_edges + 15) & ~(int64_t)15;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -94,11 +94,35 @@ k_s2s_filter_bimg(const float* __restrict__ pos, const float* __restrict__ W1, c
     dst[64] = mid;
     dst[128] = lo;
 }
+template <int P>
+__global__ void __launch_bounds__(256)
+k_s2s_filter_bimg(const float* __restrict__ pos, const float* __restrict__ W1, const float* __restrict__ b1, int relu,
+                  int h, int64_t n_edges, bf16x8* __restrict__ bimg) {
+    filter_bimg_body<P>(pos, W1, b1, relu, h, n_edges, bimg);
+}
+
+// Several filters over the same edges in one launch (the variable-N decoder has one per edge type): blockIdx.y picks the
+// filter's pointers; the work of a filter is exactly that of its own launch.
+constexpr int FILT_MAX_TYPES = 4;
+struct FilterTypes {
+    const bf16x8* img[FILT_MAX_TYPES];      // prepared images of the filter banks
+    const float* b2[FILT_MAX_TYPES];
+    const float* w0[FILT_MAX_TYPES];        // first hyper-network layer (k_s2s_filter_bimg)
+    const float* b0[FILT_MAX_TYPES];
+    bf16x8* bimg[FILT_MAX_TYPES];           // B-operand images, one buffer per filter
+    float* out[FILT_MAX_TYPES];             // [splits][n_edges][h] planes (or the result itself when splits == 1)
+};
+template <int P>
+__global__ void __launch_bounds__(256)
+k_s2s_filter_bimg_types(const float* __restrict__ pos, FilterTypes T, int relu, int h, int64_t n_edges) {
+    const int t = blockIdx.y;
+    filter_bimg_body<P>(pos, T.w0[t], T.b0[t], relu, h, n_edges, T.bimg[t]);
+}
 
 template <int R>
-__global__ void __launch_bounds__(512)             // two waves per SIMD: <= 256 registers each, no AGPR allocation
-k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2, const float* __restrict__ ea,
-                   const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits) {
+__device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img, const float* __restrict__ b2,
+                                                  const float* __restrict__ ea, const bf16x8* __restrict__ bimg,
+                                                  float* __restrict__ out, int h, int64_t n_edges, int splits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
     bf16x8* ring = reinterpret_cast<bf16x8*>(filt_smem);                        // [slot 3][kb 2][mb 4][term 3][lane]
     float* evs = reinterpret_cast<float*>(ring + FILT_NST * FILT_STAGE);        // [r][eq 4][i 16][nb 4]
@@ -261,6 +285,42 @@ k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2,
         }
         __syncthreads();                                       // ring and staged values are free for the next unit; stores issued
     }
+}
+template <int R>
+__global__ void __launch_bounds__(512)             // two waves per SIMD: <= 256 registers each, no AGPR allocation
+k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2, const float* __restrict__ ea,
+                   const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits) {
+    filter_split_body<R>(img, b2, ea, bimg, out, h, n_edges, splits);
+}
+template <int R>
+__global__ void __launch_bounds__(512)
+k_s2s_filter_split_types(FilterTypes T, const float* __restrict__ ea, int h, int64_t n_edges, int splits) {
+    const int t = blockIdx.y;
+    filter_split_body<R>(T.img[t], T.b2[t], ea, T.bimg[t], T.out[t], h, n_edges, splits);
+}
+
+// The variable-N decoder's edge messages from the present state (aether_dynamicvars.py:827-835) out of the filters' planes:
+//   M[e][c] = sum_k w[e][k] relu(sum_z planes_k[z][e][c]),  k = k0 .. K-1 in order, planes in order
+// (k_s2s_sum_planes + k_s2s_relu_scale_acc of every type, same order of additions, one launch; M is written, not added to).
+__global__ void __launch_bounds__(256)
+k_dyn_filter_combine(FilterTypes T, int n_types, int n_planes, const float* __restrict__ w /* [n_edges][K], column k0 + t */,
+                     int K, int k0, float* __restrict__ M, int h, int64_t n_edges) {
+    const int q4 = h >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_edges * q4) return;
+    const int64_t e = idx / q4;
+    const int c = (int)(idx - e * q4) * 4;
+    const size_t count = (size_t)n_edges * h, at = (size_t)e * h + c;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < n_types; ++t) {
+        f32x4 v = ld4(T.out[t] + at);
+        for (int z = 1; z < n_planes; ++z) v += ld4(T.out[t] + (size_t)z * count + at);
+        const float we = w[e * K + k0 + t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f) * we;
+        acc = acc + v;
+    }
+    st4(M + at, acc);
 }
 
 }  // namespace
