@@ -599,6 +599,32 @@ k_s2s_gumbel_select(const float* __restrict__ logits, const float* __restrict__ 
     }
 }
 
+// Up to three narrow dense layers on the same rows in one launch: Y_g[n][m] = act(b_g[m] + sum_{c < C} W_g[m][c] X[n][c]),
+// C <= 8 (the variable-N models feed 6 canonical-state columns to three gates / to mlp1: through the matrix-core GEMM
+// that took padded copies of X and of every weight -- five launches).  One thread per (row, 4 outputs); act 0 | 4 (ELU).
+struct NarrowLayers { const float* W[3]; const float* b[3]; float* Y[3]; int n; };
+__global__ void __launch_bounds__(256)
+k_s2s_narrow_layers(NarrowLayers L, const float* __restrict__ X, int ldx, int C, int M, int act, int64_t n_rows) {
+    const int q4 = M >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_rows * q4) return;
+    const int64_t n = idx / q4;
+    const int m = (int)(idx - n * q4) * 4;
+    float x[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = c < C ? X[n * ldx + c] : 0.0f;
+    for (int g = 0; g < L.n; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sv = L.b[g] != nullptr ? L.b[g][m + r] : 0.0f;
+            for (int c = 0; c < C; ++c) sv = fmaf(L.W[g][(size_t)(m + r) * C + c], x[c], sv);
+            v[r] = act == 4 ? (sv > 0.0f ? sv : expm1f(sv)) : sv;
+        }
+        st4(L.Y[g] + (size_t)n * M + m, v);
+    }
+}
+
 // The variable-N decoder's version (weights given, not sampled): k_s2s_select of every type and the weights divided by
 // the number of active types (k_s2s_scale) in one launch.  lists: type k at lists + k * list_stride; counts must be zero.
 __global__ void __launch_bounds__(256)
