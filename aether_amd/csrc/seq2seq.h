@@ -663,6 +663,17 @@ k_s2s_bn_affine(const float* __restrict__ w, const float* __restrict__ b, const 
     shift[c] = b[c] - mean[c] * sc;
 }
 
+// Up to three BatchNorm layers in one launch (blockIdx.y = layer; layers without statistics are skipped by the host).
+struct BnSets { const float* w[3]; const float* b[3]; const float* mean[3]; const float* var[3]; float* scale[3]; float* shift[3]; };
+__global__ void __launch_bounds__(256)
+k_s2s_bn_affine_sets(BnSets S, int n) {
+    const int c = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (c >= n || S.w[j] == nullptr) return;
+    const float sc = S.w[j][c] / sqrtf(S.var[j][c] + 1e-5f);
+    S.scale[j][c] = sc;
+    S.shift[j][c] = S.b[j][c] - S.mean[j][c] * sc;
+}
+
 // One LSTM step (torch.nn.LSTM gate order i, f, g, o): gates [E][4R] -> h1, c1
 __global__ void __launch_bounds__(256)
 k_s2s_lstm_cell(const float* __restrict__ gates, const float* __restrict__ c0, float* __restrict__ h1,
