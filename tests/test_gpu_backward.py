@@ -205,3 +205,26 @@ def test_fused_backward_matches_layer_by_layer_kernels(D, shape):
         assert torch.equal(g_fused[k], g_again[k]), k
         scale = float(g_layers[k].abs().max())
         assert float((g_fused[k] - g_layers[k]).abs().max()) <= 2e-5 * scale + 1e-10, (k, scale)
+
+
+@pytest.mark.parametrize("streamed", [False, True])
+def test_backward_only_flag_leaves_the_gradients_alone(streamed):
+    """Training forwards pass AETHER_FLAG_BACKWARD_ONLY (the last layer's messages are not written: only the debug fetch
+    reads them).  With the module's own KEEP flag set the forward writes everything; both must give the same bits."""
+    from aether_amd import _lib
+    from aether_amd.nn.state2state.aether import Aether
+    from aether_amd.synthetic import make_batch
+    D = 2
+    b = make_batch(8, 20, D, seed=21, device="cuda")
+    grads = []
+    for keep_all in (False, True):
+        torch.manual_seed(3)
+        m = Aether(2 * D, 64, 0.0, D, device="cuda")
+        if streamed:
+            m.flags |= _lib.FLAG_FORCE_STREAMED
+        if keep_all:
+            m.flags |= _lib.FLAG_KEEP_INTERMEDIATES
+        out = m(b["h"], b["x"], b["edges"], b["vel"], b["edge_attr"], b["charges"])
+        torch.nn.functional.mse_loss(out, b["target"]).backward()
+        grads.append((out.detach().clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
