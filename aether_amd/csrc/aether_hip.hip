@@ -1422,6 +1422,8 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
         return copy2d((const float*)(ws + W.x[name[1] - '0']), n_nodes, H, 0, H);
     if (name[0] == 'e' && name[1] >= '1' && name[1] <= '4' && !name[2])
         return copy2d((const float*)(ws + W.e[name[1] - '1']), n_edges, H, 0, H);
+    if (!strcmp(name, "efeat"))      // layer-1 edge features [E][FPAD] (kept with KEEP_INTERMEDIATES), sorted order
+        return copy2d((const float*)(ws + W.feat), n_edges, FPAD, 0, FPAD);
     return fail(AETHER_EINVAL, "debug_fetch: unknown name");
 }
 

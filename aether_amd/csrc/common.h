@@ -7,6 +7,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int H = AETHER_HIDDEN;     // 64
 // LDS row strides (floats).  A fragment read is one ds_read_b128 per lane at
@@ -44,7 +45,6 @@ __device__ __forceinline__ float silu(float x) {
 // Four values at once: the three plain multiplies / adds are written on 2-wide vectors so that they
 // become v_pk_mul_f32 / v_pk_add_f32 (fp32 MFMA shares the VALU: every instruction saved is
 // matrix-pipe time).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 silu4(f32x4 v) {
     const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
     const f32x2 tl = lo * -1.44269504088896340736f, th = hi * -1.44269504088896340736f;
@@ -69,6 +69,11 @@ __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
                  __builtin_amdgcn_rcpf(eh[1])};
 }
 __device__ __forceinline__ f32x4 dsilu_from_sigmoid(f32x4 x, f32x4 s) { return s * (1.0f + x * (1.0f - s)); }
+// A scalar the compiler has to hold in a register of its own.  Used for broadcast operands of packed fp32 math
+// (vector * scalar): left alone, the compiler folds "element 1 of a pair" into an op_sel modifier on src0 / src1 of
+// v_pk_{fma,mul,add}_f32, and that form returns a wrong low half in lanes 48-63 when the SIMD's other wave is issuing
+// bf16 MFMAs (measured: tools/micro/pkfma_mfma.hip; tools/isa_check.py rule R3 keeps it out of the library).
+__device__ __forceinline__ float own_reg(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -112,12 +117,21 @@ __device__ __forceinline__ void split_bf16x3(float x, __bf16& h, __bf16& m, __bf
 // The lane's B fragment of one 32-deep k block from two accumulator-layout blocks: element j < 4 is hidden unit
 // 32 kb + 4 q + j, element j >= 4 is 32 kb + 16 + 4 q + (j - 4).  The k order inside a block is thus a permutation
 // of the natural one; weight images (stage_split_*) are written in the same order.
+// Written on pairs: the two conversions of a pair are one v_cvt_pk_bf16_f32, the two subtractions one v_pk_add_f32
+// (the library is built without the SLP vectoriser, build.py, so packed math is whatever the sources spell out).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 h, m, l;
-        split_bf16x3(j < 4 ? v0[j] : v1[j - 4], h, m, l);
-        hi[j] = h; mid[j] = m; lo[j] = l;
+    for (int p = 0; p < 4; ++p) {
+        const f32x2 x = p < 2 ? f32x2{v0[2 * p], v0[2 * p + 1]} : f32x2{v1[2 * p - 4], v1[2 * p - 3]};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+        mid[2 * p] = m[0]; mid[2 * p + 1] = m[1];
+        lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
     }
 }
 // Weight image for split GEMMs: [term 3][row block mb][k block kb][lane 64] fragments of 8 bf16 (16 bytes); lane (m, q)
@@ -254,6 +268,9 @@ __device__ __forceinline__ void edge_features(const float* __restrict__ nj,
             s0 += rba * rel[b];
             s1 += rba * nj[NI::V + b];
             s2 += rba * nj[NI::F + b];
+#if defined(AETHER_HAZ_VARIANT) && AETHER_HAZ_VARIANT == 9     // diagnostic build: keep these sums out of packed FMAs
+            asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2));
+#endif
         }
         rrel[a] = s0; rv[a] = s1; rf[a] = s2;
     }

@@ -193,7 +193,7 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
                 for (int mb = 0; mb < 2; ++mb) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(b2s + r * 64 + 32 * chalf + 16 * mb + 4 * q);
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += bv * e4[nb];
+                    for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += bv * own_reg(e4[nb]);
                 }
             }
         }
@@ -272,7 +272,7 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
                     for (int nb = 0; nb < 4; ++nb) tmp[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[kb][nb], tmp[nb], 0, 0, 0);
                 }
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += tmp[nb] * e4[nb];       // out += ea[:, r] * Z_r
+                for (int nb = 0; nb < 4; ++nb) outv[mb][nb] += tmp[nb] * own_reg(e4[nb]);       // out += ea[:, r] * Z_r
             }
         }
         float* dst = out + (size_t)z * n_edges * h;

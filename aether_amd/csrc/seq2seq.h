@@ -570,7 +570,7 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
             const f32x4 bv = ld4(b2 + (size_t)r * h + m0 + 16 * mb + 4 * q);
             const f32x4 e4 = *reinterpret_cast<const f32x4*>(evl + r * (32 * NB));
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += bv * e4[nb];
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += bv * own_reg(e4[nb]);
         }
     }
     const float* wbase = L2w + (size_t)(m0 + i) * h + 4 * q;          // row (r h + m0 + 16 mb + i), k-group a
@@ -608,7 +608,7 @@ k_s2s_filter(const float* __restrict__ L2w, const float* __restrict__ b2, const 
                 wfetch(ring[p], sidx + PF < total ? sidx + PF : total - 1);
                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(evl + r * (32 * NB));
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) xf[nb] = hf[nb] * e4[nb];
+                for (int nb = 0; nb < NB; ++nb) xf[nb] = hf[nb] * own_reg(e4[nb]);
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll

@@ -145,3 +145,29 @@ def test_public_header_is_valid_c99_and_cpp(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "a.o")],
                    check=True)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")], check=True)
+
+
+def test_built_library_passes_the_isa_check():
+    """tools/isa_check.py on the built code object: no packed fp32 instruction with an op_sel bit on
+    src0 / src1 anywhere in the library -- the form that returned wrong low halves in lanes 48-63 next to bf16 MFMAs
+    and corrupted ~3 tiles per million in a round-2 build of k_edge_layer1.  The same scanner must flag the culprit
+    instruction when it is handed to it."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import isa_check
+    _lib.load()                                                   # builds the library if it is stale
+    txt = isa_check.disassemble(_lib.LIB_PATH)
+    kernels = list(isa_check.split_kernels(txt))
+    assert len(kernels) > 300, len(kernels)
+    bad = {name: res["r3"][:2] for name, body in kernels for res in [isa_check.check_kernel(body)] if res["r3"]}
+    assert not bad, bad
+    # the scanner itself: the instruction of the corrupting build, harmless neighbours, and the accumulator patterns
+    res = isa_check.check_kernel([
+        "v_pk_fma_f32 v[6:7], v[20:21], v[18:19], 0 op_sel_hi:[1,0,0]",
+        "v_pk_fma_f32 v[6:7], v[2:3], v[18:19], v[6:7] op_sel:[0,1,0]",
+        "v_pk_mul_f32 v[8:9], v[2:3], v[4:5] op_sel:[1,0]",
+        "v_pk_fma_f32 v[6:7], v[2:3], v[18:19], v[6:7] op_sel:[0,0,1] op_sel_hi:[1,1,0]",
+        "ds_read_b128 a[4:7], v70 offset:36992",
+        "v_mfma_f32_16x16x32_bf16 a[2:5], v[2:5], v[10:13], a[4:7]",
+    ])
+    assert len(res["r3"]) == 2 and res["bf16"] and len(res["r1"]) == 1 and len(res["r2"]) == 1, res

@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""ISA invariants of libaether_hip.so, checked on the built code object.
+
+Scans the gfx950 disassembly of every kernel.
+
+  R3  (FAILS the check) a packed fp32 VALU instruction -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- with an op_sel
+      bit on src0 or src1, i.e. whose LOW result lane reads the HIGH half of a multiplicand / addend.  Measured on the
+      MI355X (tools/micro/pkfma_mfma.hip): while the SIMD's other wave issues bf16 MFMAs this form returns a wrong low
+      result in lanes 48-63 (7e-3 of lane-results next to v_mfma_f32_16x16x32_bf16); op_sel on src2 only, and cleared
+      op_sel_hi bits, never failed.  This -- not the accumulator patterns below -- is what corrupted ~3 tiles per
+      million in the uncapped k_edge_layer1 of round 2 (tools/hazard_variants.py: variants 0-9).  Any kernel may share
+      a SIMD with another kernel's MFMA waves, so the rule covers the whole library.
+
+  R1  (reported with --all) a memory load (ds_read* / global_load* / ...) whose destination is an accumulator register
+      a[..] that a later MFMA reads as SrcC;
+  R2  (reported with --all) an MFMA whose destination tuple partially overlaps its SrcC tuple.
+      Round 2 suspected R1; isolated (tools/micro/agpr_hazard.hip: 8e8 trials each of R1, R2 and the compiler's whole
+      sliding-tuple sequence, bit-exact) and in the kernel (2 x 2 variants: every combination failed alike until the
+      packed FMAs were removed, then none did) both patterns are sound, so they do not fail the check.
+
+Usage: isa_check.py [libaether_hip.so | file.s] [--all] [--kernel SUBSTR]
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(HERE), "aether_amd", "libaether_hip.so")
+
+_REG = re.compile(r"\b([av])(?:\[(\d+):(\d+)\]|(\d+))")
+_LOADS = ("ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")
+
+
+def disassemble(path: str) -> str:
+    """gfx950 disassembly of a shared library's embedded code object (or the text of a .s file)."""
+    if path.endswith(".s"):
+        return open(path).read()
+    with tempfile.TemporaryDirectory() as td:
+        co, fat = os.path.join(td, "dev.co"), os.path.join(td, "fat.bin")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", path],
+                       check=True, capture_output=True)
+        bundler = os.path.join(LLVM, "clang-offload-bundler")
+        subprocess.run([bundler, "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={fat}", f"--output={co}"], check=True, capture_output=True)
+        if not os.path.exists(co) or os.path.getsize(co) == 0:
+            raise RuntimeError(f"no gfx950 code object in {path}")
+        out = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co],
+                             check=True, capture_output=True, text=True).stdout
+    return out
+
+
+def split_kernels(txt: str):
+    """Yield (name, [instruction text]) for every function of a disassembly or compiler .s file."""
+    cur, body = None, []
+    for ln in txt.split("\n"):
+        m = re.match(r"^[0-9a-f]* ?<([^>]+)>:$", ln) or re.match(r"^(_Z\w+|\w+):\s*(;.*)?$", ln)
+        if m and not ln.startswith((".", "\t", " ")):
+            if cur is not None:
+                yield cur, body
+            cur, body = m.group(1), []
+            continue
+        t = ln.strip()
+        if cur is None or not t or t.startswith((".", ";", "//")):
+            continue
+        t = t.split("//")[0].split(";")[0].strip()
+        if t and not t.endswith(":"):
+            body.append(t)
+    if cur is not None:
+        yield cur, body
+
+
+def regs(tok: str):
+    """('a'|'v', first, last) of a register operand, or None."""
+    m = _REG.search(tok)
+    if not m:
+        return None
+    if m.group(2) is not None:
+        return m.group(1), int(m.group(2)), int(m.group(3))
+    return m.group(1), int(m.group(4)), int(m.group(4))
+
+
+def operands(ins: str):
+    parts = ins.split(None, 1)
+    return [p.strip() for p in parts[1].split(",")] if len(parts) > 1 else []
+
+
+_PK = re.compile(r"^v_pk_(fma|mul|add|max|min)\w*_f32\b")
+_OPSEL = re.compile(r"op_sel:\[([01,]+)\]")
+
+
+def check_kernel(body):
+    """-> dict(bf16, r1 = [(load, mfma)], r2 = [mfma], r3 = [packed instruction], agpr_loads)"""
+    pending = {}                 # agpr index -> load instruction that last wrote it, nothing has overwritten it since
+    r1, r2, r3 = [], [], []
+    bf16 = False
+    n_agpr_loads = 0
+    for ins in body:
+        op = ins.split()[0]
+        ops = operands(ins)
+        if _PK.match(op):
+            m = _OPSEL.search(ins)
+            if m and "1" in m.group(1).split(",")[:2]:
+                r3.append(ins)
+            continue
+        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+            if "bf16" in op:
+                bf16 = True
+            d, c = regs(ops[0]), regs(ops[3]) if len(ops) > 3 else None
+            if c and c[0] == "a":
+                hit = sorted({pending[r] for r in range(c[1], c[2] + 1) if r in pending})
+                for ld in hit:
+                    r1.append((ld, ins))
+            if d and c and d[0] == c[0] and (d[1], d[2]) != (c[1], c[2]) and not (d[2] < c[1] or c[2] < d[1]):
+                r2.append(ins)
+            if d and d[0] == "a":
+                for r in range(d[1], d[2] + 1):
+                    pending.pop(r, None)
+            continue
+        if op.startswith(_LOADS) and ops:
+            d = regs(ops[0])
+            if d and d[0] == "a" and ops[0].lstrip().startswith("a"):
+                n_agpr_loads += 1
+                for r in range(d[1], d[2] + 1):
+                    pending[r] = ins
+            continue
+        if op.startswith("v_accvgpr_write") and ops:
+            d = regs(ops[0])
+            if d:
+                pending.pop(d[1], None)
+    return dict(bf16=bf16, r1=r1, r2=r2, r3=r3, agpr_loads=n_agpr_loads)
+
+
+def main(argv):
+    path = next((a for a in argv if not a.startswith("--")), DEFAULT_LIB)
+    show_all = "--all" in argv
+    only = argv[argv.index("--kernel") + 1] if "--kernel" in argv else None
+    txt = disassemble(path)
+    bad = 0
+    n = 0
+    for name, body in split_kernels(txt):
+        if only and only not in name:
+            continue
+        n += 1
+        res = check_kernel(body)
+        flagged = bool(res["r3"])
+        if flagged or (show_all and (res["r1"] or res["r2"] or res["agpr_loads"])):
+            print(f"{'FAIL' if flagged else 'note'} {name}: R3(packed fp32 op_sel on src0/src1)={len(res['r3'])} "
+                  f"bf16_mfma={res['bf16']} agpr_loads={res['agpr_loads']} R1(load->SrcC)={len(res['r1'])} "
+                  f"R2(partial dst/SrcC overlap)={len(res['r2'])}")
+            for pk in res["r3"][:3]:
+                print("     R3:", pk)
+            if show_all:
+                for ld, mf in res["r1"][:2]:
+                    print("     R1:", ld, "->", mf)
+                for mf in res["r2"][:2]:
+                    print("     R2:", mf)
+        bad += bool(flagged)
+    print(f"isa_check: {n} kernels scanned, {bad} failing")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
