@@ -167,7 +167,7 @@ SIGNATURES = {
     "aether_mse_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.c_void_p]),
     "aether_adamw_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
-                                    C.c_double, C.c_double, C.c_void_p]),
+                                    C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "aether_graph_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "aether_check_async_error": (C.c_int, []),
     "aether_profile_enable": (C.c_int, [C.c_int]),

@@ -476,7 +476,9 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
     auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int32_t *perm = gp(G.perm), *send_s = gp(G.send_s), *recv_s = gp(G.recv_s), *rowptr = gp(G.rowptr);
     float* nodeinfo = wp(W.nodeinfo);
-    if (prepare_weights<D>(P, ws, false, keep, Nn, E, st)) return AETHER_EHIP;     // the backward's transposed copies
+    // the backward's transposed copies -- and the split images too: aether_backward picks the fused backward from the
+    // graph alone (fused_backward_applies), whichever forward ran, and that kernel stages its recompute GEMMs from them
+    if (prepare_weights<D>(P, ws, keep, keep, Nn, E, st)) return AETHER_EHIP;
 
     {
         ProfScope ps(K_NODE_PREP, st);

@@ -319,7 +319,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     const int n_tiles = (m + 15) >> 4;
     const int na = wg.na;                                // edges [0, na) of the local order have own senders
     volatile int* arrived = reinterpret_cast<volatile int*>(smem + L::ARRIVED);
-    if (tid == 0) arrived[0] = 0;                        // ordered before any use by the prologue's barriers
+    if (tid == 0) { arrived[0] = 0; arrived[1] = 0; }    // ordered before any use by the prologue's barriers
 #ifdef AETHER_FUSED_STAMPS
     const unsigned long long t_entry = wall_clock64();
     const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
@@ -705,10 +705,21 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             // (cdna_hip_programming.md Guideline 16: "the other waves load after ... an LDS word it then sets").
             if (lane == 0) {
                 unsigned spins = 0;
+                unsigned long long t_first = 0;
                 while (__hip_atomic_load(dbg.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < layer - 1) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) {                // partner not resident: give up, never hang -- and say so
+                    // bounded by TIME (5 s of the 100 MHz wall clock), not by a spin count: when the device is shared
+                    // (another process, another stream) the partner may legitimately be scheduled late -- a count of
+                    // 2^22 polls gave up in a two-process rehearsal on one GPU
+                    if ((++spins & 1023u) == 0) {
+                        const unsigned long long now = wall_clock64();
+                        if (t_first == 0) t_first = now;
+                        if (now - t_first <= 500000000ull) continue;
+                        // partner not resident: give up, never hang -- and say so:
+                        // the host-mapped word for the next entry point / aether_check_async_error, and an LDS word that
+                        // turns this workgroup's outputs into NaN (a launch that finished on stale rows must not look valid)
                         if (dbg.errword) __hip_atomic_store(dbg.errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        arrived[1] = 1;
                         break;
                     }
                 }
@@ -995,7 +1006,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     float s = 0.f;
 #pragma unroll
                     for (int b = 0; b < D; ++b) s += ni[NI::R + a * D + b] * yl[b];
-                    const float xn = ni[NI::P + a] + s;
+                    float xn = ni[NI::P + a] + s;
+                    if (arrived[1]) xn = __builtin_nanf("");          // a hand-off wait gave up somewhere in this workgroup
                     out[(int64_t)(nb + node) * D + a] = xn;
                     if (dbg.step.vel_out)
                         dbg.step.vel_out[(int64_t)(nb + node) * D + a] = (xn - ni[NI::P + a]) / dbg.step.dt;

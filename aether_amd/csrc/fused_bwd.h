@@ -217,6 +217,7 @@ k_fused_bwd(FbArgs A) {
     const int n_tiles = (m + 15) >> 4;
     const int na = wg.na;
     const bool split = wg.partner >= 0;
+    bool gave_up = false;          // thread 0: a bounded wait on the partner workgroup timed out
     const int nbk = n > 16 ? 2 : 1;                      // node tiles of the own range
     float* sa = smem + L::STG + wave * (3 * 16 * FB_SA);     // dpre2, then G
     float* sb = sa + 16 * FB_SA;                               // h
@@ -621,10 +622,16 @@ k_fused_bwd(FbArgs A) {
             if (split && tid == 0) {         // the partner's partials of this layer: 4 waves x (layers so far)
                 const int want = NWV * (5 - l);
                 unsigned spins = 0;
+                unsigned long long t_first = 0;
                 while (__hip_atomic_load(A.flags + wg.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) {
+                    if ((++spins & 1023u) == 0) {              // bounded by time (5 s), as in fused.h
+                        const unsigned long long now = wall_clock64();
+                        if (t_first == 0) t_first = now;
+                        if (now - t_first <= 500000000ull) continue;
+                        // partner not resident: report, and poison this workgroup's
                         if (A.errword) __hip_atomic_store(A.errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        gave_up = true;                        // partial sums at exit (gradients come out NaN, not stale)
                         break;
                     }
                 }
@@ -754,6 +761,12 @@ k_fused_bwd(FbArgs A) {
     (void)published;
     if (split && tid == 0)         // the partner's counter has been consumed for the last time: re-arm it
         __hip_atomic_store(A.flags + wg.partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (split) {
+        __syncthreads();           // every wave's stores of the partials have completed (vmcnt drained): the NaN lands last
+        if (tid == 0 && gave_up) {
+            for (int l = 0; l < 4; ++l) A.partial[((size_t)blockIdx.x * 4 + l) * FB_PART] = __builtin_nanf("");
+        }
+    }
 }
 
 // Sum of the workgroups' partials in workgroup order: element e of (layer, FB_PART).  1024 threads = 256 elements x 4

@@ -70,7 +70,8 @@ struct AdamWTable {
 // writes step + 1 (every workgroup has read it by then) and re-arms the counter.
 __global__ void __launch_bounds__(256)
 k_adamw(const AdamWTable T, float* __restrict__ step, const float* __restrict__ lr_dev, int* __restrict__ counter,
-        double beta1, double beta2, double log_beta1, double log_beta2, float eps, double weight_decay, int bump) {
+        double beta1, double beta2, double log_beta1, double log_beta2, float eps, double weight_decay, float grad_scale,
+        int bump) {
     __shared__ float sh[3];
     if (threadIdx.x == 0) {
         // 1 - beta^t = -expm1(t log beta): no cancellation at small t, and no double-precision pow (microseconds on the
@@ -99,7 +100,7 @@ k_adamw(const AdamWTable T, float* __restrict__ step, const float* __restrict__ 
     for (int r = 0; r < 4; ++r) {
         const int i = base + r * 256 + (int)threadIdx.x;
         if (i < n) {
-            const float gi = g[i];
+            const float gi = g[i] * grad_scale;      // 1 / world after a sum all-reduce (data-parallel); x 1.0f is exact
             float pi = p[i] * decay;
             const float mi = m[i] + omb1 * (gi - m[i]);
             const float vi = b2 * v[i] + omb2 * gi * gi;

@@ -47,13 +47,17 @@ class FusedAdamW(torch.optim.Optimizer):
     (``aether_adamw_step``).  The step counter and the learning rate live in device memory, so a hipGraph that captured
     ``step()`` keeps counting and follows ``param_groups[i]["lr"]`` (call ``sync_lr()`` -- ``step()`` does -- after a
     scheduler changed it; ``GraphedTrainStep.step`` does so before every replay).
-    Like torch's fused AdamW it leaves the parameters' version counters alone."""
+    An eager ``step()`` bumps the parameters' version counters (the kernel writes them behind autograd's back and the
+    modules key prepared weight images on the versions); a captured one cannot -- ``GraphedTrainStep`` does it per replay.
+    ``grad_scale`` (attribute, default 1.0) multiplies every gradient as the kernel reads it: a data-parallel step sets
+    1 / world_size and all-reduces with SUM, so the mean costs no launch."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         if lr < 0 or eps < 0 or not (0 < betas[0] < 1 and 0 < betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdamW: bad hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
+        self.grad_scale = 1.0
 
     def _group_state(self, gi, group):
         hit = self._tables.get(gi)
@@ -93,7 +97,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                                                      s["exp_avg_sq"].data_ptr(), p.numel())
             old = hit or {}
             hit = self._tables[gi] = dict(
-                key=key, arr=arr, n=len(params), step=shared,
+                key=key, arr=arr, n=len(params), step=shared, params=params,
                 grads_all=[p.grad for p in group["params"]], ptrs_all=[p.data_ptr() for p in group["params"]],
                 lr=old.get("lr", torch.full((), float(group["lr"]), dtype=torch.float32, device=dev)),
                 lr_host=old.get("lr_host", float(group["lr"])),
@@ -141,6 +145,13 @@ class FusedAdamW(torch.optim.Optimizer):
             dev = hit["step"].device
             st = lib.aether_adamw_step(C.cast(hit["arr"], C.c_void_p), hit["n"], hit["step"].data_ptr(), hit["lr"].data_ptr(),
                                        hit["counter"].data_ptr(), float(b1), float(b2), float(group["eps"]),
-                                       float(group["weight_decay"]), torch.cuda.current_stream(dev).cuda_stream)
+                                       float(group["weight_decay"]), float(self.grad_scale),
+                                       torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(st, "aether_adamw_step")
+            # The kernel writes the parameters behind autograd's back.  Everything keyed on (data_ptr, _version) -- the
+            # modules' prepared weight images, plans, engine copies -- must see a new version (an eval forward
+            # between backward and step() otherwise left stale images marked fresh).  Under capture the bump would be a
+            # host-side no-op per replay: GraphedTrainStep bumps after every replay itself.
+            if not torch.cuda.is_current_stream_capturing():
+                torch.autograd.graph.increment_version(hit["params"])
         return loss

@@ -6,10 +6,12 @@ optimizer step as ~40 separate launches; on the MI355X the step is then bound by
 AdamW once (``torch.cuda.CUDAGraph``) on static input buffers and replays it: same arithmetic, one launch per step.
 Shapes and the edge index are fixed at construction (the runner's batches have a fixed shape, main.py:211-212).
 
-Data-parallel (``aether_amd.parallel.attach_data_parallel`` was called on the model): the collective stays outside the
-graphs -- forward + backward replay as one graph, the flat gradient buffer is all-reduced eagerly (RCCL) on the same
-stream, the optimizer replays as a second graph.  Every rank still pays two graph launches + one collective instead of
-~45 eager launches.
+Data-parallel (``aether_amd.parallel.attach_data_parallel`` was called on the model): forward + backward replay as one
+graph, the flat gradient buffer is SUM all-reduced eagerly (RCCL) on the same stream, the optimizer replays as a second
+graph and takes the mean as it reads the gradients (``FusedAdamW.grad_scale`` = 1 / world): two graph launches + one
+collective, no other launch.  ``graph_collective=True`` asks for the whole step -- collective included -- as ONE graph
+(RCCL collectives can be captured); if that capture fails the two-graph form is used.  It is off by default: no
+multi-GPU hardware was available to test it.
 """
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ import torch
 
 class GraphedTrainStep:
     def __init__(self, model, example_args, example_target, lr=5e-4, weight_decay=1e-12, loss_fn=None, warmup=3,
-                 optimizer="aether"):
+                 optimizer="aether", graph_collective=False):
         """``example_args``: the positional arguments of ``model.forward`` for one batch (tensors are cloned into static
         buffers; the edge index list and non-tensors are kept as they are), ``example_target``: the batch's target.
         ``loss_fn`` None: the runner's ``nn.MSELoss`` (main.py:86), loss and the seed of the backward in one launch
@@ -39,13 +41,23 @@ class GraphedTrainStep:
         else:
             raise ValueError('optimizer: "aether" or "torch"')
         self._params = [p for p in model.parameters()]
-        # data-parallel: the step owns the collective from here on (the module's backward no longer issues it)
+        # data-parallel: the step owns the collective from here on (the module's backward no longer issues it);
+        # close() hands it back
         self.dp_group = getattr(model, "dp_group", None)
+        self.world = 1
         if self.dp_group is not None:
+            import torch.distributed as dist
             if not hasattr(model, "_grad_buffers"):
                 raise ValueError("data-parallel GraphedTrainStep needs a model with one flat gradient buffer (Aether)")
             model.dp_group = None
+            self.world = dist.get_world_size(self.dp_group)
+            # the mean over ranks: folded into the optimizer's gradient read where the optimizer can do it
+            self._scale_in_optimizer = hasattr(self.optimizer, "grad_scale")
+            if self._scale_in_optimizer:
+                self.optimizer.grad_scale = 1.0 / self.world
         self.allreduce_events = None
+        self.collective_in_graph = False
+        self.flat = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                         # warm-up off the capture: lazy initialisation, workspaces
@@ -60,14 +72,27 @@ class GraphedTrainStep:
                 self.loss = self._forward_backward()
                 self.optimizer.step()
         else:
-            with torch.cuda.graph(self.graph):
-                self.loss = self._forward_backward()
-            # the .grad tensors are views of one flat buffer (grad_as_view); a narrow model (hidden_size < 64) hands out
-            # ordinary gradients cut from its padded engine's: those are flattened around the collective
-            self.flat = model._grad_buffers()[0] if self._grads_are_views() else None
-            self.opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.opt_graph):
-                self.optimizer.step()
+            self.opt_graph = None
+            if graph_collective:
+                try:
+                    with torch.cuda.graph(self.graph):
+                        self.loss = self._forward_backward()
+                        self._allreduce()
+                        self.optimizer.step()
+                    self.collective_in_graph = True
+                except Exception as ex:                          # backend cannot be captured: two graphs around an eager collective
+                    import sys
+                    print("GraphedTrainStep: collective not capturable, using two graphs:", repr(ex), file=sys.stderr)
+                    torch.cuda.synchronize()
+                    self.graph = torch.cuda.CUDAGraph()
+                    self.optimizer.zero_grad(set_to_none=True)
+            if not self.collective_in_graph:
+                with torch.cuda.graph(self.graph):
+                    self.loss = self._forward_backward()
+                self.opt_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.opt_graph):
+                    self.optimizer.step()
+            self.flat = self._flat_gradient_buffer()
 
     def _forward_backward(self):
         out = self.model(*self.args)
@@ -80,24 +105,35 @@ class GraphedTrainStep:
         loss.backward()
         return loss
 
-    def _grads_are_views(self):
-        return getattr(self.model, "hidden_size", 64) == 64
+    def _flat_gradient_buffer(self):
+        """The model's flat gradient buffer if -- judged from the gradients themselves -- every ``.grad`` the optimizer
+        reads is a view into it (``grad_as_view``); None otherwise (narrow models, ``grad_as_view = False``: ordinary
+        gradient tensors, flattened around the collective)."""
+        bufs = self.model._grad_buffers() if hasattr(self.model, "_grad_buffers") else None
+        if not bufs or bufs[0] is None:
+            return None
+        flat = bufs[0]
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        grads = [p.grad for p in self._params if p.grad is not None]
+        if not grads or not all(lo <= g.data_ptr() and g.data_ptr() + g.numel() * g.element_size() <= hi for g in grads):
+            return None
+        return flat
 
     def _allreduce(self):
         import torch.distributed as dist
-        world = dist.get_world_size(self.dp_group)
-        if not self._grads_are_views():
-            grads = [p.grad for p in self._params if p.grad is not None]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            dist.all_reduce(flat, group=self.dp_group)
-            flat.div_(world)
-            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
-            return
-        flat = getattr(self, "flat", None)
+        flat = self.flat if self.flat is not None else self._flat_gradient_buffer()
+        scale_here = not getattr(self, "_scale_in_optimizer", False)
         if flat is None:
-            flat = self.model._grad_buffers()[0]
+            grads = [p.grad for p in self._params if p.grad is not None]
+            cat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(cat, group=self.dp_group)
+            if scale_here:
+                cat.div_(self.world)
+            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(cat.split([g.numel() for g in grads]), grads)])
+            return
         dist.all_reduce(flat, group=self.dp_group)
-        flat.div_(world)
+        if scale_here:
+            flat.div_(self.world)
 
     def _eager(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -119,7 +155,7 @@ class GraphedTrainStep:
         if hasattr(self.optimizer, "sync_lr"):
             self.optimizer.sync_lr()                  # a scheduler's new learning rate -> the device scalar the graph reads
         self.graph.replay()
-        if self.dp_group is not None:
+        if self.dp_group is not None and not self.collective_in_graph:
             if self.allreduce_events is not None:
                 self.allreduce_events[0].record()
             self._allreduce()
@@ -134,3 +170,18 @@ class GraphedTrainStep:
     def time_allreduce(self, on=True):
         """Bracket the collective of the following steps with a pair of events (``allreduce_events``)."""
         self.allreduce_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if on else None)
+
+    def check(self):
+        """Synchronise and raise if a kernel of the replays reported an asynchronous error (the bounded wait of the fused
+        kernels' cross-workgroup hand-off sets a host-mapped word: a graph replay never passes through a C entry point
+        that would notice it)."""
+        from . import _lib
+        torch.cuda.synchronize()
+        _lib.check(_lib.load().aether_check_async_error(), "asynchronous kernel error during graph replays")
+
+    def close(self):
+        """Give the collective back to the module's own backward (eager data-parallel use after this step object)."""
+        if self.dp_group is not None:
+            self.model.dp_group = self.dp_group
+            if getattr(self, "_scale_in_optimizer", False):
+                self.optimizer.grad_scale = 1.0

@@ -373,15 +373,30 @@ def main():
     ap.add_argument("--nodes", type=int, default=WORKLOAD["N"])
     ap.add_argument("--seq2seq", action="store_true",
                     help="time the seq2seq model's autoregressive step (SURVEY 8a rows A8-A10) instead: its own JSON line")
-    ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg5shard"], default=None,
+    ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg5shard", "cfg5"], default=None,
                     help="BASELINE.json configuration: cfg1 2-D N=5 B=1, cfg2 (default) 2-D N=20 B=128, cfg3 3-D N=20 B=128, "
-                         "cfg5shard 2-D N=1024 B=32 (one GPU's share of config 5, streamed path)")
+                         "cfg5shard 2-D N=1024 B=32 (one GPU's share of config 5, streamed path), cfg5 the whole of config 5 "
+                         "(256 graphs of 1,024 bodies) split over the --gpus ranks with aether_amd.parallel.shard_graphs: "
+                         "STRONG scaling, every rank walks its graphs in chunks of 32")
+    ap.add_argument("--graph-collective", action="store_true",
+                    help="data-parallel training step: capture the gradient all-reduce inside the hipGraph (untested on "
+                         "multi-GPU hardware; falls back to two graphs around an eager collective)")
     args = ap.parse_args()
     args.big = False
+    args.chunks = 1
     if args.config is not None:
         args.dims, args.nodes, args.batch = {"cfg1": (2, 5, 1), "cfg2": (2, 20, 128), "cfg3": (3, 20, 128),
-                                             "cfg5shard": (2, 1024, 32)}[args.config]
-        if args.config == "cfg5shard":                # 33.5 M edges: a step is 25 ms, the CPU legs would take minutes
+                                             "cfg5shard": (2, 1024, 32), "cfg5": (2, 1024, 32)}[args.config]
+        if args.config == "cfg5":
+            # strong scaling: 256 graphs in total, rank r takes shard_graphs(256, r, world) and walks them 32 at a time
+            # (one 33.5 M-edge chunk is what the workspace is sized for; graphs are independent, so chunks are too)
+            from aether_amd.parallel import shard_graphs
+            r_, w_, _ = _dist_env()
+            lo, hi = shard_graphs(256, r_, w_)
+            if (hi - lo) % 32:
+                raise SystemExit("--config cfg5 needs 256 / world to be a multiple of 32 (1, 2, 4 or 8 ranks)")
+            args.chunks = (hi - lo) // 32
+        if args.config in ("cfg5shard", "cfg5"):      # 33.5 M edges: a step is 25 ms, the CPU legs would take minutes
             args.no_cpu_baseline, args.no_rollout = True, True
             args.steps, args.warmup = min(args.steps, 20), min(args.warmup, 3)
             args.big = True                           # training figure from 3 eager steps (a backward is ~0.1 s here)
@@ -409,6 +424,21 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    ranks_seen = None
+    if world > 1:
+        # which device does every rank sit on?  (uuid / PCI bus id: a SCALE line should show N distinct GPUs.)  Plain
+        # tensor all_gather of a fixed-size byte string -- nothing but the collective the backend certainly has.
+        pr = torch.cuda.get_device_properties(dev)
+        ident = "|".join(str(x) for x in (getattr(pr, "uuid", ""), getattr(pr, "pci_domain_id", ""), getattr(pr, "pci_bus_id", ""),
+                                          getattr(pr, "pci_device_id", ""), pr.name, os.uname().nodename, local))[:120]
+        mine = torch.zeros(128, dtype=torch.uint8, device=dev)
+        raw = torch.tensor(list(ident.encode()), dtype=torch.uint8, device=dev)
+        mine[:raw.numel()] = raw
+        allb = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allb, mine)
+        idents = [bytes(b.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for b in allb]
+        ranks_seen = {"devices": idents, "distinct_devices": len({i.rsplit("|", 1)[0] for i in idents}), "world_size": world}
+
     B, N, D = args.batch, args.nodes, args.dims
     torch.manual_seed(1)
     import contextlib, io
@@ -417,6 +447,9 @@ def main():
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}     # the stated seed-1 weights
     if args.streamed:
         model.flags = _lib.FLAG_FORCE_STREAMED
+    if args.share_gpu and world > 1:
+        # rehearsal only: ranks sharing one GPU cannot count on both workgroups of a split pair being resident together
+        _lib.check(_lib.load().aether_set_option(b"fused_split", 0), "set_option fused_split")
     for kv in args.opt:
         k, v = kv.split("=")
         _lib.check(_lib.load().aether_set_option(k.encode(), int(v)), "set_option " + kv)
@@ -425,7 +458,14 @@ def main():
     inp["edges"] = [e.to(dev) for e in host["edges"]]
     E = inp["edges"][0].numel()
     Nn = B * N
-    call = lambda: model(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+    call1 = lambda: model(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+    if args.chunks > 1:
+        def call():                                    # this rank's share of config 5: `chunks` independent 32-graph chunks
+            for _ in range(args.chunks):
+                o = call1()
+            return o
+    else:
+        call = call1
 
     model.eval()                                       # inference figures (the reference's test loop does the same)
     with torch.no_grad():
@@ -505,6 +545,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # graph replays never pass through a C entry point: ask for asynchronous kernel errors of the timed region here
+        _lib.check(_lib.load().aether_check_async_error(), "asynchronous kernel error in the timed region")
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -628,7 +670,7 @@ def main():
 
     # ---- training step: forward + HIP backward + gradient all-reduce (N > 1) + AdamW ----------------
     train = None
-    if not args.no_train:
+    if not args.no_train and args.chunks == 1:        # (config 5 on fewer than 8 ranks: forward figure only)
         model.train()
         if world > 1:
             from aether_amd.parallel import attach_data_parallel
@@ -655,13 +697,15 @@ def main():
             try:
                 from aether_amd.training import GraphedTrainStep
                 gstep = GraphedTrainStep(model, [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]],
-                                         tgt, lr=5e-4, weight_decay=1e-12)
+                                         tgt, lr=5e-4, weight_decay=1e-12, graph_collective=args.graph_collective)
                 eager_tstep = tstep
                 tstep = gstep.step
                 for _ in range(3):
                     tstep()
                 torch.cuda.synchronize()
-                train_launch = "hipgraph" if world == 1 else "hipgraph (forward + backward) + eager all-reduce + hipgraph (AdamW)"
+                train_launch = ("hipgraph" if world == 1 else
+                                "one hipgraph incl. the all-reduce" if gstep.collective_in_graph else
+                                "hipgraph (forward + backward) + eager all-reduce + hipgraph (AdamW, mean folded into its gradient read)")
             except Exception as ex:          # keep the eager figure if capture is not possible
                 print("train-step graph capture failed:", repr(ex), file=sys.stderr)
                 gstep = None
@@ -677,6 +721,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         tdt = time.perf_counter() - t0
+        _lib.check(_lib.load().aether_check_async_error(), "asynchronous kernel error in the timed training steps")
         if world > 1:
             t = torch.tensor([tdt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -696,7 +741,8 @@ def main():
             ev[1].record()
             torch.cuda.synchronize()
             coll = {"backend": dist.get_backend(grp), "world_size": dist.get_world_size(grp),
-                    "allreduce_bytes": flat.numel() * 4, "allreduce_us": 1e3 * ev[0].elapsed_time(ev[1]) / 20}
+                    "allreduce_bytes": flat.numel() * 4, "allreduce_us": 1e3 * ev[0].elapsed_time(ev[1]) / 20,
+                    "in_graph": bool(gstep is not None and gstep.collective_in_graph), "ranks_seen": ranks_seen}
         train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps, "collective": coll,
                  "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
                  "includes": ("forward + MSE loss + HIP backward + " if gstep is not None else "forward + torch MSE loss + HIP backward + ")
@@ -725,8 +771,8 @@ def main():
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
-        value = 4.0 * E * world / (dt / args.steps)
-        step_flops = E * FLOP_PER_EDGE_STEP[D] + Nn * FLOP_PER_NODE_STEP[D]
+        value = 4.0 * E * args.chunks * world / (dt / args.steps)
+        step_flops = (E * FLOP_PER_EDGE_STEP[D] + Nn * FLOP_PER_NODE_STEP[D]) * args.chunks
         line = {
             "metric": ("edge-messages/sec (forward, electrostatic N=20 batch=128 per GPU)" if (B, N, D) == (128, 20, 2)
                        else f"edge-messages/sec (forward, {D}-D N={N} batch={B} per GPU)"),
@@ -736,18 +782,19 @@ def main():
                                      "max": max(rep_ms), "note": "rank 0, the same K steps timed again after the contract's region"}
                                     if rep_ms else None),
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if args.config == "cfg5" else "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_note": ("fp32 in, fp32 out, fp32 accumulate; the edge-MLP contractions of the fused kernel run as six bf16 "
                            "matrix-core terms on operands split exactly into three bf16 pieces (fp32-equivalent: 2.3e-7 vs "
                            "2.9e-7 for the fp32 MFMA chain against fp64, tools/micro/split_tile.hip)"),
             "data": "synthetic",
             "config": {"workload": WORKLOAD["name"] if (B, N, D) == (128, 20, 2) else f"D{D}-N{N}-B{B}",
-                       "num_dims": D, "nodes_per_graph": N, "graphs_per_gpu": B, "edges_per_gpu": E,
+                       "num_dims": D, "nodes_per_graph": N, "graphs_per_gpu": B * args.chunks, "edges_per_gpu": E * args.chunks,
+                       "chunks_per_step": args.chunks,
                        "hidden": 64, "launch": (f"hipgraph ({S} steps per replay)" if use_graph else "eager"),
                        "parallelism": f"graphs sharded over {world} rank(s), no forward collective"},
-            "edges_per_s": E * world / (dt / args.steps),
+            "edges_per_s": E * args.chunks * world / (dt / args.steps),
             "step_algorithmic_tflops": step_flops * world / (dt / args.steps) / 1e12,
-            "roofline": roof, "kernels": kernels, "rollout": roll, "train": train,
+            "roofline": roof, "kernels": kernels, "rollout": roll, "train": train, "ranks_seen": ranks_seen,
         }
         if world == 1 and not args.no_cpu_baseline:
             sd_tr = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if train is not None else None

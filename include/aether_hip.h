@@ -656,6 +656,8 @@ int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_
  *   tensors (64 per launch).  `step` (device float: steps taken so far, incremented by the launch), `lr` (device float) and `counter`
  *   (device int, zero before the first call) live in device memory, so a captured launch follows the step counter and a
  *   learning-rate schedule.  fp32 arithmetic; the bias corrections 1 - beta^t as -expm1(t log beta), betas in (0, 1).
+ *   `grad_scale` multiplies every gradient as it is read (1.0: torch's AdamW exactly): a data-parallel step passes
+ *   1 / world_size after the SUM all-reduce of the flat gradient buffer, so the mean needs no launch of its own.
  */
 typedef struct {
     float* param;
@@ -668,7 +670,7 @@ size_t aether_mse_scratch_bytes(void);
 int aether_mse_loss_grad(const float* pred, const float* target, int64_t n, float* loss, float* dpred, void* scratch,
                          size_t scratch_bytes, void* stream);
 int aether_adamw_step(const AetherAdamWTensor* tensors, int n_tensors, float* step, const float* lr, int* counter,
-                      double beta1, double beta2, double eps, double weight_decay, void* stream);
+                      double beta1, double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 
 /*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when

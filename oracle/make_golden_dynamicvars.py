@@ -33,6 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
     import make_golden as MG
     import dynamicvars_oracle as DO
     MG._install_scatter_standin()
@@ -86,6 +87,7 @@ def main():
         torch.Tensor.cuda = orig_cuda
     np.savez_compressed(os.path.join(args.out, "dyn_decoder.npz"), **out)
     print("wrote dyn_decoder.npz")
+    return args.out
 
 
 MODEL_PARAMS = {"input_size": 4, "gpu": False, "decoder_hidden": 128, "num_edge_types": 3, "skip_first": True,
@@ -167,5 +169,4 @@ def model_fixture(out_dir):
 
 
 if __name__ == "__main__":
-    main()
-    model_fixture(os.path.join(REPO, "tests", "golden"))
+    model_fixture(main())                # both fixtures go where --out says

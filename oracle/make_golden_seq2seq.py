@@ -41,6 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
     for D in (2, 3):
         field_net, emb = build_reference_field(D)
         g = torch.Generator().manual_seed(77 + D)
@@ -60,6 +61,7 @@ def main():
             out["abs." + k] = np.float64(v.double().abs().sum().item())
         np.savez(os.path.join(args.out, f"s2s_field_D{D}.npz"), **out)
         print("wrote s2s_field_D%d.npz" % D, {k: tuple(v.shape) for k, v in sd.items()})
+    return args.out
 
 
 def localizer_fixtures(out_dir):
@@ -413,10 +415,10 @@ DEC_SEED = 4321
 ENC_SEED = 2468
 
 if __name__ == "__main__":
-    main()
-    localizer_fixtures(os.path.join(REPO, "tests", "golden"))
-    decoder_fixtures(os.path.join(REPO, "tests", "golden"))
-    prior_fixtures(os.path.join(REPO, "tests", "golden"))
-    future_fixture(os.path.join(REPO, "tests", "golden"))
-    dynfield_future_fixture(os.path.join(REPO, "tests", "golden"))
-    loss_fixture(os.path.join(REPO, "tests", "golden"))
+    out_dir = main()                     # every fixture goes where --out says (a dry run must not touch tests/golden)
+    localizer_fixtures(out_dir)
+    decoder_fixtures(out_dir)
+    prior_fixtures(out_dir)
+    future_fixture(out_dir)
+    dynfield_future_fixture(out_dir)
+    loss_fixture(out_dir)

@@ -228,3 +228,29 @@ def test_backward_only_flag_leaves_the_gradients_alone(streamed):
         torch.nn.functional.mse_loss(out, b["target"]).backward()
         grads.append((out.detach().clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()))
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_streamed_forward_then_fused_backward_on_a_poisoned_workspace(D):
+    """aether_backward chooses the fused backward from the graph alone, so a STREAMED forward must
+    leave everything that kernel reads -- the split weight images included -- in the workspace.  The workspace handed
+    to the forward is filled with NaN bit patterns first; the gradients must equal the layer-by-layer backward's."""
+    lib = _lib.load()
+    inp = make_batch(6, 20, D, seed=77)
+    grads = {}
+    for fused_bwd in (1, 0):
+        torch.manual_seed(1)
+        m = Aether(2 * D, 64, 0.0, D, device="cuda")
+        m.flags = _lib.FLAG_FORCE_STREAMED
+        n_nodes, n_edges = inp["x"].shape[0], inp["edges"][0].numel()
+        m._train_ws = torch.full((m._workspace_bytes(n_nodes, n_edges, True),), 0xFF, dtype=torch.uint8, device="cuda")
+        poisoned = m._train_ws.data_ptr()
+        _lib.check(lib.aether_set_option(b"fused_backward", fused_bwd), "set_option")
+        try:
+            _, grads[fused_bwd] = _loss_backward(m, inp)
+        finally:
+            _lib.check(lib.aether_set_option(b"fused_backward", 1), "set_option")
+        assert m._last_ws.data_ptr() == poisoned                 # the forward really ran on the poisoned buffer
+    for k in grads[1]:
+        assert torch.isfinite(grads[1][k]).all(), k
+        assert scale_rel_err(grads[1][k], grads[0][k]) <= GTOL, k

@@ -200,6 +200,36 @@ def test_eval_after_a_fused_optimizer_step_sees_the_updated_weights(H):
         assert scale_rel_err(v.detach().cpu(), sd[k].detach()) <= 2e-3, k
 
 
+def test_eval_between_backward_and_fused_adamw_step_does_not_leave_stale_weight_images():
+    """train forward, backward, a validation forward (which prepares and marks weight images fresh), then
+    FusedAdamW.step(), then another validation forward.  The library's optimizer writes the parameters from a kernel; it
+    has to bump their version counters itself, or the second validation forward reuses the pre-step images."""
+    from aether_amd.optim import FusedAdamW
+    D = 2
+    torch.manual_seed(5)
+    m = Aether(2 * D, 64, 0.0, D, device="cuda")
+    host = make_batch(16, 20, D, seed=9)
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in host.items()}
+    inp["edges"] = [e.cuda() for e in host["edges"]]
+    call = lambda: m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+    opt = FusedAdamW(m.parameters(), lr=1e-2)
+    versions = [p._version for p in m.parameters()]
+    opt.zero_grad(set_to_none=True)
+    torch.nn.functional.mse_loss(call(), inp["target"]).backward()
+    with torch.no_grad():
+        before = call().clone()                                      # validation between backward and step
+        again = call()
+        assert torch.equal(before, again)
+    opt.step()
+    assert all(p._version > v for p, v in zip(m.parameters(), versions))
+    with torch.no_grad():
+        got = call().cpu()
+        want = O.aether_forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, host["x"], host["vel"],
+                                host["edges"], host["edge_attr"], host["charges"])
+    assert scale_rel_err(got, want) <= 1e-5
+    assert scale_rel_err(before.cpu(), want) > 1e-4                  # the step did move the output
+
+
 @pytest.mark.parametrize("n", [1, 7, 5120, 300001])
 def test_mse_loss_grad_matches_torch(n):
     """aether_mse_loss_grad (nn.MSELoss + the seed of its backward, main.py:86,289-290) vs torch autograd in fp64."""
