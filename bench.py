@@ -81,38 +81,20 @@ def _rollout_parity(sd, inp, model, dev, T=20):
 
 
 def _mse_vs_simulated_truth(sd, model, dev, B, N, D, burn_in=29, pred=20):
-    """Metric 2 as experiments/electrostatic/evaluate.py:33-70 runs it, for the state2state module:
-    trajectories from the build's own electrostatic simulator (aether_sim_electrostatic: N charged balls + 20 static
-    field charges in a +-5 box, 5,000 leap-frog steps sampled every 100 -> 49 frames); the model sees frame
-    `burn_in - 1` (velocity = the last frame difference, dt = one frame) and predicts `pred` frames; per-step MSE
-    over (sample, particle, feature) on un-normalised values, HIP rollout and fp64 oracle side by side."""
-    from oracle import aether_oracle as O
-    from aether_amd.edges import get_edges
-    from aether_amd.rollout import rollout
-    from aether_amd.sim import ElectrostaticFieldSim
-    import contextlib, io
-    with contextlib.redirect_stdout(io.StringIO()):
-        sim = ElectrostaticFieldSim(n_balls=N, loc_std=(N / 5.0) ** (1.0 / 3.0), dim=D, static_balls=20, device=dev)
-        loc, vel, _, charges = sim.sample_trajectories(B, T=5000, sample_freq=100, as_tensor=True)
-    loc = loc[:, :, :N].float()                                  # [B, 49, N, D] moving balls only
-    q = charges[:, :N].float().reshape(B * N, 1)
-    x0 = loc[:, burn_in - 1].reshape(B * N, D).contiguous()
-    v0 = (loc[:, burn_in - 1] - loc[:, burn_in - 2]).reshape(B * N, D).contiguous()
-    truth = loc[:, burn_in:burn_in + pred].permute(1, 0, 2, 3).reshape(pred, B * N, D).cpu()
-    edges = get_edges(B, N)
+    """Metric 2 as experiments/electrostatic/evaluate.py:33-70 runs it, for the state2state module, as a
+    parity statement (oracle/metric2.py): the HIP device rollout AND the fp32 oracle against the fp64 oracle on
+    trajectories of the build's electrostatic simulator -- with the stated seed-1 weights, whose rollout is chaotic
+    (MSE 0.05 -> 5: no fp32 evaluation, the reference's included, holds 1e-5 there), and with the same model after 200
+    captured training steps on one-frame targets of the burn-in frames, where the MSE difference does hold 1e-5."""
+    from oracle import metric2 as M2
+    data = M2.simulate(dev, B, N, D, burn_in, pred)
+    out = {"seed1_weights": M2.report(sd, model, data)}
     model.load_state_dict({k: v.to(dev) for k, v in sd.items()})
-    with torch.no_grad():
-        got = rollout(model, x0, v0, [e.to(dev) for e in edges], q, pred).cpu()
-        sd64 = {k: v.double() for k, v in sd.items()}
-        want = O.rollout(sd64, x0.cpu().double(), v0.cpu().double(), edges, q.cpu().double(), pred)
-    m_hip = ((got.double() - truth.double()) ** 2).mean(dim=(1, 2))
-    m_ora = ((want - truth.double()) ** 2).mean(dim=(1, 2))
-    pick = [0, 9, pred - 1]
-    return {"protocol": f"burn-in {burn_in} frames, predict {pred}; electrostatic simulator, {B} x {N} balls + 20 static charges",
-            "mse_hip_steps_1_10_20": [float(m_hip[k]) for k in pick],
-            "mse_oracle_fp64_steps_1_10_20": [float(m_ora[k]) for k in pick],
-            "max_rel_mse_difference_over_steps": float(((m_hip - m_ora).abs() / m_ora).max()), "tolerance": 1e-5,
-            "trajectory_max_rel_err": float((got.double() - want).abs().max() / want.abs().max())}
+    loss = M2.train_on_frames(model, data, steps=200, lr=1e-3)
+    sd_t = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    out["after_200_training_steps"] = dict(M2.report(sd_t, model, data), final_training_loss=loss)
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    return out
 
 
 def _parity(sd, inp, model, dev, sd_trained=None):
