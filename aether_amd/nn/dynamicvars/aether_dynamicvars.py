@@ -138,12 +138,71 @@ class AetherDynamicVars(nn.Module):
                                                     n_present=n_t)
         return last, new_h, new_c, new_dec
 
+    def reserve(self, n_objects_max, k=10):
+        """Size the workspaces of the three stages for scenes of up to ``n_objects_max`` present objects (kNN graphs with
+        ``k`` neighbours).  Captured steps (``predict_future(graph=True)``) bake workspace addresses into their graphs, so
+        no stage may re-allocate after the first capture: this runs before it, outside any capture."""
+        lib = _lib.load()
+        dev = next(self.parameters()).device
+        need_f = need_e = need_d = 0
+        ps_e = self.encoder._param_struct()
+        for n in range(2, int(n_objects_max) + 1):                    # host arithmetic only; the sizes need not be monotone
+            E = n * min(int(k), n - 1)
+            need_f = max(need_f, lib.aether_dyn_field_workspace_bytes(n, self.field_hidden))
+            need_e = max(need_e, lib.aether_dyn_prior_workspace_bytes(self.encoder.hidden_size, self.encoder.rnn_hidden_size,
+                                                                      ps_e[2], n, E))
+            need_d = max(need_d, lib.aether_dyn_decoder_workspace_bytes(self.decoder.msg_out_shape, n, E))
+        for mod, need in ((self, need_f), (self.encoder, need_e), (self.decoder, need_d)):
+            if mod._ws is None or mod._ws.numel() < need or mod._ws.device != dev:
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.AetherHipError("reserve() must run outside graph capture")
+                mod._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+
+    def _captured_step(self, args):
+        """``_step_core`` as a hipGraph replay, one graph per (present objects, edges, slots) signature.
+
+        Round 2 tried this and met a GPU memory access fault at the largest scene of a test.  The recorded
+        facts point at buffer lifetime, not at the kernels (the eager path launches the same ones): the stages re-allocated
+        their workspace whenever a step needed more than the last -- inside a capture that is an allocation from the
+        graph's pool, and the buffer it replaced went back to a pool that earlier graphs still write to on replay.  Here
+        nothing persistent is allocated during capture: workspaces are sized for the largest scene first (``reserve``),
+        weight-derived caches are built by an eager warm-up call of the same signature, and the capture is discarded if a
+        workspace pointer moved nevertheless.  The warm-up also validates, once per signature, the sizes the host
+        hands down: the mask really has ``n_present`` non-zero entries."""
+        state, present, ni, gs, gr, e2n, ph, pc, dec, u = args
+        key = (int(ni.numel()), int(gs.numel()), tuple(e2n.shape), tuple(state.shape), tuple(ph.shape), tuple(dec.shape))
+        cache = self.__dict__.setdefault("_step_graphs", {})
+        hit = cache.get(key)
+        if hit is None:
+            if int((present != 0).sum()) != key[0]:                  # one device round trip per NEW signature only
+                raise ValueError("node_inds and the mask disagree about the number of present objects")
+            self.reserve(state.shape[1])
+            static = [a.clone() for a in args]
+            self._step_core(*static)                                  # eager: image caches, pointer structs, lazy init
+            torch.cuda.synchronize()
+            ptrs = (self._ws.data_ptr(), self.encoder._ws.data_ptr(), self.decoder._ws.data_ptr())
+            g = torch.cuda.CUDAGraph()
+            pool = self.__dict__.setdefault("_step_pool", torch.cuda.graph_pool_handle())
+            with torch.cuda.graph(g, pool=pool):
+                outs = self._step_core(*static)
+            if ptrs != (self._ws.data_ptr(), self.encoder._ws.data_ptr(), self.decoder._ws.data_ptr()):
+                raise _lib.AetherHipError("a workspace was re-allocated during capture: the graph is not safe to replay")
+            hit = cache[key] = (g, static, outs)
+        g, static, outs = hit
+        for dst, src in zip(static, args):
+            dst.copy_(src)
+        g.replay()
+        # graphs share one memory pool: a later replay of another signature may reuse these buffers
+        return tuple(o.clone() for o in outs)
+
     @torch.no_grad()
-    def predict_future(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
+    def predict_future(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None, graph=False):
         """:245-273.  inputs [1, T, Nmax, 4], masks / burn_in_masks [1, T, Nmax], node_inds[0][t], graph_info[0][t]: the
         present objects and their graph per time step.  ``uniform``: per-step Gumbel draws (list of [E_t, K]).
         With B > 1 scenes (inputs [B, T, Nmax, 4], node_inds[b][t], graph_info[b][t], uniform[t][b]) every time step is
-        ONE batched call per stage (predict_future_batched) -- the reference raises on batch > 1 (:588-591)."""
+        ONE batched call per stage (predict_future_batched) -- the reference raises on batch > 1 (:588-591).
+        ``graph=True`` (one scene): every step replays a captured hipGraph of its signature (``_captured_step``) -- one
+        launch per step instead of ~110; bit-identical to the eager loop."""
         if inputs.size(0) > 1:
             return self.predict_future_batched(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         n_steps = inputs.size(1) - 1
@@ -167,7 +226,7 @@ class AetherDynamicVars(nn.Module):
                 args = (state.to(torch.float32), present.to(dev).to(torch.float32), ni_t.to(dev), gs, gr, e2n,
                         prior_state[0], prior_state[1], dec_state.to(torch.float32),
                         u_t.to(dev).reshape(gs.numel(), self.num_edge_types).to(torch.float32))
-                last, new_h, new_c, dec_state = self._step_core(*args)
+                last, new_h, new_c, dec_state = self._captured_step(args) if graph else self._step_core(*args)
                 prior_state = (new_h, new_c)
             else:                                                  # nobody or one object: the stages' own early exits
                 field, _ = self.predict_field(state, present, n_present=n_t)

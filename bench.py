@@ -34,6 +34,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 WORKLOAD = dict(name="electrostatic-2d-N20-B128", B=128, N=20, D=2)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF; never the 2:1-sparsity figure)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense
 FLOP_PER_EDGE_LAYER_N = 2 * (192 * 64 + 64 * 64)      # locs.py:206-212 on [x_s|x_r|e] (192 -> 64 -> 64)
 FLOP_PER_EDGE_STEP = {2: 108672, 3: 109824}
@@ -615,6 +616,29 @@ def main():
                         "executed_flop_per_launch": executed,
                         "source_of_traffic_and_executed": "profiles/traffic.json (rocprofv3 --pmc passes of this command)"
                                                           if traffic is not None else None}
+                # Which pipe binds?  `frac` above prices the reference formulation's flops against the fp32 MFMA peak (the
+                # precision delivered); the kernel executes its contractions as bf16 terms, so three more fractions say what
+                # the hardware is doing (PMC passes of this command, profiles/traffic.json): the bf16 matrix pipe, the fp32
+                # MFMAs (which issue on the vector ALU) and the vector ALU's instruction issue.  None can exceed 1.
+                pm = tj.get(dom_name + "_pipes") if traffic is not None and isinstance(tj, dict) else None
+                if pm:
+                    t_s = launch_us * 1e-6
+                    clk, simds = 2.4e9, 1024                      # peak shader clock the guide's peaks assume; 256 CUs x 4 SIMDs
+                    pipes = {
+                        "fp32_equivalent": roof["frac"],
+                        "bf16_matrix_pipe": pm["bf16_mfma_insts"] * 16384.0 / t_s / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+                        "fp32_mfma_on_valu": pm["fp32_mfma_insts"] * 2048.0 / t_s / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                        "valu_issue": (pm["valu_insts"] * 4.0 + pm["fp32_mfma_insts"] * 32.0) / (simds * t_s * clk),
+                    }
+                    roof["pipes"] = {k: float(f"{v:.4f}") for k, v in pipes.items()}
+                    roof["pipes_note"] = ("bf16_matrix_pipe: executed v_mfma_f32_16x16x32_bf16 x 16,384 FLOP over 2.5 PFLOP/s dense; "
+                                          "fp32_mfma_on_valu: executed v_mfma_f32_16x16x4_f32 x 2,048 FLOP over 157.3 TFLOP/s; valu_issue: "
+                                          "(VALU instructions x 4 cycles + fp32 MFMAs x 32 cycles) over 1,024 SIMDs x launch time x 2.4 GHz "
+                                          "-- a lower bound (transcendentals take 8); measured matrix-pipe busy "
+                                          f"{pm.get('matrix_pipe_busy')}")
+                    exec_only = {k: v for k, v in pipes.items() if k != "fp32_equivalent"}
+                    roof["binding_pipe"] = max(exec_only, key=exec_only.get)
+                    assert all(v <= 1.0 for v in exec_only.values()), exec_only
                 if roof["frac"] > 1.0:
                     # possible off the headline size: `achieved` counts the reference formulation's flops (192 -> 64 first
                     # layer per edge), the kernel executes ~0.6x of them (node-term split) and runs the 64 x 64

@@ -274,3 +274,49 @@ def test_decoder_and_encoder_two_objects():
                                              (st[0].cuda(), st[1].cuda()), field.cuda())
     assert scale_rel_err(gl.cpu(), wl) <= TOL and scale_rel_err(gh0.cpu(), wh0) <= TOL and scale_rel_err(gc0.cpu(), wc0) <= TOL
 
+
+
+def test_predict_future_captured_steps_equal_the_eager_loop():
+    """``predict_future(graph=True)``: every step replays a captured hipGraph of its signature.  14 steps over scenes
+    whose number of present objects changes (24 -> 12 -> 3 -> 40, the last being the size at which round 2's attempt
+    ended in a memory access fault: workspaces re-allocated during capture) -- bit-identical to the eager
+    loop, twice (the second pass replays every graph from the cache), and a mask that disagrees with node_inds raises."""
+    from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+    import sys, os
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_dynamicvars import MODEL_PARAMS, perturb_bn_
+    params = dict(MODEL_PARAMS, decoder_hidden=256, encoder_hidden=256, num_edge_types=4, pos_representation="polar",
+                  field_hidden=128, encoder_rnn_hidden=64)
+    torch.manual_seed(31)
+    model = AetherDynamicVars(params, device=None).eval()
+    perturb_bn_(model)
+    model = model.cuda()
+    g = torch.Generator().manual_seed(32)
+    T, N = 15, 40
+    inputs = torch.randn(1, T, N, 4, generator=g)
+    counts = [24, 24, 12, 12, 3, 3, 40, 40, 24, 12, 40, 3, 24, 40, 40]
+    masks = torch.zeros(1, T, N)
+    for t, c in enumerate(counts):
+        masks[0, t, torch.randperm(N, generator=g)[:c]] = 1
+    burn = torch.ones(1, T, N)
+    burn[:, 5:] = 0
+    node_inds, graph_info, U = [], [], []
+    for step in range(T):
+        nv = int(masks[0, step].sum())
+        send, recv = get_knn_graph_info(inputs[0, step].cuda(), masks[0, step].cuda(), nv)
+        e2n = torch.argsort(recv, stable=True).view(-1, min(10, nv - 1))
+        graph_info.append((send, recv, e2n))
+        node_inds.append(masks[0, step].nonzero()[:, -1].cuda())
+        U.append(torch.rand(send.numel(), 4, generator=g).cuda())
+    args = (inputs.cuda(), masks.cuda(), [node_inds], [graph_info], burn.cuda())
+    eager = model.predict_future(*args, uniform=U[:T - 1])
+    for rep in range(2):
+        got = model.predict_future(*args, uniform=U[:T - 1], graph=True)
+        assert torch.equal(got, eager), rep
+    assert len(model._step_graphs) == 4                       # one graph per signature: 24, 12, 3 and 40 present objects
+    bad = masks.clone()
+    bad[0, 0, :] = 1                                            # the mask now says 40 objects, node_inds still 24
+    model._step_graphs.clear()
+    with pytest.raises(ValueError):
+        model.predict_future(inputs.cuda(), bad.cuda(), [node_inds], [graph_info], burn.cuda(), uniform=U[:T - 1], graph=True)

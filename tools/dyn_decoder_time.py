@@ -62,3 +62,11 @@ for N in (20, 40):
     dt = time.perf_counter() - t0
     print("predict_future N=%d, %d steps: %.1f ms (%.2f ms per step: field + kNN + prior step + sample + decoder step)"
           % (N, T - 1, dt * 1e3, dt * 1e3 / (T - 1)))
+    model.predict_future(inputs[:, :5], masks[:, :5], node_inds, graph_info, burn[:, :5], graph=True)       # capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.predict_future(inputs, masks, node_inds, graph_info, burn, graph=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("predict_future N=%d, graph=True (one captured step per signature): %.1f ms (%.2f ms per step)"
+          % (N, dt * 1e3, dt * 1e3 / (T - 1)))
