@@ -212,6 +212,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int64_t FUSED_TABLE_MAX_EDGES = 4 << 20;
 int g_fused_split = 1;        // aether_set_option("fused_split", 0|1): two workgroups per group when CUs are idle
+int g_fused_pair_stride = 8;  // aether_set_option("fused_pair_stride", 1|8): distance of the two workgroups of a split group
+                              // (8: both on one XCD -- workgroup b runs on XCD b % 8 -- 47.25 -> 46.56 us per launch at cfg2; a
+                              // placement hint only: the hand-off protocol is the cross-XCD one either way)
 
 struct GraphLayout {
     size_t perm, send_s, recv_s, rowptr, gsel, wgdesc, tdesc, tsel, tdst, lorder, nrange, hflags, sperm, srowptr, keys,
@@ -891,6 +894,11 @@ int aether_set_option(const char* name, int value) {
         g_fused_split = value != 0;
         return AETHER_OK;
     }
+    if (!strcmp(name, "fused_pair_stride")) {     // takes effect at the next aether_graph_build
+        if (value != 1 && value != 8) return fail(AETHER_EINVAL, "set_option: fused_pair_stride is 1 or 8");
+        g_fused_pair_stride = (int)value;
+        return AETHER_OK;
+    }
     if (!strcmp(name, "fused_backward")) {   // 0: layer-by-layer backward kernels even for small-graph groups
         g_fused_backward = value != 0;
         return AETHER_OK;
@@ -1091,9 +1099,7 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
             };
             for (int pass = 0; pass < 2; ++pass) {
             wgs.clear(); tiles.clear(); mgn = 0; mge = 0;
-            for (int k = 0; k < n_grp; ++k) {
-                const int a = grp[k], b = grp[k + 1];
-                if (!split) { add_wg(a, b, a, b, -1); continue; }
+            auto split_point = [&](int a, int b) {
                 const int64_t tot = h_rowptr[b] - h_rowptr[a];
                 int nm = a + 1;
                 int64_t best = -1;
@@ -1101,9 +1107,24 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
                     int64_t left = h_rowptr[c] - h_rowptr[a], d = left * 2 > tot ? left * 2 - tot : tot - left * 2;
                     if (best < 0 || d < best) { best = d; nm = c; }
                 }
-                const int idx = (int)wgs.size();
-                add_wg(a, b, a, nm, idx + 1);
-                add_wg(a, b, nm, b, idx);
+                return nm;
+            };
+            // Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8: tools/micro/xcc_map.hip).
+            // With option "fused_pair_stride" = 8 the two halves of a group sit 8 apart (blocks of 16: the eight first
+            // halves, then the eight second halves), i.e. on the SAME XCD and behind the same L2; 1 = adjacent (different XCDs).
+            const int pstride = split ? g_fused_pair_stride : 1;
+            for (int k0 = 0; k0 < n_grp; k0 += pstride) {
+                const int kn = std::min(pstride, n_grp - k0);
+                if (!split) { add_wg(grp[k0], grp[k0 + 1], grp[k0], grp[k0 + 1], -1); continue; }
+                const int base = (int)wgs.size();
+                for (int j = 0; j < kn; ++j) {
+                    const int a = grp[k0 + j], b = grp[k0 + j + 1];
+                    add_wg(a, b, a, split_point(a, b), base + kn + j);
+                }
+                for (int j = 0; j < kn; ++j) {
+                    const int a = grp[k0 + j], b = grp[k0 + j + 1];
+                    add_wg(a, b, split_point(a, b), b, base + j);
+                }
             }
             // a split workgroup keeps two runs of partial rows in LDS (FusedLds::PART_ROWS): at most 16 tiles
             if (split && mge > 16 * 16) { split = false; continue; }

@@ -674,7 +674,8 @@ int aether_adamw_step(const AetherAdamWTensor* tensors, int n_tensors, float* st
 
 /*
  * Tuning knobs (process-wide; not thread-safe): "fused_split" 0|1 (two workgroups per group when
- * there are fewer groups than half the CUs; read by aether_graph_build),
+ * there are fewer groups than half the CUs; read by aether_graph_build), "fused_pair_stride" 1|8 (index distance of the
+ * two workgroups of a split group: 8, the default, puts both on one XCD; read by aether_graph_build),
  * "outer_defer_max_edges" n (aether_backward keeps every layer's weight-gradient operands and
  * multiplies them in one launch when n_edges <= n, default 2^20; changes aether_workspace_bytes),
  * "filter_wg_target" n (the anisotropic-filter GEMM of the seq2seq / variable-N steps splits its k-groups, up to
