@@ -322,8 +322,13 @@ class Aether(nn.Module):
         if hidden_size == 3 * num_dims:
             raise ValueError("hidden_size == 3 * num_dims is not supported (the reference then builds layer_1 without its "
                              "res Linear, locs.py:214-218)")
-        if dropout_prob != 0.0:
-            raise ValueError("dropout_prob must be 0.0 (the runner's value, main.py:143)")
+        if not (0.0 <= float(dropout_prob) < 1.0):
+            raise ValueError("dropout_prob must lie in [0, 1)")
+        # nn.Dropout sits between the layers of out_mlp (locs.py:160-168).  In eval() it is the identity, which is what
+        # the kernels compute for any p; a TRAINING forward with p > 0 is refused (forward below): the runner constructs
+        # Aether with dropout_prob=0.0 (experiments/lorentz/main.py:143), and torch's CUDA and CPU generators would give
+        # different masks anyway, so there is nothing to be bit-compatible with
+        self.dropout_prob = float(dropout_prob)
         self.gnn = _GNN(input_size, hidden_size, dropout_prob, num_dims,
                         additional_features=num_dims)
         self.num_dims = num_dims
@@ -496,6 +501,9 @@ class Aether(nn.Module):
             # return a result whose input gradients would silently be missing
             raise NotImplementedError("aether_amd.Aether: gradients w.r.t. x / vel / edge_attr_orig / charges are not "
                                       "implemented (parameter gradients only); detach the inputs")
+        if self.dropout_prob > 0.0 and self.training:     # (nn.Dropout keys on the module's mode, not on autograd's)
+            raise NotImplementedError("aether_amd.Aether: dropout_prob > 0 is supported in eval() mode only (identity); "
+                                      "a train()-mode forward with active dropout is not implemented")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         if self.hidden_size != 64:      # narrow model: the zero-padded 64-wide engine computes it (same kernels)
             eng = self._sync_engine()

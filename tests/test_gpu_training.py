@@ -317,3 +317,25 @@ def test_graphed_step_with_library_loss_and_optimizer_matches_the_torch_ones():
         assert abs(a - b) <= 1e-5 * abs(b)
     for k in res["torch"][1]:
         assert scale_rel_err(res["aether"][1][k], res["torch"][1][k]) <= 1e-4, k
+
+
+def test_dropout_is_identity_in_eval_and_refused_in_training():
+    """out_mlp's nn.Dropout (locs.py:160-168): identity in eval(), so a model built with dropout_prob > 0 gives the
+    p = 0 result there; a training forward with active dropout is refused loudly (not implemented)."""
+    D = 2
+    inp = make_batch(4, 20, D, seed=3)
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    dev["edges"] = [e.cuda() for e in inp["edges"]]
+    torch.manual_seed(1)
+    m0 = Aether(2 * D, 64, 0.0, D, device="cuda")
+    torch.manual_seed(1)
+    m1 = Aether(2 * D, 64, 0.3, D, device="cuda")
+    call = lambda m: m(dev["h"], dev["x"], dev["edges"], dev["vel"], dev["edge_attr"], dev["charges"])
+    m0.eval(); m1.eval()
+    with torch.no_grad():
+        assert torch.equal(call(m0), call(m1))
+    m1.train()
+    with pytest.raises(NotImplementedError):
+        call(m1)
+    with torch.no_grad(), pytest.raises(NotImplementedError):      # nn.Dropout keys on train(), not on autograd
+        call(m1)

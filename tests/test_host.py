@@ -65,7 +65,9 @@ def test_ctor_rejects_unsupported():
     with pytest.raises(ValueError):
         Aether(4, 6, 0.0, 2, device="cpu")               # hidden_size == 3 D: the reference drops layer_1.res there
     with pytest.raises(ValueError):
-        Aether(4, 64, 0.1, 2, device="cpu")
+        Aether(4, 64, 1.0, 2, device="cpu")              # dropout_prob in [0, 1)
+    m = Aether(4, 64, 0.1, 2, device="cpu")              # p > 0: same parameters / state_dict (nn.Dropout has none) ...
+    assert list(m.state_dict().keys()) == list(Aether(4, 64, 0.0, 2, device="cpu").state_dict().keys())
 
 
 def test_narrow_hidden_size_keeps_the_reference_parameter_shapes():
