@@ -32,6 +32,7 @@
 #include "fused.h"
 #include "backward.h"
 #include "fused_bwd.h"
+#include "edge_acc.h"
 #include "seq2seq.h"
 #include "s2s_filter.h"
 #include "s2s_step.h"
@@ -261,6 +262,8 @@ constexpr int OUTER_MAX_CHUNKS = 256;      // workgroups (= partials) per task
 // Up to this many edges the backward keeps the operands of every layer's weight gradients alive and
 // multiplies all of them in one launch at the end (12 more [E, 64] buffers: 3 KiB per edge).
 int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defer_max_edges", n)
+int g_edge_acc = 1;                             // aether_set_option("edge_acc", 0|1): above that threshold, the edge-level weight
+                                                // gradients are accumulated inside the edge kernel (edge_acc.h)
 int g_outer_tiles_per_wave = 0;                 // aether_set_option("outer_tiles_per_wave", n): 16-row tiles per wave of k_outer (0: by task size)
 int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
 int g_linear_kwaves = 4;                        // aether_set_option("linear_kwaves", 1 | 4): waves of a workgroup that split a small layer's k-groups
@@ -315,8 +318,10 @@ struct WsLayout {
             DPSl[k] = own ? take(nn * H) : DPSl[0];
             DPRl[k] = own ? take(nn * H) : DPRl[0];
             Gl[k] = own ? take(ee * H) : Gl[0];
-            H1l[k] = own ? take(ee * H) : H1l[0];
-            DP2l[k] = own ? take(ee * H) : DP2l[0];
+            // (not deferred + edge_acc: h and dpre2 never leave the edge kernel -- 2 x 8.6 GB less at config 5's shard)
+            const bool rows_needed = defer || !g_edge_acc;
+            H1l[k] = own ? take(rows_needed ? ee * H : 64) : H1l[0];
+            DP2l[k] = own ? take(rows_needed ? ee * H : 64) : DP2l[0];
         }
         wt = take((size_t)160 * 1024); DN = take(nn * H);
         O1 = take(nn * H); O2 = take(nn * H); DPO1 = take(nn * H); DPO2 = take(nn * H); DY = take(nn * 16);
@@ -630,6 +635,9 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     const unsigned ngrid = (unsigned)ntile;
     const unsigned egrid = (unsigned)((etile + 3) / 4 < 512 ? (etile + 3) / 4 : 512);    // 2 workgroups per CU
     auto optin = [&](const void* k, size_t lds) -> int { return ensure_dynamic_lds(k, lds); };
+    // edge-level weight gradients inside the edge kernel (edge_acc.h): one 4-wave workgroup per CU, one partial each
+    const unsigned agrid = (unsigned)((etile + 3) / 4 < 256 ? (etile + 3) / 4 : 256);
+    const bool acc_path = g_edge_acc && !W.defer && E > 0 && (size_t)agrid * EA_PART <= W.partial_cap * (size_t)OUTER_PART;
     // ---- transposed weight copies (one launch)
     TransposeBatch TB;
     const BwdWT WT = transposed_weights<D>(P, wp(W.wt), TB);     // written by the forward (prepare_weights)
@@ -668,7 +676,29 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         if (E > 0) {
             const size_t lds = (size_t)(4 * H * LDW) * 4;
             ProfScope* pse = new ProfScope(KB_EDGE, st);
-            if (l == 1) {
+            if (acc_path) {
+                // large graphs: the two edge-level products of the layer accumulate inside the edge kernel (edge_acc.h)
+                const size_t lds_a = (size_t)(2 * SPLIT_WIMG + 2 * H * LDW + 4 * EA_STG) * 4;
+                EdgeAccOut O{};
+                O.w2 = gw2; O.b2 = gb2;
+                if (l == 1) {
+                    if (optin(reinterpret_cast<const void*>(kb_edge_acc<true>), lds_a)) return AETHER_EHIP;
+                    kb_edge_acc<true><<<dim3(agrid), dim3(256), lds_a, st>>>(
+                        P.l1_msg_w0, F1, P.l1_msg_b0, w2, b2, WT.msg_w0t[0], WT.msg_w2t[0], nullptr, nullptr, nullptr,
+                        wp(W.feat), send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), 1, bG, wp(W.DA), partial,
+                        wp(W.wimg) + fused_wimg_offset(1, 0), wp(W.wimg) + fused_wimg_offset(1, 1), E);
+                    O.we = Gr.l1_msg_w0; O.ldwe = F1; O.ncols = F1; O.b1 = Gr.l1_msg_b0; O.nb_e = 2;
+                } else {
+                    if (optin(reinterpret_cast<const void*>(kb_edge_acc<false>), lds_a)) return AETHER_EHIP;
+                    kb_edge_acc<false><<<dim3(agrid), dim3(256), lds_a, st>>>(
+                        P.ln_msg_w0[l - 2], 0, nullptr, w2, b2, WT.msg_w0t[l - 1] + 2 * H * H, WT.msg_w2t[l - 1],
+                        wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), nullptr, send_s, recv_s, rowptr, wp(W.DN),
+                        wp(W.DE), l < 4 ? 1 : 0, bG, nullptr, partial, wp(W.wimg) + fused_wimg_offset(l, 0),
+                        wp(W.wimg) + fused_wimg_offset(l, 1), E);
+                    O.we = Gr.ln_msg_w0[l - 2] + 2 * H; O.ldwe = 3 * H; O.ncols = H; O.b1 = nullptr; O.nb_e = 4;
+                }
+                k_edge_acc_reduce<<<dim3(EA_PART / 64), dim3(1024), 0, st>>>(partial, (int)agrid, O);
+            } else if (l == 1) {
                 if (optin(reinterpret_cast<const void*>(kb_edge<true>), lds)) return AETHER_EHIP;
                 kb_edge<true><<<dim3(egrid), dim3(256), lds, st>>>(
                     P.l1_msg_w0, F1, P.l1_msg_b0, w2, b2, WT.msg_w0t[0], WT.msg_w2t[0], nullptr, nullptr, nullptr,
@@ -682,9 +712,11 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
                     wp(W.DE), l < 4 ? 1 : 0, bG, bH1, bDP2, nullptr, E);
             }
             delete pse;
-            L.add(bDP2, H, H, bH1, H, H, E, gw2, H, gb2);
-            if (l == 1) L.add(bG, H, H, wp(W.feat), FPAD, F1, E, Gr.l1_msg_w0, F1, Gr.l1_msg_b0);
-            else L.add(bG, H, H, wp(W.e[l - 2]), H, H, E, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
+            if (!acc_path) {
+                L.add(bDP2, H, H, bH1, H, H, E, gw2, H, gb2);
+                if (l == 1) L.add(bG, H, H, wp(W.feat), FPAD, F1, E, Gr.l1_msg_w0, F1, Gr.l1_msg_b0);
+                else L.add(bG, H, H, wp(W.e[l - 2]), H, H, E, Gr.ln_msg_w0[l - 2] + 2 * H, 3 * H, nullptr);
+            }
         } else {
             HIP_OK(hipMemsetAsync(gw2, 0, (size_t)H * H * 4, st));
             HIP_OK(hipMemsetAsync(gb2, 0, (size_t)H * 4, st));
@@ -901,6 +933,10 @@ int aether_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "fused_backward")) {   // 0: layer-by-layer backward kernels even for small-graph groups
         g_fused_backward = value != 0;
+        return AETHER_OK;
+    }
+    if (!strcmp(name, "edge_acc")) {                // changes aether_workspace_bytes(): set before sizing workspaces
+        g_edge_acc = value != 0;
         return AETHER_OK;
     }
     if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces

@@ -1,0 +1,279 @@
+// edge_acc.h -- edge MLP backward of one layer for LARGE graphs with the layer's edge-level weight gradients
+// accumulated on chip (round 3).  Included after backward.h and fused_bwd.h.
+//
+// backward.h's kb_edge writes, per edge and layer, the rows G = dL/dpre1, h and dpre2 (768 B) for k_outer to multiply
+// afterwards (which reads them again, with e_prev: 1 KB): at the 33.5 M-edge shard of BASELINE config 5 that is 34 GB of
+// HBM traffic per layer for the two products and 24 ms of a 106 ms training step (profiles/r02_cfg5shard_bench.json).
+// kb_edge_acc keeps the tile's four operand tiles in wave-private LDS rows and accumulates
+//     dW2 += dpre2 (x) h          dW_e += G (x) e_prev   (layer 1: dW1 += G (x) features)         db2 += dpre2, db1 += G
+// in registers over all tiles of the wave (fused_bwd.h's block scheme, fb_outer16), as k_fused_bwd does for small graphs;
+// only G (read by the node-sum kernels) and the message gradient DE / DA still go to memory.  One 4-wave workgroup per CU
+// (the accumulators need the AGPR half of the register file); at the end the four waves add up in wave order through LDS
+// and write ONE partial per workgroup; k_edge_acc_reduce adds the partials in workgroup order (fixed 16-group tree):
+// no atomics, bit-stable.  Used when the deferred all-in-one product launch does not apply (E > outer_defer_max_edges).
+#pragma once
+
+namespace {
+
+constexpr int EA_REGS = 128 + 32;                   // accumulator registers per lane: dW2 64 | dW_e 64 | db2 16 | db1 16
+constexpr int EA_PART = EA_REGS * 64;               // floats per workgroup partial, [register][lane]
+constexpr int EA_STG = 4 * 16 * FB_SA;              // staging floats per wave: dpre2 | h | G | e_prev (features)
+
+template <bool FIRST>
+__global__ void __launch_bounds__(256)
+kb_edge_acc(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64][192]*/, int f1,
+            const float* __restrict__ b_in, const float* __restrict__ w2g, const float* __restrict__ b2g,
+            const float* __restrict__ w_in_t /*FIRST: W1^T [32][64] else W_e^T [64][64]*/,
+            const float* __restrict__ w2t, const float* __restrict__ Ps, const float* __restrict__ Pr,
+            const float* __restrict__ e_prev, const float* __restrict__ feat,
+            const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
+            const int32_t* __restrict__ rowptr, const float* __restrict__ DN, float* __restrict__ DE,
+            int have_de, float* __restrict__ G, float* __restrict__ DA, float* __restrict__ partial,
+            const float* __restrict__ img_in /*split image of W_e (FIRST: of W1, K padded to 32)*/,
+            const float* __restrict__ img_2 /*split image of W2*/, int64_t n_edges) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // the two recompute products run as six bf16 terms on the forward's split images (common.h gemm_split: fp32-equivalent,
+    // 96 matrix-pipe instructions of 16 cycles for 128 fp32 MFMAs of 32); the two transposed products stay fp32 MFMAs
+    float* wi = smem;                  // split image of W_in [SPLIT_WIMG] (FIRST: half of it)
+    float* w2 = wi + SPLIT_WIMG;       // split image of W2
+    float* w2ts = w2 + SPLIT_WIMG;     // W2^T   [64][LDW]
+    float* wit = w2ts + H * LDW;       // W_in^T [64 | 32][LDW]
+    float* stg = wit + H * LDW;        // [4 waves][4][16][FB_SA]
+    for (int idx = threadIdx.x; idx < (FIRST ? SPLIT_WIMG / 2 : SPLIT_WIMG) / 4; idx += 256) st4(wi + 4 * idx, ld4(img_in + 4 * idx));
+    for (int idx = threadIdx.x; idx < SPLIT_WIMG / 4; idx += 256) st4(w2 + 4 * idx, ld4(img_2 + 4 * idx));
+    if (FIRST) {
+        for (int idx = threadIdx.x; idx < FPAD * (H / 4); idx += 256) {
+            const int r = idx >> 4, c = (idx & 15) * 4;
+            st4(wit + r * LDW + c, ld4(w_in_t + (size_t)r * H + c));
+        }
+    } else {
+        stage_weight64<256>(wit, w_in_t, H);
+    }
+    stage_weight64<256>(w2ts, w2t, H);
+    (void)w_in; (void)f1; (void)w2g;      // (kept in the signature: same argument list as kb_edge)
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    float* sa = stg + wave * EA_STG;   // dpre2
+    float* sb = sa + 16 * FB_SA;       // h
+    float* sg = sb + 16 * FB_SA;       // G
+    float* sc = sg + 16 * FB_SA;       // e_prev / features
+    const int64_t tiles = (n_edges + 15) >> 4;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    f32x4 accW2[4][4], bs2[4], bs1[4];
+    f32x4 accWe[4][FIRST ? 2 : 4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        bs2[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bs1[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) accW2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < (FIRST ? 2 : 4); ++b) accWe[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto clampk = [&](int64_t tt) { const int64_t k = 16 * tt + i; return k < n_edges ? k : n_edges - 1; };
+    if (t < tiles) {
+        // Software pipeline, two stages deep (one wave per SIMD: nobody else hides a tile's memory round trip): the ROWS of
+        // tile t + stride and the INDICES of tile t + 2 stride are requested while tile t computes.
+        f32x4 nbop[4], nps[4], npr[4], ndn[4], ndev[4];      // (P_s and P_r rows stay apart: adding them here would wait for them)
+        int ndeg;
+        auto request_rows = [&](int64_t kk, int32_t ss, int32_t rr) {
+            if (FIRST) {
+                nbop[0] = ld4(feat + kk * FPAD + 4 * q);
+                nbop[1] = ld4(feat + kk * FPAD + 16 + 4 * q);
+            } else {
+                load_tile64(nbop, e_prev, kk, H, q);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    nps[mb] = ld4(Ps + (int64_t)ss * H + 16 * mb + 4 * q);
+                    npr[mb] = ld4(Pr + (int64_t)rr * H + 16 * mb + 4 * q);
+                }
+            }
+            load_tile64(ndn, DN, rr, H, q);
+            if (have_de) load_tile64(ndev, DE, kk, H, q);
+            ndeg = rowptr[rr + 1] - rowptr[rr];
+        };
+        {
+            const int64_t k0 = clampk(t);
+            request_rows(k0, send_s[k0], recv_s[k0]);
+        }
+        int64_t kn = clampk(t + stride < tiles ? t + stride : t);
+        int32_t s_n = send_s[kn], r_n = recv_s[kn];
+        for (; t < tiles; t += stride) {
+            int z = 0;
+            asm volatile("" : "+v"(z));      // opaque offset: weight fragments are re-read from LDS per tile
+            const int64_t k = 16 * t + i;
+            const bool ok = k < n_edges;
+            // ---- this tile's rows: requested one iteration ago
+            f32x4 bop[4], p1[4], dnv[4], dev[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) { bop[mb] = nbop[mb]; dnv[mb] = ndn[mb]; dev[mb] = ndev[mb]; }
+            if (FIRST) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(b_in + 16 * mb + 4 * q);
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) p1[mb] = nps[mb] + npr[mb];
+            }
+            const float inv = 1.0f / (float)(ndeg > 1 ? ndeg : 1);
+            // ---- the next tile's rows and the indices of the tile after it
+            request_rows(kn, s_n, r_n);
+            kn = clampk(t + 2 * stride < tiles ? t + 2 * stride : t);
+            s_n = send_s[kn];
+            r_n = recv_s[kn];
+            // the previous tile's products have read the staging rows (same wave: program order); park e_prev / features now
+            if (FIRST) {
+                st4(sc + i * FB_SA + 4 * q, ok ? bop[0] : f32x4{0.f, 0.f, 0.f, 0.f});
+                st4(sc + i * FB_SA + 16 + 4 * q, ok ? bop[1] : f32x4{0.f, 0.f, 0.f, 0.f});
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) st4(sc + i * FB_SA + 16 * mb + 4 * q, ok ? bop[mb] : f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            // ---- forward recompute: pre1, h = silu(pre1), pre2
+            f32x4 p2[4], h[4], sg1[4];
+            if (FIRST) {
+                f32x4 b2[2] = {bop[0], bop[1]};
+                gemm_split<4, 1>(wi + z, b2, p1, lane);
+            } else {
+                gemm_split<4, 2>(wi + z, bop, p1, lane);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                sg1[mb] = sigmoid4(p1[mb]);
+                h[mb] = p1[mb] * sg1[mb];
+                p2[mb] = ld4(b2g + 16 * mb + 4 * q);
+            }
+            gemm_split<4, 2>(w2 + z, h, p2, lane);
+            // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
+            f32x4 d2[4], dh[4], g[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x4 de = dnv[mb] * inv;
+                if (have_de) de += dev[mb];
+                d2[mb] = de * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
+                if (!ok) d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};             // rows past the end contribute nothing to the products
+                dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            gemm_tile<4, 4>(w2ts + z, LDW, d2, dh, i, q);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu_from_sigmoid(p1[mb], sg1[mb]);
+            if (FIRST) {
+                f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                gemm_tile<2, 4>(wit + z, LDW, g, da, i, q);
+                if (ok) { st4(DA + k * FPAD + 4 * q, da[0]); st4(DA + k * FPAD + 16 + 4 * q, da[1]); }
+            } else {
+                f32x4 dep[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_tile<4, 4>(wit + z, LDW, g, dep, i, q);
+                if (ok) store_tile64(DE, k, H, q, dep);
+            }
+            if (ok) store_tile64(G, k, H, q, g);
+            // ---- the layer's edge-level weight gradients, on chip
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
+                st4(sb + i * FB_SA + 16 * mb + 4 * q, h[mb]);
+                st4(sg + i * FB_SA + 16 * mb + 4 * q, g[mb]);          // (g of a row past the end is 0: dh = W2^T 0)
+                bs2[mb] += d2[mb];
+                bs1[mb] += g[mb];
+            }
+            __builtin_amdgcn_wave_barrier();
+            fb_outer16<4>(sa, sb, accW2, i, q);
+            fb_outer16<FIRST ? 2 : 4>(sg, sc, accWe, i, q);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- four waves -> one partial: every wave parks its accumulators [register][lane] in LDS (the weights are dead),
+    // thread t adds the four copies of its elements in wave order
+    __syncthreads();
+    float* red = smem;                                       // [4 waves][EA_PART] = 160 KB > LDS: two halves of 80 registers
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        float* mine = red + wave * (EA_PART / 2);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (half == 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) mine[((a * 4 + b) * 4 + rr) * 64 + lane] = accW2[a][b][rr];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) mine[(64 + a * 4 + rr) * 64 + lane] = bs2[a][rr];
+            } else {
+#pragma unroll
+                for (int b = 0; b < (FIRST ? 2 : 4); ++b)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) mine[((a * 4 + b) * 4 + rr) * 64 + lane] = accWe[a][b][rr];
+                if (FIRST) {
+#pragma unroll
+                    for (int b = 2; b < 4; ++b)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) mine[((a * 4 + b) * 4 + rr) * 64 + lane] = 0.0f;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) mine[(64 + a * 4 + rr) * 64 + lane] = bs1[a][rr];
+            }
+        }
+        __syncthreads();
+        float* dst = partial + (size_t)blockIdx.x * EA_PART + half * (EA_PART / 2);
+        for (int e = threadIdx.x; e < EA_PART / 2; e += 256)
+            dst[e] = ((red[e] + red[EA_PART / 2 + e]) + red[2 * (EA_PART / 2) + e]) + red[3 * (EA_PART / 2) + e];
+    }
+}
+
+// Sum of the workgroups' partials (workgroup order, fixed 16-group tree) and the scatter into the gradient tensors.
+// Partial layout per workgroup: half 0 = [dW2 64 regs | db2 16 regs][lane], half 1 = [dW_e 64 regs | db1 16 regs][lane];
+// register (mb, nb, r) of lane (i, q) of a <4, NB> product is element (m = 4 (4 q + r) + mb, n = NB i + nb) (fb_outer16);
+// a bias register (mb, r) of lane (i, q) is hidden unit 16 mb + 4 q + r summed over the lane's edges: add the 16 lanes i.
+struct EdgeAccOut {
+    float* w2; float* b2;              // [64][64], [64]
+    float* we; int ldwe; int ncols;    // dW_e -> we[m * ldwe + n], n < ncols (layer 1: [64][F1], NB = 2; else columns 128..191 of [64][192])
+    float* b1;                         // layer 1 only (layers 2-4: the bias gradient comes with dP_r)
+    int nb_e;                          // 2 (layer 1) or 4
+};
+__global__ void __launch_bounds__(1024)
+k_edge_acc_reduce(const float* __restrict__ partial, int n_wgs, EdgeAccOut O) {
+    // blockIdx.x: 64 consecutive elements of a partial; 16 groups of 64 threads take every 16th workgroup... in order:
+    // group g adds workgroups [g * per, (g + 1) * per) sequentially, the 16 sums are combined in order
+    const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + t;
+    const int per = (n_wgs + 15) / 16;
+    const int w0 = grp * per, w1 = w0 + per < n_wgs ? w0 + per : n_wgs;
+    float s = 0.0f;
+    for (int w = w0; w < w1; ++w) s += partial[(size_t)w * EA_PART + e];
+    __shared__ float red[16][64];
+    red[grp][t] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    float tot = red[0][t];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) tot += red[g][t];
+    const int half = e / (EA_PART / 2), f = e % (EA_PART / 2);
+    const int reg = f >> 6, lane = f & 63, i = lane & 15, q = lane >> 4;
+    if (reg < 64) {
+        const int mb = reg >> 4, nb = (reg >> 2) & 3, r = reg & 3;
+        const int m = 4 * (4 * q + r) + mb;
+        if (half == 0) {
+            O.w2[m * H + 4 * i + nb] = tot;
+        } else if (nb < O.nb_e) {
+            const int n = O.nb_e * i + nb;
+            if (n < O.ncols) O.we[(size_t)m * O.ldwe + n] = tot;
+        }
+        return;
+    }
+    // bias registers: the 16 lanes i of a (register, q) hold partial sums of the same hidden unit
+    red[0][t] = tot;                     // (group 0 only from here on: no other thread touches red)
+    __builtin_amdgcn_wave_barrier();
+    if (i == 0) {
+        float b = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b += red[0][16 * q + j];
+        const int br = reg - 64, unit = 16 * (br >> 2) + 4 * q + (br & 3);
+        if (half == 0) O.b2[unit] = b;
+        else if (O.b1) O.b1[unit] = b;
+    }
+}
+
+}  // namespace

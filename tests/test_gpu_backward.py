@@ -101,14 +101,49 @@ def test_per_layer_weight_gradient_launches_match_deferred(D):
     m = _model(D, "fused")
     try:
         _lib.check(lib.aether_set_option(b"fused_backward", 0), "set_option")      # the layer-by-layer kernels (backward.h)
+        _lib.check(lib.aether_set_option(b"edge_acc", 0), "set_option")            # (edge_acc.h sums in another order: below)
         _, deferred = _loss_backward(m, inp)
         _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 0), "set_option")
         _, per_layer = _loss_backward(m, inp)
     finally:
         _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 1 << 20), "set_option")
+        _lib.check(lib.aether_set_option(b"edge_acc", 1), "set_option")
         _lib.check(lib.aether_set_option(b"fused_backward", 1), "set_option")
     for k in deferred:
         assert torch.equal(deferred[k], per_layer[k]), k
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_edge_level_weight_gradients_accumulated_in_the_edge_kernel(D):
+    """Large graphs (E > outer_defer_max_edges; forced here): kb_edge_acc keeps dpre2, h, G and e_prev of a tile on chip
+    and accumulates dW2, dW_e (layer 1: dW1), db2, db1 in registers (edge_acc.h) instead of writing the rows for k_outer.
+    All 47 gradients against the oracle's autograd and against the row-tensor path, twice (bit-stable); ragged tile
+    counts (N = 37: 1,332 edges per graph, not a multiple of 16) and fewer tiles than waves."""
+    lib = _lib.load()
+    sd = load_state_dict(D)
+    for (B, N, seed) in [(7, 37, 81), (1, 6, 82), (3, 70, 83)]:
+        inp = make_batch(B, N, D, seed=seed)
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out = O.aether_forward(sdg, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+        torch.nn.functional.mse_loss(out, inp["target"]).backward()
+        m = _model(D, "streamed")
+        res = {}
+        try:
+            _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 0), "set_option")
+            for acc in (1, 0, 1):
+                _lib.check(lib.aether_set_option(b"edge_acc", acc), "set_option")
+                _, g = _loss_backward(m, inp)
+                if acc == 1 and 1 in res:
+                    for k in g:
+                        assert torch.equal(g[k], res[1][k]), k            # same bits on a second run
+                res[acc] = g
+        finally:
+            _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 1 << 20), "set_option")
+            _lib.check(lib.aether_set_option(b"edge_acc", 1), "set_option")
+        for k in res[1]:
+            assert torch.isfinite(res[1][k]).all(), k
+            assert scale_rel_err(res[1][k], sdg[k].grad) <= GTOL, (B, N, k)
+            assert scale_rel_err(res[1][k], res[0][k]) <= GTOL, (B, N, k)
 
 
 def test_backward_is_deterministic_and_optimizer_step_runs():
