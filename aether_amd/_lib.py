@@ -126,6 +126,9 @@ SIGNATURES = {
                                  [C.c_double] * 3 + [C.c_void_p] * 4),
     "aether_sim_gravitational": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 5 +
                                  [C.c_double] * 3 + [C.c_void_p] * 4),
+    "aether_backward_inputs": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo), C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aether_backward_field": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 6 +
                               [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aether_dynamic_field_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),

@@ -33,6 +33,7 @@
 #include "backward.h"
 #include "fused_bwd.h"
 #include "edge_acc.h"
+#include "input_grad.h"
 #include "seq2seq.h"
 #include "s2s_filter.h"
 #include "s2s_step.h"
@@ -1392,6 +1393,43 @@ int aether_backward(const AetherParams* params, const AetherParams* grads, int n
                                       (char*)workspace, grad_out, st);
     return backward_impl<3>(*params, *grads, n_nodes, n_edges, x, vel, charges, (const char*)graph,
                             (char*)workspace, grad_out, st);
+}
+
+int aether_backward_inputs(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x,
+                           const float* vel, const float* charges, const void* graph, const AetherGraphInfo* info,
+                           void* workspace, size_t workspace_bytes, const float* out, const float* grad_out, float* grad_x,
+                           float* grad_vel, float* grad_edge_attr, void* stream) {
+    if (!params || !x || !vel || !charges || !graph || !info || !workspace || !out || !grad_out || !grad_x || !grad_vel)
+        return fail(AETHER_EINVAL, "backward_inputs: null pointer");
+    if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "backward_inputs: num_dims must be 2 or 3");
+    if (n_nodes <= 0 || n_edges < 0 || info->n_nodes != n_nodes || info->n_edges != n_edges)
+        return fail(AETHER_EINVAL, "backward_inputs: bad sizes");
+    if (workspace_bytes < aether_workspace_bytes(n_nodes, n_edges, num_dims, 1))
+        return fail(AETHER_ESPACE, "backward_inputs: workspace too small (the workspace of the forward / aether_backward pair)");
+    hipStream_t st = (hipStream_t)stream;
+    if (take_async_error()) return AETHER_EHIP;
+    GraphLayout G(n_edges, n_nodes, false);
+    WsLayout W(n_nodes, n_edges, num_dims, true);
+    const char* g = (const char*)graph;
+    char* ws = (char*)workspace;
+    auto gp = [&](size_t off) { return reinterpret_cast<const int32_t*>(g + off); };
+    auto wp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const dim3 grid((unsigned)((n_nodes + 7) / 8));
+    if (num_dims == 2)
+        kb_inputs<2><<<grid, dim3(256), 0, st>>>(*params, x, vel, charges, wp(W.nodeinfo), out, grad_out, wp(W.DA), wp(W.DN),
+                                               wp(W.DF), gp(G.rowptr), gp(G.send_s), gp(G.recv_s), gp(G.srowptr),
+                                               gp(G.sperm), grad_x, grad_vel, n_nodes);
+    else
+        kb_inputs<3><<<grid, dim3(256), 0, st>>>(*params, x, vel, charges, wp(W.nodeinfo), out, grad_out, wp(W.DA), wp(W.DN),
+                                               wp(W.DF), gp(G.rowptr), gp(G.send_s), gp(G.recv_s), gp(G.srowptr),
+                                               gp(G.sperm), grad_x, grad_vel, n_nodes);
+    if (grad_edge_attr && n_edges > 0) {
+        const int D = num_dims, col0 = 7 * D + D * (D - 1) / 2;
+        kb_edge_attr_grad<<<dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st>>>(wp(W.DA), gp(G.perm), col0, grad_edge_attr,
+                                                                                       n_edges);
+    }
+    HIP_OK(hipGetLastError());
+    return AETHER_OK;
 }
 
 int aether_backward_field(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,

@@ -621,6 +621,11 @@ def main():
                 # the hardware is doing (PMC passes of this command, profiles/traffic.json): the bf16 matrix pipe, the fp32
                 # MFMAs (which issue on the vector ALU) and the vector ALU's instruction issue.  None can exceed 1.
                 pm = tj.get(dom_name + "_pipes") if traffic is not None and isinstance(tj, dict) else None
+                if pm is None and os.path.exists(tpath) and dom_name == "k_fused":      # other measured shapes: keyed by workload
+                    try:
+                        pm = json.load(open(tpath)).get(f"D{D}-N{N}-B{B}", {}).get("k_fused_pipes")
+                    except Exception:
+                        pm = None
                 if pm:
                     t_s = launch_us * 1e-6
                     clk, simds = 2.4e9, 1024                      # peak shader clock the guide's peaks assume; 256 CUs x 4 SIMDs

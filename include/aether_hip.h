@@ -219,6 +219,20 @@ int aether_rollout_dynamic_field(const AetherParams* params, const AetherDynFiel
                                  const AetherGraphInfo* info, void* workspace, size_t workspace_bytes,
                                  float* field_scratch, float* trajectory, int steps, float dt, int flags, void* stream);
 /*
+ * Gradients with respect to the INPUTS of the step (round 3) -- the reference's forward is differentiable in x / vel
+ * (nn/state2state/aether.py:169-186).  Call after aether_backward, on the same workspace (it reads what that call left:
+ * dL/d(layer-1 edge features), dL/dn_1, dL/df) with `out` = the forward's output and the same grad_out:
+ *   grad_x [n_nodes][D], grad_vel [n_nodes][D] (overwritten); grad_edge_attr [n_edges][2] in the caller's edge order, or
+ *   NULL.  The built-in field only (not the aether_forward_field variant).  Positions and velocities enter through
+ *   x + R(v) y, the field net's inputs, rel_feat = [0 | R^T v | R^T f] and the local-frame edge features (r, Euler angles
+ *   of R_i^T R_j, distance, bearing, R_i^T v_j, R_i^T f_j); charges are an index (no gradient).
+ */
+int aether_backward_inputs(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x,
+                           const float* vel, const float* charges, const void* graph, const AetherGraphInfo* info,
+                           void* workspace, size_t workspace_bytes, const float* out, const float* grad_out, float* grad_x,
+                           float* grad_vel, float* grad_edge_attr, void* stream);
+
+/*
  * Training of the dynamic-field variant.  aether_backward_field = aether_backward for a step that ran through
  * aether_forward_field with AETHER_FLAG_KEEP_INTERMEDIATES: gradients of the GNN / res / out-MLP tensors into
  * `grads` (grads->field_* are not written) and dL/dfield into grad_field [n_nodes][D].

@@ -7,7 +7,7 @@ files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=Tr
 acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
 for f in files:
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(k_\w+(<[^>]*>)?)", row["Kernel_Name"])
+        m = re.search(r"((?:k|kb)_\w+(<[^>]*>)?)", row["Kernel_Name"])
         k = m.group(1) if m else "other"
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[k][row["Counter_Name"]] += 1
 for k in sorted(acc):
