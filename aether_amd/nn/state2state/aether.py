@@ -156,6 +156,8 @@ class _AetherStep(torch.autograd.Function):
         out, saved = _AetherStep.launch(module, True, x, vel, edge_attr, charges, graph, n_edges)
         ctx.module = module
         ctx.saved = saved
+        if any(ctx.needs_input_grad[1:4]):       # x / vel / edge_attr: aether_backward_inputs recovers y = R^T (out - x)
+            ctx.save_for_backward(out)
         return out
 
     @staticmethod
@@ -181,6 +183,23 @@ class _AetherStep(torch.autograd.Function):
                                  x.data_ptr(), vel.data_ptr(), charges.data_ptr(), graph.data_ptr(),
                                  C.byref(ginfo), ws.data_ptr(), ws.numel(), g.data_ptr(), stream)
         _lib.check(st, "aether_backward")
+        gx = gv = gea = None
+        if any(ctx.needs_input_grad[1:4]):
+            # gradients w.r.t. the inputs (the reference's forward is differentiable in them, aether.py:169-186): one more
+            # kernel over what aether_backward left in the workspace
+            (out_saved,) = ctx.saved_tensors
+            gx, gv = torch.empty_like(x), torch.empty_like(x)
+            if ctx.needs_input_grad[3]:
+                gea = torch.empty(n_edges, 2, dtype=torch.float32, device=x.device)
+            st = lib.aether_backward_inputs(C.byref(module._param_struct()), D, x.shape[0], n_edges, x.data_ptr(),
+                                            vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                            ws.data_ptr(), ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(),
+                                            gv.data_ptr(), gea.data_ptr() if gea is not None else None, stream)
+            _lib.check(st, "aether_backward_inputs")
+            if not ctx.needs_input_grad[1]:
+                gx = None
+            if not ctx.needs_input_grad[2]:
+                gv = None
         if module.dp_group is not None:            # one fused all-reduce of the flat buffer (RCCL)
             import torch.distributed as dist
             dist.all_reduce(dst_flat, group=module.dp_group)
@@ -201,7 +220,7 @@ class _AetherStep(torch.autograd.Function):
                 out.append(None)
             else:
                 out.append(dv.clone())
-        return (None,) * _AetherStep.N_FIXED + tuple(out)
+        return (None, gx, gv, gea, None, None, None) + tuple(out)
 
 
 def _pad_blocks(name, shape, H):
@@ -228,9 +247,13 @@ class _PaddedStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, outer, x, send, recv, vel, edge_attr, charges, *params):
         eng = outer._engine
+        # inputs that need a gradient become leaves of the inner graph
+        need_in = (ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        inner = [t.detach().requires_grad_(True) if n else t for t, n in zip((x, vel, edge_attr), need_in)]
         with torch.enable_grad():
-            out = eng(None, x, [send, recv], vel, edge_attr, charges)
+            out = eng(None, inner[0], [send, recv], inner[1], inner[2], charges)
         ctx.outer, ctx.inner_out = outer, out
+        ctx.inner_inputs = [t for t, n in zip(inner, need_in) if n]
         return out.detach()
 
     @staticmethod
@@ -238,7 +261,11 @@ class _PaddedStep(torch.autograd.Function):
         outer = ctx.outer
         eng = outer._engine
         eparams = [p for _, p in eng.named_parameters()]
-        grads = torch.autograd.grad(ctx.inner_out, eparams, grad_out.contiguous(), allow_unused=True)
+        grads = torch.autograd.grad(ctx.inner_out, eparams + ctx.inner_inputs, grad_out.contiguous(), allow_unused=True)
+        gin = list(grads[len(eparams):])
+        grads = grads[:len(eparams)]
+        need_in = (ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        gx, gv, gea = (gin.pop(0) if n else None for n in need_in)
         need = ctx.needs_input_grad[_PaddedStep.N_FIXED:]
         out = []
         for (name, p), g, n in zip(outer.named_parameters(), grads, need):
@@ -256,7 +283,7 @@ class _PaddedStep(torch.autograd.Function):
             dist.all_reduce(flat, group=outer.dp_group)
             flat.div_(dist.get_world_size(outer.dp_group))
             torch._foreach_copy_(have, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in have]), have)])
-        return (None,) * _PaddedStep.N_FIXED + tuple(out)
+        return (None, gx, None, None, gv, gea, None) + tuple(out)
 
 
 class _FieldNetwork(nn.Module):
@@ -494,30 +521,27 @@ class Aether(nn.Module):
         E = send.numel()
         if recv.numel() != E or edge_attr_orig.shape != (E, 2) or charges.numel() != n_nodes:
             raise ValueError("edge index / edge_attr / charges shapes do not match")
-        if torch.is_grad_enabled() and (x.requires_grad or vel.requires_grad or edge_attr_orig.requires_grad
-                                        or charges.requires_grad):
-            # the reference's forward is differentiable in x / vel (aether.py:169-186); the HIP backward produces
-            # parameter gradients only (the runner detaches its inputs, main.py:243-247): refuse rather than
-            # return a result whose input gradients would silently be missing
-            raise NotImplementedError("aether_amd.Aether: gradients w.r.t. x / vel / edge_attr_orig / charges are not "
-                                      "implemented (parameter gradients only); detach the inputs")
+        # the reference's forward is differentiable in x / vel / edge_attr_orig (aether.py:169-186): so is this one
+        # (aether_backward_inputs); charges are an embedding index, no gradient flows to them there either
+        wants_in = torch.is_grad_enabled() and (x.requires_grad or vel.requires_grad or edge_attr_orig.requires_grad)
         if self.dropout_prob > 0.0 and self.training:     # (nn.Dropout keys on the module's mode, not on autograd's)
             raise NotImplementedError("aether_amd.Aether: dropout_prob > 0 is supported in eval() mode only (identity); "
                                       "a train()-mode forward with active dropout is not implemented")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        f32g = (lambda t: t.to(torch.float32).contiguous() if t.requires_grad else f32(t)) if wants_in else f32
         if self.hidden_size != 64:      # narrow model: the zero-padded 64-wide engine computes it (same kernels)
             eng = self._sync_engine()
-            if not (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)):
+            if not (wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist))):
                 with torch.no_grad():
                     return eng(h, x, edges, vel, edge_attr_orig, charges)
-            return _PaddedStep.apply(self, f32(x), send, recv, f32(vel), f32(edge_attr_orig), f32(charges), *self._plist)
+            return _PaddedStep.apply(self, f32g(x), send, recv, f32g(vel), f32g(edge_attr_orig), f32(charges), *self._plist)
         graph = self.prepare_graph((send, recv), n_nodes)
         if self._plist is None:         # nn.Module.parameters() walks the module tree: 0.15 ms per call
             self._plist = [p for _, p in self.named_parameters()]
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
+        train = wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist))
         if not train:           # inference: no autograd node, no parameter list to marshal
             return _AetherStep.launch(self, False, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E)[0]
-        return _AetherStep.apply(self, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E,
+        return _AetherStep.apply(self, f32g(x), f32g(vel), f32g(edge_attr_orig), f32(charges), graph, E,
                                  *self._plist)
 
     # -- device rollout ---------------------------------------------------------------
