@@ -40,6 +40,7 @@
 #include "dynfield.h"
 #include "s2s_dynfield.h"
 #include "knn.h"
+#include "dyn_step.h"
 #include "sim.h"
 #include "train_step.h"
 
@@ -136,7 +137,11 @@ int* async_error_word() {
 }
 int take_async_error() {
     if (g_async_host && *(volatile int*)g_async_host) {
+        const int code = *(volatile int*)g_async_host;
         *(volatile int*)g_async_host = 0;
+        if (code == 2)
+            return fail(AETHER_EHIP, "an earlier aether_dyn_step found a different number of non-zero mask entries than "
+                                     "n_present: its outputs were filled with NaN");
         return fail(AETHER_EHIP, "an earlier launch gave up waiting for its partner workgroup (split-mode hand-off): "
                                  "the results of that launch are invalid");
     }
@@ -918,6 +923,7 @@ const char* aether_last_error(void) { return g_err; }
 #include "host_seq2seq.inc"
 #include "host_s2s_step.inc"
 #include "host_dynamicvars.inc"
+#include "host_dyn_step.inc"
 #include "host_sim.inc"
 #include "host_train.inc"
 

@@ -1,0 +1,181 @@
+// dyn_step.h -- the glue of one prediction step of the variable-N model:
+//   AetherDynamicVars.predict_future's loop body, nn/dynamicvars/aether_dynamicvars.py:245-273 -> :64-79 (field),
+//   :672-699 (prior step with its own kNN graph and the per-pair LSTM slots), :133-145 (sampling), :775-870 (decoder).
+// The three stages (aether_dyn_field, aether_dyn_prior_step, aether_dyn_decoder_step) and aether_knn_edges exist; between
+// them the Python module ran ~60 torch launches per step (mask -> index list, gathers, scatters, a stable sort for the
+// receiver CSR, slot arithmetic).  Here that is seven small kernels, so aether_dyn_step is ONE C call per step.
+// All of it is index / copy work on a few hundred objects: single-workgroup kernels where a scan is needed, no atomics on
+// floats, results independent of scheduling.
+#pragma once
+#include "common.h"
+#include "knn.h"
+
+namespace {
+
+constexpr int DYN_MAX_OBJECTS = KNN_MAX_OBJECTS;
+
+// Present objects of the scene: idx[c] = row of the c-th non-zero mask entry (ascending), cidx[row] = c or -1;
+// cur_in[c] = state[idx[c]] (4 floats), cur_h[c] = hidden[idx[c]] (h floats), rowptr_dec[c] = c * deg (c <= n_present).
+// status[0] = the number of present objects found.  When it differs from n_present (host-supplied) the async error word is
+// set to 2 and the rows past the found count repeat row 0 (memory-safe; aether_dyn_step's finish kernel then writes NaN).
+__global__ void __launch_bounds__(256)
+k_dyn_present(const float* __restrict__ state, const float* __restrict__ mask, const float* __restrict__ hidden, int n_max,
+              int n_present, int h, int deg, int64_t* __restrict__ idx, int* __restrict__ cidx, float* __restrict__ cur_in,
+              float* __restrict__ cur_h, int64_t* __restrict__ rowptr_dec, int* __restrict__ status, int* __restrict__ errword) {
+    extern __shared__ int dyn_lds[];
+    int* flag = dyn_lds;                 // [n_max] -> exclusive count of present objects
+    int* rows = flag + n_max;            // [n_present] rows of the present objects
+    int* part = rows + n_present;        // [257]
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n_max; j += 256) flag[j] = mask[j] != 0.0f ? 1 : 0;
+    for (int c = tid; c < n_present; c += 256) rows[c] = 0;
+    __syncthreads();
+    const int found = block_exclusive_scan(flag, n_max, part);
+    for (int j = tid; j < n_max; j += 256) {
+        const bool present = mask[j] != 0.0f;
+        const int c = flag[j];
+        cidx[j] = present && c < n_present ? c : -1;
+        if (present && c < n_present) rows[c] = j;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        status[0] = found;
+        if (found != n_present && errword) *errword = 2;
+    }
+    for (int c = tid; c < n_present; c += 256) idx[c] = rows[c];
+    for (int c = tid; c <= n_present; c += 256) rowptr_dec[c] = (int64_t)c * deg;
+    for (int t = tid; t < n_present * 4; t += 256) cur_in[t] = state[(size_t)rows[t >> 2] * 4 + (t & 3)];
+    const int h4 = h >> 2;
+    for (int t = tid; t < n_present * h4; t += 256) {
+        const int c = t / h4, o = t - c * h4;
+        st4(cur_h + (size_t)c * h + 4 * o, ld4(hidden + (size_t)rows[c] * h + 4 * o));
+    }
+}
+
+// ext_full[row] = [state[row] (4) | field of the row (2), zero when absent]: the un-compacted array the decoder's edge
+// features read with compacted indices (the reference's quirk, aether_dynamicvars.py:823)
+__global__ void __launch_bounds__(256)
+k_dyn_ext(const float* __restrict__ state, const float* __restrict__ field_c, const int* __restrict__ cidx, int n_max,
+          float* __restrict__ ext_full) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_max * 6) return;
+    const int row = t / 6, col = t - row * 6;
+    float v;
+    if (col < 4) v = state[(size_t)row * 4 + col];
+    else { const int c = cidx[row]; v = c >= 0 ? field_c[(size_t)c * 2 + col - 4] : 0.0f; }
+    ext_full[t] = v;
+}
+
+// (order, rowptr) = edge ids grouped by receiver, stable (torch.argsort(recv, stable=True) + the CSR offsets): counts by
+// integer LDS atomics, a scan, then chunks of 256 edges in id order -- an edge's place is its receiver's row start + the
+// edges of that receiver in earlier chunks + those before it in its own chunk.  One workgroup; n <= 8192 objects.
+// When the mask disagreed with n_present (status[0] != n_nodes) the kNN graph it was built from has other sizes than the
+// buffers' users assume: its first n_edges entries are clamped into range here, so that the stages -- whose results are
+// discarded (k_dyn_finish writes NaN) -- read inside their arrays.
+__global__ void __launch_bounds__(256)
+k_dyn_csr(int64_t* __restrict__ send, int64_t* __restrict__ recv, int64_t n_edges, int n_nodes, const int* __restrict__ status,
+          int64_t* __restrict__ order, int64_t* __restrict__ rowptr) {
+    extern __shared__ int dyn_lds[];
+    int* start = dyn_lds;                // [n_nodes] counts -> row starts -> running fill position
+    int* part = start + n_nodes;         // [257]
+    int* chunk = part + 257;             // [256] receivers of the current chunk
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n_nodes; j += 256) start[j] = 0;
+    if (status[0] != n_nodes) {
+        for (int64_t e = tid; e < n_edges; e += 256) {
+            const int64_t a = send[e], b = recv[e];
+            send[e] = a < 0 ? 0 : (a >= n_nodes ? n_nodes - 1 : a);
+            recv[e] = b < 0 ? 0 : (b >= n_nodes ? n_nodes - 1 : b);
+        }
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < n_edges; e += 256) {
+        const int64_t r = recv[e];
+        if (r >= 0 && r < n_nodes) atomicAdd(start + (int)r, 1);
+    }
+    __syncthreads();
+    const int total = block_exclusive_scan(start, n_nodes, part);
+    for (int j = tid; j < n_nodes; j += 256) rowptr[j] = start[j];
+    if (tid == 0) rowptr[n_nodes] = total;
+    __syncthreads();
+    for (int64_t base = 0; base < n_edges; base += 256) {
+        const int64_t e = base + tid;
+        int r = -1;
+        if (e < n_edges) { const int64_t rr = recv[e]; r = rr >= 0 && rr < n_nodes ? (int)rr : -1; }
+        chunk[tid] = r;
+        __syncthreads();
+        int before = 0, after = 0;
+        if (r >= 0) {
+            for (int t = 0; t < 256; ++t) {
+                const bool same = chunk[t] == r;
+                before += (same && t < tid) ? 1 : 0;
+                after += (same && t > tid) ? 1 : 0;
+            }
+            order[start[r] + before] = e;
+        }
+        __syncthreads();
+        if (r >= 0 && after == 0) start[r] += before + 1;      // the last edge of r in this chunk moves r's fill position
+        __syncthreads();
+    }
+}
+
+// LSTM state rows of the caller's edges: one slot per ordered pair of objects (aether_dynamicvars.py:680-686),
+// slot = gs (n_max - 1) + gr - (gr >= gs) with gs, gr the un-compacted rows of the edge's ends; gathers h0, c0.
+__global__ void __launch_bounds__(256)
+k_dyn_slots_gather(const int64_t* __restrict__ gsend, const int64_t* __restrict__ grecv, const int64_t* __restrict__ node_inds,
+                   int n_present, int n_max, int64_t n_edges, int R, const float* __restrict__ prior_h,
+                   const float* __restrict__ prior_c, int64_t* __restrict__ slot, float* __restrict__ h0,
+                   float* __restrict__ c0) {
+    const int r4 = R >> 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_edges * r4) return;
+    const int64_t e = t / r4;
+    const int o = (int)(t - e * r4);
+    int64_t a = gsend[e], b = grecv[e];
+    a = a < 0 ? 0 : (a >= n_present ? n_present - 1 : a);          // (out-of-range ids are refused on the host side of the
+    b = b < 0 ? 0 : (b >= n_present ? n_present - 1 : b);          //  module; clamped here to stay inside the arrays)
+    const int64_t gs = node_inds[a], gr = node_inds[b];
+    int64_t s = gs * (n_max - 1) + gr - (gr >= gs ? 1 : 0);
+    const int64_t n_slots = (int64_t)n_max * (n_max - 1);
+    s = s < 0 ? 0 : (s >= n_slots ? n_slots - 1 : s);
+    if (o == 0) slot[e] = s;
+    st4(h0 + e * R + 4 * o, ld4(prior_h + s * R + 4 * o));
+    st4(c0 + e * R + 4 * o, ld4(prior_c + s * R + 4 * o));
+}
+
+__global__ void __launch_bounds__(256)
+k_dyn_slots_scatter(const int64_t* __restrict__ slot, const float* __restrict__ h1, const float* __restrict__ c1,
+                    int64_t n_edges, int R, float* __restrict__ prior_h, float* __restrict__ prior_c) {
+    const int r4 = R >> 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_edges * r4) return;
+    const int64_t e = t / r4;
+    const int o = (int)(t - e * r4);
+    const int64_t s = slot[e];
+    st4(prior_h + s * R + 4 * o, ld4(h1 + e * R + 4 * o));
+    st4(prior_c + s * R + 4 * o, ld4(c1 + e * R + 4 * o));
+}
+
+// prediction [n_max][4] = the decoder's rows at the present objects, zero elsewhere (:866-868); hidden[idx[c]] = new_h[c].
+// NaN everywhere when the mask disagreed with n_present (status[0] != n_present).
+__global__ void __launch_bounds__(256)
+k_dyn_finish(const float* __restrict__ out_c, const float* __restrict__ new_h, const int* __restrict__ cidx,
+             const int64_t* __restrict__ idx, const int* __restrict__ status, int n_max, int n_present, int h,
+             float* __restrict__ prediction, float* __restrict__ hidden) {
+    const bool bad = status[0] != n_present;
+    const float poison = __int_as_float(0x7fc00000);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int h4 = h >> 2;
+    if (t < (int64_t)n_max * 4) {
+        const int row = (int)(t >> 2), c = cidx[row];
+        prediction[t] = bad ? poison : (c >= 0 ? out_c[(size_t)c * 4 + (t & 3)] : 0.0f);
+    }
+    if (t < (int64_t)n_present * h4) {
+        const int c = (int)(t / h4), o = (int)(t - (int64_t)c * h4);
+        f32x4 v = ld4(new_h + (size_t)c * h + 4 * o);
+        if (bad) v = f32x4{poison, poison, poison, poison};
+        st4(hidden + (size_t)idx[c] * h + 4 * o, v);
+    }
+}
+
+}  // namespace

@@ -25,7 +25,15 @@ class _DynFieldQueryParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("B", "ang_w", "ang_b", "w0", "b0", "w2", "b2", "w4", "b4")]
 
 
+class _DynStepConfig(C.Structure):                      # AetherDynStepConfig of include/aether_hip.h
+    _fields_ = [(n, C.c_int) for n in ("field_hidden", "encoder_hidden", "rnn_hidden", "prior_layers", "prior_hidden",
+                                       "num_edge_types", "decoder_hidden", "skip_first", "encoder_polar", "decoder_polar",
+                                       "knn_k")] + [("gumbel_tau", C.c_float)]
+
+
 class AetherDynamicVars(nn.Module):
+    one_call_step = True        # predict_future's steps go through aether_dyn_step (False: the three staged calls + torch glue)
+
     def __init__(self, params, device="cuda"):
         super().__init__()
         self.encoder = Encoder(params, device=None)                       # creation order of :19-62
@@ -51,6 +59,15 @@ class AetherDynamicVars(nn.Module):
     def load(self, path):
         self.load_state_dict(torch.load(path))
 
+    def _field_struct(self):
+        fn = self.field_net
+        tensors = [self.coordinate_embedding.B, self.angular_embedding.weight, self.angular_embedding.bias, fn[0].weight,
+                   fn[0].bias, fn[2].weight, fn[2].bias, fn[4].weight, fn[4].bias]
+        for t in tensors:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise _lib.AetherHipError("field parameters must be contiguous fp32 CUDA tensors")
+        return _DynFieldQueryParams(*[t.data_ptr() for t in tensors])
+
     @torch.no_grad()
     def predict_field(self, x, masks=None, n_present=None):
         """:64-79.  x [..., Nmax, 4] -> (field [..., Nmax, 2], zero where masks is 0; coords of the present objects).
@@ -74,13 +91,7 @@ class AetherDynamicVars(nn.Module):
         if n == 0:
             return predicted_field, coords
         h = self.field_hidden
-        fn = self.field_net
-        tensors = [self.coordinate_embedding.B, self.angular_embedding.weight, self.angular_embedding.bias, fn[0].weight,
-                   fn[0].bias, fn[2].weight, fn[2].bias, fn[4].weight, fn[4].bias]
-        for t in tensors:
-            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-                raise _lib.AetherHipError("field parameters must be contiguous fp32 CUDA tensors")
-        ps = _DynFieldQueryParams(*[t.data_ptr() for t in tensors])
+        ps = self._field_struct()
         need = lib.aether_dyn_field_workspace_bytes(n, h)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
@@ -125,10 +136,57 @@ class AetherDynamicVars(nn.Module):
                                                    n_present=n_present)
         return predictions, decoder_hidden, edges
 
+    def _step_config(self):
+        enc, dec = self.encoder, self.decoder
+        _, n_layers, prior_hidden = enc._param_struct()
+        return _DynStepConfig(self.field_hidden, enc.hidden_size, enc.rnn_hidden_size, n_layers, prior_hidden,
+                              self.num_edge_types, dec.msg_out_shape, 1 if dec.skip_first_edge_type else 0,
+                              1 if enc.pos_representation == "polar" else 0, 1 if dec.pos_representation == "polar" else 0,
+                              10, float(self.gumbel_temp))
+
+    @torch.no_grad()
+    def _step_one_call(self, state, present, node_inds_t, gsend, grecv, e2n, prior_h, prior_c, dec_state, uniform_t):
+        """``_step_core`` as ONE library call (``aether_dyn_step``): the same stage kernels, the index work between them in
+        seven small kernels of the library instead of ~60 torch launches; bit-identical to the staged path."""
+        lib = _lib.load()
+        dev = state.device
+        if self.encoder.training:
+            raise _lib.AetherHipError("the prior step uses BatchNorm running statistics: call .eval() first")
+        Nmax, n, E = int(state.shape[1]), int(node_inds_t.numel()), int(gsend.numel())
+        if grecv.numel() != E or e2n.ndim != 2 or e2n.shape[0] != n or uniform_t.numel() != E * self.num_edge_types:
+            raise ValueError("graph_info / uniform do not match the present objects")
+        i64 = lambda t: t.to(device=dev, dtype=torch.int64).contiguous()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        state, present, uniform_t = f32(state), f32(present).reshape(-1), f32(uniform_t)
+        ni, gs, gr, e2n = i64(node_inds_t), i64(gsend), i64(grecv), i64(e2n)
+        new_h, new_c, new_dec = f32(prior_h).clone(), f32(prior_c).clone(), f32(dec_state).clone()
+        cfg = self._step_config()
+        need = lib.aether_dyn_step_workspace_bytes(C.byref(cfg), Nmax, n, E)
+        if need == 0:
+            raise _lib.AetherHipError("aether_dyn_step_workspace_bytes: " + lib.aether_last_error().decode())
+        ws = self.__dict__.get("_step_ws")
+        if ws is None or ws.numel() < need or ws.device != dev:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.AetherHipError("the step workspace must be reserved outside graph capture (reserve())")
+            ws = self.__dict__["_step_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        pred = torch.empty(1, Nmax, 4, dtype=torch.float32, device=dev)
+        fs = self._field_struct()
+        ps_e = self.encoder._param_struct()[0]
+        ps_d = self.decoder._param_struct()
+        st = lib.aether_dyn_step(C.byref(fs), C.byref(ps_e), C.byref(ps_d), C.byref(cfg), Nmax, n, E, state.data_ptr(),
+                                 present.data_ptr(), ni.data_ptr(), gs.data_ptr(), gr.data_ptr(), e2n.data_ptr(),
+                                 int(e2n.shape[1]), new_h.data_ptr(), new_c.data_ptr(), new_dec.data_ptr(),
+                                 uniform_t.data_ptr(), pred.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                 torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_dyn_step")
+        return pred, new_h, new_c, new_dec
+
     @torch.no_grad()
     def _step_core(self, state, present, node_inds_t, gsend, grecv, e2n, prior_h, prior_c, dec_state, uniform_t):
         """One step of ``predict_future`` for one scene: (prediction [1, Nmax, 4], prior state h, c, decoder state).  The
         number of present objects is ``node_inds_t.numel()`` (host-known): no stage reads a count back from the device."""
+        if self.one_call_step:
+            return self._step_one_call(state, present, node_inds_t, gsend, grecv, e2n, prior_h, prior_c, dec_state, uniform_t)
         n_t = int(node_inds_t.numel())
         gi = (gsend, grecv, e2n)
         field, _ = self.predict_field(state, present, n_present=n_t)
@@ -152,6 +210,17 @@ class AetherDynamicVars(nn.Module):
             need_e = max(need_e, lib.aether_dyn_prior_workspace_bytes(self.encoder.hidden_size, self.encoder.rnn_hidden_size,
                                                                       ps_e[2], n, E))
             need_d = max(need_d, lib.aether_dyn_decoder_workspace_bytes(self.decoder.msg_out_shape, n, E))
+        if self.one_call_step:
+            cfg = self._step_config()
+            need_s = 0
+            for n in range(2, int(n_objects_max) + 1):
+                need_s = max(need_s, lib.aether_dyn_step_workspace_bytes(C.byref(cfg), int(n_objects_max), n,
+                                                                         n * min(int(k), n - 1)))
+            ws = self.__dict__.get("_step_ws")
+            if ws is None or ws.numel() < need_s or ws.device != dev:
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.AetherHipError("reserve() must run outside graph capture")
+                self.__dict__["_step_ws"] = torch.empty(need_s, dtype=torch.uint8, device=dev)
         for mod, need in ((self, need_f), (self.encoder, need_e), (self.decoder, need_d)):
             if mod._ws is None or mod._ws.numel() < need or mod._ws.device != dev:
                 if torch.cuda.is_current_stream_capturing():
@@ -180,12 +249,14 @@ class AetherDynamicVars(nn.Module):
             static = [a.clone() for a in args]
             self._step_core(*static)                                  # eager: image caches, pointer structs, lazy init
             torch.cuda.synchronize()
-            ptrs = (self._ws.data_ptr(), self.encoder._ws.data_ptr(), self.decoder._ws.data_ptr())
+            wsp = lambda: (self._ws.data_ptr(), self.encoder._ws.data_ptr(), self.decoder._ws.data_ptr(),
+                           self.__dict__["_step_ws"].data_ptr() if self.__dict__.get("_step_ws") is not None else 0)
+            ptrs = wsp()
             g = torch.cuda.CUDAGraph()
             pool = self.__dict__.setdefault("_step_pool", torch.cuda.graph_pool_handle())
             with torch.cuda.graph(g, pool=pool):
                 outs = self._step_core(*static)
-            if ptrs != (self._ws.data_ptr(), self.encoder._ws.data_ptr(), self.decoder._ws.data_ptr()):
+            if ptrs != wsp():
                 raise _lib.AetherHipError("a workspace was re-allocated during capture: the graph is not safe to replay")
             hit = cache[key] = (g, static, outs)
         g, static, outs = hit

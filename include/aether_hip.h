@@ -660,6 +660,39 @@ int aether_dyn_field(const AetherDynFieldQueryParams* params, int hidden, int64_
                      void* workspace, size_t workspace_bytes, float* field, void* stream);
 
 /*
+ * One prediction step of the variable-N model as ONE call (round 3): the body of AetherDynamicVars.predict_future's loop
+ * (nn/dynamicvars/aether_dynamicvars.py:245-273) for one scene -- field at the present objects (:64-79), the encoder's
+ * own kNN graph + prior step with the per-pair LSTM slots gathered and scattered (:672-699), the hard Gumbel sample
+ * (:133-141) and the decoder step (:775-870) -- with the index work between the stages (mask -> rows, receiver CSR of the
+ * kNN graph, slot arithmetic, scatter of the results) in seven small kernels instead of ~60 framework launches.
+ *   state [n_objects_max][4] : the scene's rows (observed objects: ground truth, the others: the last prediction, :264)
+ *   mask  [n_objects_max]    : non-zero = present; n_present = their number, known to the caller (len(node_inds)).
+ *                              A mask that disagrees makes the step's outputs NaN and the next call return AETHER_EHIP.
+ *   node_inds int64[n_present] or NULL (= the mask's non-zero rows, ascending): rows of the present objects
+ *   graph_send, graph_recv int64[n_edges], edge2node int64[n_present][in_degree] : the data set's graph_info of the step, in
+ *                              the numbering of the present objects (single_ind_data.py:186-217);
+ *                              n_edges = n_present * min(knn_k, n_present - 1), as the encoder's own graph has
+ *   prior_h, prior_c [n_objects_max (n_objects_max - 1)][rnn_hidden] : one LSTM slot per ordered pair, UPDATED IN PLACE
+ *   decoder_hidden [n_objects_max][decoder_hidden] : UPDATED IN PLACE at the present rows
+ *   uniform [n_edges][K] : the U(0,1) draw of gumbel_softmax;  edge_types [n_edges][K] (one-hot, out) or NULL
+ *   prediction [n_objects_max][4] : the decoder's output at the present rows, zero elsewhere (:866-868)
+ * Every stage is the entry point documented above (same kernels, same order): results equal the staged calls bit for bit.
+ */
+typedef struct AetherDynStepConfig {
+    int field_hidden, encoder_hidden, rnn_hidden, prior_layers, prior_hidden, num_edge_types, decoder_hidden;
+    int skip_first, encoder_polar, decoder_polar, knn_k;
+    float gumbel_tau;
+} AetherDynStepConfig;
+size_t aether_dyn_step_workspace_bytes(const AetherDynStepConfig* config, int n_objects_max, int64_t n_present,
+                                       int64_t n_edges);
+int aether_dyn_step(const AetherDynFieldQueryParams* field_params, const AetherDynPriorParams* prior_params,
+                    const AetherDynDecoderParams* decoder_params, const AetherDynStepConfig* config, int n_objects_max,
+                    int64_t n_present, int64_t n_edges, const float* state, const float* mask, const int64_t* node_inds,
+                    const int64_t* graph_send, const int64_t* graph_recv, const int64_t* edge2node, int in_degree,
+                    float* prior_h, float* prior_c, float* decoder_hidden, const float* uniform, float* prediction,
+                    float* edge_types, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The rest of the runner's training step (experiments/lorentz/main.py:86,164,289-292): nn.MSELoss with the seed of its
  * backward, and optim.AdamW over every parameter tensor -- one launch each (torch: 4 + 3).
  *

@@ -315,8 +315,22 @@ def test_predict_future_captured_steps_equal_the_eager_loop():
         got = model.predict_future(*args, uniform=U[:T - 1], graph=True)
         assert torch.equal(got, eager), rep
     assert len(model._step_graphs) == 4                       # one graph per signature: 24, 12, 3 and 40 present objects
+    # the one-call step (aether_dyn_step) runs the staged path's kernels on the same rows: identical bits
+    model.one_call_step = False
+    try:
+        staged = model.predict_future(*args, uniform=U[:T - 1])
+    finally:
+        model.one_call_step = True
+    assert torch.equal(staged, eager)
     bad = masks.clone()
     bad[0, 0, :] = 1                                            # the mask now says 40 objects, node_inds still 24
     model._step_graphs.clear()
     with pytest.raises(ValueError):
         model.predict_future(inputs.cuda(), bad.cuda(), [node_inds], [graph_info], burn.cuda(), uniform=U[:T - 1], graph=True)
+    # eagerly the library notices by itself: NaN outputs for the step and an error from the next call / the explicit check
+    out = model.predict_future(inputs[:, :2].cuda(), bad[:, :2].cuda(), [node_inds], [graph_info], burn[:, :2].cuda(),
+                               uniform=U[:1])
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+    assert _lib.load().aether_check_async_error() != 0
+    assert _lib.load().aether_check_async_error() == 0
