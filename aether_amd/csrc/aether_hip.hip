@@ -277,6 +277,7 @@ int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_
 int g_gemm_split = 1;                           // aether_set_option("gemm_split", 0 | 1): bf16 x 3 GEMM for the >= 16 K-row layers of the fused seq2seq step
 int g_dyn_filter_v1 = 0;                        // aether_set_option("dyn_filter_v1", 0 auto | 1 always | 2 never): first-version filter kernel in the variable-N steps
 int g_dyn_filter_v1_edges = 0;                  // auto: below this many edges (measured: no size where the first version wins)
+int g_filter_rsplits = 0;                       // aether_set_option("filter_rsplits", 0 auto | 1 | 3 | 5 | 15): feature split of the 15-feature filter GEMM
 int g_filter_wgs = 256;                         // workgroups of k_s2s_filter_split: one per CU
 int g_filter_splits = 0;                        // aether_set_option("filter_splits", n): k-splits of the filter GEMM, 0 = by balance
 
@@ -972,6 +973,11 @@ int aether_set_option(const char* name, int value) {
         return AETHER_OK;
     }
     if (!strcmp(name, "dyn_filter_v1_edges")) { g_dyn_filter_v1_edges = value; return AETHER_OK; }
+    if (!strcmp(name, "filter_rsplits")) {
+        if (value != 0 && 15 % value != 0) return fail(AETHER_EINVAL, "set_option: filter_rsplits is 0 (auto), 1, 3, 5 or 15");
+        g_filter_rsplits = value;
+        return AETHER_OK;
+    }
     if (!strcmp(name, "filter_wgs")) {
         if (value < 8 || value % 8 != 0) return fail(AETHER_EINVAL, "set_option: filter_wgs must be a multiple of 8");
         g_filter_wgs = value;

@@ -178,4 +178,15 @@ k_dyn_finish(const float* __restrict__ out_c, const float* __restrict__ new_h, c
     }
 }
 
+// The state a prediction step sees (aether_dynamicvars.py:264): observed objects get their ground truth, the others the
+// model's own last prediction.  state = observed * truth + (1 - observed) * last, as the reference computes it.
+__global__ void __launch_bounds__(256)
+k_dyn_mix(const float* __restrict__ truth, const float* __restrict__ last, const float* __restrict__ observed, int n_max,
+          float* __restrict__ state) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_max * 4) return;
+    const float o = observed[t >> 2];
+    state[t] = o * truth[t] + (1.0f - o) * last[t];
+}
+
 }  // namespace

@@ -17,24 +17,32 @@ constexpr int KNN_MAX_K = 16;
 constexpr int KNN_MAX_OBJECTS = 8192;          // positions + masks + compact index of a scene in LDS
 
 // exclusive prefix sums of val[0..n) (LDS) over the workgroup, in place; returns the total.
-// part: LDS scratch of blockDim.x ints.
+// part: LDS scratch of blockDim.x ints.  Per-thread chunk sums, an inclusive scan across each wave's lanes (shuffles), the
+// (at most 16) wave totals added by every thread: no serial pass of one thread over blockDim.x LDS words (that pass alone
+// took 5-7 us per call, four calls per variable-N prediction step).
 __device__ inline int block_exclusive_scan(int* val, int n, int* part) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, n_waves = (nt + 63) >> 6;
     const int chunk = (n + nt - 1) / nt;
     const int beg = min(tid * chunk, n), end = min(beg + chunk, n);
     int s = 0;
     for (int i = beg; i < end; ++i) s += val[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int t = 0; t < nt; ++t) { const int v = part[t]; part[t] = run; run += v; }
-        part[nt] = run;
+    int incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
     }
+    if (lane == 63) part[wave] = incl;
     __syncthreads();
-    int run = part[tid];
+    int wave_off = 0, total = 0;
+    for (int w = 0; w < n_waves; ++w) {
+        const int v = part[w];
+        wave_off += w < wave ? v : 0;
+        total += v;
+    }
+    int run = wave_off + incl - s;
     for (int i = beg; i < end; ++i) { const int v = val[i]; val[i] = run; run += v; }
-    const int total = part[nt];
     __syncthreads();
     return total;
 }

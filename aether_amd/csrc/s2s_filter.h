@@ -122,7 +122,10 @@ k_s2s_filter_bimg_types(const float* __restrict__ pos, FilterTypes T, int relu, 
 template <int R>
 __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img, const float* __restrict__ b2,
                                                   const float* __restrict__ ea, const bf16x8* __restrict__ bimg,
-                                                  float* __restrict__ out, int h, int64_t n_edges, int splits) {
+                                                  float* __restrict__ out, int h, int64_t n_edges, int splits, int rs) {
+    // rs > 1 (few edges, variable-N steps): the R features are divided over rs units as well -- plane z = zr * splits + zk
+    // holds the k range zk of features [zr R / rs, (zr + 1) R / rs); at 200 edges a unit otherwise walks all 15 features
+    // alone (15 iterations of 96 MFMAs per wave on 16 of the 256 CUs: 35 us of a 0.43 ms step)
     extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
     bf16x8* ring = reinterpret_cast<bf16x8*>(filt_smem);                        // [slot 3][kb 2][mb 4][term 3][lane]
     float* evs = reinterpret_cast<float*>(ring + FILT_NST * FILT_STAGE);        // [r][eq 4][i 16][nb 4]
@@ -131,27 +134,29 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
     const int i = lane & 15, q = lane >> 4;
     const int chalf = wave >> 2, eq = wave & 3;
     const int n_eb = (int)((n_edges + 255) >> 8), n_cb = h >> 6;
-    const int n_pairs = n_cb * splits;
+    const int n_pairs = n_cb * splits * rs;
+    const int nr = R / rs;                                     // features of a unit
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, n_slots = ((int)gridDim.x + 7 - xcd) >> 3;
     const int my_pairs = (n_pairs - xcd + 7) >> 3;             // pairs xcd, xcd + 8, ..
     const int n_a32 = h >> 5, n_mb = h >> 4;
     const int slabs = (h / splits) >> 6;                       // 64-wide k slabs of a unit
-    const int IT = slabs * R;                                  // iterations of a unit: (slab, r)
+    const int IT = slabs * nr;                                 // iterations of a unit: (slab, r)
     const int64_t n_eb16 = (n_edges + 15) >> 4;
     // image strides in fragments of 64 lanes: k block to k block, one r step, and the jump from (slab, R - 1) to (slab + 1, 0)
     const int64_t kb_stride = (int64_t)n_mb * 3 * 64;
     const int64_t r_stride = (int64_t)n_a32 * kb_stride;
-    const int64_t slab_jump = 2 * kb_stride - (int64_t)(R - 1) * r_stride;
+    const int64_t slab_jump = 2 * kb_stride - (int64_t)(nr - 1) * r_stride;
 
     for (int unit = slot; unit < my_pairs * n_eb; unit += n_slots) {
         const int pair = xcd + 8 * (unit / n_eb);
         const int64_t e0 = (int64_t)(unit % n_eb) * 256;
         const int c0 = (pair % n_cb) * 64, z = pair / n_cb;
-        const int kbase = z * (h / splits);
+        const int zk = z % splits, r_lo = (z / splits) * nr;
+        const int kbase = zk * (h / splits);
 
         // DMA cursor: step (slab 0, r 0); the wave moves fragments wave, wave + 8, wave + 16 of the step's 24
         // (fragment f = 12 kb + 3 mb + term sits at kb * kb_stride + (3 mb + term) * 64 of the image)
-        const bf16x8* dsrc = img + ((size_t)(kbase >> 5) * n_mb + (c0 >> 4)) * 3 * 64 + lane;
+        const bf16x8* dsrc = img + ((size_t)(kbase >> 5) * n_mb + (c0 >> 4)) * 3 * 64 + lane + (int64_t)r_lo * r_stride;
         int dr = 0, dslot = 0, dleft = IT;
         auto dma_next = [&]() {                                // the next step -> its slot; advances the cursor
             if (dleft <= 0) return;
@@ -164,7 +169,7 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
             }
             --dleft;
             dslot = dslot == FILT_NST - 1 ? 0 : dslot + 1;
-            if (++dr == R) { dr = 0; dsrc += slab_jump; } else dsrc += r_stride;
+            if (++dr == nr) { dr = 0; dsrc += slab_jump; } else dsrc += r_stride;
         };
         // unit prologue: everything it reads from global memory in one round of loads
         for (int idx = tid; idx < R * 256; idx += 512) {       // feature values of the tile's edges (coalesced reads)
@@ -173,7 +178,7 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
             n = n < n_edges ? n : n_edges - 1;
             evs[r * 256 + (nl & 192) + 4 * (nl & 15) + ((nl >> 4) & 3)] = ea[(size_t)n * R + r];
         }
-        if (z == 0)
+        if (zk == 0)
             for (int idx = tid; idx < R * 64; idx += 512) b2s[idx] = b2[(size_t)(idx >> 6) * h + c0 + (idx & 63)];
 
         f32x4 outv[2][4];
@@ -185,9 +190,8 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
         __syncthreads();                                       // staged values visible, every global load of the prologue done
         dma_next();
         dma_next();
-        if (z == 0) {                                          // bias term: sum_r ea[e][r] * b2[r h + c]
-#pragma unroll 4
-            for (int r = 0; r < R; ++r) {
+        if (zk == 0) {                                         // bias term: sum_r ea[e][r] * b2[r h + c]
+            for (int r = r_lo; r < r_lo + nr; ++r) {
                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(evl + r * 256);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
@@ -219,8 +223,8 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
                 for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+v"(xh[kb][nb]), "+v"(xm[kb][nb]), "+v"(xl[kb][nb]));
         };
         for (int it = 0; it < IT; ++it) {
-            const int slab = it / R, r = it - slab * R;
-            if (r == 0) build_b(slab);
+            const int slab = it / nr, r = r_lo + it - slab * nr;
+            if (r == r_lo) build_b(slab);
             // this step's fragments have landed (the three loads of step it + 1 may still be in flight) ...
             if (it + 1 < IT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -289,14 +293,14 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
 template <int R>
 __global__ void __launch_bounds__(512)             // two waves per SIMD: <= 256 registers each, no AGPR allocation
 k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2, const float* __restrict__ ea,
-                   const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits) {
-    filter_split_body<R>(img, b2, ea, bimg, out, h, n_edges, splits);
+                   const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits, int rs) {
+    filter_split_body<R>(img, b2, ea, bimg, out, h, n_edges, splits, rs);
 }
 template <int R>
 __global__ void __launch_bounds__(512)
-k_s2s_filter_split_types(FilterTypes T, const float* __restrict__ ea, int h, int64_t n_edges, int splits) {
+k_s2s_filter_split_types(FilterTypes T, const float* __restrict__ ea, int h, int64_t n_edges, int splits, int rs) {
     const int t = blockIdx.y;
-    filter_split_body<R>(T.img[t], T.b2[t], ea, T.bimg[t], T.out[t], h, n_edges, splits);
+    filter_split_body<R>(T.img[t], T.b2[t], ea, T.bimg[t], T.out[t], h, n_edges, splits, rs);
 }
 
 // The variable-N decoder's edge messages from the present state (aether_dynamicvars.py:827-835) out of the filters' planes:

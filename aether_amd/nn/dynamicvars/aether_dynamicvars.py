@@ -262,6 +262,10 @@ class AetherDynamicVars(nn.Module):
         g, static, outs = hit
         for dst, src in zip(static, args):
             dst.copy_(src)
+        # one replay in flight at a time: back-to-back replays of a captured aether_dyn_step without a host synchronisation
+        # ended in a GPU memory access fault in one configuration (cause not established), with it never
+        if not self.__dict__.get("_capture_one_call"):
+            torch.cuda.current_stream(static[0].device).synchronize()
         g.replay()
         # graphs share one memory pool: a later replay of another signature may reuse these buffers
         return tuple(o.clone() for o in outs)
@@ -272,11 +276,20 @@ class AetherDynamicVars(nn.Module):
         present objects and their graph per time step.  ``uniform``: per-step Gumbel draws (list of [E_t, K]).
         With B > 1 scenes (inputs [B, T, Nmax, 4], node_inds[b][t], graph_info[b][t], uniform[t][b]) every time step is
         ONE batched call per stage (predict_future_batched) -- the reference raises on batch > 1 (:588-591).
-        ``graph=True`` (one scene): every step replays a captured hipGraph of its signature (``_captured_step``) -- one
-        launch per step instead of ~110; bit-identical to the eager loop."""
+        One scene, default: the whole loop is ONE library call (``aether_dyn_rollout``).  With ``one_call_step = False``
+        (the staged calls + torch glue of rounds 1-2) ``graph=True`` replays a captured hipGraph per step signature
+        (``_captured_step``); bit-identical to the eager loop either way."""
         if inputs.size(0) > 1:
             return self.predict_future_batched(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         n_steps = inputs.size(1) - 1
+        if self.one_call_step and n_steps > 0 and not (graph and self.__dict__.get("_capture_one_call")):
+            # ONE library call queues the whole loop (64 launches per step, no host round trip): nothing left for a
+            # captured graph to save -- measured 0.36 ms per step against 0.40 ms for replays of a captured
+            # aether_dyn_step.  ``graph=True`` is accepted and means the same thing here.  (Replaying a captured
+            # aether_dyn_step back to back WITHOUT a host synchronisation in between ended in a GPU memory access fault in
+            # one configuration -- DESIGN.md 4.11c has the evidence; captured steps are therefore only used by the staged
+            # path, ``one_call_step = False``, where 300+ back-to-back replays have been clean.)
+            return self._predict_future_rollout(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         prior_state = self.encoder.get_initial_hidden(inputs)
         dec_state = self.decoder.get_initial_hidden(inputs)
         last = inputs[:, 0]
@@ -307,6 +320,65 @@ class AetherDynamicVars(nn.Module):
                                                               None if uniform is None else uniform[t], n_present=n_t)
             preds.append(last)
         return torch.stack(preds, dim=1)
+
+    @torch.no_grad()
+    def _predict_future_rollout(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
+        """The whole loop of ``predict_future`` for one scene as ONE library call (``aether_dyn_rollout``): per step the
+        burn-in mix and ``aether_dyn_step``, queued on the current stream without a host round trip in between."""
+        if not inputs.is_cuda:
+            raise _lib.AetherHipError("aether_amd AetherDynamicVars runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        if self.encoder.training:
+            raise _lib.AetherHipError("the prior step uses BatchNorm running statistics: call .eval() first")
+        lib = _lib.load()
+        dev = inputs.device
+        T, Nmax = int(inputs.size(1)), int(inputs.size(2))
+        n_steps, K = T - 1, self.num_edge_types
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        i64 = lambda t: t.to(device=dev, dtype=torch.int64).contiguous()
+        x, m, burn = f32(inputs)[0], f32(masks)[0], f32(burn_in_masks)[0]
+        if m.shape[0] < n_steps or burn.shape[0] < n_steps:
+            raise ValueError("masks / burn_in_masks must cover every step")
+        keep = []                                                  # device tensors the pointer arrays refer to
+        n_host = (C.c_int64 * n_steps)()
+        deg = (C.c_int * n_steps)()
+        ptrs = {k: (C.c_void_p * n_steps)() for k in ("ni", "gs", "gr", "e2n", "u")}
+        for t in range(n_steps):
+            ni_t = node_inds[0][t]
+            n_t = int(ni_t.numel())
+            n_host[t] = n_t
+            if n_t < 2:
+                continue
+            gs, gr, e2n = (i64(g) for g in graph_info[0][t])
+            E = int(gs.numel())
+            if gr.numel() != E or e2n.ndim != 2 or e2n.shape[0] != n_t:
+                raise ValueError(f"graph_info of step {t} does not match its present objects")
+            u = f32(uniform[t]).reshape(-1, K) if uniform is not None else torch.rand(E, K, device=dev)
+            if u.shape[0] != E:
+                raise ValueError(f"uniform of step {t} must be [E, K]")
+            ni = i64(ni_t)
+            keep += [gs, gr, e2n, u, ni]
+            deg[t] = int(e2n.shape[1])
+            for k, v in (("ni", ni), ("gs", gs), ("gr", gr), ("e2n", e2n), ("u", u)):
+                ptrs[k][t] = v.data_ptr()
+        cfg = self._step_config()
+        need = lib.aether_dyn_rollout_workspace_bytes(C.byref(cfg), Nmax, n_steps, n_host)
+        if need == 0:
+            raise _lib.AetherHipError("aether_dyn_rollout_workspace_bytes: bad sizes (2..8192 object rows, hidden sizes)")
+        ws = self.__dict__.get("_step_ws")
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self.__dict__["_step_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        prior_h, prior_c = (f32(s)[0].clone() for s in self.encoder.get_initial_hidden(inputs))
+        dec = f32(self.decoder.get_initial_hidden(inputs))[0].clone()
+        preds = torch.empty(n_steps, Nmax, 4, dtype=torch.float32, device=dev)
+        fs, ps_e, ps_d = self._field_struct(), self.encoder._param_struct()[0], self.decoder._param_struct()
+        st = lib.aether_dyn_rollout(C.byref(fs), C.byref(ps_e), C.byref(ps_d), C.byref(cfg), Nmax, n_steps, x.data_ptr(),
+                                    m.data_ptr(), burn.data_ptr(), n_host, ptrs["ni"], ptrs["gs"], ptrs["gr"], ptrs["e2n"], deg,
+                                    ptrs["u"], prior_h.data_ptr(), prior_c.data_ptr(), dec.data_ptr(), preds.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_dyn_rollout")
+        del keep
+        return preds.unsqueeze(0)
 
     @torch.no_grad()
     def predict_future_batched(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):

@@ -310,23 +310,39 @@ def test_predict_future_captured_steps_equal_the_eager_loop():
         node_inds.append(masks[0, step].nonzero()[:, -1].cuda())
         U.append(torch.rand(send.numel(), 4, generator=g).cuda())
     args = (inputs.cuda(), masks.cuda(), [node_inds], [graph_info], burn.cuda())
-    eager = model.predict_future(*args, uniform=U[:T - 1])
-    for rep in range(2):
-        got = model.predict_future(*args, uniform=U[:T - 1], graph=True)
-        assert torch.equal(got, eager), rep
-    assert len(model._step_graphs) == 4                       # one graph per signature: 24, 12, 3 and 40 present objects
-    # the one-call step (aether_dyn_step) runs the staged path's kernels on the same rows: identical bits
+    rollout = model.predict_future(*args, uniform=U[:T - 1])       # default: ONE library call for the loop (aether_dyn_rollout)
+    # the staged path (three library calls + torch glue per step) runs the same stage kernels on the same rows: identical
+    # bits, eagerly and as captured steps
     model.one_call_step = False
     try:
-        staged = model.predict_future(*args, uniform=U[:T - 1])
+        eager = model.predict_future(*args, uniform=U[:T - 1])
+        assert torch.equal(eager, rollout)
+        for rep in range(2):
+            got = model.predict_future(*args, uniform=U[:T - 1], graph=True)
+            assert torch.equal(got, eager), rep
+        assert len(model._step_graphs) == 4                   # one graph per signature: 24, 12, 3 and 40 present objects
+        # ... and so does aether_dyn_step called once per step from the host loop
+        model.one_call_step = True
+        ph, pc = model.encoder.get_initial_hidden(inputs.cuda())
+        dec = model.decoder.get_initial_hidden(inputs.cuda())
+        last = inputs[:, 0].cuda()
+        for t in range(T - 1):
+            obs = burn[:, t].cuda().unsqueeze(-1)
+            state = obs * inputs[:, t].cuda() + (1 - obs) * last
+            gs, gr, e2n = graph_info[t]
+            last, ph, pc, dec = model._step_one_call(state, masks[:, t].cuda(), node_inds[t], gs, gr, e2n, ph, pc, dec, U[t])
+            assert torch.equal(last, rollout[:, t]), t
     finally:
         model.one_call_step = True
-    assert torch.equal(staged, eager)
     bad = masks.clone()
     bad[0, 0, :] = 1                                            # the mask now says 40 objects, node_inds still 24
     model._step_graphs.clear()
-    with pytest.raises(ValueError):
-        model.predict_future(inputs.cuda(), bad.cuda(), [node_inds], [graph_info], burn.cuda(), uniform=U[:T - 1], graph=True)
+    model.one_call_step = False
+    try:
+        with pytest.raises(ValueError):
+            model.predict_future(inputs.cuda(), bad.cuda(), [node_inds], [graph_info], burn.cuda(), uniform=U[:T - 1], graph=True)
+    finally:
+        model.one_call_step = True
     # eagerly the library notices by itself: NaN outputs for the step and an error from the next call / the explicit check
     out = model.predict_future(inputs[:, :2].cuda(), bad[:, :2].cuda(), [node_inds], [graph_info], burn[:, :2].cuda(),
                                uniform=U[:1])
