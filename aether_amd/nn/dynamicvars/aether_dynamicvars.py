@@ -159,7 +159,10 @@ class AetherDynamicVars(nn.Module):
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         state, present, uniform_t = f32(state), f32(present).reshape(-1), f32(uniform_t)
         ni, gs, gr, e2n = i64(node_inds_t), i64(gsend), i64(grecv), i64(e2n)
-        new_h, new_c, new_dec = f32(prior_h).clone(), f32(prior_c).clone(), f32(dec_state).clone()
+        if self.__dict__.get("_kernel_copies"):        # diagnostic (tools/dyn_graph_repro.py): copies as kernels, not memcpy nodes
+            new_h, new_c, new_dec = (torch.add(f32(t), 0.0) for t in (prior_h, prior_c, dec_state))
+        else:
+            new_h, new_c, new_dec = f32(prior_h).clone(), f32(prior_c).clone(), f32(dec_state).clone()
         cfg = self._step_config()
         need = lib.aether_dyn_step_workspace_bytes(C.byref(cfg), Nmax, n, E)
         if need == 0:
