@@ -66,6 +66,7 @@ FLAG_FORCE_FUSED = 4
 FLAG_WORKSPACE_REUSED = 8
 FLAG_WEIGHTS_PREPARED = 16
 FLAG_BACKWARD_ONLY = 32
+FLAG_DROPOUT = 64
 
 # name -> (restype, argtypes); every symbol include/aether_hip.h declares
 SIGNATURES = {
@@ -126,6 +127,7 @@ SIGNATURES = {
                                  [C.c_double] * 3 + [C.c_void_p] * 4),
     "aether_sim_gravitational": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 5 +
                                  [C.c_double] * 3 + [C.c_void_p] * 4),
+    "aether_dropout_mask_offset": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "aether_backward_inputs": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo), C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -286,7 +286,7 @@ struct WsLayout {
     // forward (always)
     size_t nodeinfo, x[5], ps[3], pr[3], e[4], aggr, part, stamps, flags, velbuf[2], wimg, fwd_total;
     // saved by the forward under KEEP_INTERMEDIATES for the backward
-    size_t n[4], feat;
+    size_t n[4], feat, drop, dropword;      // drop: [2][n_nodes][64] dropout scale masks (caller-written), dropword: applied?
     // backward temporaries
     // Operands of the weight-gradient outer products are per layer when `defer` (all of them are then
     // multiplied in ONE launch at the end of the backward); otherwise the layers share one set.
@@ -315,6 +315,7 @@ struct WsLayout {
         fwd_total = off;
         for (auto& v : n) v = take(nn * H);
         feat = take(ee * FPAD);
+        drop = take(nn * 2 * H); dropword = take(64);
         defer = E <= g_outer_defer_max_edges;
         const int sets = defer ? 4 : 1;
         for (int k = 0; k < 5; ++k) DXl[k] = (defer || k < 2) ? take(nn * H) : DXl[k - 2];
@@ -548,7 +549,7 @@ int streamed_impl(const AetherParams& P, int64_t Nn, int64_t E, const float* x, 
             ProfScope ps(K_NODE_LAST, st);
             k_node_update<D, true><<<dim3(node_grid), dim3(256), 0, st>>>(
                 P, l, wp(W.x[l - 1]), wp(W.aggr), wp(W.x[l]), nullptr, nullptr, nodeinfo, x,
-                out, keep ? wp(W.n[l - 1]) : nullptr, step.vel_out, step.dt, Nn);
+                out, keep ? wp(W.n[l - 1]) : nullptr, step.vel_out, step.dt, Nn, step.drop1, step.drop2, step.dropword);
         }
     }
     HIP_OK(hipGetLastError());
@@ -652,7 +653,8 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
     {
         { ProfScope ps(KB_OUT, st);
         kb_out<D><<<dim3(ngrid), dim3(256), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
-                                                   wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
+                                                   wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn, wp(W.drop),
+                                                   wp(W.drop) + (size_t)Nn * H, reinterpret_cast<const int*>(ws + W.dropword)); }
         L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
         L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
         L.add(wp(W.DY), 16, D, wp(W.O2), H, H, Nn, Gr.out_w6, H, Gr.out_b6);
@@ -810,7 +812,8 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
     // ---- out MLP
     { ProfScope ps(KB_OUT, st);
     kb_out<D><<<dim3(ngrid), dim3(256), 0, st>>>(P, WT, wp(W.x[4]), wp(W.nodeinfo), g_out, wp(W.DXl[4]), wp(W.O1),
-                                               wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn); }
+                                               wp(W.O2), wp(W.DPO1), wp(W.DPO2), wp(W.DY), Nn, wp(W.drop),
+                                               wp(W.drop) + (size_t)Nn * H, reinterpret_cast<const int*>(ws + W.dropword)); }
     L.add(wp(W.DPO1), H, H, wp(W.x[4]), H, H, Nn, Gr.out_w0, H, Gr.out_b0);
     L.add(wp(W.DPO2), H, H, wp(W.O1), H, H, Nn, Gr.out_w3, H, Gr.out_b3);
     L.add(wp(W.DY), 16, D, wp(W.O2), H, H, Nn, Gr.out_w6, H, Gr.out_b6);
@@ -1242,6 +1245,11 @@ size_t aether_workspace_bytes(int64_t n_nodes, int64_t n_edges, int num_dims, in
     return WsLayout(n_nodes, n_edges, num_dims, keep_for_backward != 0).total;
 }
 
+size_t aether_dropout_mask_offset(int64_t n_nodes, int64_t n_edges, int num_dims) {
+    if (n_nodes <= 0 || n_edges < 0 || (num_dims != 2 && num_dims != 3)) return 0;
+    return WsLayout(n_nodes, n_edges, num_dims, true).drop;
+}
+
 static int forward_common(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges,
                           const float* x, const float* vel, const float* charges,
                           const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
@@ -1265,7 +1273,15 @@ static int forward_common(const AetherParams* params, int num_dims, int64_t n_no
     const bool keep = (flags & AETHER_FLAG_KEEP_INTERMEDIATES) != 0;
     const bool reused = (flags & AETHER_FLAG_WORKSPACE_REUSED) != 0;
     const bool prepared = (flags & AETHER_FLAG_WEIGHTS_PREPARED) != 0;
-    const StepExtras no_extras{nullptr, nullptr, 1.0f, field, (flags & AETHER_FLAG_BACKWARD_ONLY) != 0};
+    StepExtras no_extras{nullptr, nullptr, 1.0f, field, (flags & AETHER_FLAG_BACKWARD_ONLY) != 0};
+    if ((flags & AETHER_FLAG_DROPOUT) && !keep)
+        return fail(AETHER_EINVAL, "forward: AETHER_FLAG_DROPOUT needs AETHER_FLAG_KEEP_INTERMEDIATES (the masks live in the training workspace)");
+    if (keep) {
+        const WsLayout W(n_nodes, n_edges, num_dims, true);
+        float* masks = reinterpret_cast<float*>((char*)workspace + W.drop);
+        if (flags & AETHER_FLAG_DROPOUT) { no_extras.drop1 = masks; no_extras.drop2 = masks + (size_t)n_nodes * H; }
+        no_extras.dropword = reinterpret_cast<int*>((char*)workspace + W.dropword);
+    }
     if (fused) {
         if (num_dims == 2)
             return fused_impl<2>(*params, n_nodes, n_edges, *info, x, vel, charges, edge_attr_orig,

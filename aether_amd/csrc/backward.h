@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256)
 kb_out(AetherParams P, BwdWT WT, const float* __restrict__ x4, const float* __restrict__ nodeinfo,
         const float* __restrict__ g_out, float* __restrict__ DX, float* __restrict__ O1,
         float* __restrict__ O2, float* __restrict__ DPO1, float* __restrict__ DPO2,
-        float* __restrict__ DY, int64_t n_nodes) {
+        float* __restrict__ DY, int64_t n_nodes, const float* __restrict__ drop1 = nullptr,
+        const float* __restrict__ drop2 = nullptr, const int* __restrict__ dropword = nullptr) {
     using NI = NodeInfo<D>;
     __shared__ __attribute__((aligned(16))) float sbuf[3][16 * LDW];      // o1 | d2 | d1 rows of the tile's 16 nodes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -298,6 +299,12 @@ kb_out(AetherParams P, BwdWT WT, const float* __restrict__ x4, const float* __re
     }
     const f32x4 w6f = ld4(WT.out_w6t + row * 16 + 4 * q);
     f32x4 p1 = ld4(P.out_b0 + 16 * wave + 4 * q), p2 = ld4(P.out_b3 + 16 * wave + 4 * q);
+    // dropout masks of the forward (scale 0 or 1 / (1 - p) per node and channel), when it applied any
+    f32x4 m1 = f32x4{1.f, 1.f, 1.f, 1.f}, m2 = m1;
+    if (dropword != nullptr && *dropword != 0) {
+        m1 = ld4(drop1 + nc * H + 16 * wave + 4 * q);
+        m2 = ld4(drop2 + nc * H + 16 * wave + 4 * q);
+    }
     // dy = R^T g (rows 0..D-1 of a 16-row block: lanes q == 0, registers 0..D-1); every wave computes it
     f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q == 0 && ok) {
@@ -321,7 +328,7 @@ kb_out(AetherParams P, BwdWT WT, const float* __restrict__ x4, const float* __re
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) p1 = mfma16(w0f[a][b], xt[a][b], p1);
-    const f32x4 o1 = silu4(p1);
+    const f32x4 o1 = silu4(p1) * m1;
     mine(sbuf[0], o1);
     out(O1, o1);
     __syncthreads();
@@ -331,12 +338,12 @@ kb_out(AetherParams P, BwdWT WT, const float* __restrict__ x4, const float* __re
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) p2 = mfma16(w3f[a][b], t[a][b], p2);
-    out(O2, silu4(p2));
+    out(O2, silu4(p2) * m2);
     // d2 = (Wo6^T dy) * silu'(p2)   (K = 16, only k < D non-zero)
     f32x4 d2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 4; ++b) d2 = mfma16(w6f[b], dy[b], d2);
-    d2 = d2 * dsilu4(p2);
+    d2 = d2 * dsilu4(p2) * m2;
     mine(sbuf[1], d2);
     out(DPO2, d2);
     __syncthreads();
@@ -346,7 +353,7 @@ kb_out(AetherParams P, BwdWT WT, const float* __restrict__ x4, const float* __re
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) d1 = mfma16(w3tf[a][b], t[a][b], d1);
-    d1 = d1 * dsilu4(p1);
+    d1 = d1 * dsilu4(p1) * m1;
     mine(sbuf[2], d1);
     out(DPO1, d1);
     __syncthreads();

@@ -210,7 +210,13 @@ __device__ __forceinline__ void stage_weight64(float* lds, const float* __restri
 // experiments/lorentz/main.py:243-246) instead of reading it; `vel_out` != nullptr also writes the
 // next velocity (x_next - x) / dt next to the output; `ext_field` != nullptr replaces the built-in field net
 // by a precomputed per-node field [n_nodes][D] (the dynamic-field variant, aether_dynamic_field).
-struct StepExtras { const float* qattr; float* vel_out; float dt; const float* ext_field; bool skip_e4 = false; };
+struct StepExtras {
+    const float* qattr; float* vel_out; float dt; const float* ext_field; bool skip_e4 = false;
+    // training with dropout_prob > 0 (locs.py:160-168: nn.Dropout after the two SiLUs of the out MLP): the scale masks
+    // [n_nodes][64] (0 or 1 / (1 - p)) the caller wrote into the workspace, or null; dropword (device): 1 when this forward
+    // applied them -- aether_backward reads it
+    const float* drop1 = nullptr; const float* drop2 = nullptr; int* dropword = nullptr;
+};
 
 template <int D> struct NodeInfo {
     // [p(D) v(D) f(D) R(D*D row-major) cv(D) cf(D)], padded to a multiple of 4 floats

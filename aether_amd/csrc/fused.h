@@ -972,7 +972,15 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc = mfma16(wsv[a][b], xv[b], acc);
             }
-            st4(o1 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
+            f32x4 v = silu4(acc);
+            if constexpr (KEEP) {
+                if (dbg.step.drop1 != nullptr && 16 * tn + i < n)
+                    v = v * ld4(dbg.step.drop1 + (int64_t)(nb + 16 * tn + i) * H + 16 * mb + 4 * q);
+            }
+            st4(o1 + (16 * tn + i) * LDW + 16 * mb + 4 * q, v);
+        }
+        if constexpr (KEEP) {
+            if (blockIdx.x == 0 && tid == 0 && dbg.step.dropword != nullptr) *dbg.step.dropword = dbg.step.drop1 != nullptr ? 1 : 0;
         }
         lds_barrier();
         if (act) {
@@ -983,7 +991,12 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc = mfma16(wrv[a][b], xv[b], acc);
             }
-            st4(o2 + (16 * tn + i) * LDW + 16 * mb + 4 * q, silu4(acc));
+            f32x4 v = silu4(acc);
+            if constexpr (KEEP) {
+                if (dbg.step.drop2 != nullptr && 16 * tn + i < n)
+                    v = v * ld4(dbg.step.drop2 + (int64_t)(nb + 16 * tn + i) * H + 16 * mb + 4 * q);
+            }
+            st4(o2 + (16 * tn + i) * LDW + 16 * mb + 4 * q, v);
         }
         lds_barrier();
         if (wave < 2 && 16 * wave < n) {

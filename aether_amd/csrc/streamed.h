@@ -470,7 +470,8 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
               float* __restrict__ x_out, float* __restrict__ Ps, float* __restrict__ Pr,
               const float* __restrict__ nodeinfo, const float* __restrict__ pos,
               float* __restrict__ out, float* __restrict__ nsave, float* __restrict__ vel_out, float dt,
-              int64_t n_nodes) {
+              int64_t n_nodes, const float* __restrict__ drop1 = nullptr, const float* __restrict__ drop2 = nullptr,
+              int* __restrict__ dropword = nullptr) {
     using NI = NodeInfo<D>;
     constexpr int LDUU = 2 * H + 8;
     __shared__ __attribute__((aligned(16))) float ubuf[16 * LDUU];       // u, later o1 | o2 (cols 0-63 | 64-127)
@@ -561,7 +562,10 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) c0v = mfma16(wcf[0][a][b], xv[a][b], c0v);
-        st4(ubuf + i * LDUU + 16 * wave + 4 * q, silu4(c0v));            // o1 (u is dead: all waves passed B)
+        if (dropword != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *dropword = drop1 != nullptr ? 1 : 0;
+        f32x4 o1v = silu4(c0v);
+        if (drop1 != nullptr) o1v = o1v * ld4(drop1 + nc * H + 16 * wave + 4 * q);      // nn.Dropout (locs.py:163)
+        st4(ubuf + i * LDUU + 16 * wave + 4 * q, o1v);                   // o1 (u is dead: all waves passed B)
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -569,7 +573,9 @@ k_node_update(AetherParams P, int layer /*1..4*/, const float* __restrict__ x_pr
 #pragma unroll
             for (int b = 0; b < 4; ++b) c1v = mfma16(wcf[1][a][b], ov[b], c1v);
         }
-        st4(ubuf + i * LDUU + H + 16 * wave + 4 * q, silu4(c1v));        // o2
+        f32x4 o2v = silu4(c1v);
+        if (drop2 != nullptr) o2v = o2v * ld4(drop2 + nc * H + 16 * wave + 4 * q);      // (locs.py:166)
+        st4(ubuf + i * LDUU + H + 16 * wave + 4 * q, o2v);               // o2
         __syncthreads();
         if (wave == 0) {
             f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};

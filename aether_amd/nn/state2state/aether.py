@@ -97,6 +97,9 @@ class _AetherStep(torch.autograd.Function):
             # training: keep what the backward reads, not the last layer's messages (only aether_debug_fetch reads them)
             flags |= _lib.FLAG_KEEP_INTERMEDIATES | _lib.FLAG_BACKWARD_ONLY
         keep = bool(flags & _lib.FLAG_KEEP_INTERMEDIATES)
+        dropout = train and module.dropout_prob > 0.0 and module.training
+        if dropout:
+            flags |= _lib.FLAG_DROPOUT
         ws_bytes = module._workspace_bytes(n_nodes, n_edges, keep)
         ws_key = None
         if train:
@@ -136,6 +139,17 @@ class _AetherStep(torch.autograd.Function):
             if fused and module._wimg_key == wkey and module._may_reuse_weight_images():
                 flags |= _lib.FLAG_WEIGHTS_PREPARED
             module._wimg_key = None
+        if dropout:
+            # nn.Dropout after the two SiLUs of the out MLP (locs.py:163,166): scale masks drawn by torch, written straight
+            # into their place in the training workspace (same distribution as nn.Dropout, not its random stream)
+            off = lib.aether_dropout_mask_offset(n_nodes, n_edges, D)
+            masks = ws[off:off + 2 * n_nodes * 64 * 4].view(torch.float32).view(2, n_nodes, 64)
+            given = module.__dict__.get("_dropout_masks")          # tests: explicit masks [2, n_nodes, 64]
+            if given is not None:
+                masks.copy_(given.to(device=x.device, dtype=torch.float32))
+            else:
+                keep_p = 1.0 - module.dropout_prob
+                masks.bernoulli_(keep_p).mul_(1.0 / keep_p)
         out = torch.empty_like(x)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         st = lib.aether_forward(module._param_struct_ref(), D, n_nodes, n_edges,
@@ -524,21 +538,20 @@ class Aether(nn.Module):
         # the reference's forward is differentiable in x / vel / edge_attr_orig (aether.py:169-186): so is this one
         # (aether_backward_inputs); charges are an embedding index, no gradient flows to them there either
         wants_in = torch.is_grad_enabled() and (x.requires_grad or vel.requires_grad or edge_attr_orig.requires_grad)
-        if self.dropout_prob > 0.0 and self.training:     # (nn.Dropout keys on the module's mode, not on autograd's)
-            raise NotImplementedError("aether_amd.Aether: dropout_prob > 0 is supported in eval() mode only (identity); "
-                                      "a train()-mode forward with active dropout is not implemented")
+        # nn.Dropout keys on the module's mode, not on autograd's: a train()-mode forward applies it even under no_grad
+        drops = self.dropout_prob > 0.0 and self.training
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         f32g = (lambda t: t.to(torch.float32).contiguous() if t.requires_grad else f32(t)) if wants_in else f32
         if self.hidden_size != 64:      # narrow model: the zero-padded 64-wide engine computes it (same kernels)
             eng = self._sync_engine()
-            if not (wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist))):
+            if not (drops or wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist))):
                 with torch.no_grad():
                     return eng(h, x, edges, vel, edge_attr_orig, charges)
             return _PaddedStep.apply(self, f32g(x), send, recv, f32g(vel), f32g(edge_attr_orig), f32(charges), *self._plist)
         graph = self.prepare_graph((send, recv), n_nodes)
         if self._plist is None:         # nn.Module.parameters() walks the module tree: 0.15 ms per call
             self._plist = [p for _, p in self.named_parameters()]
-        train = wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist))
+        train = drops or wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist))
         if not train:           # inference: no autograd node, no parameter list to marshal
             return _AetherStep.launch(self, False, f32(x), f32(vel), f32(edge_attr_orig), f32(charges), graph, E)[0]
         return _AetherStep.apply(self, f32g(x), f32g(vel), f32g(edge_attr_orig), f32(charges), graph, E,

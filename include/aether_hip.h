@@ -86,6 +86,14 @@ typedef struct AetherGraphInfo {
 /* With AETHER_FLAG_KEEP_INTERMEDIATES: keep only what aether_backward reads -- the last layer's messages e4 (12 MB at
  * N=20, batch=128; 8.6 GB for a 33.5 M-edge shard) are then not written (aether_debug_fetch("e4") is undefined). */
 #define AETHER_FLAG_BACKWARD_ONLY 32
+/* Training with dropout_prob > 0 (round 3).  The reference's only Dropout layers follow the two SiLUs of the out MLP
+ * (nn/state2state/locs/locs.py:160-168).  The caller draws the masks: float[2][n_nodes][64] of SCALES (0 or 1 / (1 - p)),
+ * written at byte offset aether_dropout_mask_offset(n_nodes, n_edges, num_dims) of the training workspace before
+ * aether_forward(... AETHER_FLAG_KEEP_INTERMEDIATES | AETHER_FLAG_DROPOUT); aether_backward on the same workspace applies
+ * the same masks (a word the forward leaves there says whether it used any).  The module fills them with torch's bernoulli_:
+ * the same distribution as nn.Dropout, not its random stream. */
+#define AETHER_FLAG_DROPOUT 64
+size_t aether_dropout_mask_offset(int64_t n_nodes, int64_t n_edges, int num_dims);
 
 /* Library / build identification (host string, static storage). */
 const char* aether_version(void);

@@ -156,15 +156,20 @@ def gnn_layer(sd, prefix, x, e_in, send, recv, first):
     return x, m
 
 
-def out_mlp(sd, x):
-    """locs.py:160-168 with Dropout p=0 (runner: main.py:143)."""
+def out_mlp(sd, x, dropout_masks=None):
+    """locs.py:160-168.  ``dropout_masks``: the two scale masks [n_nodes, hidden] (0 or 1 / (1 - p)) nn.Dropout would apply
+    after the SiLUs in train() mode (:163, :166); None = Dropout p=0 / eval (runner: main.py:143)."""
     x = F.silu(_linear(sd, "gnn.out_mlp.0", x))
+    if dropout_masks is not None:
+        x = x * dropout_masks[0]
     x = F.silu(_linear(sd, "gnn.out_mlp.3", x))
+    if dropout_masks is not None:
+        x = x * dropout_masks[1]
     return _linear(sd, "gnn.out_mlp.6", x)
 
 
 # --------------------------------------------------------------------- whole
-def aether_forward(sd, x, vel, edges, edge_attr_orig, charges, return_all=False, field=None):
+def aether_forward(sd, x, vel, edges, edge_attr_orig, charges, return_all=False, field=None, dropout_masks=None):
     """aether.py:169-186.  ``sd`` maps reference state_dict keys to tensors.  ``field``: a precomputed
     per-node field replaces the built-in field net (the dynamic-field variant, dynamic_field_aether.py:84-97,
     is this function with ``dynamic_field`` below)."""
@@ -183,7 +188,7 @@ def aether_forward(sd, x, vel, edges, edge_attr_orig, charges, return_all=False,
     for k in range(1, 5):
         h, e = gnn_layer(sd, f"gnn.layer_{k}", h, e, send, recv, first=(k == 1))
         res[f"x{k}"], res[f"e{k}"] = h, e
-    pred = out_mlp(sd, h)
+    pred = out_mlp(sd, h, dropout_masks)
     res["pred_local"] = pred
     pred = apply_rot(R, pred)                                       # local_to_global.py:12-13
     res["pred_global"] = pred

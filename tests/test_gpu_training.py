@@ -71,7 +71,7 @@ def test_drop_in_error_behaviour():
     bad[1][3] = inp["x"].shape[0]                       # receiver out of range
     with pytest.raises(_lib.AetherHipError, match="outside"):
         m(*args(edges=bad))
-    for ctor in (lambda: Aether(4, 128, 0.0, 2), lambda: Aether(4, 64, 0.1, 2), lambda: Aether(4, 64, 0.0, 4)):
+    for ctor in (lambda: Aether(4, 128, 0.0, 2), lambda: Aether(4, 64, 1.0, 2), lambda: Aether(4, 64, 0.0, 4)):
         with pytest.raises(ValueError):
             ctor()
     # C ABI: a workspace that is too small is refused, nothing is launched
@@ -319,9 +319,10 @@ def test_graphed_step_with_library_loss_and_optimizer_matches_the_torch_ones():
         assert scale_rel_err(res["aether"][1][k], res["torch"][1][k]) <= 1e-4, k
 
 
-def test_dropout_is_identity_in_eval_and_refused_in_training():
+def test_dropout_is_identity_in_eval_and_active_in_training():
     """out_mlp's nn.Dropout (locs.py:160-168): identity in eval(), so a model built with dropout_prob > 0 gives the
-    p = 0 result there; a training forward with active dropout is refused loudly (not implemented)."""
+    p = 0 result there; in train() mode -- with or without autograd, as nn.Dropout keys on the module's mode -- the two
+    masks are drawn per call: scales 0 or 1 / (1 - p) with the right frequency, different from call to call."""
     D = 2
     inp = make_batch(4, 20, D, seed=3)
     dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
@@ -333,9 +334,80 @@ def test_dropout_is_identity_in_eval_and_refused_in_training():
     call = lambda m: m(dev["h"], dev["x"], dev["edges"], dev["vel"], dev["edge_attr"], dev["charges"])
     m0.eval(); m1.eval()
     with torch.no_grad():
-        assert torch.equal(call(m0), call(m1))
+        ref = call(m0)
+        assert torch.equal(ref, call(m1))
     m1.train()
-    with pytest.raises(NotImplementedError):
-        call(m1)
-    with torch.no_grad(), pytest.raises(NotImplementedError):      # nn.Dropout keys on train(), not on autograd
-        call(m1)
+    a = call(m1)
+    lib = _lib.load()
+    n_nodes, n_edges = dev["x"].shape[0], dev["edges"][0].numel()
+    off = lib.aether_dropout_mask_offset(n_nodes, n_edges, D)
+    masks = m1._last_ws[off:off + 2 * n_nodes * 64 * 4].view(torch.float32).view(2, n_nodes, 64).clone()
+    vals = torch.unique(masks)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.7) < 1e-6
+    assert abs(float((masks == 0).float().mean()) - 0.3) < 0.02                 # 10,240 draws
+    with torch.no_grad():
+        b = call(m1)
+    assert not torch.equal(a.detach(), b) and not torch.equal(b, ref)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+
+
+@pytest.mark.parametrize("path", ["fused", "streamed"])
+@pytest.mark.parametrize("D", [2, 3])
+def test_dropout_training_step_matches_oracle_with_the_same_masks(D, path):
+    """Forward, all 47 parameter gradients and the input gradients of a train()-mode step with dropout_prob = 0.25 against
+    the oracle's autograd with the SAME two masks (the module takes explicit masks through a test hook; otherwise it draws
+    them with torch's bernoulli_)."""
+    sd = load_state_dict(D)
+    for (B, N, seed) in [(6, 9, 81), (3, 40, 82)]:
+        inp = make_batch(B, N, D, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        masks = (torch.rand(2, B * N, 64, generator=g) >= 0.25).float() / 0.75
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xg, vg = inp["x"].clone().requires_grad_(True), inp["vel"].clone().requires_grad_(True)
+        want = O.aether_forward(sdg, xg, vg, inp["edges"], inp["edge_attr"], inp["charges"], dropout_masks=masks)
+        torch.nn.functional.mse_loss(want, inp["target"]).backward()
+        m = Aether(2 * D, 64, 0.25, D, device="cuda")
+        m.load_state_dict(sd)
+        m.flags = _lib.FLAG_FORCE_FUSED if path == "fused" and N < 40 else (_lib.FLAG_FORCE_STREAMED if path == "streamed" else 0)
+        m.train()
+        m._dropout_masks = masks
+        x, v = inp["x"].cuda().requires_grad_(True), inp["vel"].cuda().requires_grad_(True)
+        out = m(inp["h"].cuda(), x, [e.cuda() for e in inp["edges"]], v, inp["edge_attr"].cuda(), inp["charges"].cuda())
+        assert scale_rel_err(out.detach().cpu(), want.detach()) <= 1e-5, (B, N)
+        torch.nn.functional.mse_loss(out, inp["target"].cuda()).backward()
+        for k, p in m.named_parameters():
+            assert scale_rel_err(p.grad.cpu(), sdg[k].grad) <= 5e-5, (B, N, k)
+        assert scale_rel_err(x.grad.cpu(), xg.grad) <= 5e-5 and scale_rel_err(v.grad.cpu(), vg.grad) <= 1e-4
+        # the same model in eval(): no masks, the p = 0 result
+        m.eval()
+        with torch.no_grad():
+            ev = m(inp["h"].cuda(), inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(),
+                   inp["edge_attr"].cuda(), inp["charges"].cuda())
+        plain = O.aether_forward(sd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+        assert scale_rel_err(ev.cpu(), plain) <= 1e-5
+
+
+def test_dropout_inside_a_captured_training_step():
+    """GraphedTrainStep with dropout_prob > 0: the mask draw is part of the captured graph (torch's graph-safe Philox
+    offsets), so every replay trains with fresh masks; the loss stays finite and goes down."""
+    from aether_amd.training import GraphedTrainStep
+    D = 2
+    inp = make_batch(8, 20, D, seed=91)
+    dev = "cuda"
+    torch.manual_seed(3)
+    m = Aether(2 * D, 64, 0.1, D, device=dev).train()
+    args = [inp["h"].to(dev), inp["x"].to(dev), [e.to(dev) for e in inp["edges"]], inp["vel"].to(dev), inp["edge_attr"].to(dev),
+            inp["charges"].to(dev)]
+    gs = GraphedTrainStep(m, args, inp["target"].to(dev), lr=1e-3, weight_decay=1e-12, warmup=1)
+    lib = _lib.load()
+    off = lib.aether_dropout_mask_offset(inp["x"].shape[0], inp["edges"][0].numel(), D)
+    losses, seen = [], []
+    for _ in range(30):
+        losses.append(float(gs.step(args, inp["target"].to(dev))))
+        seen.append(m._last_ws[off:off + 4096].clone())
+    gs.check()
+    assert all(l == l and l < 1e6 for l in losses)
+    assert sum(losses[-5:]) < sum(losses[:5])
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
