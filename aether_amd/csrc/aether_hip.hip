@@ -687,7 +687,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
             ProfScope* pse = new ProfScope(KB_EDGE, st);
             if (acc_path) {
                 // large graphs: the two edge-level products of the layer accumulate inside the edge kernel (edge_acc.h)
-                const size_t lds_a = (size_t)(2 * SPLIT_WIMG + 2 * H * LDW + 4 * EA_STG) * 4;
+                const size_t lds_a = (size_t)(4 * SPLIT_WIMG + 4 * EA_STG) * 4;      // four split images + a staging pair per wave
                 EdgeAccOut O{};
                 O.w2 = gw2; O.b2 = gb2;
                 if (l == 1) {

@@ -17,7 +17,7 @@ namespace {
 
 constexpr int EA_REGS = 128 + 32;                   // accumulator registers per lane: dW2 64 | dW_e 64 | db2 16 | db1 16
 constexpr int EA_PART = EA_REGS * 64;               // floats per workgroup partial, [register][lane]
-constexpr int EA_STG = 4 * 16 * FB_SA;              // staging floats per wave: dpre2 | h | G | e_prev (features)
+constexpr int EA_STG = 2 * 16 * FB_SA;              // staging floats per wave: one operand pair at a time (dpre2 | h, then G | e_prev)
 
 template <bool FIRST>
 __global__ void __launch_bounds__(256)
@@ -32,32 +32,32 @@ kb_edge_acc(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64]
             const float* __restrict__ img_in /*split image of W_e (FIRST: of W1, K padded to 32)*/,
             const float* __restrict__ img_2 /*split image of W2*/, int64_t n_edges) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // the two recompute products run as six bf16 terms on the forward's split images (common.h gemm_split: fp32-equivalent,
-    // 96 matrix-pipe instructions of 16 cycles for 128 fp32 MFMAs of 32); the two transposed products stay fp32 MFMAs
+    // All four products of a tile run as six bf16 terms on split images (common.h gemm_split: fp32-equivalent, 96
+    // matrix-pipe instructions of 16 cycles for 128 fp32 MFMAs of 32 that would issue on the vector ALU): the two recompute
+    // products on the forward's images, the two transposed ones (dh = W2^T dpre2, de = W_in^T G) on images of the transposed
+    // copies built here.  (Round 3, first version: the transposed products as fp32 MFMAs -- 128 of the tile's 256.)
     float* wi = smem;                  // split image of W_in [SPLIT_WIMG] (FIRST: half of it)
     float* w2 = wi + SPLIT_WIMG;       // split image of W2
-    float* w2ts = w2 + SPLIT_WIMG;     // W2^T   [64][LDW]
-    float* wit = w2ts + H * LDW;       // W_in^T [64 | 32][LDW]
-    float* stg = wit + H * LDW;        // [4 waves][4][16][FB_SA]
+    float* w2ts = w2 + SPLIT_WIMG;     // split image of W2^T
+    float* wit = w2ts + SPLIT_WIMG;    // split image of W_in^T (FIRST: W1^T, 32 rows: half of it)
+    float* stg = wit + SPLIT_WIMG;     // [4 waves][2][16][FB_SA]
     for (int idx = threadIdx.x; idx < (FIRST ? SPLIT_WIMG / 2 : SPLIT_WIMG) / 4; idx += 256) st4(wi + 4 * idx, ld4(img_in + 4 * idx));
     for (int idx = threadIdx.x; idx < SPLIT_WIMG / 4; idx += 256) st4(w2 + 4 * idx, ld4(img_2 + 4 * idx));
-    if (FIRST) {
-        for (int idx = threadIdx.x; idx < FPAD * (H / 4); idx += 256) {
-            const int r = idx >> 4, c = (idx & 15) * 4;
-            st4(wit + r * LDW + c, ld4(w_in_t + (size_t)r * H + c));
+    for (int idx = threadIdx.x; idx < H * H / 4; idx += 256) {
+        const int r = idx >> 4, c = (idx & 15) * 4;
+        stage_split4<4, 2>(w2ts, r, c, ld4(w2t + (size_t)r * H + c));
+        if (FIRST) {
+            if (r < FPAD) stage_split4<2, 2>(wit, r, c, ld4(w_in_t + (size_t)r * H + c));
+        } else {
+            stage_split4<4, 2>(wit, r, c, ld4(w_in_t + (size_t)r * H + c));
         }
-    } else {
-        stage_weight64<256>(wit, w_in_t, H);
     }
-    stage_weight64<256>(w2ts, w2t, H);
     (void)w_in; (void)f1; (void)w2g;      // (kept in the signature: same argument list as kb_edge)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    float* sa = stg + wave * EA_STG;   // dpre2
-    float* sb = sa + 16 * FB_SA;       // h
-    float* sg = sb + 16 * FB_SA;       // G
-    float* sc = sg + 16 * FB_SA;       // e_prev / features
+    float* sa = stg + wave * EA_STG;   // dpre2, then G
+    float* sb = sa + 16 * FB_SA;       // h, then e_prev / features
     const int64_t tiles = (n_edges + 15) >> 4;
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t t = (int64_t)blockIdx.x * 4 + wave;
@@ -122,14 +122,6 @@ kb_edge_acc(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64]
             kn = clampk(t + 2 * stride < tiles ? t + 2 * stride : t);
             s_n = send_s[kn];
             r_n = recv_s[kn];
-            // the previous tile's products have read the staging rows (same wave: program order); park e_prev / features now
-            if (FIRST) {
-                st4(sc + i * FB_SA + 4 * q, ok ? bop[0] : f32x4{0.f, 0.f, 0.f, 0.f});
-                st4(sc + i * FB_SA + 16 + 4 * q, ok ? bop[1] : f32x4{0.f, 0.f, 0.f, 0.f});
-            } else {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) st4(sc + i * FB_SA + 16 * mb + 4 * q, ok ? bop[mb] : f32x4{0.f, 0.f, 0.f, 0.f});
-            }
             // ---- forward recompute: pre1, h = silu(pre1), pre2
             f32x4 p2[4], h[4], sg1[4];
             if (FIRST) {
@@ -155,33 +147,39 @@ kb_edge_acc(const float* __restrict__ w_in /*FIRST: W1 [64][F1] else msg_w0 [64]
                 if (!ok) d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};             // rows past the end contribute nothing to the products
                 dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            gemm_tile<4, 4>(w2ts + z, LDW, d2, dh, i, q);
+            gemm_split<4, 2>(w2ts + z, d2, dh, lane);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu_from_sigmoid(p1[mb], sg1[mb]);
             if (FIRST) {
                 f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                gemm_tile<2, 4>(wit + z, LDW, g, da, i, q);
+                gemm_split<2, 2>(wit + z, g, da, lane);
                 if (ok) { st4(DA + k * FPAD + 4 * q, da[0]); st4(DA + k * FPAD + 16 + 4 * q, da[1]); }
             } else {
                 f32x4 dep[4];
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_tile<4, 4>(wit + z, LDW, g, dep, i, q);
+                gemm_split<4, 2>(wit + z, g, dep, lane);
                 if (ok) store_tile64(DE, k, H, q, dep);
             }
             if (ok) store_tile64(G, k, H, q, g);
-            // ---- the layer's edge-level weight gradients, on chip
+            // ---- the layer's edge-level weight gradients, on chip: one operand pair in the wave's staging rows at a time
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
                 st4(sb + i * FB_SA + 16 * mb + 4 * q, h[mb]);
-                st4(sg + i * FB_SA + 16 * mb + 4 * q, g[mb]);          // (g of a row past the end is 0: dh = W2^T 0)
                 bs2[mb] += d2[mb];
                 bs1[mb] += g[mb];
             }
             __builtin_amdgcn_wave_barrier();
             fb_outer16<4>(sa, sb, accW2, i, q);
-            fb_outer16<FIRST ? 2 : 4>(sg, sc, accWe, i, q);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                st4(sa + i * FB_SA + 16 * mb + 4 * q, g[mb]);          // (g of a row past the end is 0: dh = W2^T 0)
+                if (!FIRST || mb < 2) st4(sb + i * FB_SA + 16 * mb + 4 * q, ok ? bop[mb] : f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            __builtin_amdgcn_wave_barrier();
+            fb_outer16<FIRST ? 2 : 4>(sa, sb, accWe, i, q);
             __builtin_amdgcn_wave_barrier();
         }
     }
