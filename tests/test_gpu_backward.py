@@ -257,6 +257,29 @@ def test_input_gradients_match_oracle_autograd(D):
         assert torch.equal(only_v["vel"], got["vel"])
 
 
+@pytest.mark.parametrize("D", [2, 3])
+def test_input_gradients_on_random_multigraphs(D):
+    """Self loops, duplicate edges, nodes without in- or out-edges, components of 1..40 nodes (the batch of
+    test_gradients_on_random_multigraphs): d/dx, d/dvel, d/dedge_attr of both dispatch paths against the oracle's fp64
+    autograd.  (A self loop has rel = 0: distance and bearing sit at their clamps, where both sides give zero slope.)"""
+    from test_gpu_configs import _random_multigraph_batch
+    sd = load_state_dict(D)
+    inp = _random_multigraph_batch(31, D)
+    g = torch.Generator().manual_seed(31)
+    inp["target"] = inp["x"] + 0.1 * torch.randn(inp["x"].shape, generator=g)
+    want = _oracle_input_gradients(sd, inp, torch.float64)
+    o32 = _oracle_input_gradients(sd, inp, torch.float32)
+    for path in ("default", "streamed"):
+        m = _model(D, "streamed")
+        if path == "default":
+            m.flags = 0
+        got, _ = _input_gradients(m, inp)
+        for k, gk in got.items():
+            assert torch.isfinite(gk).all(), (path, k)
+            err, err32 = scale_rel_err(gk, want[k]), scale_rel_err(o32[k], want[k])
+            assert err <= max(GTOL, 4 * err32), (path, k, err, err32)
+
+
 def test_input_gradients_of_a_narrow_model_and_with_frozen_parameters():
     D = 3
     inp = make_batch(4, 9, D, seed=66)
