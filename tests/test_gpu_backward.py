@@ -2,7 +2,11 @@
 import pytest
 import torch
 
-from conftest import GRAD_CASES, load_case, load_state_dict, scale_rel_err
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, GRAD_CASES, load_case, load_state_dict, scale_rel_err
 from aether_amd import _lib
 from aether_amd.nn.state2state.aether import Aether
 from aether_amd.synthetic import make_batch
@@ -278,6 +282,32 @@ def test_input_gradients_on_random_multigraphs(D):
             assert torch.isfinite(gk).all(), (path, k)
             err, err32 = scale_rel_err(gk, want[k]), scale_rel_err(o32[k], want[k])
             assert err <= max(GTOL, 4 * err32), (path, k, err, err32)
+
+
+@pytest.mark.parametrize("path", ["fused", "streamed"])
+@pytest.mark.parametrize("tag", ["dropout", "inputgrad"])
+@pytest.mark.parametrize("D", [2, 3])
+def test_dropout_step_and_input_gradients_match_the_reference_itself(D, tag, path):
+    """The same fixtures against the HIP path: a train()-mode step with the masks the REFERENCE's nn.Dropout layers drew
+    (dropout_prob = 0.25), and the reference's own d/dx, d/dvel, d/dedge_attr -- not only the oracle's."""
+    d = np.load(os.path.join(GOLDEN, f"case_D{D}_{tag}.npz"))
+    inp, ref, _, meta = load_case(f"case_D{D}_{tag}.npz")
+    p = float(d["dropout_prob"][0])
+    m = Aether(2 * D, 64, p, D, device="cuda")
+    m.load_state_dict(load_state_dict(D))
+    m.flags = _lib.FLAG_FORCE_FUSED if path == "fused" else _lib.FLAG_FORCE_STREAMED
+    m.train()
+    if p > 0:
+        m._dropout_masks = torch.stack([torch.from_numpy(d["mask1"]), torch.from_numpy(d["mask2"])])
+    leaves = {k: inp[k].cuda().requires_grad_(True) for k in ("x", "vel", "edge_attr")}
+    out = m(inp["h"].cuda(), leaves["x"], [e.cuda() for e in inp["edges"]], leaves["vel"], leaves["edge_attr"],
+            inp["charges"].cuda())
+    assert scale_rel_err(out.detach().cpu(), ref["out"]) <= 1e-5
+    torch.nn.functional.mse_loss(out, inp["target"].cuda()).backward()
+    for k, q in m.named_parameters():
+        assert scale_rel_err(q.grad.cpu(), ref["grad." + k]) <= GTOL, k
+    for k, v in leaves.items():
+        assert scale_rel_err(v.grad.cpu(), ref["grad_in." + k]) <= 2 * GTOL, k
 
 
 def test_input_gradients_of_a_narrow_model_and_with_frozen_parameters():

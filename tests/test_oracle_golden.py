@@ -55,6 +55,32 @@ def test_parameter_gradients_match_reference(D, case):
         assert err <= 2e-5, (k, err)
 
 
+
+@pytest.mark.parametrize("tag", ["dropout", "inputgrad"])
+@pytest.mark.parametrize("D", [2, 3])
+def test_dropout_masks_and_input_gradients_match_reference(D, tag):
+    """Fixtures of oracle/make_golden_dropout.py: the reference itself in train() mode with dropout_prob = 0.25 (the masks its
+    two nn.Dropout layers drew, captured by hooks) and with its inputs as autograd leaves.  The oracle with those masks
+    reproduces the reference's output, its 47 parameter gradients and d/dx, d/dvel, d/dedge_attr."""
+    d = np.load(os.path.join(GOLDEN, f"case_D{D}_{tag}.npz"))
+    inp, ref, _, meta = load_case(f"case_D{D}_{tag}.npz")
+    masks = None
+    if float(d["dropout_prob"][0]) > 0:
+        masks = [torch.from_numpy(d["mask1"]), torch.from_numpy(d["mask2"])]
+        keep = 1.0 - float(d["dropout_prob"][0])
+        for m in masks:
+            assert set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1.0) / np.float32(keep))}
+    sd = {k: v.clone().requires_grad_(True) for k, v in load_state_dict(D).items()}
+    leaves = {k: inp[k].clone().requires_grad_(True) for k in ("x", "vel", "edge_attr")}
+    out = O.aether_forward(sd, leaves["x"], leaves["vel"], inp["edges"], leaves["edge_attr"], inp["charges"],
+                           dropout_masks=masks)
+    assert scale_rel_err(out.detach(), ref["out"]) <= 1e-5
+    torch.nn.functional.mse_loss(out, inp["target"]).backward()
+    for k, v in sd.items():
+        assert scale_rel_err(v.grad, ref["grad." + k]) <= 2e-5, k
+    for k, v in leaves.items():
+        assert scale_rel_err(v.grad, ref["grad_in." + k]) <= 2e-5, k
+
 @pytest.mark.parametrize("D", [2, 3])
 def test_degenerate_inputs_finite_and_wrap_aware(D):
     """Zero velocity, coincident particles, anti-parallel headings, v || +-z.
