@@ -265,8 +265,9 @@ class AetherDynamicVars(nn.Module):
         g, static, outs = hit
         for dst, src in zip(static, args):
             dst.copy_(src)
-        # one replay in flight at a time: back-to-back replays of a captured aether_dyn_step without a host synchronisation
-        # ended in a GPU memory access fault in one configuration (cause not established), with it never
+        # one replay in flight at a time: replays of a captured step enqueued behind a running one ended in a GPU memory
+        # access fault while the decoder's all-types filter kernel was a graph node (bisected to that node
+        # and the runtime's graph packet capture; the library no longer launches it) -- kept as a second line of defence
         if not self.__dict__.get("_capture_one_call"):
             torch.cuda.current_stream(static[0].device).synchronize()
         g.replay()
@@ -286,12 +287,11 @@ class AetherDynamicVars(nn.Module):
             return self.predict_future_batched(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         n_steps = inputs.size(1) - 1
         if self.one_call_step and n_steps > 0 and not (graph and self.__dict__.get("_capture_one_call")):
-            # ONE library call queues the whole loop (64 launches per step, no host round trip): nothing left for a
-            # captured graph to save -- measured 0.36 ms per step against 0.40 ms for replays of a captured
-            # aether_dyn_step.  ``graph=True`` is accepted and means the same thing here.  (Replaying a captured
-            # aether_dyn_step back to back WITHOUT a host synchronisation in between ended in a GPU memory access fault in
-            # one configuration -- DESIGN.md 4.11c has the evidence; captured steps are therefore only used by the staged
-            # path, ``one_call_step = False``, where 300+ back-to-back replays have been clean.)
+            # ONE library call queues the whole loop (66 launches per step, no host round trip): nothing left for a
+            # captured graph to save -- measured 0.37 ms per step against 0.41 ms for replays of a captured
+            # aether_dyn_step.  ``graph=True`` is accepted and means the same thing here.  (replays of a
+            # captured step in flight behind each other faulted while the decoder's all-types filter kernel was a graph
+            # node -- a runtime replay problem, bisected and avoided in the library.)
             return self._predict_future_rollout(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         prior_state = self.encoder.get_initial_hidden(inputs)
         dec_state = self.decoder.get_initial_hidden(inputs)
