@@ -145,7 +145,8 @@ class AetherDynamicVars(nn.Module):
                               10, float(self.gumbel_temp))
 
     @torch.no_grad()
-    def _step_one_call(self, state, present, node_inds_t, gsend, grecv, e2n, prior_h, prior_c, dec_state, uniform_t):
+    def _step_one_call(self, state, present, node_inds_t, gsend, grecv, e2n, prior_h, prior_c, dec_state, uniform_t,
+                       pass_node_inds=True, return_edge_types=False):
         """``_step_core`` as ONE library call (``aether_dyn_step``): the same stage kernels, the index work between them in
         seven small kernels of the library instead of ~60 torch launches; bit-identical to the staged path."""
         lib = _lib.load()
@@ -173,15 +174,20 @@ class AetherDynamicVars(nn.Module):
                 raise _lib.AetherHipError("the step workspace must be reserved outside graph capture (reserve())")
             ws = self.__dict__["_step_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
         pred = torch.empty(1, Nmax, 4, dtype=torch.float32, device=dev)
+        edge_types = torch.empty(E, self.num_edge_types, dtype=torch.float32, device=dev) if return_edge_types else None
         fs = self._field_struct()
         ps_e = self.encoder._param_struct()[0]
         ps_d = self.decoder._param_struct()
+        # node_inds = None: the library takes the mask's non-zero rows (what the data set's node_inds are)
         st = lib.aether_dyn_step(C.byref(fs), C.byref(ps_e), C.byref(ps_d), C.byref(cfg), Nmax, n, E, state.data_ptr(),
-                                 present.data_ptr(), ni.data_ptr(), gs.data_ptr(), gr.data_ptr(), e2n.data_ptr(),
-                                 int(e2n.shape[1]), new_h.data_ptr(), new_c.data_ptr(), new_dec.data_ptr(),
-                                 uniform_t.data_ptr(), pred.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                 present.data_ptr(), ni.data_ptr() if pass_node_inds else None, gs.data_ptr(), gr.data_ptr(),
+                                 e2n.data_ptr(), int(e2n.shape[1]), new_h.data_ptr(), new_c.data_ptr(), new_dec.data_ptr(),
+                                 uniform_t.data_ptr(), pred.data_ptr(),
+                                 edge_types.data_ptr() if edge_types is not None else None, ws.data_ptr(), ws.numel(),
                                  torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(st, "aether_dyn_step")
+        if return_edge_types:
+            return pred, new_h, new_c, new_dec, edge_types
         return pred, new_h, new_c, new_dec
 
     @torch.no_grad()

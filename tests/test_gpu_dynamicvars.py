@@ -330,8 +330,16 @@ def test_predict_future_captured_steps_equal_the_eager_loop():
             obs = burn[:, t].cuda().unsqueeze(-1)
             state = obs * inputs[:, t].cuda() + (1 - obs) * last
             gs, gr, e2n = graph_info[t]
+            if t == 3:      # node_inds left to the library (the mask's rows) and the sampled edge types handed back
+                alt = model._step_one_call(state, masks[:, t].cuda(), node_inds[t], gs, gr, e2n, ph, pc, dec, U[t],
+                                           pass_node_inds=False, return_edge_types=True)
+                onehot = alt[4]
+                assert onehot.shape == (gs.numel(), 4) and torch.equal(onehot.sum(1), torch.ones(gs.numel(), device="cuda"))
             last, ph, pc, dec = model._step_one_call(state, masks[:, t].cuda(), node_inds[t], gs, gr, e2n, ph, pc, dec, U[t])
             assert torch.equal(last, rollout[:, t]), t
+            if t == 3:
+                for a, b in zip(alt[:4], (last, ph, pc, dec)):
+                    assert torch.equal(a, b)
     finally:
         model.one_call_step = True
     bad = masks.clone()
