@@ -173,3 +173,33 @@ def test_built_library_passes_the_isa_check():
         "v_mfma_f32_16x16x32_bf16 a[2:5], v[2:5], v[10:13], a[4:7]",
     ])
     assert len(res["r3"]) == 2 and res["bf16"] and len(res["r1"]) == 1 and len(res["r2"]) == 1, res
+
+
+def test_host_side_size_functions_of_the_round_3_entries():
+    """Pure host arithmetic of the C ABI (no GPU): the dropout masks lie inside the training workspace, 256-byte aligned;
+    aether_dyn_step's workspace covers its four stages and refuses the sizes the step would refuse; the rollout's covers
+    its largest step."""
+    import ctypes as C
+    from aether_amd import _lib
+    from aether_amd.nn.dynamicvars.aether_dynamicvars import _DynStepConfig
+    lib = _lib.load()
+    for (nn_, ee, D) in [(2560, 48640, 2), (100, 0, 3), (32768, 33521664, 2)]:
+        off = lib.aether_dropout_mask_offset(nn_, ee, D)
+        total = lib.aether_workspace_bytes(nn_, ee, D, 1)
+        assert off % 256 == 0 and off + 2 * nn_ * 64 * 4 <= total
+        assert off >= lib.aether_workspace_bytes(nn_, ee, D, 0) or ee == 0          # behind the inference part
+    assert lib.aether_dropout_mask_offset(0, 0, 2) == 0 and lib.aether_dropout_mask_offset(5, 5, 4) == 0
+    cfg = _DynStepConfig(256, 256, 64, 3, 128, 4, 256, 1, 0, 0, 10, 0.5)
+    need = lib.aether_dyn_step_workspace_bytes(C.byref(cfg), 40, 24, 240)
+    parts = (lib.aether_dyn_field_workspace_bytes(24, 256) + lib.aether_knn_workspace_bytes(1, 40, 10)
+             + lib.aether_dyn_prior_workspace_bytes(256, 64, 128, 24, 240) + lib.aether_dyn_decoder_workspace_bytes(256, 24, 240))
+    assert need > parts
+    assert lib.aether_dyn_step_workspace_bytes(C.byref(cfg), 40, 24, 239) == 0          # not n * min(k, n - 1) edges
+    assert lib.aether_dyn_step_workspace_bytes(C.byref(cfg), 40, 1, 0) == 0             # a step needs two present objects
+    assert lib.aether_dyn_step_workspace_bytes(C.byref(cfg), 40, 41, 410) == 0          # more present than rows
+    bad = _DynStepConfig(256, 200, 64, 3, 128, 4, 256, 1, 0, 0, 10, 0.5)                # encoder hidden not a multiple of 128
+    assert lib.aether_dyn_step_workspace_bytes(C.byref(bad), 40, 24, 240) == 0
+    counts = (C.c_int64 * 4)(24, 0, 3, 40)
+    roll = lib.aether_dyn_rollout_workspace_bytes(C.byref(cfg), 40, 4, counts)
+    assert roll >= lib.aether_dyn_step_workspace_bytes(C.byref(cfg), 40, 40, 400)
+    assert roll >= need
