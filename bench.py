@@ -682,103 +682,113 @@ def main():
     # ---- training step: forward + HIP backward + gradient all-reduce (N > 1) + AdamW ----------------
     train = None
     if not args.no_train and args.chunks == 1:        # (config 5 on fewer than 8 ranks: forward figure only)
-        model.train()
-        if world > 1:
-            from aether_amd.parallel import attach_data_parallel
-            attach_data_parallel(model)
-        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12)     # main.py:86,164
-        tgt = inp["target"]
+        # The whole leg runs inside a function: whatever goes wrong in it (a collective that fails on every rank, a capture
+        # that is refused) must not cost the run its headline line -- the forward figure above is already measured.
+        def train_leg():
+            train = None
+            model.train()
+            if world > 1:
+                from aether_amd.parallel import attach_data_parallel
+                attach_data_parallel(model)
+            opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12)     # main.py:86,164
+            tgt = inp["target"]
 
-        def tstep():
-            opt.zero_grad(set_to_none=True)
-            o = call()
-            loss = torch.nn.functional.mse_loss(o, tgt)
-            loss.backward()
-            opt.step()
-        tsteps = 3 if args.big else max(10, args.steps // 4)
-        for _ in range(1 if args.big else 5):
-            tstep()
-        torch.cuda.synchronize()
-        train_launch = "eager"
-        gstep = None
-        if use_graph and not args.big:
-            # whole training step as hipGraph replays (aether_amd.training.GraphedTrainStep): one graph at N = 1; with
-            # N > 1 forward + backward replay as one graph, the flat gradient buffer is all-reduced eagerly (RCCL),
-            # AdamW (one launch, aether_amd.optim.FusedAdamW) replays as a second graph
-            try:
-                from aether_amd.training import GraphedTrainStep
-                gstep = GraphedTrainStep(model, [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]],
-                                         tgt, lr=5e-4, weight_decay=1e-12, graph_collective=args.graph_collective)
-                eager_tstep = tstep
-                tstep = gstep.step
-                for _ in range(3):
-                    tstep()
-                torch.cuda.synchronize()
-                train_launch = ("hipgraph" if world == 1 else
-                                "one hipgraph incl. the all-reduce" if gstep.collective_in_graph else
-                                "hipgraph (forward + backward) + eager all-reduce + hipgraph (AdamW, mean folded into its gradient read)")
-            except Exception as ex:          # keep the eager figure if capture is not possible
-                print("train-step graph capture failed:", repr(ex), file=sys.stderr)
-                gstep = None
-                torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(tsteps):
-            tstep()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        tdt = time.perf_counter() - t0
-        _lib.check(_lib.load().aether_check_async_error(), "asynchronous kernel error in the timed training steps")
-        if world > 1:
-            t = torch.tensor([tdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tdt = float(t.item())
-        coll = None
-        if world > 1:
-            # the collective alone: the flat gradient buffer of the model, timed with events on the compute stream
-            flat = model._grad_buffers()[0]
-            grp = gstep.dp_group if gstep is not None else model.dp_group
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            for _ in range(3):
-                dist.all_reduce(flat, group=grp)
-            torch.cuda.synchronize()
-            ev[0].record()
-            for _ in range(20):
-                dist.all_reduce(flat, group=grp)
-            ev[1].record()
-            torch.cuda.synchronize()
-            coll = {"backend": dist.get_backend(grp), "world_size": dist.get_world_size(grp),
-                    "allreduce_bytes": flat.numel() * 4, "allreduce_us": 1e3 * ev[0].elapsed_time(ev[1]) / 20,
-                    "in_graph": bool(gstep is not None and gstep.collective_in_graph), "ranks_seen": ranks_seen}
-        train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps, "collective": coll,
-                 "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
-                 "includes": ("forward + MSE loss + HIP backward + " if gstep is not None else "forward + torch MSE loss + HIP backward + ")
-                             + ((("RCCL" if coll["backend"] == "nccl" else coll["backend"]) + " grad all-reduce + ") if world > 1 else "")
-                             + ("AdamW (aether_adamw_step), " if gstep is not None else "torch AdamW, ") + train_launch + " launches"}
-        if rank == 0:       # per-kernel breakdown of one training step (rank-local: no collective in here)
-            saved_group, model.dp_group = model.dp_group, None       # (GraphedTrainStep already detached it)
-            lib = _lib.load()
-            nk = lib.aether_profile_kernels()
-            lib.aether_profile_enable(1)
-            ks = 2 if args.big else 10
-            if gstep is not None:
-                tstep = eager_tstep
-            for _ in range(ks):
+            def tstep():
+                opt.zero_grad(set_to_none=True)
+                o = call()
+                loss = torch.nn.functional.mse_loss(o, tgt)
+                loss.backward()
+                opt.step()
+            tsteps = 3 if args.big else max(10, args.steps // 4)
+            for _ in range(1 if args.big else 5):
                 tstep()
             torch.cuda.synchronize()
-            ms = (C.c_double * nk)()
-            cnt = (C.c_int64 * nk)()
-            _lib.check(lib.aether_profile_read(ms, cnt, nk), "aether_profile_read")
-            lib.aether_profile_enable(0)
-            train["kernels_us_per_step"] = {lib.aether_profile_kernel_name(k).decode(): 1e3 * ms[k] / ks
-                                            for k in range(nk) if cnt[k]}
-            model.dp_group = saved_group
-        if world > 1:
-            dist.barrier()
+            train_launch = "eager"
+            gstep = None
+            if use_graph and not args.big:
+                # whole training step as hipGraph replays (aether_amd.training.GraphedTrainStep): one graph at N = 1; with
+                # N > 1 forward + backward replay as one graph, the flat gradient buffer is all-reduced eagerly (RCCL),
+                # AdamW (one launch, aether_amd.optim.FusedAdamW) replays as a second graph
+                try:
+                    from aether_amd.training import GraphedTrainStep
+                    gstep = GraphedTrainStep(model, [inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"]],
+                                             tgt, lr=5e-4, weight_decay=1e-12, graph_collective=args.graph_collective)
+                    eager_tstep = tstep
+                    tstep = gstep.step
+                    for _ in range(3):
+                        tstep()
+                    torch.cuda.synchronize()
+                    train_launch = ("hipgraph" if world == 1 else
+                                    "one hipgraph incl. the all-reduce" if gstep.collective_in_graph else
+                                    "hipgraph (forward + backward) + eager all-reduce + hipgraph (AdamW, mean folded into its gradient read)")
+                except Exception as ex:          # keep the eager figure if capture is not possible
+                    print("train-step graph capture failed:", repr(ex), file=sys.stderr)
+                    gstep = None
+                    torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(tsteps):
+                tstep()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tdt = time.perf_counter() - t0
+            _lib.check(_lib.load().aether_check_async_error(), "asynchronous kernel error in the timed training steps")
+            if world > 1:
+                t = torch.tensor([tdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tdt = float(t.item())
+            coll = None
+            if world > 1:
+                # the collective alone: the flat gradient buffer of the model, timed with events on the compute stream
+                flat = model._grad_buffers()[0]
+                grp = gstep.dp_group if gstep is not None else model.dp_group
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                for _ in range(3):
+                    dist.all_reduce(flat, group=grp)
+                torch.cuda.synchronize()
+                ev[0].record()
+                for _ in range(20):
+                    dist.all_reduce(flat, group=grp)
+                ev[1].record()
+                torch.cuda.synchronize()
+                coll = {"backend": dist.get_backend(grp), "world_size": dist.get_world_size(grp),
+                        "allreduce_bytes": flat.numel() * 4, "allreduce_us": 1e3 * ev[0].elapsed_time(ev[1]) / 20,
+                        "in_graph": bool(gstep is not None and gstep.collective_in_graph), "ranks_seen": ranks_seen}
+            train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps, "collective": coll,
+                     "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
+                     "includes": ("forward + MSE loss + HIP backward + " if gstep is not None else "forward + torch MSE loss + HIP backward + ")
+                                 + ((("RCCL" if coll["backend"] == "nccl" else coll["backend"]) + " grad all-reduce + ") if world > 1 else "")
+                                 + ("AdamW (aether_adamw_step), " if gstep is not None else "torch AdamW, ") + train_launch + " launches"}
+            if rank == 0:       # per-kernel breakdown of one training step (rank-local: no collective in here)
+                saved_group, model.dp_group = model.dp_group, None       # (GraphedTrainStep already detached it)
+                lib = _lib.load()
+                nk = lib.aether_profile_kernels()
+                lib.aether_profile_enable(1)
+                ks = 2 if args.big else 10
+                if gstep is not None:
+                    tstep = eager_tstep
+                for _ in range(ks):
+                    tstep()
+                torch.cuda.synchronize()
+                ms = (C.c_double * nk)()
+                cnt = (C.c_int64 * nk)()
+                _lib.check(lib.aether_profile_read(ms, cnt, nk), "aether_profile_read")
+                lib.aether_profile_enable(0)
+                train["kernels_us_per_step"] = {lib.aether_profile_kernel_name(k).decode(): 1e3 * ms[k] / ks
+                                                for k in range(nk) if cnt[k]}
+                model.dp_group = saved_group
+            if world > 1:
+                dist.barrier()
+            return train
+        try:
+            train = train_leg()
+        except Exception as ex:
+            print("training leg failed:", repr(ex), file=sys.stderr)
+            train = {"error": repr(ex)}
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
