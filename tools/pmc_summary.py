@@ -11,6 +11,6 @@ for f in files:
         k = m.group(1) if m else "other"
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[k][row["Counter_Name"]] += 1
 for k in sorted(acc):
-    if not k.startswith("k_"):
+    if not k.startswith(("k_", "kb_")):
         continue
     print(k, " ".join(f"{c}={acc[k][c]/cnt[k][c]:.4g}" for c in sorted(acc[k])), f"(n={max(cnt[k].values())})")
