@@ -128,8 +128,10 @@ class DynamicFieldAether(nn.Module):
             raise ValueError("the HIP kernels are built for hidden_size=64 (experiments/lorentz/main.py:42-43)")
         if num_dims not in (2, 3) or input_size != 2 * num_dims:
             raise ValueError("num_dims must be 2 or 3 and input_size == 2*num_dims")
-        if dropout_prob != 0.0:
-            raise ValueError("dropout_prob must be 0.0 (the runner's value, main.py:149)")
+        if not (0.0 <= float(dropout_prob) < 1.0):
+            raise ValueError("dropout_prob must lie in [0, 1)")
+        # (the runner passes 0.0, main.py:149; > 0: identity in eval(), the out MLP's two masks in train() -- as Aether)
+        self.dropout_prob = float(dropout_prob)
         self.gnn = _GNN(input_size, hidden_size, dropout_prob, num_dims, additional_features=num_dims)
         self.num_dims = num_dims
         self.field_net = _LatentFieldNetwork(num_dims, 32, 16)
@@ -223,6 +225,16 @@ class DynamicFieldAether(nn.Module):
         if train:                           # the backward reads this forward's intermediates: one workspace per call
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
             flags |= _lib.FLAG_KEEP_INTERMEDIATES | (0 if self.flags & _lib.FLAG_KEEP_INTERMEDIATES else _lib.FLAG_BACKWARD_ONLY)
+            if self.dropout_prob > 0.0 and self.training:
+                # nn.Dropout after the two SiLUs of the out MLP (locs.py:163,166): scale masks into the training workspace
+                off = lib.aether_dropout_mask_offset(n_nodes, E, D)
+                masks = ws[off:off + 2 * n_nodes * 64 * 4].view(torch.float32).view(2, n_nodes, 64)
+                given = self.__dict__.get("_dropout_masks")          # tests: explicit masks [2, n_nodes, 64]
+                if given is not None:
+                    masks.copy_(given.to(device=x.device, dtype=torch.float32))
+                else:
+                    masks.bernoulli_(1.0 - self.dropout_prob).mul_(1.0 / (1.0 - self.dropout_prob))
+                flags |= _lib.FLAG_DROPOUT
         else:
             if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
                 self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
@@ -301,4 +313,6 @@ class DynamicFieldAether(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _DynStep.apply(self, x, vel, ea, charges, graph, E, int(num_nodes), *self.parameters())
         with torch.no_grad():
-            return self._launch(x, vel, ea, charges, graph, E, int(num_nodes), train=False)[0]
+            # (a train()-mode forward applies dropout even without autograd, as nn.Dropout does)
+            drops = self.dropout_prob > 0.0 and self.training
+            return self._launch(x, vel, ea, charges, graph, E, int(num_nodes), train=drops)[0]

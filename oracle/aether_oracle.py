@@ -229,10 +229,10 @@ def dynamic_field(sd, x, vel, charges, num_nodes):
     return lin("wrapper.linear_3", y)
 
 
-def dynamic_field_aether_forward(sd, x, vel, edges, edge_attr_orig, charges, num_nodes):
+def dynamic_field_aether_forward(sd, x, vel, edges, edge_attr_orig, charges, num_nodes, dropout_masks=None):
     """DynamicFieldAether.forward (dynamic_field_aether.py:79-100)."""
     return aether_forward(sd, x, vel, edges, edge_attr_orig, charges,
-                          field=dynamic_field(sd, x, vel, charges, num_nodes))
+                          field=dynamic_field(sd, x, vel, charges, num_nodes), dropout_masks=dropout_masks)
 
 
 def cut_margin(edge_attr_local, D):

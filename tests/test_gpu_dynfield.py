@@ -90,6 +90,40 @@ def test_dynamic_field_gradients_vs_oracle_autograd(D, flags):
             assert scale_rel_err(p.grad.cpu(), sdg[k].grad) <= GTOL, (B, N, k)
 
 
+@pytest.mark.parametrize("D", [2, 3])
+def test_dynamic_field_dropout_step_vs_oracle_with_the_same_masks(D):
+    """dropout_prob = 0.2 in train() mode: forward and every parameter gradient against the oracle's autograd with the same
+    two out-MLP masks; eval() is the p = 0 model."""
+    from aether_amd.nn.state2state.dynamic_field_aether import DynamicFieldAether
+    d, sd, m0 = _load(D)
+    m = DynamicFieldAether(2 * D, 64, 0.2, D, device="cuda")
+    m.load_state_dict(sd)
+    B, N = 6, 9
+    inp = make_batch(B, N, D, seed=77)
+    g = torch.Generator().manual_seed(78)
+    masks = (torch.rand(2, B * N, 64, generator=g) >= 0.2).float() / 0.8
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = O.dynamic_field_aether_forward(sdg, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"], N,
+                                          dropout_masks=masks)
+    torch.nn.functional.mse_loss(want, inp["target"]).backward()
+    args = (None, inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(), inp["edge_attr"].cuda(),
+            inp["charges"].cuda(), N)
+    m.train()
+    m._dropout_masks = masks
+    out = m(*args)
+    assert scale_rel_err(out.detach().cpu(), want.detach()) <= TOL
+    torch.nn.functional.mse_loss(out, inp["target"].cuda()).backward()
+    for k, p in m.named_parameters():
+        if k.endswith("gate_nn.2.bias"):
+            continue
+        assert scale_rel_err(p.grad.cpu(), sdg[k].grad) <= GTOL, k
+    with torch.no_grad():
+        assert torch.equal(m(*args), out.detach())                 # train() mode without autograd: the same masks apply
+        m.eval()
+        plain = O.dynamic_field_aether_forward(sd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"], N)
+        assert scale_rel_err(m(*args).cpu(), plain) <= TOL
+
+
 def test_dynamic_field_training_step_reduces_loss():
     """A few optimizer steps through the drop-in module, as the runner's loop does (main.py:200-260); gradients
     accumulate like autograd's; a second backward through the same graph is refused by autograd itself."""
