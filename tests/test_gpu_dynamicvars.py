@@ -276,6 +276,60 @@ def test_decoder_and_encoder_two_objects():
 
 
 
+def test_rollout_with_an_empty_step_equals_the_staged_loop():
+    """A time step without any present object inside the sequence: aether_dyn_rollout writes zeros for it and leaves the
+    prior / decoder state alone (aether_dynamicvars.py:841-843), exactly as the staged loop does; a step with ONE present
+    object is refused by both (the reference fails there as well)."""
+    from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+    import sys, os
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_dynamicvars import MODEL_PARAMS, perturb_bn_
+    params = dict(MODEL_PARAMS, decoder_hidden=256, encoder_hidden=256, num_edge_types=4, pos_representation="cart",
+                  field_hidden=128, encoder_rnn_hidden=64)
+    torch.manual_seed(41)
+    model = AetherDynamicVars(params, device=None).eval()
+    perturb_bn_(model)
+    model = model.cuda()
+    g = torch.Generator().manual_seed(42)
+    T, N = 7, 16
+    inputs = torch.randn(1, T, N, 4, generator=g)
+    counts = [9, 9, 0, 5, 0, 16, 16]
+    masks = torch.zeros(1, T, N)
+    for t, c in enumerate(counts):
+        masks[0, t, torch.randperm(N, generator=g)[:c]] = 1
+    burn = torch.ones(1, T, N)
+    burn[:, 3:] = 0
+    node_inds, graph_info, U = [], [], []
+    for step in range(T):
+        nv = counts[step]
+        node_inds.append(masks[0, step].nonzero()[:, -1].cuda())
+        if nv >= 2:
+            send, recv = get_knn_graph_info(inputs[0, step].cuda(), masks[0, step].cuda(), nv)
+            graph_info.append((send, recv, torch.argsort(recv, stable=True).view(-1, min(10, nv - 1))))
+            U.append(torch.rand(send.numel(), 4, generator=g).cuda())
+        else:
+            e = torch.empty(0, dtype=torch.int64, device="cuda")
+            graph_info.append((e, e, e.view(0, 1)))
+            U.append(torch.empty(0, 4, device="cuda"))
+    args = (inputs.cuda(), masks.cuda(), [node_inds], [graph_info], burn.cuda())
+    got = model.predict_future(*args, uniform=U[:T - 1])
+    assert float(got[0, 2].abs().max()) == 0.0 and float(got[0, 4].abs().max()) == 0.0
+    model.one_call_step = False
+    try:
+        want = model.predict_future(*args, uniform=U[:T - 1])
+    finally:
+        model.one_call_step = True
+    assert torch.equal(got, want)
+    one = masks.clone()
+    one[0, 1] = 0
+    one[0, 1, 3] = 1                                          # exactly one present object at step 1
+    ni1 = list(node_inds)
+    ni1[1] = one[0, 1].nonzero()[:, -1].cuda()
+    with pytest.raises(_lib.AetherHipError):
+        model.predict_future(inputs.cuda(), one.cuda(), [ni1], [graph_info], burn.cuda(), uniform=U[:T - 1])
+
+
 def test_predict_future_captured_steps_equal_the_eager_loop():
     """``predict_future(graph=True)``: every step replays a captured hipGraph of its signature.  14 steps over scenes
     whose number of present objects changes (24 -> 12 -> 3 -> 40, the last being the size at which round 2's attempt
