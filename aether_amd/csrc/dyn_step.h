@@ -21,8 +21,12 @@ constexpr int DYN_MAX_OBJECTS = KNN_MAX_OBJECTS;
 __global__ void __launch_bounds__(256)
 k_dyn_present(const float* __restrict__ state, const float* __restrict__ mask, const float* __restrict__ hidden, int n_max,
               int n_present, int h, int deg, int64_t* __restrict__ idx, int* __restrict__ cidx, float* __restrict__ cur_in,
-              float* __restrict__ cur_h, int64_t* __restrict__ rowptr_dec, int* __restrict__ status, int* __restrict__ errword) {
+              float* __restrict__ cur_h, int64_t* __restrict__ rowptr_dec, int* __restrict__ status, int* __restrict__ errword,
+              int64_t* __restrict__ knn_sums /* [2]: zeroed for the kNN builder */, int* __restrict__ dec_counts /* [64]: zeroed
+              for the decoder's per-type edge lists (two memset nodes less per step) */) {
     extern __shared__ int dyn_lds[];
+    if (threadIdx.x < 2) knn_sums[threadIdx.x] = 0;
+    if (threadIdx.x < 64) dec_counts[threadIdx.x] = 0;
     int* flag = dyn_lds;                 // [n_max] -> exclusive count of present objects
     int* rows = flag + n_max;            // [n_present] rows of the present objects
     int* part = rows + n_present;        // [257]
@@ -154,6 +158,38 @@ k_dyn_slots_scatter(const int64_t* __restrict__ slot, const float* __restrict__ 
     const int64_t s = slot[e];
     st4(prior_h + s * R + 4 * o, ld4(h1 + e * R + 4 * o));
     st4(prior_c + s * R + 4 * o, ld4(c1 + e * R + 4 * o));
+}
+
+// k_dyn_slots_scatter and the hard Gumbel sample of the edge types (k_s2s_gumbel_hard, nn/utils/model_utils.py:58-118) in one
+// launch: both only need the prior step's outputs.
+__global__ void __launch_bounds__(256)
+k_dyn_scatter_sample(const int64_t* __restrict__ slot, const float* __restrict__ h1, const float* __restrict__ c1,
+                     int64_t n_edges, int R, float* __restrict__ prior_h, float* __restrict__ prior_c,
+                     const float* __restrict__ logits, const float* __restrict__ uniform, float tau, int K,
+                     float* __restrict__ edges) {
+    const int r4 = R >> 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n_edges * r4) {
+        const int64_t e = t / r4;
+        const int o = (int)(t - e * r4);
+        const int64_t s = slot[e];
+        st4(prior_h + s * R + 4 * o, ld4(h1 + e * R + 4 * o));
+        st4(prior_c + s * R + 4 * o, ld4(c1 + e * R + 4 * o));
+    }
+    if (t < n_edges) {                         // the arithmetic of k_s2s_gumbel_hard, statement for statement
+        const int64_t e = t;
+        float y[4], mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float g = -logf(1e-10f - logf(uniform[e * K + k] + 1e-10f));
+            y[k] = (logits[e * K + k] + g) / tau;
+            mx = fmaxf(mx, y[k]);
+        }
+        float sum = 0.0f;
+        for (int k = 0; k < K; ++k) { y[k] = expf(y[k] - mx); sum += y[k]; }
+        int best = 0;
+        for (int k = 0; k < K; ++k) { y[k] = y[k] / sum; if (y[k] > y[best]) best = k; }
+        for (int k = 0; k < K; ++k) edges[e * K + k] = ((k == best ? 1.0f : 0.0f) - y[k]) + y[k];
+    }
 }
 
 // prediction [n_max][4] = the decoder's rows at the present objects, zero elsewhere (:866-868); hidden[idx[c]] = new_h[c].

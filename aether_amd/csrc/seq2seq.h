@@ -271,13 +271,24 @@ __device__ __forceinline__ void aug_edge(const float* xj, const float* xi, float
 template <int D>
 __global__ void __launch_bounds__(256)
 k_s2s_aug_nodes(const float* __restrict__ x, float* __restrict__ rel_feat, float* __restrict__ Rinv,
-                int64_t n_nodes) {
+                int64_t n_nodes, const float* __restrict__ inputs = nullptr, const float* __restrict__ field = nullptr,
+                float* __restrict__ ext_out = nullptr) {
+    // inputs != null: x[n] = [inputs[n] (2D) | field[n] (D)] is put together here and written to ext_out (k_s2s_extend
+    // folded in: one launch less per stage of the variable-N step)
     using A = AugDims<D>;
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= n_nodes) return;
     float xi[3 * D];
+    if (inputs != nullptr) {
 #pragma unroll
-    for (int t = 0; t < 3 * D; ++t) xi[t] = x[n * 3 * D + t];
+        for (int t = 0; t < 3 * D; ++t) {
+            xi[t] = t < 2 * D ? inputs[n * 2 * D + t] : field[n * D + (t - 2 * D)];
+            ext_out[n * 3 * D + t] = xi[t];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 3 * D; ++t) xi[t] = x[n * 3 * D + t];
+    }
     float row[A::RF];
     float R[D][D];
     if constexpr (D == 2) {
@@ -317,7 +328,8 @@ __global__ void __launch_bounds__(256)
 k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, const int64_t* __restrict__ recv,
                 const float* __restrict__ rel_feat, int polar, float* __restrict__ edge_attr,
                 float* __restrict__ edge_pos, int64_t n_edges, const int64_t* __restrict__ x_send = nullptr,
-                const int64_t* __restrict__ x_recv = nullptr /* rows of x, when they differ from send / recv */) {
+                const int64_t* __restrict__ x_recv = nullptr /* rows of x, when they differ from send / recv */,
+                int out_cols = 0 /* > 0: only the first out_cols columns, rows packed at that stride (k_s2s_pad_rows folded in) */) {
     using A = AugDims<D>;
     constexpr int LDR = A::EA + 1;                                   // odd row stride: conflict-free column writes
     __shared__ float rows[256 * LDR];
@@ -343,9 +355,10 @@ k_s2s_aug_edges(const float* __restrict__ x, const int64_t* __restrict__ send, c
     __syncthreads();
     const int64_t left = n_edges - e0;
     const int cnt = (int)(left < 256 ? left : 256);
-    for (int idx = threadIdx.x; idx < cnt * A::EA; idx += 256) {
-        const int r = idx / A::EA, c = idx - r * A::EA;
-        edge_attr[e0 * A::EA + idx] = rows[r * LDR + c];
+    const int oc = out_cols > 0 ? out_cols : A::EA;
+    for (int idx = threadIdx.x; idx < cnt * oc; idx += 256) {
+        const int r = idx / oc, c = idx - r * oc;
+        edge_attr[e0 * oc + idx] = rows[r * LDR + c];
     }
     for (int idx = threadIdx.x; idx < cnt * A::EP; idx += 256) {
         const int r = idx / A::EP, c = idx - r * A::EP;
@@ -509,6 +522,28 @@ k_s2s_unit_velocity(const float* __restrict__ x, float* __restrict__ dst, int64_
     dst[n * 16 + 1] = vy / nrm;
 #pragma unroll
     for (int c = 2; c < 16; ++c) dst[n * 16 + c] = 0.0f;
+}
+
+// Inputs of the variable-N field net in one launch (aether_dynamicvars.py:64-79): cat[n] = [Fourier features of the position
+// (h) | angular_embedding(unit velocity) (h)] -- k_s2s_rff + k_s2s_unit_velocity + a zero-padded weight copy + a K = 2 Linear
+// before (four launches of a ~60-launch step).  x [n][4] = [pos | vel]; Bm [2][h / 2]; ang_w [h][2], ang_b [h].
+__global__ void __launch_bounds__(256)
+k_dyn_field_embed(const float* __restrict__ x, const float* __restrict__ Bm, const float* __restrict__ ang_w,
+                  const float* __restrict__ ang_b, int h, float* __restrict__ cat, int64_t n_points) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_points * h) return;
+    const int64_t n = idx / h;
+    const int j = (int)(idx - n * h), half = h >> 1;
+    const float px = x[n * 4], py = x[n * 4 + 1], vx = x[n * 4 + 2], vy = x[n * 4 + 3];
+    if (j < half) {
+        float p = 0.0f;
+        p = fmaf(TWO_PI_S2S * px, Bm[j], p);
+        p = fmaf(TWO_PI_S2S * py, Bm[half + j], p);
+        cat[n * 2 * h + j] = sinf(p);
+        cat[n * 2 * h + half + j] = cosf(p);
+    }
+    const float nrm = fmaxf(sqrtf(vx * vx + vy * vy), 1e-12f);
+    cat[n * 2 * h + h + j] = fmaf(ang_w[2 * j + 1], vy / nrm, fmaf(ang_w[2 * j], vx / nrm, ang_b[j]));
 }
 
 // dst[i] = src[i] * s
