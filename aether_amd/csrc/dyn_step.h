@@ -3,7 +3,7 @@
 //   :672-699 (prior step with its own kNN graph and the per-pair LSTM slots), :133-145 (sampling), :775-870 (decoder).
 // The three stages (aether_dyn_field, aether_dyn_prior_step, aether_dyn_decoder_step) and aether_knn_edges exist; between
 // them the Python module ran ~60 torch launches per step (mask -> index list, gathers, scatters, a stable sort for the
-// receiver CSR, slot arithmetic).  Here that is seven small kernels, so aether_dyn_step is ONE C call per step.
+// receiver CSR, slot arithmetic).  Here that is five small kernels, so aether_dyn_step is ONE C call per step.
 // All of it is index / copy work on a few hundred objects: single-workgroup kernels where a scan is needed, no atomics on
 // floats, results independent of scheduling.
 #pragma once
@@ -54,20 +54,6 @@ k_dyn_present(const float* __restrict__ state, const float* __restrict__ mask, c
         const int c = t / h4, o = t - c * h4;
         st4(cur_h + (size_t)c * h + 4 * o, ld4(hidden + (size_t)rows[c] * h + 4 * o));
     }
-}
-
-// ext_full[row] = [state[row] (4) | field of the row (2), zero when absent]: the un-compacted array the decoder's edge
-// features read with compacted indices (the reference's quirk, aether_dynamicvars.py:823)
-__global__ void __launch_bounds__(256)
-k_dyn_ext(const float* __restrict__ state, const float* __restrict__ field_c, const int* __restrict__ cidx, int n_max,
-          float* __restrict__ ext_full) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_max * 6) return;
-    const int row = t / 6, col = t - row * 6;
-    float v;
-    if (col < 4) v = state[(size_t)row * 4 + col];
-    else { const int c = cidx[row]; v = c >= 0 ? field_c[(size_t)c * 2 + col - 4] : 0.0f; }
-    ext_full[t] = v;
 }
 
 // (order, rowptr) = edge ids grouped by receiver, stable (torch.argsort(recv, stable=True) + the CSR offsets): counts by
@@ -124,14 +110,24 @@ k_dyn_csr(int64_t* __restrict__ send, int64_t* __restrict__ recv, int64_t n_edge
 }
 
 // LSTM state rows of the caller's edges: one slot per ordered pair of objects (aether_dynamicvars.py:680-686),
+// and -- riding along -- ext_full[row] = [state[row] (4) | field of the row (2), zero when absent]: the un-compacted array
+// the decoder's edge features read with compacted indices (the reference's quirk, :823);
 // slot = gs (n_max - 1) + gr - (gr >= gs) with gs, gr the un-compacted rows of the edge's ends; gathers h0, c0.
 __global__ void __launch_bounds__(256)
 k_dyn_slots_gather(const int64_t* __restrict__ gsend, const int64_t* __restrict__ grecv, const int64_t* __restrict__ node_inds,
                    int n_present, int n_max, int64_t n_edges, int R, const float* __restrict__ prior_h,
                    const float* __restrict__ prior_c, int64_t* __restrict__ slot, float* __restrict__ h0,
-                   float* __restrict__ c0) {
+                   float* __restrict__ c0, const float* __restrict__ state = nullptr, const float* __restrict__ field_c = nullptr,
+                   const int* __restrict__ cidx = nullptr, float* __restrict__ ext_full = nullptr) {
     const int r4 = R >> 2;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ext_full != nullptr && t < (int64_t)n_max * 6) {          // k_dyn_ext's work rides along (one launch less)
+        const int row = (int)(t / 6), col = (int)(t - (int64_t)row * 6);
+        float v;
+        if (col < 4) v = state[(size_t)row * 4 + col];
+        else { const int c = cidx[row]; v = c >= 0 ? field_c[(size_t)c * 2 + col - 4] : 0.0f; }
+        ext_full[t] = v;
+    }
     if (t >= n_edges * r4) return;
     const int64_t e = t / r4;
     const int o = (int)(t - e * r4);

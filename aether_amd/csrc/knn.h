@@ -150,7 +150,8 @@ k_knn_scan(const int64_t* __restrict__ scene_nodes, const int64_t* __restrict__ 
 __global__ void __launch_bounds__(256)
 k_knn_write(const float* __restrict__ masks, const int* __restrict__ nbr, const int* __restrict__ cnt, int N, int k,
             const int64_t* __restrict__ node_off, const int64_t* __restrict__ edge_off, int64_t* __restrict__ send,
-            int64_t* __restrict__ recv) {
+            int64_t* __restrict__ recv, const int64_t* __restrict__ scene_sums = nullptr /* one scene: {edges, nodes} */,
+            int64_t* __restrict__ totals = nullptr) {
     extern __shared__ float knn_lds[];
     int* compact = reinterpret_cast<int*>(knn_lds);   // [N] -> exclusive count of present objects
     int* eoff = compact + N;                            // [N] -> exclusive count of edges
@@ -164,7 +165,9 @@ k_knn_write(const float* __restrict__ masks, const int* __restrict__ nbr, const 
     __syncthreads();
     block_exclusive_scan(compact, N, part);
     block_exclusive_scan(eoff, N, part);
-    const int64_t nb = node_off[s], eb = edge_off[s];
+    // one scene (node_off == null): offsets are zero and the totals are the scene's sums -- no scan launch
+    const int64_t nb = node_off ? node_off[s] : 0, eb = edge_off ? edge_off[s] : 0;
+    if (totals != nullptr && tid == 0) { totals[0] = scene_sums[0]; totals[1] = scene_sums[1]; }
     for (int idx = tid; idx < N * k; idx += 256) {
         const int i = idx / k, r = idx - i * k;
         if (r >= cnt[(size_t)s * N + i]) continue;

@@ -293,8 +293,8 @@ class AetherDynamicVars(nn.Module):
             return self.predict_future_batched(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         n_steps = inputs.size(1) - 1
         if self.one_call_step and n_steps > 0 and not (graph and self.__dict__.get("_capture_one_call")):
-            # ONE library call queues the whole loop (66 launches per step, no host round trip): nothing left for a
-            # captured graph to save -- measured 0.37 ms per step against 0.41 ms for replays of a captured
+            # ONE library call queues the whole loop (52 launches per step, no host round trip): nothing left for a
+            # captured graph to save -- measured 0.35 ms per step against 0.41 ms for replays of a captured
             # aether_dyn_step.  ``graph=True`` is accepted and means the same thing here.  (replays of a
             # captured step in flight behind each other faulted while the decoder's all-types filter kernel was a graph
             # node -- a runtime replay problem, bisected and avoided in the library.)

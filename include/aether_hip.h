@@ -709,7 +709,7 @@ int aether_dyn_step(const AetherDynFieldQueryParams* field_params, const AetherD
  * n_steps: n_present, in_degree, and the per-step device pointers node_inds (or NULL, or NULL entries), graph_send,
  * graph_recv, edge2node, uniform.  Steps without present objects yield zeros and leave the states alone (:841-843); a step
  * with exactly one is refused (the reference fails there too).  No host synchronisation: the whole loop is queued on
- * `stream` (66 launches per step).
+ * `stream` (52 launches per step).
  */
 size_t aether_dyn_rollout_workspace_bytes(const AetherDynStepConfig* config, int n_objects_max, int n_steps,
                                           const int64_t* n_present);
