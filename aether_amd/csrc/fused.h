@@ -281,6 +281,9 @@ k_graph_gtiles(const int32_t* __restrict__ recv_s, int64_t n_edges, uint32_t* __
     gsel[(size_t)blockIdx.x * 64 + lane] = w;
 }
 
+#ifndef AETHER_R3_DEFER
+#define AETHER_R3_DEFER 0      // diagnostic: 1 = three-tile variants request the node-phase weights after the tile loop (spill-free, slower)
+#endif
 template <int D, int NW, int ROUNDS, bool KEEP>
 __global__ void __launch_bounds__(NW * 64)
 k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ vel,
@@ -748,19 +751,19 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             asm volatile("" ::: "memory");
         };
         auto front_act = [&](int r, f32x4 (&acc)[4], f32x4 (&h1)[4], bool last) {
-            if (last) issue_loads(1);
+            if (last && !(AETHER_R3_DEFER && ROUNDS >= 3)) issue_loads(1);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
         };
         auto back = [&](int r, const f32x4 (&h1)[4], bool last) {
             const int tile = NW * r + wave;
             f32x4 acc2[4];
-            if (last) issue_loads(2);
+            if (last && !(AETHER_R3_DEFER && ROUNDS >= 3)) issue_loads(2);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
             if constexpr (SPLITG) gemm_split<4, 2>(wB, h1, acc2, lane);
             else gemm_tile<4, 4>(wB, LDW, h1, acc2, i, q);
-            if (last) issue_loads(3);
+            if (last && !(AETHER_R3_DEFER && ROUNDS >= 3)) issue_loads(3);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) e[r][mb] = silu4(acc2[mb]);
             if constexpr (KEEP) {
@@ -797,7 +800,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (last) issue_loads(4);
+            if (last && !(AETHER_R3_DEFER && ROUNDS >= 3)) issue_loads(4);
         };
         {
             const int nvalid = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;    // wave-uniform
@@ -824,6 +827,9 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     back(r, h1, last);
                     FUSED_WSTAMP(layer, r, 5);
                 }
+            }
+            if constexpr (AETHER_R3_DEFER && ROUNDS >= 3) {
+                if (nvalid > 0) { issue_loads(1); issue_loads(2); issue_loads(3); issue_loads(4); }
             }
         }
         FUSED_STAMP(4 + 8 * (layer - 1) + 2);
