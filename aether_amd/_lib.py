@@ -130,12 +130,14 @@ SIGNATURES = {
     "aether_dropout_mask_offset": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "aether_backward_inputs": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo), C.c_void_p, C.c_size_t,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aether_backward_field": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 6 +
                               [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aether_dynamic_field_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "aether_dynamic_field_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 5 +
                                       [C.c_size_t, C.c_void_p]),
+    "aether_dynamic_field_backward_inputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 5 +
+                                             [C.c_size_t, C.c_void_p, C.c_void_p]),
     "aether_dyn_decoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64]),
     "aether_dyn_decoder_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64] +
                                 [C.c_void_p] * 9 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1426,7 +1426,7 @@ int aether_backward(const AetherParams* params, const AetherParams* grads, int n
 int aether_backward_inputs(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x,
                            const float* vel, const float* charges, const void* graph, const AetherGraphInfo* info,
                            void* workspace, size_t workspace_bytes, const float* out, const float* grad_out, float* grad_x,
-                           float* grad_vel, float* grad_edge_attr, void* stream) {
+                           float* grad_vel, float* grad_edge_attr, const float* field_input_grad, void* stream) {
     if (!params || !x || !vel || !charges || !graph || !info || !workspace || !out || !grad_out || !grad_x || !grad_vel)
         return fail(AETHER_EINVAL, "backward_inputs: null pointer");
     if (num_dims != 2 && num_dims != 3) return fail(AETHER_EINVAL, "backward_inputs: num_dims must be 2 or 3");
@@ -1446,11 +1446,11 @@ int aether_backward_inputs(const AetherParams* params, int num_dims, int64_t n_n
     if (num_dims == 2)
         kb_inputs<2><<<grid, dim3(256), 0, st>>>(*params, x, vel, charges, wp(W.nodeinfo), out, grad_out, wp(W.DA), wp(W.DN),
                                                wp(W.DF), gp(G.rowptr), gp(G.send_s), gp(G.recv_s), gp(G.srowptr),
-                                               gp(G.sperm), grad_x, grad_vel, n_nodes);
+                                               gp(G.sperm), grad_x, grad_vel, n_nodes, field_input_grad);
     else
         kb_inputs<3><<<grid, dim3(256), 0, st>>>(*params, x, vel, charges, wp(W.nodeinfo), out, grad_out, wp(W.DA), wp(W.DN),
                                                wp(W.DF), gp(G.rowptr), gp(G.send_s), gp(G.recv_s), gp(G.srowptr),
-                                               gp(G.sperm), grad_x, grad_vel, n_nodes);
+                                               gp(G.sperm), grad_x, grad_vel, n_nodes, field_input_grad);
     if (grad_edge_attr && n_edges > 0) {
         const int D = num_dims, col0 = 7 * D + D * (D - 1) / 2;
         kb_edge_attr_grad<<<dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st>>>(wp(W.DA), gp(G.perm), col0, grad_edge_attr,
@@ -1497,6 +1497,14 @@ int aether_dynamic_field_backward(const AetherDynFieldParams* p, const AetherDyn
                                   int64_t n_graphs, int nodes_per_graph, const float* x, const float* vel,
                                   const float* charges, const float* grad_field, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+    return aether_dynamic_field_backward_inputs(p, grads, num_dims, n_graphs, nodes_per_graph, x, vel, charges, grad_field,
+                                                workspace, workspace_bytes, nullptr, stream);
+}
+
+int aether_dynamic_field_backward_inputs(const AetherDynFieldParams* p, const AetherDynFieldParams* grads, int num_dims,
+                                         int64_t n_graphs, int nodes_per_graph, const float* x, const float* vel,
+                                         const float* charges, const float* grad_field, void* workspace,
+                                         size_t workspace_bytes, float* grad_field_inputs, void* stream) {
     if (!p || !grads || !x || !vel || !charges || !grad_field || !workspace)
         return fail(AETHER_EINVAL, "dynamic_field_backward: null pointer");
     {
@@ -1513,10 +1521,12 @@ int aether_dynamic_field_backward(const AetherDynFieldParams* p, const AetherDyn
     hipStream_t st = (hipStream_t)stream;
     float* partial = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
     if (num_dims == 2) {
-        kb_dynfield<2><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph);
+        kb_dynfield<2><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph,
+                                                                       grad_field_inputs);
         k_dynfield_reduce<2><<<dim3((DynOff<2>::total + 31) / 32), dim3(256), 0, st>>>(partial, n_graphs, *grads);
     } else {
-        kb_dynfield<3><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph);
+        kb_dynfield<3><<<dim3((unsigned)n_graphs), dim3(256), 0, st>>>(*p, x, vel, charges, grad_field, partial, nodes_per_graph,
+                                                                       grad_field_inputs);
         k_dynfield_reduce<3><<<dim3((DynOff<3>::total + 31) / 32), dim3(256), 0, st>>>(partial, n_graphs, *grads);
     }
     HIP_OK(hipGetLastError());

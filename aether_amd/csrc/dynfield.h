@@ -193,7 +193,8 @@ __device__ __forceinline__ float dsilu_f(float s) {       // d/ds [s sigmoid(s)]
 template <int D>
 __global__ void __launch_bounds__(256)
 kb_dynfield(AetherDynFieldParams P, const float* __restrict__ x, const float* __restrict__ vel,
-            const float* __restrict__ charges, const float* __restrict__ gfield, float* __restrict__ partial, int N) {
+            const float* __restrict__ charges, const float* __restrict__ gfield, float* __restrict__ partial, int N,
+            float* __restrict__ gz = nullptr /* [nodes][2D]: dL/d[p | v] through the field, or null (round 3) */) {
     using OF = DynOff<D>;
     constexpr int XI = 2 * D, FI = 2 * D + 16, CH = 32, LH = DFH + 1;
     __shared__ float gate[DYNFIELD_MAX_NODES];              // softmax weights w_n
@@ -393,6 +394,14 @@ kb_dynfield(AetherDynFieldParams P, const float* __restrict__ x, const float* __
         __syncthreads();
         outer_acc(OF::lin1_w, DFH, FI, &da[0][0], LH, &zs[0][0], FI, cnt);
         col_acc(OF::lin1_b, DFH, &da[0][0], LH, cnt);
+        if (gz != nullptr) {                                          // dL/d[p | v] through the FiLM net's first Linear
+            for (int idx = tid; idx < cnt * XI; idx += 256) {
+                const int n = idx / XI, k = idx - n * XI;
+                float sgz = 0.0f;
+                for (int o = 0; o < DFH; ++o) sgz = fmaf(P.lin1_w[o * FI + k], da[n][o], sgz);
+                gz[(base + c0 + n) * XI + k] = sgz;
+            }
+        }
         if (tid < 48) {                                               // class embedding rows
             const int c = tid >> 4, j = tid & 15;
             float s = 0.0f;
@@ -497,6 +506,14 @@ kb_dynfield(AetherDynFieldParams P, const float* __restrict__ x, const float* __
         col_acc(OF::nn_b0, DFH, &da[0][0], LH, cnt);
         outer_acc(OF::gate_w0, DFH, XI, &db[0][0], LH, &zs[0][0], FI, cnt);
         col_acc(OF::gate_b0, DFH, &db[0][0], LH, cnt);
+        if (gz != nullptr) {            // ... and through the graph summary: the node's row enters nn and gate_nn
+            for (int idx = tid; idx < cnt * XI; idx += 256) {          // (same thread -> element map as section B: no race)
+                const int n = idx / XI, k = idx - n * XI;
+                float sgz = 0.0f;
+                for (int o = 0; o < DFH; ++o) sgz = fmaf(P.nn_w0[o * XI + k], da[n][o], fmaf(P.gate_w0[o * XI + k], db[n][o], sgz));
+                gz[(base + c0 + n) * XI + k] += sgz;
+            }
+        }
         __syncthreads();
     }
     for (int e = tid; e < DFH * DFH; e += 256) g[OF::nn_w2 + e] = dsum[e >> 5] * ubar[e & 31];

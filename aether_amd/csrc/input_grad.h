@@ -106,7 +106,9 @@ kb_inputs(AetherParams P, const float* __restrict__ x, const float* __restrict__
           const float* __restrict__ DA, const float* __restrict__ DN1, const float* __restrict__ DF,
           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
           const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm, float* __restrict__ grad_x,
-          float* __restrict__ grad_v, int64_t n_nodes) {
+          float* __restrict__ grad_v, int64_t n_nodes,
+          const float* __restrict__ field_gz = nullptr /* [n_nodes][2D]: dL/d[p | v] through an EXTERNAL field (the
+          dynamic-field variant, aether_dynamic_field_backward_inputs); null = the built-in field net, recomputed below */) {
     using NI = NodeInfo<D>;
     constexpr int FIN = 2 * D + 16;
     constexpr int O = D * (D - 1) / 2;
@@ -240,6 +242,19 @@ kb_inputs(AetherParams P, const float* __restrict__ x, const float* __restrict__
             gv[0] += dth * (-v1 / den);
             gv[1] += dth * (v0 / den);
         }
+    }
+    if (field_gz != nullptr) {              // (uniform branch: no barrier is skipped by part of a workgroup)
+        if (!ok || t >= 2 * D) return;
+        const float dzx = field_gz[n * 2 * D + t];
+        float resx = 0.f;
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            if (t == b) resx = gp[b] + dzx;
+            if (t == D + b) resx = gv[b] + dzx;
+        }
+        if (t < D) grad_x[n * D + t] = resx;
+        else grad_v[n * D + t - D] = resx;
+        return;
     }
     // ---- the field net's inputs: recompute its backward from dL/df (thread t owns hidden unit t), dz = W0^T dpre1
     long ci = (long)(charges[nc] + 1.0f);

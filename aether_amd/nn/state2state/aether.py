@@ -208,7 +208,7 @@ class _AetherStep(torch.autograd.Function):
             st = lib.aether_backward_inputs(C.byref(module._param_struct()), D, x.shape[0], n_edges, x.data_ptr(),
                                             vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
                                             ws.data_ptr(), ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(),
-                                            gv.data_ptr(), gea.data_ptr() if gea is not None else None, stream)
+                                            gv.data_ptr(), gea.data_ptr() if gea is not None else None, None, stream)
             _lib.check(st, "aether_backward_inputs")
             if not ctx.needs_input_grad[1]:
                 gx = None

@@ -80,6 +80,8 @@ class _DynStep(torch.autograd.Function):
     def forward(ctx, module, x, vel, ea, charges, graph, n_edges, num_nodes, *params):
         out, field, ws = module._launch(x, vel, ea, charges, graph, n_edges, num_nodes, train=True)
         ctx.module, ctx.saved = module, (x, vel, charges, graph, ws, n_edges, num_nodes)
+        if any(ctx.needs_input_grad[1:4]):       # x / vel / edge_attr: aether_backward_inputs recovers y = R^T (out - x)
+            ctx.save_for_backward(out)
         return out
 
     @staticmethod
@@ -106,17 +108,37 @@ class _DynStep(torch.autograd.Function):
         n_graphs = n_nodes // num_nodes
         need = lib.aether_dynamic_field_backward_workspace_bytes(D, n_graphs)
         dws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        _lib.check(lib.aether_dynamic_field_backward(C.byref(fps), C.byref(gfs), D, n_graphs, num_nodes, x.data_ptr(),
-                                                     vel.data_ptr(), charges.data_ptr(), grad_field.data_ptr(),
-                                                     dws.data_ptr(), dws.numel(), stream),
-                   "aether_dynamic_field_backward")
+        want_in = any(ctx.needs_input_grad[1:4])
+        gz = torch.empty(n_nodes, 2 * D, dtype=torch.float32, device=x.device) if want_in else None
+        _lib.check(lib.aether_dynamic_field_backward_inputs(C.byref(fps), C.byref(gfs), D, n_graphs, num_nodes, x.data_ptr(),
+                                                            vel.data_ptr(), charges.data_ptr(), grad_field.data_ptr(),
+                                                            dws.data_ptr(), dws.numel(),
+                                                            gz.data_ptr() if gz is not None else None, stream),
+                   "aether_dynamic_field_backward_inputs")
         module.last_grad_field = grad_field
+        gx = gv = gea = None
+        if want_in:
+            # gradients w.r.t. the inputs (dynamic_field_aether.py:79-100 is differentiable in them): the GNN / frame part
+            # from what aether_backward_field left in the workspace, the part through the latent field from gz
+            (out_saved,) = ctx.saved_tensors
+            gx, gv = torch.empty_like(x), torch.empty_like(x)
+            if ctx.needs_input_grad[3]:
+                gea = torch.empty(n_edges, 2, dtype=torch.float32, device=x.device)
+            _lib.check(lib.aether_backward_inputs(C.byref(ps), D, n_nodes, n_edges, x.data_ptr(), vel.data_ptr(),
+                                                  charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                                  ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(), gv.data_ptr(),
+                                                  gea.data_ptr() if gea is not None else None, gz.data_ptr(), stream),
+                       "aether_backward_inputs")
+            if not ctx.needs_input_grad[1]:
+                gx = None
+            if not ctx.needs_input_grad[2]:
+                gv = None
         if module.dp_group is not None:            # one all-reduce of the flat gradient buffer (RCCL), then the mean
             import torch.distributed as dist
             dist.all_reduce(flat, group=module.dp_group)
             flat.div_(dist.get_world_size(module.dp_group))
         need_g = ctx.needs_input_grad[_DynStep.N_FIXED:]
-        return (None,) * _DynStep.N_FIXED + tuple(grads[n] if k else None for n, k in zip(names, need_g))
+        return (None, gx, gv, gea, None, None, None, None) + tuple(grads[n] if k else None for n, k in zip(names, need_g))
 
 
 class DynamicFieldAether(nn.Module):
@@ -303,14 +325,13 @@ class DynamicFieldAether(nn.Module):
             raise ValueError("x/vel must be [B * num_nodes, num_dims]")
         if recv.numel() != E or edge_attr_orig.shape != (E, 2) or charges.numel() != n_nodes:
             raise ValueError("edge index / edge_attr / charges shapes do not match")
-        if torch.is_grad_enabled() and (x.requires_grad or vel.requires_grad or edge_attr_orig.requires_grad
-                                        or charges.requires_grad):
-            raise NotImplementedError("aether_amd.DynamicFieldAether: gradients w.r.t. x / vel / edge_attr_orig / charges "
-                                      "are not implemented (parameter gradients only); detach the inputs")
+        # differentiable in x / vel / edge_attr_orig, as the reference's forward (dynamic_field_aether.py:79-100)
+        wants_in = torch.is_grad_enabled() and (x.requires_grad or vel.requires_grad or edge_attr_orig.requires_grad)
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
-        x, vel, ea, charges = f32(x), f32(vel), f32(edge_attr_orig), f32(charges)
+        f32g = (lambda t: t.to(torch.float32).contiguous() if t.requires_grad else f32(t)) if wants_in else f32
+        x, vel, ea, charges = f32g(x), f32g(vel), f32g(edge_attr_orig), f32(charges)
         graph = self._graphs.get(send.contiguous(), recv.contiguous(), n_nodes)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             return _DynStep.apply(self, x, vel, ea, charges, graph, E, int(num_nodes), *self.parameters())
         with torch.no_grad():
             # (a train()-mode forward applies dropout even without autograd, as nn.Dropout does)

@@ -231,14 +231,16 @@ int aether_rollout_dynamic_field(const AetherParams* params, const AetherDynFiel
  * (nn/state2state/aether.py:169-186).  Call after aether_backward, on the same workspace (it reads what that call left:
  * dL/d(layer-1 edge features), dL/dn_1, dL/df) with `out` = the forward's output and the same grad_out:
  *   grad_x [n_nodes][D], grad_vel [n_nodes][D] (overwritten); grad_edge_attr [n_edges][2] in the caller's edge order, or
- *   NULL.  The built-in field only (not the aether_forward_field variant).  Positions and velocities enter through
+ *   NULL.  field_input_grad = NULL: the built-in field net (its input gradient is recomputed from dL/df).  For a step that
+ *   ran through aether_forward_field: after aether_backward_field, float[n_nodes][2D] = dL/d[x | vel] THROUGH the external
+ *   field, e.g. from aether_dynamic_field_backward_inputs below.  Positions and velocities enter through
  *   x + R(v) y, the field net's inputs, rel_feat = [0 | R^T v | R^T f] and the local-frame edge features (r, Euler angles
  *   of R_i^T R_j, distance, bearing, R_i^T v_j, R_i^T f_j); charges are an index (no gradient).
  */
 int aether_backward_inputs(const AetherParams* params, int num_dims, int64_t n_nodes, int64_t n_edges, const float* x,
                            const float* vel, const float* charges, const void* graph, const AetherGraphInfo* info,
                            void* workspace, size_t workspace_bytes, const float* out, const float* grad_out, float* grad_x,
-                           float* grad_vel, float* grad_edge_attr, void* stream);
+                           float* grad_vel, float* grad_edge_attr, const float* field_input_grad, void* stream);
 
 /*
  * Training of the dynamic-field variant.  aether_backward_field = aether_backward for a step that ran through
@@ -247,7 +249,7 @@ int aether_backward_inputs(const AetherParams* params, int num_dims, int64_t n_n
  * aether_dynamic_field_backward then differentiates LatentFieldNetwork (dynamic_field_aether.py:31-48: FiLM field
  * net, FiLM modulators, attention pooling): `grads` holds one output pointer per tensor of `params`;
  * workspace: aether_dynamic_field_backward_workspace_bytes(num_dims, n_graphs) bytes (one partial gradient row per
- * graph, added over the graphs in order: no atomics).  Positions / velocities are data: no gradient w.r.t. them.
+ * graph, added over the graphs in order: no atomics).
  */
 int aether_backward_field(const AetherParams* params, const AetherParams* grads, int num_dims, int64_t n_nodes,
                           int64_t n_edges, const float* x, const float* vel, const float* charges,
@@ -258,6 +260,13 @@ int aether_dynamic_field_backward(const AetherDynFieldParams* params, const Aeth
                                   int64_t n_graphs, int nodes_per_graph, const float* x, const float* vel,
                                   const float* charges, const float* grad_field, void* workspace,
                                   size_t workspace_bytes, void* stream);
+/* The same, and grad_field_inputs [n_nodes][2D] (or NULL) = dL/d[x | vel] through the field: the FiLM net's first Linear and
+ * the graph summary's nn / gate_nn (every node's row enters its graph's attention pooling).  Feed it to
+ * aether_backward_inputs(field_input_grad). */
+int aether_dynamic_field_backward_inputs(const AetherDynFieldParams* params, const AetherDynFieldParams* grads, int num_dims,
+                                         int64_t n_graphs, int nodes_per_graph, const float* x, const float* vel,
+                                         const float* charges, const float* grad_field, void* workspace,
+                                         size_t workspace_bytes, float* grad_field_inputs, void* stream);
 
 /*
  * seq2seq Aether, field query: replaces Aether.predict_field

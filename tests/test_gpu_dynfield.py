@@ -124,6 +124,45 @@ def test_dynamic_field_dropout_step_vs_oracle_with_the_same_masks(D):
         assert scale_rel_err(m(*args).cpu(), plain) <= TOL
 
 
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_FORCE_STREAMED])
+@pytest.mark.parametrize("D", [2, 3])
+def test_dynamic_field_input_gradients_vs_oracle_autograd(D, flags):
+    """The reference's DynamicFieldAether.forward is differentiable in x / vel / edge_attr_orig (dynamic_field_aether.py:
+    79-100): d/dx and d/dvel now also run through the latent field -- the FiLM net's inputs and every node's row in its
+    graph's attention pooling (aether_dynamic_field_backward_inputs) -- on top of the frames / features / residual part
+    (aether_backward_inputs).  Against the oracle's fp64 autograd, the fp32 oracle's own distance beside it; parameter
+    gradients of the same backward unchanged."""
+    d, sd, m = _load(D)
+    m.flags = flags
+    for (B, N, seed) in [(4, 5, 21), (6, 20, 22), (2, 40, 23)]:
+        inp = make_batch(B, N, D, seed=seed)
+
+        def oracle(dtype):
+            c = lambda t: t.to(dtype) if t.is_floating_point() else t
+            leaves = {k: c(inp[k]).clone().requires_grad_(True) for k in ("x", "vel", "edge_attr")}
+            out = O.dynamic_field_aether_forward({k: c(v) for k, v in sd.items()}, leaves["x"], leaves["vel"], inp["edges"],
+                                                 leaves["edge_attr"], c(inp["charges"]), N)
+            torch.nn.functional.mse_loss(out, c(inp["target"])).backward()
+            return {k: v.grad for k, v in leaves.items()}
+
+        want, o32 = oracle(torch.float64), oracle(torch.float32)
+        m.zero_grad(set_to_none=True)
+        leaves = {k: inp[k].cuda().requires_grad_(True) for k in ("x", "vel", "edge_attr")}
+        out = m(None, leaves["x"], [e.cuda() for e in inp["edges"]], leaves["vel"], leaves["edge_attr"], inp["charges"].cuda(), N)
+        torch.nn.functional.mse_loss(out, inp["target"].cuda()).backward()
+        pg = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        for k, v in leaves.items():
+            assert torch.isfinite(v.grad).all(), (B, N, k)
+            err, err32 = scale_rel_err(v.grad.cpu(), want[k]), scale_rel_err(o32[k], want[k])
+            assert err <= max(GTOL, 4 * err32), (B, N, k, err, err32)
+        m.zero_grad(set_to_none=True)                                   # parameters only: the same parameter gradients
+        out = m(None, inp["x"].cuda(), [e.cuda() for e in inp["edges"]], inp["vel"].cuda(), inp["edge_attr"].cuda(),
+                inp["charges"].cuda(), N)
+        torch.nn.functional.mse_loss(out, inp["target"].cuda()).backward()
+        for k, p in m.named_parameters():
+            assert torch.equal(p.grad, pg[k]), k
+
+
 def test_dynamic_field_training_step_reduces_loss():
     """A few optimizer steps through the drop-in module, as the runner's loop does (main.py:200-260); gradients
     accumulate like autograd's; a second backward through the same graph is refused by autograd itself."""
