@@ -798,6 +798,34 @@ def main():
         ms_step = 1e3 * dt / args.steps
         value = 4.0 * E * args.chunks * world / (dt / args.steps)
         step_flops = (E * FLOP_PER_EDGE_STEP[D] + Nn * FLOP_PER_NODE_STEP[D]) * args.chunks
+        other = None
+        if (B, N, D) == (32, 1024, 2):
+            # HBM and pipe fractions of the OTHER heavy kernels of the config-5 shard, from the committed PMC
+            # passes (profiles/traffic.json -> cfg5shard.r03_final) over the launch times measured in THIS run
+            try:
+                pm5 = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))["cfg5shard"]["r03_final"]
+
+                def fracs(c, t_us, launches=1):
+                    t = t_us * 1e-6
+                    by = (2.0 * c["fetch_kb"] + c["write_kb"]) * 1024.0 * launches
+                    out = {"avg_launch_us": t_us / launches, "hbm_bytes_per_launch": by / launches,
+                           "hbm_frac": by / t / 8e12,
+                           "bf16_matrix_pipe": c["mfma_bf16"] * launches * 16384.0 / t / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+                           "fp32_mfma_on_valu": c["mfma_f32"] * launches * 2048.0 / t / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                           "valu_issue": (c["valu"] * 4.0 + c["mfma_f32"] * 32.0) * launches / (1024.0 * t * 2.4e9)}
+                    assert all(v <= 1.0 for k, v in out.items() if k not in ("avg_launch_us", "hbm_bytes_per_launch")), out
+                    return out
+                other = {"source": pm5["source"]}
+                if kernels and "k_edge_layer1" in kernels:
+                    other["k_edge_layer1"] = fracs(pm5["k_edge_layer1"], kernels["k_edge_layer1"]["avg_us"])
+                if kernels and "k_edge_layer" in kernels:
+                    other["k_edge_layer"] = fracs(pm5["k_edge_layer"], kernels["k_edge_layer"]["avg_us"])
+                kb = (train or {}).get("kernels_us_per_step", {}).get("kb_edge")
+                if kb:      # four launches per step: layers 4, 3, 2 (kb_edge_acc<false>) and layer 1 (<true>), timed together
+                    both = {k: 3.0 * pm5["kb_edge_acc_false"][k] + pm5["kb_edge_acc_true"][k] for k in pm5["kb_edge_acc_false"]}
+                    other["kb_edge_acc (4 launches)"] = fracs({k: v / 4.0 for k, v in both.items()}, kb, launches=4)
+            except Exception as ex:
+                other = {"error": repr(ex)}
         line = {
             "metric": ("edge-messages/sec (forward, electrostatic N=20 batch=128 per GPU)" if (B, N, D) == (128, 20, 2)
                        else f"edge-messages/sec (forward, {D}-D N={N} batch={B} per GPU)"),
@@ -819,7 +847,7 @@ def main():
                        "parallelism": f"graphs sharded over {world} rank(s), no forward collective"},
             "edges_per_s": E * args.chunks * world / (dt / args.steps),
             "step_algorithmic_tflops": step_flops * world / (dt / args.steps) / 1e12,
-            "roofline": roof, "kernels": kernels, "rollout": roll, "train": train, "ranks_seen": ranks_seen,
+            "roofline": roof, "roofline_other": other, "kernels": kernels, "rollout": roll, "train": train, "ranks_seen": ranks_seen,
         }
         if world == 1 and not args.no_cpu_baseline:
             sd_tr = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if train is not None else None
