@@ -387,6 +387,30 @@ def test_dropout_training_step_matches_oracle_with_the_same_masks(D, path):
         assert scale_rel_err(ev.cpu(), plain) <= 1e-5
 
 
+def test_dropout_with_a_narrow_model():
+    """hidden_size 32 runs zero-padded on the 64-wide engine: with dropout_prob > 0 in train() mode the engine draws the
+    masks (the padded channels stay zero whatever their mask says); gradients are finite, eval() equals the p = 0 model."""
+    D = 2
+    inp = make_batch(4, 9, D, seed=5)
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    dev["edges"] = [e.cuda() for e in inp["edges"]]
+    torch.manual_seed(2)
+    m0 = Aether(2 * D, 32, 0.0, D, device="cuda")
+    torch.manual_seed(2)
+    m1 = Aether(2 * D, 32, 0.4, D, device="cuda")
+    call = lambda m: m(dev["h"], dev["x"], dev["edges"], dev["vel"], dev["edge_attr"], dev["charges"])
+    m0.eval(); m1.eval()
+    with torch.no_grad():
+        ref = call(m0)
+        assert torch.equal(ref, call(m1))
+    m1.train()
+    out = call(m1)
+    assert not torch.equal(out.detach(), ref)
+    torch.nn.functional.mse_loss(out, dev["target"]).backward()
+    for k, p in m1.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
 def test_dropout_inside_a_captured_training_step():
     """GraphedTrainStep with dropout_prob > 0: the mask draw is part of the captured graph (torch's graph-safe Philox
     offsets), so every replay trains with fresh masks; the loss stays finite and goes down."""
