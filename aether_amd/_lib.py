@@ -175,6 +175,24 @@ SIGNATURES = {
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "aether_debug_fetch": (C.c_int64, [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "aether_workspace_bytes_h": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "aether_dropout_mask_offset_h": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "aether_forward_h": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo),
+                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "aether_backward_h": (C.c_int, [C.POINTER(AetherParams), C.POINTER(AetherParams), C.c_int, C.c_int, C.c_int64,
+                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(AetherGraphInfo), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "aether_backward_inputs_h": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo), C.c_void_p,
+                                           C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    "aether_rollout_h": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo), C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "aether_debug_fetch_h": (C.c_int64, [C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
     "aether_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "aether_mse_scratch_bytes": (C.c_size_t, []),
     "aether_mse_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

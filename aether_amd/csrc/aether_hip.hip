@@ -34,6 +34,7 @@
 #include "fused_bwd.h"
 #include "edge_acc.h"
 #include "input_grad.h"
+#include "wide.h"
 #include "seq2seq.h"
 #include "s2s_filter.h"
 #include "s2s_step.h"
@@ -916,6 +917,8 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
     return AETHER_OK;
 }
 
+#include "wide_impl.inc"
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -1561,5 +1564,7 @@ int64_t aether_debug_fetch(const char* name, int num_dims, int64_t n_nodes, int6
         return copy2d((const float*)(ws + W.feat), n_edges, FPAD, 0, FPAD);
     return fail(AETHER_EINVAL, "debug_fetch: unknown name");
 }
+
+#include "host_wide.inc"
 
 }  // extern "C"

@@ -707,7 +707,7 @@ kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ 
          float* __restrict__ RELF, float* __restrict__ Z, float* __restrict__ H1f,
          float* __restrict__ H2f, float* __restrict__ DPH1, float* __restrict__ DPH2,
          float* __restrict__ DF, float* __restrict__ DZE, float* __restrict__ ONEHOT, float* __restrict__ grad_field,
-         int64_t n_nodes) {
+         int64_t n_nodes, int hid = H /* width of DN1 / rows of W_res (wide.h) */) {
     using NI = NodeInfo<D>;
     constexpr int FIN = 2 * D + 16;
     constexpr int O = D * (D - 1) / 2;
@@ -727,9 +727,8 @@ kb_field(AetherParams P, const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
         for (int d = 0; d < D; ++d) dcf[d] += DA[(int64_t)k * FPAD + C_CF + d];
     }
-#pragma unroll
-    for (int o = t; o < H; o += 32) {
-        const float gg = DN1[nc * H + o];
+    for (int o = t; o < hid; o += 32) {
+        const float gg = DN1[nc * hid + o];
 #pragma unroll
         for (int d = 0; d < D; ++d) dcf[d] += P.l1_res_w[o * 3 * D + 2 * D + d] * gg;
     }

@@ -108,7 +108,8 @@ kb_inputs(AetherParams P, const float* __restrict__ x, const float* __restrict__
           const int32_t* __restrict__ srowptr, const int32_t* __restrict__ sperm, float* __restrict__ grad_x,
           float* __restrict__ grad_v, int64_t n_nodes,
           const float* __restrict__ field_gz = nullptr /* [n_nodes][2D]: dL/d[p | v] through an EXTERNAL field (the
-          dynamic-field variant, aether_dynamic_field_backward_inputs); null = the built-in field net, recomputed below */) {
+          dynamic-field variant, aether_dynamic_field_backward_inputs); null = the built-in field net, recomputed below */,
+          int hid = H /* width of DN1 / rows of W_res (wide.h) */) {
     using NI = NodeInfo<D>;
     constexpr int FIN = 2 * D + 16;
     constexpr int O = D * (D - 1) / 2;
@@ -178,8 +179,8 @@ kb_inputs(AetherParams P, const float* __restrict__ x, const float* __restrict__
         }
     }
     // ---- layer_1.res(rel_feat): columns D..2D-1 (R^T v) and 2D..3D-1 (R^T f) of W_res^T dn_1
-    for (int o = t; o < H; o += 32) {
-        const float gg = DN1[nc * H + o];
+    for (int o = t; o < hid; o += 32) {
+        const float gg = DN1[nc * hid + o];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             dcv[d] += P.l1_res_w[o * 3 * D + D + d] * gg;

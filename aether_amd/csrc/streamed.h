@@ -113,7 +113,7 @@ k_node_prep(AetherParams P, const float* __restrict__ x, const float* __restrict
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc0[mb] = mfma16(ar[mb][s4], rk, acc0[mb]);
     }
-    if (live) {
+    if (live && x0 != nullptr) {            // null: the caller computes x0 itself (wide.h, hidden > 64)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) st4(x0 + node * H + 16 * mb + 4 * q, acc0[mb]);
     }

@@ -142,9 +142,11 @@ class _AetherStep(torch.autograd.Function):
         if dropout:
             # nn.Dropout after the two SiLUs of the out MLP (locs.py:163,166): scale masks drawn by torch, written straight
             # into their place in the training workspace (same distribution as nn.Dropout, not its random stream)
-            off = lib.aether_dropout_mask_offset(n_nodes, n_edges, D)
-            masks = ws[off:off + 2 * n_nodes * 64 * 4].view(torch.float32).view(2, n_nodes, 64)
-            given = module.__dict__.get("_dropout_masks")          # tests: explicit masks [2, n_nodes, 64]
+            kw = module._kw
+            off = (lib.aether_dropout_mask_offset(n_nodes, n_edges, D) if kw == 64 else
+                   lib.aether_dropout_mask_offset_h(n_nodes, n_edges, D, kw))
+            masks = ws[off:off + 2 * n_nodes * kw * 4].view(torch.float32).view(2, n_nodes, kw)
+            given = module.__dict__.get("_dropout_masks")          # tests: explicit masks [2, n_nodes, width]
             if given is not None:
                 masks.copy_(given.to(device=x.device, dtype=torch.float32))
             else:
@@ -152,10 +154,16 @@ class _AetherStep(torch.autograd.Function):
                 masks.bernoulli_(keep_p).mul_(1.0 / keep_p)
         out = torch.empty_like(x)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        st = lib.aether_forward(module._param_struct_ref(), D, n_nodes, n_edges,
-                                x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
-                                edge_attr.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
-                                ws.numel(), out.data_ptr(), flags, stream)
+        if module._kw == 64:
+            st = lib.aether_forward(module._param_struct_ref(), D, n_nodes, n_edges,
+                                    x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
+                                    edge_attr.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                    ws.numel(), out.data_ptr(), flags, stream)
+        else:       # hidden_size > 64: the layer-by-layer GEMM path (csrc/wide.h), width as an argument
+            st = lib.aether_forward_h(module._param_struct_ref(), D, module._kw, n_nodes, n_edges,
+                                      x.data_ptr(), vel.data_ptr(), charges.data_ptr(), None,
+                                      edge_attr.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                      ws.numel(), out.data_ptr(), flags & ~_lib.FLAG_FORCE_STREAMED, stream)
         _lib.check(st, "aether_forward")
         module._ws_key = ws_key
         if not train:
@@ -193,9 +201,15 @@ class _AetherStep(torch.autograd.Function):
             dst_flat, dst_struct, dst_views = flat, gstruct, views
         g = grad_out.to(torch.float32).contiguous()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        st = lib.aether_backward(C.byref(module._param_struct()), C.byref(dst_struct), D, x.shape[0], n_edges,
-                                 x.data_ptr(), vel.data_ptr(), charges.data_ptr(), graph.data_ptr(),
-                                 C.byref(ginfo), ws.data_ptr(), ws.numel(), g.data_ptr(), stream)
+        kw = module._kw
+        if kw == 64:
+            st = lib.aether_backward(C.byref(module._param_struct()), C.byref(dst_struct), D, x.shape[0], n_edges,
+                                     x.data_ptr(), vel.data_ptr(), charges.data_ptr(), graph.data_ptr(),
+                                     C.byref(ginfo), ws.data_ptr(), ws.numel(), g.data_ptr(), stream)
+        else:
+            st = lib.aether_backward_h(C.byref(module._param_struct()), C.byref(dst_struct), D, kw, x.shape[0], n_edges,
+                                       x.data_ptr(), vel.data_ptr(), charges.data_ptr(), graph.data_ptr(),
+                                       C.byref(ginfo), ws.data_ptr(), ws.numel(), g.data_ptr(), None, stream)
         _lib.check(st, "aether_backward")
         gx = gv = gea = None
         if any(ctx.needs_input_grad[1:4]):
@@ -205,10 +219,16 @@ class _AetherStep(torch.autograd.Function):
             gx, gv = torch.empty_like(x), torch.empty_like(x)
             if ctx.needs_input_grad[3]:
                 gea = torch.empty(n_edges, 2, dtype=torch.float32, device=x.device)
-            st = lib.aether_backward_inputs(C.byref(module._param_struct()), D, x.shape[0], n_edges, x.data_ptr(),
-                                            vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
-                                            ws.data_ptr(), ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(),
-                                            gv.data_ptr(), gea.data_ptr() if gea is not None else None, None, stream)
+            if kw == 64:
+                st = lib.aether_backward_inputs(C.byref(module._param_struct()), D, x.shape[0], n_edges, x.data_ptr(),
+                                                vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                                ws.data_ptr(), ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(),
+                                                gv.data_ptr(), gea.data_ptr() if gea is not None else None, None, stream)
+            else:
+                st = lib.aether_backward_inputs_h(C.byref(module._param_struct()), D, kw, x.shape[0], n_edges, x.data_ptr(),
+                                                  vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                                  ws.data_ptr(), ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(),
+                                                  gv.data_ptr(), gea.data_ptr() if gea is not None else None, None, stream)
             _lib.check(st, "aether_backward_inputs")
             if not ctx.needs_input_grad[1]:
                 gx = None
@@ -237,24 +257,31 @@ class _AetherStep(torch.autograd.Function):
         return (None, gx, gv, gea, None, None, None) + tuple(out)
 
 
-def _pad_blocks(name, shape, H):
-    """Where a parameter of a model with hidden_size H < 64 lives inside the same-named parameter of the 64-wide model the
-    kernels are built for: a list of (source slices, destination slices).  Hidden vectors sit at the start of their
-    64-wide (update MLP: 128-wide) counterparts; the first message layer of layers 2-4 reads [x_send | x_recv | e], three
-    H-wide column blocks that go to the starts of the three 64-wide blocks.  Everything else in the wide parameters stays
-    zero, which makes the padded channels exactly zero through SiLU, the mean and the residuals: the wide model computes
-    the narrow one."""
+def _kernel_width(hidden_size):
+    """Width the kernels compute a model of this hidden_size at: 64 (fused / streamed kernels) up to 64, the next multiple
+    of 64 above (csrc/wide.h)."""
+    return 64 if hidden_size <= 64 else -(-hidden_size // 64) * 64
+
+
+def _pad_blocks(name, shape, H, kw=64):
+    """Where a parameter of a model with hidden_size H lives inside the same-named parameter of the kw-wide model the
+    kernels are built for (kw = 64, or the next multiple of 64 above H): a list of (source slices, destination slices).
+    Hidden vectors sit at the start of their kw-wide (update MLP: 2 kw-wide) counterparts; the first message layer of
+    layers 2-4 reads [x_send | x_recv | e], three H-wide column blocks that go to the starts of the three kw-wide blocks.
+    Everything else in the wide parameters stays zero, which makes the padded channels exactly zero through SiLU, the mean
+    and the residuals: the wide model computes the narrow one."""
     full = tuple(slice(0, n) for n in shape)
     if name.startswith("field_net."):
         return [(full, full)]
     if name.endswith("message_fn.0.weight") and not name.startswith("gnn.layer_1."):
-        return [((slice(0, H), slice(b * H, (b + 1) * H)), (slice(0, H), slice(64 * b, 64 * b + H))) for b in range(3)]
+        return [((slice(0, H), slice(b * H, (b + 1) * H)), (slice(0, H), slice(kw * b, kw * b + H))) for b in range(3)]
     return [(full, full)]                  # top / top-left aligned
 
 
 class _PaddedStep(torch.autograd.Function):
-    """forward / backward of a model with hidden_size < 64 through its zero-padded 64-wide engine (same kernels): the
-    engine's autograd node is recorded in an inner graph, its parameter gradients are cut back to the narrow shapes."""
+    """forward / backward of a model whose hidden_size is not a kernel width (64, or a multiple of 64 above) through its
+    zero-padded engine of that width (same kernels): the engine's autograd node is recorded in an inner graph, its
+    parameter gradients are cut back to the narrow shapes."""
 
     N_FIXED = 7
 
@@ -287,7 +314,7 @@ class _PaddedStep(torch.autograd.Function):
                 out.append(None)
                 continue
             d = torch.empty_like(p)
-            for ss, ds in _pad_blocks(name, p.shape, outer.hidden_size):
+            for ss, ds in _pad_blocks(name, p.shape, outer.hidden_size, outer._kw):
                 d[ss] = g[ds]
             out.append(d)
         if outer.dp_group is not None:             # data-parallel: one all-reduce of the narrow gradients, flat
@@ -355,9 +382,8 @@ class Aether(nn.Module):
 
     def __init__(self, input_size, hidden_size, dropout_prob, num_dims, device="cuda"):
         super().__init__()
-        if not (1 <= hidden_size <= 64):
-            raise ValueError("hidden_size must be at most 64: the HIP kernels are built 64 wide (narrower models run "
-                             "zero-padded on them, exactly; wider ones are not supported) -- experiments/lorentz/main.py:42-43")
+        if not (1 <= hidden_size <= 4096):
+            raise ValueError("hidden_size must lie in [1, 4096] (experiments/lorentz/main.py:42-43)")
         if num_dims not in (2, 3) or input_size != 2 * num_dims:
             raise ValueError("num_dims must be 2 or 3 and input_size == 2*num_dims")
         if hidden_size == 3 * num_dims:
@@ -366,14 +392,16 @@ class Aether(nn.Module):
         if not (0.0 <= float(dropout_prob) < 1.0):
             raise ValueError("dropout_prob must lie in [0, 1)")
         # nn.Dropout sits between the layers of out_mlp (locs.py:160-168).  In eval() it is the identity, which is what
-        # the kernels compute for any p; a TRAINING forward with p > 0 is refused (forward below): the runner constructs
-        # Aether with dropout_prob=0.0 (experiments/lorentz/main.py:143), and torch's CUDA and CPU generators would give
-        # different masks anyway, so there is nothing to be bit-compatible with
+        # the kernels compute for any p; a train()-mode forward with p > 0 applies the two scale masks (_AetherStep.launch:
+        # drawn with bernoulli_, same distribution as nn.Dropout, not its random stream).  rollout() is an inference path:
+        # it raises in train() mode with p > 0 instead of silently skipping the masks.
         self.dropout_prob = float(dropout_prob)
         self.gnn = _GNN(input_size, hidden_size, dropout_prob, num_dims,
                         additional_features=num_dims)
         self.num_dims = num_dims
         self.hidden_size = hidden_size
+        # width the kernels run this model at: 64 (fused / streamed), or the next multiple of 64 above (csrc/wide.h)
+        self._kw = _kernel_width(hidden_size)
         self.field_net = _FieldNetwork(num_dims, 32, 16)
         self._graphs = GraphCache()
         self.flags = 0                    # _lib.FLAG_* bits passed to aether_forward
@@ -390,12 +418,12 @@ class Aether(nn.Module):
         self._plist = None
         self._ws_bytes = {}
         self.to(device)
-        if hidden_size != 64:
-            # the 64-wide engine: same class, its parameters are the zero-padded images of this model's (kept out of
+        if hidden_size != self._kw:
+            # the engine of kernel width: same class, its parameters are the zero-padded images of this model's (kept out of
             # state_dict / parameters(); its random initialisation is discarded and must not consume this model's RNG stream)
             import contextlib, io
             with torch.random.fork_rng(devices=[]), contextlib.redirect_stdout(io.StringIO()):
-                eng = Aether(input_size, 64, dropout_prob, num_dims, device=device)
+                eng = Aether(input_size, self._kw, dropout_prob, num_dims, device=device)
             eng.grad_as_view = False
             eng.requires_grad_(True)
             with torch.no_grad():
@@ -423,7 +451,7 @@ class Aether(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _sync_engine(self):
-        """Copy this model's parameters into their places in the 64-wide engine when any of them changed."""
+        """Copy this model's parameters into their places in the padded engine when any of them changed."""
         eng = self._engine
         if self._plist is None:
             self._plist = [p for _, p in self.named_parameters()]
@@ -435,7 +463,7 @@ class Aether(nn.Module):
         if self._engine_key != key or train:
             with torch.no_grad():
                 for (name, p), (_, ep) in zip(self.named_parameters(), eng.named_parameters()):
-                    for ss, ds in _pad_blocks(name, p.shape, self.hidden_size):
+                    for ss, ds in _pad_blocks(name, p.shape, self.hidden_size, self._kw):
                         ep[ds].copy_(p[ss])
             self.__dict__["_engine_key"] = None if train else key
         eng.flags = self.flags
@@ -461,6 +489,8 @@ class Aether(nn.Module):
         return self._pstruct[2]
 
     def _workspace_bytes(self, n_nodes, n_edges, keep):
+        if self._kw != 64:
+            return _lib.load().aether_workspace_bytes_h(n_nodes, n_edges, self.num_dims, self._kw, 1 if keep else 0)
         if keep:         # the training layout depends on a library option (outer_defer_max_edges): always ask
             return _lib.load().aether_workspace_bytes(n_nodes, n_edges, self.num_dims, 1)
         key = (n_nodes, n_edges)
@@ -542,7 +572,7 @@ class Aether(nn.Module):
         drops = self.dropout_prob > 0.0 and self.training
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         f32g = (lambda t: t.to(torch.float32).contiguous() if t.requires_grad else f32(t)) if wants_in else f32
-        if self.hidden_size != 64:      # narrow model: the zero-padded 64-wide engine computes it (same kernels)
+        if self.hidden_size != self._kw:      # not a kernel width: the zero-padded engine computes it (same kernels)
             eng = self._sync_engine()
             if not (drops or wants_in or (torch.is_grad_enabled() and any(p.requires_grad for p in self._plist))):
                 with torch.no_grad():
@@ -567,7 +597,9 @@ class Aether(nn.Module):
         if not x.is_cuda:
             raise _lib.AetherHipError("aether_amd.Aether runs on an MI355X only; got a CPU tensor "
                                       "(there is no CPU fallback)")
-        if self.hidden_size != 64:
+        if self.dropout_prob > 0.0 and self.training:
+            raise RuntimeError("Aether.rollout is an inference path (no dropout masks): call .eval() first")
+        if self.hidden_size != self._kw:
             return self._sync_engine().rollout(x, vel, edges, charges, steps, dt)
         lib = _lib.load()
         send, recv = edges
@@ -580,9 +612,19 @@ class Aether(nn.Module):
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         x, vel, charges = f32(x), f32(vel), f32(charges)
         graph, ginfo = self.prepare_graph((send, recv), n_nodes)
-        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 0)
+        ws_bytes = self._workspace_bytes(n_nodes, E, False)
         ws = self._workspace(ws_bytes, x.device)
         flags = self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES
+        if self._kw != 64:
+            traj = torch.empty(int(steps), n_nodes, D, dtype=torch.float32, device=x.device)
+            if int(steps) > 0:
+                st = lib.aether_rollout_h(C.byref(self._param_struct()), D, self._kw, n_nodes, E, x.data_ptr(), vel.data_ptr(),
+                                          charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(), ws.numel(),
+                                          traj.data_ptr(), int(steps), float(dt), 0,
+                                          torch.cuda.current_stream(x.device).cuda_stream)
+                _lib.check(st, "aether_rollout_h")
+                self._last_ws = ws
+            return traj
         fused = ginfo.n_groups > 0 and E > 0 and not (flags & _lib.FLAG_FORCE_STREAMED)
         ws_key = (ws.data_ptr(), n_nodes, E, D, False, graph.data_ptr()) if fused else None
         if ws_key is not None and self._ws_key == ws_key:
@@ -611,9 +653,14 @@ class Aether(nn.Module):
         dev = next(self.parameters()).device
         rows = n_edges if name.startswith("e") else n_nodes
         dst = torch.empty(rows, cols, dtype=torch.float32, device=dev)
-        n = lib.aether_debug_fetch(name.encode(), self.num_dims, n_nodes, n_edges,
-                                   self._last_ws.data_ptr(), dst.data_ptr(),
-                                   torch.cuda.current_stream(dev).cuda_stream)
+        if self._kw == 64:
+            n = lib.aether_debug_fetch(name.encode(), self.num_dims, n_nodes, n_edges,
+                                       self._last_ws.data_ptr(), dst.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            n = lib.aether_debug_fetch_h(name.encode(), self.num_dims, self._kw, n_nodes, n_edges,
+                                         self._last_ws.data_ptr(), dst.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(n, "aether_debug_fetch")
         assert n == rows * cols, (n, rows, cols)
         return dst

@@ -269,6 +269,41 @@ int aether_dynamic_field_backward_inputs(const AetherDynFieldParams* params, con
                                          size_t workspace_bytes, float* grad_field_inputs, void* stream);
 
 /*
+ * Any hidden_size (round 4).  The reference builds Aether / DynamicFieldAether with whatever `--nf` says
+ * (experiments/lorentz/main.py:42-43,143; nn/state2state/aether.py:143-158, nn/state2state/locs/locs.py:142-181): every
+ * [64]-sized dimension of AetherParams above becomes [hidden], [128] becomes [2 hidden], [192] becomes [3 hidden].
+ * The calls below are the calls above with the width as an argument:
+ *   hidden == 64        : exactly the functions above (fused / streamed 64-wide kernels);
+ *   hidden == 64 m > 64 : layer-by-layer on one generic split-bf16 MFMA GEMM kernel with fused epilogues (csrc/wide.h);
+ *   other widths        : not accepted here -- zero-pad the parameters to the next multiple of 64 (padded channels stay
+ *                         exactly zero through SiLU, the mean and the residuals; the Python module does this).
+ * `field` (forward) / `grad_field` (backward) may be NULL (the built-in field net) or the external field of
+ * aether_forward_field / aether_backward_field.  Workspaces are sized by aether_workspace_bytes_h; the dropout masks are
+ * float[2][n_nodes][hidden] at aether_dropout_mask_offset_h.  aether_debug_fetch_h reads a KEEP_INTERMEDIATES workspace.
+ */
+size_t aether_workspace_bytes_h(int64_t n_nodes, int64_t n_edges, int num_dims, int hidden, int keep_for_backward);
+size_t aether_dropout_mask_offset_h(int64_t n_nodes, int64_t n_edges, int num_dims, int hidden);
+int aether_forward_h(const AetherParams* params, int num_dims, int hidden, int64_t n_nodes, int64_t n_edges,
+                     const float* x, const float* vel, const float* charges, const float* field,
+                     const float* edge_attr_orig, const void* graph, const AetherGraphInfo* info,
+                     void* workspace, size_t workspace_bytes, float* out, int flags, void* stream);
+int aether_backward_h(const AetherParams* params, const AetherParams* grads, int num_dims, int hidden, int64_t n_nodes,
+                      int64_t n_edges, const float* x, const float* vel, const float* charges, const void* graph,
+                      const AetherGraphInfo* info, void* workspace, size_t workspace_bytes, const float* grad_out,
+                      float* grad_field, void* stream);
+int aether_backward_inputs_h(const AetherParams* params, int num_dims, int hidden, int64_t n_nodes, int64_t n_edges,
+                             const float* x, const float* vel, const float* charges, const void* graph,
+                             const AetherGraphInfo* info, void* workspace, size_t workspace_bytes, const float* out,
+                             const float* grad_out, float* grad_x, float* grad_vel, float* grad_edge_attr,
+                             const float* field_input_grad, void* stream);
+int aether_rollout_h(const AetherParams* params, int num_dims, int hidden, int64_t n_nodes, int64_t n_edges, const float* x0,
+                     const float* vel0, const float* charges, const void* graph, const AetherGraphInfo* info,
+                     void* workspace, size_t workspace_bytes, float* trajectory, int steps, float dt, int flags,
+                     void* stream);
+int64_t aether_debug_fetch_h(const char* name, int num_dims, int hidden, int64_t n_nodes, int64_t n_edges,
+                             const void* workspace, float* dst, void* stream);
+
+/*
  * seq2seq Aether, field query: replaces Aether.predict_field
  * (nn/seq2seq/aether.py:86-90) = FourierFeatureMapper (nn/nn/fourier_feature_mapper.py:7-21) followed by
  * field_net (aether.py:72-78).  Unlike the state2state field it sees positions only.
