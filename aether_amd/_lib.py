@@ -191,6 +191,9 @@ SIGNATURES = {
     "aether_rollout_h": (C.c_int, [C.POINTER(AetherParams), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.POINTER(AetherGraphInfo), C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "aether_rollout_dynamic_field_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int] +
+                                       [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                                           C.c_void_p]),
     "aether_debug_fetch_h": (C.c_int64, [C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
     "aether_set_option": (C.c_int, [C.c_char_p, C.c_int]),

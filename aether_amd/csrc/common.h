@@ -274,9 +274,6 @@ __device__ __forceinline__ void edge_features(const float* __restrict__ nj,
             s0 += rba * rel[b];
             s1 += rba * nj[NI::V + b];
             s2 += rba * nj[NI::F + b];
-#if defined(AETHER_HAZ_VARIANT) && AETHER_HAZ_VARIANT == 9     // diagnostic build: keep these sums out of packed FMAs
-            asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2));
-#endif
         }
         rrel[a] = s0; rv[a] = s1; rf[a] = s2;
     }

@@ -122,7 +122,9 @@ k_s2s_filter_bimg_types(const float* __restrict__ pos, FilterTypes T, int relu, 
 template <int R>
 __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img, const float* __restrict__ b2,
                                                   const float* __restrict__ ea, const bf16x8* __restrict__ bimg,
-                                                  float* __restrict__ out, int h, int64_t n_edges, int splits, int rs) {
+                                                  float* __restrict__ out, int h, int64_t n_edges, int splits, int rs, int n_wgs) {
+    // n_wgs = workgroups along x, as an explicit argument: the kernels below consume NO implicit (hidden) kernel argument
+    // -- gridDim.x would be hidden_block_count_x.
     // rs > 1 (few edges, variable-N steps): the R features are divided over rs units as well -- plane z = zr * splits + zk
     // holds the k range zk of features [zr R / rs, (zr + 1) R / rs); at 200 edges a unit otherwise walks all 15 features
     // alone (15 iterations of 96 MFMAs per wave on 16 of the 256 CUs: 35 us of a 0.43 ms step)
@@ -136,7 +138,7 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
     const int n_eb = (int)((n_edges + 255) >> 8), n_cb = h >> 6;
     const int n_pairs = n_cb * splits * rs;
     const int nr = R / rs;                                     // features of a unit
-    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, n_slots = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, n_slots = (n_wgs + 7 - xcd) >> 3;
     const int my_pairs = (n_pairs - xcd + 7) >> 3;             // pairs xcd, xcd + 8, ..
     const int n_a32 = h >> 5, n_mb = h >> 4;
     const int slabs = (h / splits) >> 6;                       // 64-wide k slabs of a unit
@@ -293,14 +295,16 @@ __device__ __forceinline__ void filter_split_body(const bf16x8* __restrict__ img
 template <int R>
 __global__ void __launch_bounds__(512)             // two waves per SIMD: <= 256 registers each, no AGPR allocation
 k_s2s_filter_split(const bf16x8* __restrict__ img, const float* __restrict__ b2, const float* __restrict__ ea,
-                   const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits, int rs) {
-    filter_split_body<R>(img, b2, ea, bimg, out, h, n_edges, splits, rs);
+                   const bf16x8* __restrict__ bimg, float* __restrict__ out, int h, int64_t n_edges, int splits, int rs,
+                   int n_wgs /* = gridDim.x */) {
+    filter_split_body<R>(img, b2, ea, bimg, out, h, n_edges, splits, rs, n_wgs);
 }
 template <int R>
 __global__ void __launch_bounds__(512)
-k_s2s_filter_split_types(FilterTypes T, const float* __restrict__ ea, int h, int64_t n_edges, int splits, int rs) {
+k_s2s_filter_split_types(FilterTypes T, const float* __restrict__ ea, int h, int64_t n_edges, int splits, int rs,
+                         int n_wgs /* = gridDim.x */) {
     const int t = blockIdx.y;
-    filter_split_body<R>(T.img[t], T.b2[t], ea, T.bimg[t], T.out[t], h, n_edges, splits, rs);
+    filter_split_body<R>(T.img[t], T.b2[t], ea, T.bimg[t], T.out[t], h, n_edges, splits, rs, n_wgs);
 }
 
 // The variable-N decoder's edge messages from the present state (aether_dynamicvars.py:827-835) out of the filters' planes:

@@ -157,55 +157,8 @@ __device__ __forceinline__ void tile_receiver_sums(const f32x4 (&e)[4], float* w
 // Phase A (one thread per edge): local-frame edge features, aether.py:52-100 +
 // geometry.py:76-101, followed by [rel_feat[recv] | edge_attr_orig] (aether.py:99,177).
 // Phase B (one wave per 16-edge tile): e1 = SiLU(W2 SiLU(W1 a + b1) + b2), locs.py:206-212.
-// Diagnostic builds only (tools/hazard_variants.py): AETHER_L1_BOUNDS lifts the register cap of
-// k_edge_layer1 and AETHER_HAZ_VARIANT picks one way of handling its accumulators, so that the rare-tile corruption
-// of round 2 can be attributed to one instruction pattern.  The product build defines neither.
-#ifndef AETHER_L1_BOUNDS
-#define AETHER_L1_BOUNDS __launch_bounds__(256, 2)
-#endif
-#ifndef AETHER_HAZ_VARIANT
-#define AETHER_HAZ_VARIANT 0
-#endif
-#if AETHER_HAZ_VARIANT == 1      // accumulator initial values pass through VGPRs (no memory load lands in an AGPR)
-#define AETHER_HAZ_AFTER_LOAD(A) asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]));
-#define AETHER_HAZ_AFTER_GEMM(A)
-#elif AETHER_HAZ_VARIANT == 2    // loads land in AGPRs and the four tuples are pinned whole (no sliding dst / SrcC overlap)
-#define AETHER_HAZ_AFTER_LOAD(A) asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));
-#define AETHER_HAZ_AFTER_GEMM(A) asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));
-#elif AETHER_HAZ_VARIANT == 3    // as 2, with a full wait and 8 idle states between the loads and the first MFMA
-#define AETHER_HAZ_AFTER_LOAD(A) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));
-#define AETHER_HAZ_AFTER_GEMM(A) asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));
-#elif AETHER_HAZ_VARIANT == 4    // through VGPRs, then pinned whole in AGPRs (neither pattern)
-#define AETHER_HAZ_AFTER_LOAD(A) asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3])); \
-                                 asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));
-#define AETHER_HAZ_AFTER_GEMM(A) asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));
-#else
-#define AETHER_HAZ_AFTER_LOAD(A)
-#define AETHER_HAZ_AFTER_GEMM(A)
-#endif
-// second experiment (variants 5-8, all on the uncapped build): where does "always the batch's last tile" come from?
-#if AETHER_HAZ_VARIANT == 5      // tiles of a batch in reverse order: does the failure follow the position or the rows?
-#define AETHER_HAZ_TILE_ORDER(tt) (3 - (tt))
-#else
-#define AETHER_HAZ_TILE_ORDER(tt) (tt)
-#endif
-#if AETHER_HAZ_VARIANT == 6      // everything of a batch complete before the next batch's features are built
-#define AETHER_HAZ_END_OF_BATCH asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-#define AETHER_HAZ_END_OF_BATCH
-#endif
-#if AETHER_HAZ_VARIANT == 7      // feature rows complete in LDS before any lane reads another lane's row
-#define AETHER_HAZ_AFTER_FEATURE_WRITE asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-#define AETHER_HAZ_AFTER_FEATURE_WRITE
-#endif
-#if AETHER_HAZ_VARIANT == 8      // all eight operand reads back before the first tile starts
-#define AETHER_HAZ_AFTER_BOP_READ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-#define AETHER_HAZ_AFTER_BOP_READ
-#endif
 template <int D>
-__global__ void AETHER_L1_BOUNDS
+__global__ void __launch_bounds__(256, 2)
 k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
               const float* __restrict__ edge_attr_orig, const int32_t* __restrict__ perm,
               const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
@@ -283,7 +236,6 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
             for (int t = 0; t < FPAD; t += 4) st4(fr + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
         }
         __builtin_amdgcn_wave_barrier();
-        AETHER_HAZ_AFTER_FEATURE_WRITE
         f32x4 bop[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -291,10 +243,8 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
             bop[t][1] = ld4(wfeat + (16 * t + i) * LDF + 16 + 4 * q);
         }
         __builtin_amdgcn_wave_barrier();    // features are in registers: the rows become tile staging
-        AETHER_HAZ_AFTER_BOP_READ
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int t = AETHER_HAZ_TILE_ORDER(tt);
+        for (int t = 0; t < 4; ++t) {
             const int64_t k = batch * 64 + 16 * t + i;
             if (batch * 64 + 16 * t < n_edges) {                       // wave-uniform
                 const int64_t tile = batch * 4 + t;
@@ -304,15 +254,11 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
                     acc[mb] = ld4(bias + 16 * mb + 4 * q);
                     acc2[mb] = ld4(bias + H + 16 * mb + 4 * q);
                 }
-                AETHER_HAZ_AFTER_LOAD(acc)
-                AETHER_HAZ_AFTER_LOAD(acc2)
                 gemm_split<4, 1>(w1, bop[t], acc, lane);
-                AETHER_HAZ_AFTER_GEMM(acc)
                 f32x4 h1[4];
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) h1[mb] = silu4(acc[mb]);
                 gemm_split<4, 2>(w2, h1, acc2, lane);
-                AETHER_HAZ_AFTER_GEMM(acc2)
                 f32x4 eo[4];
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) eo[mb] = silu4(acc2[mb]);
@@ -324,7 +270,6 @@ k_edge_layer1(AetherParams P, const float* __restrict__ nodeinfo,
                 tile_receiver_sums(eo, wfeat, gsel[tile * 64 + lane], rcv, tile, part, i, q, lane);
             }
         }
-        AETHER_HAZ_END_OF_BATCH
     }
 }
 

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
-from .aether import GraphCache, _GNN
+from .aether import GraphCache, _GNN, _kernel_width, _pad_blocks
 
 
 class _AttentionalAggregation(nn.Module):
@@ -93,18 +93,26 @@ class _DynStep(torch.autograd.Function):
         ps, fps = module._structs(x.device)
         names, offsets, total = module._grad_layout()
         flat = torch.zeros(total, dtype=torch.float32, device=x.device)        # one buffer, one memset
-        grads = {n: flat[o:o + p.numel()].view_as(p) for (n, p), o in zip(module.named_parameters(), offsets)}
-        gtensors = dict(grads)
+        kshapes = module._kernel_shapes()
+        # kernel-side views: a GNN tensor of a model whose hidden_size is not a kernel width has the padded shape
+        kgrads = {n: flat[o:o + int(np.prod(kshapes[n]))].view(kshapes[n]) for n, o in zip(names, offsets)}
+        gtensors = dict(kgrads)
         gtensors.update(module._dummy)                               # field_net.net.* slots: not written in this mode
         gs = _lib.params_struct(gtensors)
-        gfs = module._dyn_struct(grads)
+        gfs = module._dyn_struct(kgrads)
         g = grad_out.to(torch.float32).contiguous()
         grad_field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.aether_backward_field(C.byref(ps), C.byref(gs), D, n_nodes, n_edges, x.data_ptr(), vel.data_ptr(),
-                                             charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
-                                             ws.numel(), g.data_ptr(), grad_field.data_ptr(), stream),
-                   "aether_backward_field")
+        kw = module._kw
+        if kw == 64:
+            st = lib.aether_backward_field(C.byref(ps), C.byref(gs), D, n_nodes, n_edges, x.data_ptr(), vel.data_ptr(),
+                                           charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                           ws.numel(), g.data_ptr(), grad_field.data_ptr(), stream)
+        else:
+            st = lib.aether_backward_h(C.byref(ps), C.byref(gs), D, kw, n_nodes, n_edges, x.data_ptr(), vel.data_ptr(),
+                                       charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                       ws.numel(), g.data_ptr(), grad_field.data_ptr(), stream)
+        _lib.check(st, "aether_backward_field")
         n_graphs = n_nodes // num_nodes
         need = lib.aether_dynamic_field_backward_workspace_bytes(D, n_graphs)
         dws = torch.empty(need, dtype=torch.uint8, device=x.device)
@@ -124,10 +132,10 @@ class _DynStep(torch.autograd.Function):
             gx, gv = torch.empty_like(x), torch.empty_like(x)
             if ctx.needs_input_grad[3]:
                 gea = torch.empty(n_edges, 2, dtype=torch.float32, device=x.device)
-            _lib.check(lib.aether_backward_inputs(C.byref(ps), D, n_nodes, n_edges, x.data_ptr(), vel.data_ptr(),
-                                                  charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
-                                                  ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(), gv.data_ptr(),
-                                                  gea.data_ptr() if gea is not None else None, gz.data_ptr(), stream),
+            _lib.check(lib.aether_backward_inputs_h(C.byref(ps), D, kw, n_nodes, n_edges, x.data_ptr(), vel.data_ptr(),
+                                                    charges.data_ptr(), graph.data_ptr(), C.byref(ginfo), ws.data_ptr(),
+                                                    ws.numel(), out_saved.data_ptr(), g.data_ptr(), gx.data_ptr(), gv.data_ptr(),
+                                                    gea.data_ptr() if gea is not None else None, gz.data_ptr(), stream),
                        "aether_backward_inputs")
             if not ctx.needs_input_grad[1]:
                 gx = None
@@ -138,6 +146,7 @@ class _DynStep(torch.autograd.Function):
             dist.all_reduce(flat, group=module.dp_group)
             flat.div_(dist.get_world_size(module.dp_group))
         need_g = ctx.needs_input_grad[_DynStep.N_FIXED:]
+        grads = module._narrow_grads(kgrads)
         return (None, gx, gv, gea, None, None, None, None) + tuple(grads[n] if k else None for n, k in zip(names, need_g))
 
 
@@ -146,16 +155,25 @@ class DynamicFieldAether(nn.Module):
 
     def __init__(self, input_size, hidden_size, dropout_prob, num_dims, device="cuda"):
         super().__init__()
-        if hidden_size != 64:
-            raise ValueError("the HIP kernels are built for hidden_size=64 (experiments/lorentz/main.py:42-43)")
+        if not (1 <= hidden_size <= 4096):
+            raise ValueError("hidden_size must lie in [1, 4096] (experiments/lorentz/main.py:42-43)")
         if num_dims not in (2, 3) or input_size != 2 * num_dims:
             raise ValueError("num_dims must be 2 or 3 and input_size == 2*num_dims")
+        if hidden_size == 3 * num_dims:
+            raise ValueError("hidden_size == 3 * num_dims is not supported (the reference then builds layer_1 without its "
+                             "res Linear, locs.py:214-218)")
         if not (0.0 <= float(dropout_prob) < 1.0):
             raise ValueError("dropout_prob must lie in [0, 1)")
         # (the runner passes 0.0, main.py:149; > 0: identity in eval(), the out MLP's two masks in train() -- as Aether)
         self.dropout_prob = float(dropout_prob)
         self.gnn = _GNN(input_size, hidden_size, dropout_prob, num_dims, additional_features=num_dims)
         self.num_dims = num_dims
+        self.hidden_size = hidden_size
+        # width the kernels run the GNN at: 64 (fused / streamed), or the next multiple of 64 above (csrc/wide.h); a model of
+        # another width runs on zero-padded copies of its GNN parameters (exact: padded channels stay zero), as Aether does
+        self._kw = _kernel_width(hidden_size)
+        self._kshapes = None
+        self._padded = None
         self.field_net = _LatentFieldNetwork(num_dims, 32, 16)
         self._graphs = GraphCache()
         self.flags = 0
@@ -203,9 +221,52 @@ class DynamicFieldAether(nn.Module):
         if self._dummy is None or next(iter(self._dummy.values())).device != device:
             self._dummy = {k: torch.zeros(*shape, device=device) for k, shape in dummy.items()}
         tensors = {k: v for k, v in sd.items()}
+        if self.hidden_size != self._kw:
+            tensors.update(self._padded_gnn(device))
         tensors.update(self._dummy)
         ps = _lib.params_struct(tensors)
         return ps, self._dyn_struct(sd)
+
+    def _kernel_shapes(self):
+        """{parameter name: shape of the tensor the kernels see} -- the GNN's at kernel width."""
+        if self._kshapes is None:
+            shapes = {n: tuple(p.shape) for n, p in self.named_parameters()}
+            if self.hidden_size != self._kw:
+                with torch.device("meta"):
+                    wide = _GNN(2 * self.num_dims, self._kw, 0.0, self.num_dims, additional_features=self.num_dims)
+                shapes.update({"gnn." + n: tuple(p.shape) for n, p in wide.named_parameters()})
+            self._kshapes = shapes
+        return self._kshapes
+
+    def _padded_gnn(self, device):
+        """Zero-padded kernel-width copies of the GNN parameters, refreshed from the parameters (every call: an optimizer
+        step may lie between two calls, and inside a captured step the copies have to be part of the graph)."""
+        ks = self._kernel_shapes()
+        if self._padded is None or next(iter(self._padded.values())).device != device:
+            self._padded = {n: torch.zeros(ks[n], dtype=torch.float32, device=device)
+                            for n, _ in self.named_parameters() if n.startswith("gnn.")}
+            self._struct_cache = None
+        with torch.no_grad():
+            for n, p in self.named_parameters():
+                if n.startswith("gnn."):
+                    for ss, ds in _pad_blocks(n, p.shape, self.hidden_size, self._kw):
+                        self._padded[n][ds].copy_(p[ss])
+        return self._padded
+
+    def _narrow_grads(self, kgrads):
+        """Kernel-side gradients cut back to the parameters' shapes."""
+        if self.hidden_size == self._kw:
+            return kgrads
+        out = {}
+        for n, p in self.named_parameters():
+            g = kgrads[n]
+            if n.startswith("gnn."):
+                d = torch.empty_like(p)
+                for ss, ds in _pad_blocks(n, p.shape, self.hidden_size, self._kw):
+                    d[ss] = g[ds]
+                g = d
+            out[n] = g
+        return out
 
     _DYN_NAMES = ["summary_net.summary_net.gate_nn.0", "summary_net.summary_net.gate_nn.2", "summary_net.summary_net.nn.0",
                   "summary_net.summary_net.nn.2", "wrapper.linear_1", "wrapper.linear_2", "wrapper.linear_3",
@@ -216,10 +277,11 @@ class DynamicFieldAether(nn.Module):
         """(parameter names, offsets into one flat gradient buffer (64-float aligned), total floats)."""
         if getattr(self, "_glayout", None) is None:
             names, offsets, total = [], [], 0
+            ks = self._kernel_shapes()
             for n, p in self.named_parameters():
                 names.append(n)
                 offsets.append(total)
-                total += (p.numel() + 63) // 64 * 64
+                total += (int(np.prod(ks[n])) + 63) // 64 * 64
             self._glayout = (names, offsets, total)
         return self._glayout
 
@@ -235,23 +297,30 @@ class DynamicFieldAether(nn.Module):
         lib = _lib.load()
         graph, ginfo = graph
         n_nodes, D, E = x.shape[0], self.num_dims, n_edges
+        if self.hidden_size != self._kw:
+            self._padded_gnn(x.device)      # refresh the kernel-width copies of the GNN parameters
+        kw = self._kw
         ps, fps = self._structs(x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
         _lib.check(lib.aether_dynamic_field(C.byref(fps), D, n_nodes // int(num_nodes), int(num_nodes), x.data_ptr(),
                                             vel.data_ptr(), charges.data_ptr(), field.data_ptr(), stream),
                    "aether_dynamic_field")
-        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 1 if train else 0)
+        ws_bytes = lib.aether_workspace_bytes_h(n_nodes, E, D, kw, 1 if train else 0)
         flags = self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES
+        if kw != 64:
+            flags &= ~(_lib.FLAG_FORCE_FUSED | _lib.FLAG_FORCE_STREAMED)
         ws_key = None
         if train:                           # the backward reads this forward's intermediates: one workspace per call
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
             flags |= _lib.FLAG_KEEP_INTERMEDIATES | (0 if self.flags & _lib.FLAG_KEEP_INTERMEDIATES else _lib.FLAG_BACKWARD_ONLY)
             if self.dropout_prob > 0.0 and self.training:
                 # nn.Dropout after the two SiLUs of the out MLP (locs.py:163,166): scale masks into the training workspace
-                off = lib.aether_dropout_mask_offset(n_nodes, E, D)
-                masks = ws[off:off + 2 * n_nodes * 64 * 4].view(torch.float32).view(2, n_nodes, 64)
-                given = self.__dict__.get("_dropout_masks")          # tests: explicit masks [2, n_nodes, 64]
+                off = lib.aether_dropout_mask_offset_h(n_nodes, E, D, kw)
+                masks = ws[off:off + 2 * n_nodes * kw * 4].view(torch.float32).view(2, n_nodes, kw)
+                given = self.__dict__.get("_dropout_masks")          # tests: explicit masks [2, n_nodes, width]
+                if given is not None and given.shape[-1] != kw:      # a narrow model's masks: padded channels are zero anyway
+                    given = torch.nn.functional.pad(given, (0, kw - given.shape[-1]), value=1.0)
                 if given is not None:
                     masks.copy_(given.to(device=x.device, dtype=torch.float32))
                 else:
@@ -267,10 +336,15 @@ class DynamicFieldAether(nn.Module):
                 flags |= _lib.FLAG_WORKSPACE_REUSED
         self._ws_key = None
         out = torch.empty_like(x)
-        _lib.check(lib.aether_forward_field(C.byref(ps), D, n_nodes, E, x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
-                                            field.data_ptr(), ea.data_ptr(), graph.data_ptr(), C.byref(ginfo),
-                                            ws.data_ptr(), ws.numel(), out.data_ptr(), flags, stream),
-                   "aether_forward_field")
+        if kw == 64:
+            st = lib.aether_forward_field(C.byref(ps), D, n_nodes, E, x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
+                                          field.data_ptr(), ea.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                          ws.data_ptr(), ws.numel(), out.data_ptr(), flags, stream)
+        else:       # hidden_size > 64: csrc/wide.h with the external field
+            st = lib.aether_forward_h(C.byref(ps), D, kw, n_nodes, E, x.data_ptr(), vel.data_ptr(), charges.data_ptr(),
+                                      field.data_ptr(), ea.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                      ws.data_ptr(), ws.numel(), out.data_ptr(), flags, stream)
+        _lib.check(st, "aether_forward_field")
         self._ws_key = ws_key
         self.last_field = field
         return out, field, ws
@@ -294,8 +368,12 @@ class DynamicFieldAether(nn.Module):
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         x, vel, charges = f32(x), f32(vel), f32(charges)
         graph, ginfo = self._graphs.get(send.contiguous(), recv.contiguous(), n_nodes)
+        if self.dropout_prob > 0.0 and self.training:
+            raise RuntimeError("DynamicFieldAether.rollout is an inference path (no dropout masks): call .eval() first")
+        if self.hidden_size != self._kw:
+            self._padded_gnn(x.device)
         ps, fps = self._structs(x.device)
-        ws_bytes = lib.aether_workspace_bytes(n_nodes, E, D, 0)
+        ws_bytes = lib.aether_workspace_bytes_h(n_nodes, E, D, self._kw, 0)
         if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
             self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         self._ws_key = None
@@ -303,11 +381,14 @@ class DynamicFieldAether(nn.Module):
         if int(steps) <= 0:
             return traj
         field = torch.empty(n_nodes, D, dtype=torch.float32, device=x.device)
-        st = lib.aether_rollout_dynamic_field(C.byref(ps), C.byref(fps), D, n_nodes, E, int(num_nodes), x.data_ptr(),
-                                              vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
-                                              self._ws.data_ptr(), self._ws.numel(), field.data_ptr(), traj.data_ptr(),
-                                              int(steps), float(dt), self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES,
-                                              torch.cuda.current_stream(x.device).cuda_stream)
+        flags = self.flags & ~_lib.FLAG_KEEP_INTERMEDIATES
+        if self._kw != 64:
+            flags &= ~(_lib.FLAG_FORCE_FUSED | _lib.FLAG_FORCE_STREAMED)
+        st = lib.aether_rollout_dynamic_field_h(C.byref(ps), C.byref(fps), D, self._kw, n_nodes, E, int(num_nodes), x.data_ptr(),
+                                                vel.data_ptr(), charges.data_ptr(), graph.data_ptr(), C.byref(ginfo),
+                                                self._ws.data_ptr(), self._ws.numel(), field.data_ptr(), traj.data_ptr(),
+                                                int(steps), float(dt), flags,
+                                                torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(st, "aether_rollout_dynamic_field")
         return traj
 

@@ -300,6 +300,11 @@ int aether_rollout_h(const AetherParams* params, int num_dims, int hidden, int64
                      const float* vel0, const float* charges, const void* graph, const AetherGraphInfo* info,
                      void* workspace, size_t workspace_bytes, float* trajectory, int steps, float dt, int flags,
                      void* stream);
+int aether_rollout_dynamic_field_h(const AetherParams* params, const AetherDynFieldParams* dyn_params, int num_dims,
+                                   int hidden, int64_t n_nodes, int64_t n_edges, int nodes_per_graph, const float* x0,
+                                   const float* vel0, const float* charges, const void* graph, const AetherGraphInfo* info,
+                                   void* workspace, size_t workspace_bytes, float* field_scratch, float* trajectory,
+                                   int steps, float dt, int flags, void* stream);
 int64_t aether_debug_fetch_h(const char* name, int num_dims, int hidden, int64_t n_nodes, int64_t n_edges,
                              const void* workspace, float* dst, void* stream);
 

@@ -252,3 +252,52 @@ def test_dynamic_field_graphed_train_step():
             assert abs(lg - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
     for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
         assert scale_rel_err(p.detach().cpu(), q.detach().cpu()) <= 1e-5, k
+
+
+# ---------------------------------------------------------------- any hidden_size (round 4)
+@pytest.mark.parametrize("D,H", [(2, 32), (3, 96), (2, 128), (3, 192)])
+def test_dynamic_field_any_hidden_size_vs_oracle(D, H):
+    """DynamicFieldAether(hidden_size = --nf) (experiments/lorentz/main.py:42-43,148-149; dynamic_field_aether.py:51-100):
+    the GNN runs at the kernel width (64, or the next multiple of 64 on csrc/wide.h), other widths zero-padded.  Forward,
+    dL/dfield, every parameter gradient, the input gradients and the device rollout against the oracle."""
+    torch.manual_seed(21)
+    m = DynamicFieldAether(2 * D, H, 0.0, D, device="cuda")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    assert sd["gnn.layer_2.message_fn.0.weight"].shape == (H, 3 * H) and sd["gnn.layer_1.update_fn.0.weight"].shape == (2 * H, H)
+    B, N = 5, 8
+    inp = make_batch(B, N, D, seed=31)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hx, hv, he = (inp[k].clone().requires_grad_(True) for k in ("x", "vel", "edge_attr"))
+    field = O.dynamic_field(sdg, hx, hv, inp["charges"], N)
+    field.retain_grad()
+    want = O.aether_forward(sdg, hx, hv, inp["edges"], he, inp["charges"], field=field)
+    torch.nn.functional.mse_loss(want, inp["target"]).backward()
+    edges = [e.cuda() for e in inp["edges"]]
+    with torch.no_grad():
+        out0 = m(None, inp["x"].cuda(), edges, inp["vel"].cuda(), inp["edge_attr"].cuda(), inp["charges"].cuda(), N)
+    assert scale_rel_err(out0.cpu(), want.detach()) <= TOL
+    m.zero_grad(set_to_none=True)
+    xg, vg, eg = (inp[k].cuda().requires_grad_(True) for k in ("x", "vel", "edge_attr"))
+    out = m(None, xg, edges, vg, eg, inp["charges"].cuda(), N)
+    assert scale_rel_err(out.detach().cpu(), want.detach()) <= TOL
+    torch.nn.functional.mse_loss(out, inp["target"].cuda()).backward()
+    assert scale_rel_err(m.last_grad_field.cpu(), field.grad) <= GTOL
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and torch.isfinite(p.grad).all(), k
+        if k.endswith("gate_nn.2.bias"):
+            continue
+        ref = sdg[k].grad
+        assert float((p.grad.cpu() - ref).abs().max()) <= GTOL * max(float(ref.abs().max()), 1e-3), k
+    for got_g, ref_g, name in ((xg.grad, hx.grad, "x"), (vg.grad, hv.grad, "vel"), (eg.grad, he.grad, "edge_attr")):
+        assert float((got_g.cpu() - ref_g).abs().max()) <= GTOL * max(float(ref_g.abs().max()), 1e-3), name
+    # device rollout: the latent field recomputed from the current state every step
+    traj = m.rollout(inp["x"].cuda(), inp["vel"].cuda(), edges, inp["charges"].cuda(), 3, num_nodes=N).cpu()
+    rows, cols = inp["edges"]
+    qprod = inp["charges"][rows] * inp["charges"][cols]
+    x, v = inp["x"], inp["vel"]
+    with torch.no_grad():
+        for t in range(3):
+            dist = torch.sqrt(torch.sum((x[rows] - x[cols]) ** 2, 1)).unsqueeze(1)
+            xn = O.dynamic_field_aether_forward(sd, x, v, inp["edges"], torch.cat([qprod, dist], 1), inp["charges"], N)
+            v, x = (xn - x) / 1.0, xn
+            assert scale_rel_err(traj[t], x) <= TOL, t

@@ -71,7 +71,7 @@ def test_drop_in_error_behaviour():
     bad[1][3] = inp["x"].shape[0]                       # receiver out of range
     with pytest.raises(_lib.AetherHipError, match="outside"):
         m(*args(edges=bad))
-    for ctor in (lambda: Aether(4, 128, 0.0, 2), lambda: Aether(4, 64, 1.0, 2), lambda: Aether(4, 64, 0.0, 4)):
+    for ctor in (lambda: Aether(4, 0, 0.0, 2), lambda: Aether(4, 6, 0.0, 2), lambda: Aether(4, 64, 1.0, 2), lambda: Aether(4, 64, 0.0, 4)):
         with pytest.raises(ValueError):
             ctor()
     # C ABI: a workspace that is too small is refused, nothing is launched
@@ -91,6 +91,14 @@ def test_drop_in_error_behaviour():
                             C.byref(info), ws.data_ptr(), ws.numel(), out.data_ptr(), 0,
                             torch.cuda.current_stream().cuda_stream)
     assert rc == -1
+    # the width-generic entry points accept multiples of 64 only (other widths are zero-padded by the module)
+    assert lib.aether_workspace_bytes_h(10, 40, D, 100, 0) == 0 and lib.aether_workspace_bytes_h(10, 40, D, 128, 0) > 0
+    assert lib.aether_workspace_bytes_h(10, 40, D, 64, 0) == need
+    rc = lib.aether_forward_h(C.byref(m._param_struct()), D, 100, 10, 40, inp["x"].data_ptr(), inp["vel"].data_ptr(),
+                              inp["charges"].data_ptr(), None, inp["edge_attr"].data_ptr(), graph.data_ptr(),
+                              C.byref(info), ws.data_ptr(), ws.numel(), out.data_ptr(), 0,
+                              torch.cuda.current_stream().cuda_stream)
+    assert rc == -1 and b"multiple of 64" in lib.aether_last_error()
 
 
 def test_graphed_train_step_matches_eager():

@@ -4,7 +4,8 @@
 k_edge_layer1 compiled WITHOUT its register cap (accumulators in AGPRs) produced ~3 wrong 16-edge tiles per million.
 The uncapped build differs from the product build in two patterns (tools/isa_check.py): R1, LDS loads that land in
 accumulator registers and feed a bf16 MFMA's SrcC, and R2, bf16 MFMAs whose destination tuple partially overlaps the
-SrcC tuple.  csrc/streamed.h has diagnostic variants (AETHER_HAZ_VARIANT) forming a 2 x 2 design:
+SrcC tuple.  The diagnostic variants below form a 2 x 2 design.  They are NOT in the product sources (round 4): build()
+copies csrc/ to a scratch directory and patches its own copy of k_edge_layer1 / edge_features there (PATCHES):
 
     variant 0: R1 + R2 (as compiled in round 2)      variant 1: R2 only        variant 2: R1 only
     variant 3: R1 with a full wait + 8 idle states    variant 4: neither (accumulators still in AGPRs)
@@ -25,20 +26,72 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
+# ---- the diagnostic variants as source patches of a scratch copy of csrc/ (the product compiles ONE k_edge_layer1)
+_AFTER_LOAD = {
+    1: 'asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]));',                 # through VGPRs (no load lands in an AGPR)
+    2: 'asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));',                 # loads land in AGPRs, tuples pinned whole
+    3: 'asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_nop 7" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));',   # + full wait, 8 idle states
+    4: 'asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3])); asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));',
+}
+_AFTER_GEMM = {v: 'asm volatile("" : "+a"(A[0]), "+a"(A[1]), "+a"(A[2]), "+a"(A[3]));' for v in (2, 3, 4)}
+
+
+def _patch_sources(v, root):
+    """Apply variant v to the copy of csrc/ under root.  Every anchor has to be found exactly once."""
+    def sub(path, old, new):
+        s = open(path).read()
+        assert s.count(old) == 1, (path, old)
+        open(path, "w").write(s.replace(old, new))
+    st = os.path.join(root, "csrc", "streamed.h")
+    sub(st, "__global__ void __launch_bounds__(256, 2)\nk_edge_layer1(", "__global__ void __launch_bounds__(256)\nk_edge_layer1(")
+    if v in _AFTER_LOAD:
+        sub(st, "                gemm_split<4, 1>(w1, bop[t], acc, lane);\n",
+            "                { auto& A = acc; %s }\n                { auto& A = acc2; %s }\n"
+            "                gemm_split<4, 1>(w1, bop[t], acc, lane);\n%s" %
+            (_AFTER_LOAD[v], _AFTER_LOAD[v], ("                { auto& A = acc; %s }\n" % _AFTER_GEMM[v]) if v in _AFTER_GEMM else ""))
+        if v in _AFTER_GEMM:
+            sub(st, "                gemm_split<4, 2>(w2, h1, acc2, lane);\n",
+                "                gemm_split<4, 2>(w2, h1, acc2, lane);\n                { auto& A = acc2; %s }\n" % _AFTER_GEMM[v])
+    if v == 5:      # tiles of a batch in reverse order: does the failure follow the position or the rows?
+        sub(st, "        for (int t = 0; t < 4; ++t) {\n            const int64_t k = batch * 64 + 16 * t + i;",
+            "        for (int tt = 0; tt < 4; ++tt) {\n            const int t = 3 - tt;\n            const int64_t k = batch * 64 + 16 * t + i;")
+    if v == 6:      # everything of a batch complete before the next batch's features are built
+        sub(st, "                tile_receiver_sums(eo, wfeat, gsel[tile * 64 + lane], rcv, tile, part, i, q, lane);\n            }\n        }\n",
+            "                tile_receiver_sums(eo, wfeat, gsel[tile * 64 + lane], rcv, tile, part, i, q, lane);\n            }\n        }\n"
+            '        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");\n')
+    if v == 7:      # feature rows complete in LDS before any lane reads another lane's row
+        sub(st, "        __builtin_amdgcn_wave_barrier();\n        f32x4 bop[4][2];\n",
+            '        __builtin_amdgcn_wave_barrier();\n        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n        f32x4 bop[4][2];\n')
+    if v == 8:      # all eight operand reads back before the first tile starts
+        sub(st, "        __builtin_amdgcn_wave_barrier();    // features are in registers: the rows become tile staging\n",
+            "        __builtin_amdgcn_wave_barrier();    // features are in registers: the rows become tile staging\n"
+            '        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n')
+    if v == 9:      # the frame sums of the feature build kept out of packed FMAs
+        sub(os.path.join(root, "csrc", "common.h"), "            s2 += rba * nj[NI::F + b];\n",
+            '            s2 += rba * nj[NI::F + b];\n            asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2));\n')
+
+
 def build(variants=range(5)):
+    import shutil
+    import tempfile
     from aether_amd import build as B
     procs = []
+    scratch = tempfile.mkdtemp(prefix="aether_haz_")
     for v in variants:
+        root = os.path.join(scratch, f"v{v}", "aether_amd")
+        shutil.copytree(os.path.join(REPO, "aether_amd", "csrc"), os.path.join(root, "csrc"))
+        shutil.copytree(os.path.join(REPO, "include"), os.path.join(scratch, f"v{v}", "include"))
+        _patch_sources(v, root)
         out = os.path.join(REPO, "aether_amd", f"libaether_hip_haz{v}.so")
         # variants 0-9 reproduce round 2's build: SLP vectoriser on (it is what forms the packed FMAs with op_sel);
         # variant 10 is the uncapped kernel under the product's flags (build.py: -fno-slp-vectorize) -- the fix
         flags = [f for f in B.FLAGS if f != "-fno-slp-vectorize"] if v < 10 else list(B.FLAGS)
-        cmd = [B.hipcc_path(), *flags, "-DAETHER_L1_BOUNDS=__launch_bounds__(256)", f"-DAETHER_HAZ_VARIANT={v}",
-               B.SRC, "-o", out]
+        cmd = [B.hipcc_path(), *flags, os.path.join(root, "csrc", "aether_hip.hip"), "-o", out]
         procs.append((v, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
     for v, p in procs:
         assert p.wait() == 0, v
         print("built variant", v, flush=True)
+    shutil.rmtree(scratch, ignore_errors=True)
 
 
 def run(which, reps):
