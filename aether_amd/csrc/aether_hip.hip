@@ -280,7 +280,6 @@ int g_dyn_filter_v1 = 0;                        // aether_set_option("dyn_filter
 int g_dyn_filter_v1_edges = 0;                  // auto: below this many edges (measured: no size where the first version wins)
 int g_filter_rsplits = 0;                       // aether_set_option("filter_rsplits", 0 auto | 1 | 3 | 5 | 15): feature split of the 15-feature filter GEMM
 int g_filter_wgs = 256;                         // workgroups of k_s2s_filter_split: one per CU
-int g_dyn_filter_types_kernel = 0;              // aether_set_option("dyn_filter_types_kernel", 0 | 1): the variable-N decoder's filters of all edge types as ONE launch
 int g_filter_splits = 0;                        // aether_set_option("filter_splits", n): k-splits of the filter GEMM, 0 = by balance
 
 
@@ -980,7 +979,6 @@ int aether_set_option(const char* name, int value) {
         return AETHER_OK;
     }
     if (!strcmp(name, "dyn_filter_v1_edges")) { g_dyn_filter_v1_edges = value; return AETHER_OK; }
-    if (!strcmp(name, "dyn_filter_types_kernel")) { g_dyn_filter_types_kernel = value != 0; return AETHER_OK; }
     if (!strcmp(name, "filter_rsplits")) {
         if (value != 0 && 15 % value != 0) return fail(AETHER_EINVAL, "set_option: filter_rsplits is 0 (auto), 1, 3, 5 or 15");
         g_filter_rsplits = value;

@@ -61,7 +61,14 @@ def test_state_dict_surface_and_default_init(D):
 
 def test_ctor_rejects_unsupported():
     with pytest.raises(ValueError):
-        Aether(4, 128, 0.0, 2, device="cpu")             # wider than the kernels
+        Aether(4, 0, 0.0, 2, device="cpu")               # no width
+    from aether_amd.nn.state2state.dynamic_field_aether import DynamicFieldAether
+    for cls in (Aether, DynamicFieldAether):             # any width the reference accepts (experiments/lorentz/main.py:42-43)
+        for H in (20, 64, 96, 128):
+            m = cls(4, H, 0.0, 2, device="cpu")
+            sd = m.state_dict()
+            assert sd["gnn.layer_3.message_fn.0.weight"].shape == (H, 3 * H) and sd["gnn.out_mlp.6.weight"].shape == (2, H)
+            assert m._kw == (64 if H <= 64 else 128)
     with pytest.raises(ValueError):
         Aether(4, 6, 0.0, 2, device="cpu")               # hidden_size == 3 D: the reference drops layer_1.res there
     with pytest.raises(ValueError):
@@ -173,6 +180,12 @@ def test_built_library_passes_the_isa_check():
         "v_mfma_f32_16x16x32_bf16 a[2:5], v[2:5], v[10:13], a[4:7]",
     ])
     assert len(res["r3"]) == 2 and res["bf16"] and len(res["r1"]) == 1 and len(res["r2"]) == 1, res
+    # rule R4: the by-value-struct kernels of a captured variable-N step consume no hidden kernel
+    # arguments -- round 3's k_s2s_filter_split_types read gridDim.x and faulted as a graph node replayed back to back
+    assert isa_check.check_hidden_args(_lib.LIB_PATH) == []
+    notes = isa_check.kernel_notes(_lib.LIB_PATH)
+    split_types = [v for k, v in notes.items() if "k_s2s_filter_split_types" in k]
+    assert split_types and all(seg <= 256 and not hidden for seg, hidden in split_types), split_types
 
 
 def test_host_side_size_functions_of_the_round_3_entries():

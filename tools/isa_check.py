@@ -18,6 +18,12 @@ Scans the gfx950 disassembly of every kernel.
       sliding-tuple sequence, bit-exact) and in the kernel (2 x 2 variants: every combination failed alike until the
       packed FMAs were removed, then none did) both patterns are sound, so they do not fail the check.
 
+  R4  (FAILS the check, library input only) a kernel that takes a by-value struct of pointer arrays (FilterTypes: the
+      k_s2s_filter_*_types / k_dyn_filter_combine family, nodes of every captured variable-N step) must consume NO implicit
+      ("hidden") kernel argument.  Round 3's k_s2s_filter_split_types<15> read gridDim.x (hidden_block_count_x at the end
+      of a 480-byte kernarg segment) on a 2-D grid; as a graph node replayed back to back it ended in a GPU memory access
+      fault (20 of 20 runs).  With the workgroup count as an explicit argument the same reproducer passes.
+
 Usage: isa_check.py [libaether_hip.so | file.s] [--all] [--kernel SUBSTR]
 """
 from __future__ import annotations
@@ -52,6 +58,34 @@ def disassemble(path: str) -> str:
         out = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co],
                              check=True, capture_output=True, text=True).stdout
     return out
+
+
+def kernel_notes(path: str):
+    """{kernel name: (kernarg segment bytes, [hidden_* argument kinds])} from the code object's metadata notes."""
+    with tempfile.TemporaryDirectory() as td:
+        co, fat = os.path.join(td, "dev.co"), os.path.join(td, "fat.bin")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", path],
+                       check=True, capture_output=True)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
+                       check=True, capture_output=True)
+        txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
+                             text=True).stdout
+    out = {}
+    for blk in txt.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        seg = re.search(r"\.kernarg_segment_size:\s+(\d+)", blk)
+        if name:
+            out[name.group(1)] = (int(seg.group(1)) if seg else -1, re.findall(r"\.value_kind:\s+(hidden_\w+)", blk))
+    return out
+
+
+R4_KERNELS = ("k_s2s_filter_split_types", "k_s2s_filter_bimg_types", "k_dyn_filter_combine")
+
+
+def check_hidden_args(path: str):
+    """Rule R4 -> [(kernel, hidden kinds)] of the by-value-struct kernels that consume hidden kernel arguments."""
+    return [(n, h) for n, (_, h) in kernel_notes(path).items() if h and any(k in n for k in R4_KERNELS)]
 
 
 def split_kernels(txt: str):
@@ -160,6 +194,10 @@ def main(argv):
                 for mf in res["r2"][:2]:
                     print("     R2:", mf)
         bad += bool(flagged)
+    if not path.endswith(".s") and not only:
+        for name, hidden in check_hidden_args(path):
+            print(f"FAIL {name}: R4(by-value struct kernel consumes hidden kernel arguments)={sorted(set(hidden))}")
+            bad += 1
     print(f"isa_check: {n} kernels scanned, {bad} failing")
     return 1 if bad else 0
 
