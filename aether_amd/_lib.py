@@ -152,8 +152,8 @@ SIGNATURES = {
     "aether_dyn_step_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int64, C.c_int64]),
     "aether_dyn_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_int] +
                         [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
-    "aether_dyn_rollout_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "aether_dyn_rollout": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 14 + [C.c_void_p, C.c_size_t,
+    "aether_dyn_rollout_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aether_dyn_rollout": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 15 + [C.c_void_p, C.c_size_t,
                                                                                                C.c_void_p]),
     "aether_sim_charged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_double, C.c_void_p,

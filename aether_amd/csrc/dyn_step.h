@@ -162,15 +162,20 @@ __global__ void __launch_bounds__(256)
 k_dyn_scatter_sample(const int64_t* __restrict__ slot, const float* __restrict__ h1, const float* __restrict__ c1,
                      int64_t n_edges, int R, float* __restrict__ prior_h, float* __restrict__ prior_c,
                      const float* __restrict__ logits, const float* __restrict__ uniform, float tau, int K,
-                     float* __restrict__ edges) {
+                     float* __restrict__ edges, const int* __restrict__ status = nullptr, int n_present = 0) {
     const int r4 = R >> 2;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < n_edges * r4) {
         const int64_t e = t / r4;
         const int o = (int)(t - e * r4);
         const int64_t s = slot[e];
-        st4(prior_h + s * R + 4 * o, ld4(h1 + e * R + 4 * o));
-        st4(prior_c + s * R + 4 * o, ld4(c1 + e * R + 4 * o));
+        f32x4 hv = ld4(h1 + e * R + 4 * o), cv = ld4(c1 + e * R + 4 * o);
+        if (status != nullptr && status[0] != n_present) {       // the mask disagreed with n_present: the stages ran on clamped
+            const float poison = __int_as_float(0x7fc00000);     // index lists -- their rows are garbage: NaN, as the outputs
+            hv = f32x4{poison, poison, poison, poison}; cv = hv;
+        }
+        st4(prior_h + s * R + 4 * o, hv);
+        st4(prior_c + s * R + 4 * o, cv);
     }
     if (t < n_edges) {                         // the arithmetic of k_s2s_gumbel_hard, statement for statement
         const int64_t e = t;

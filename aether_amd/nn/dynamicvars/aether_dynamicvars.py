@@ -350,6 +350,8 @@ class AetherDynamicVars(nn.Module):
             raise ValueError("masks / burn_in_masks must cover every step")
         keep = []                                                  # device tensors the pointer arrays refer to
         n_host = (C.c_int64 * n_steps)()
+        e_host = (C.c_int64 * n_steps)()
+        e2n_max = []                                               # largest edge id of every step's edge2node (one sync below)
         deg = (C.c_int * n_steps)()
         ptrs = {k: (C.c_void_p * n_steps)() for k in ("ni", "gs", "gr", "e2n", "u")}
         for t in range(n_steps):
@@ -367,13 +369,24 @@ class AetherDynamicVars(nn.Module):
                 raise ValueError(f"uniform of step {t} must be [E, K]")
             ni = i64(ni_t)
             keep += [gs, gr, e2n, u, ni]
+            e_host[t] = E
+            e2n_max.append((t, E, e2n.max() if e2n.numel() else None))
             deg[t] = int(e2n.shape[1])
             for k, v in (("ni", ni), ("gs", gs), ("gr", gr), ("e2n", e2n), ("u", u)):
                 ptrs[k][t] = v.data_ptr()
         cfg = self._step_config()
-        need = lib.aether_dyn_rollout_workspace_bytes(C.byref(cfg), Nmax, n_steps, n_host)
+        # edge2node holds edge ids of the step's graph: an id >= E would index past the step's message rows
+        live = [(t, E, mx) for t, E, mx in e2n_max if mx is not None]
+        if live:
+            mxs = torch.stack([mx for _, _, mx in live]).cpu().tolist()
+            for (t, E, _), mx in zip(live, mxs):
+                if mx >= E:
+                    raise ValueError(f"graph_info of step {t}: edge2node names edge {mx}, the graph has {E} edges")
+        need = lib.aether_dyn_rollout_workspace_bytes(C.byref(cfg), Nmax, n_steps, n_host, e_host)
         if need == 0:
-            raise _lib.AetherHipError("aether_dyn_rollout_workspace_bytes: bad sizes (2..8192 object rows, hidden sizes)")
+            raise _lib.AetherHipError("aether_dyn_rollout_workspace_bytes: bad sizes (2..8192 object rows, hidden sizes, or a "
+                                      "step whose graph does not list n * min(knn_k, n - 1) edges, the size of the encoder's "
+                                      "own kNN graph)")
         ws = self.__dict__.get("_step_ws")
         if ws is None or ws.numel() < need or ws.device != dev:
             ws = self.__dict__["_step_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -382,7 +395,7 @@ class AetherDynamicVars(nn.Module):
         preds = torch.empty(n_steps, Nmax, 4, dtype=torch.float32, device=dev)
         fs, ps_e, ps_d = self._field_struct(), self.encoder._param_struct()[0], self.decoder._param_struct()
         st = lib.aether_dyn_rollout(C.byref(fs), C.byref(ps_e), C.byref(ps_d), C.byref(cfg), Nmax, n_steps, x.data_ptr(),
-                                    m.data_ptr(), burn.data_ptr(), n_host, ptrs["ni"], ptrs["gs"], ptrs["gr"], ptrs["e2n"], deg,
+                                    m.data_ptr(), burn.data_ptr(), n_host, e_host, ptrs["ni"], ptrs["gs"], ptrs["gr"], ptrs["e2n"], deg,
                                     ptrs["u"], prior_h.data_ptr(), prior_c.data_ptr(), dec.data_ptr(), preds.data_ptr(),
                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(st, "aether_dyn_rollout")

@@ -755,20 +755,23 @@ int aether_dyn_step(const AetherDynFieldQueryParams* field_params, const AetherD
  * burn_in_masks[t] (:264), then one aether_dyn_step.  Device arrays: inputs [n_steps + 1][n_objects_max][4] (row
  * n_steps is not read), masks, burn_in_masks [n_steps][n_objects_max] (at least), predictions [n_steps][n_objects_max][4];
  * prior_h / prior_c / decoder_hidden as in aether_dyn_step (initial state in, final state out).  HOST arrays of length
- * n_steps: n_present, in_degree, and the per-step device pointers node_inds (or NULL, or NULL entries), graph_send,
- * graph_recv, edge2node, uniform.  Steps without present objects yield zeros and leave the states alone (:841-843); a step
- * with exactly one is refused (the reference fails there too).  No host synchronisation: the whole loop is queued on
- * `stream` (52 launches per step).
+ * n_steps: n_present, n_edges (entries of the step's graph_send / graph_recv / uniform rows; as in aether_dyn_step it has
+ * to equal n_present * min(knn_k, n_present - 1), the size of the encoder's own kNN graph), in_degree, and the per-step
+ * device pointers node_inds (or NULL, or NULL entries), graph_send, graph_recv, edge2node, uniform.  Steps without present
+ * objects yield zeros and leave the states alone (:841-843); a step with exactly one is refused (the reference fails there
+ * too).  EVERY step is validated on the host before the first launch: a refused call has queued nothing and touched no
+ * state.  No host synchronisation: the whole loop is queued on `stream` (52 launches per step).  A mask that disagrees
+ * with n_present poisons that step's outputs AND the LSTM state rows it would have written with NaN (async error word).
  */
 size_t aether_dyn_rollout_workspace_bytes(const AetherDynStepConfig* config, int n_objects_max, int n_steps,
-                                          const int64_t* n_present);
+                                          const int64_t* n_present, const int64_t* n_edges);
 int aether_dyn_rollout(const AetherDynFieldQueryParams* field_params, const AetherDynPriorParams* prior_params,
                        const AetherDynDecoderParams* decoder_params, const AetherDynStepConfig* config, int n_objects_max,
                        int n_steps, const float* inputs, const float* masks, const float* burn_in_masks,
-                       const int64_t* n_present, const int64_t* const* node_inds, const int64_t* const* graph_send,
-                       const int64_t* const* graph_recv, const int64_t* const* edge2node, const int* in_degree,
-                       const float* const* uniform, float* prior_h, float* prior_c, float* decoder_hidden,
-                       float* predictions, void* workspace, size_t workspace_bytes, void* stream);
+                       const int64_t* n_present, const int64_t* n_edges, const int64_t* const* node_inds,
+                       const int64_t* const* graph_send, const int64_t* const* graph_recv, const int64_t* const* edge2node,
+                       const int* in_degree, const float* const* uniform, float* prior_h, float* prior_c,
+                       float* decoder_hidden, float* predictions, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * The rest of the runner's training step (experiments/lorentz/main.py:86,164,289-292): nn.MSELoss with the seed of its

@@ -412,3 +412,21 @@ def test_predict_future_captured_steps_equal_the_eager_loop():
     assert torch.isnan(out).all()
     assert _lib.load().aether_check_async_error() != 0
     assert _lib.load().aether_check_async_error() == 0
+    # the one-call loop validates every step's graph BEFORE anything is queued -- a graph that lists another number
+    # of edges than the encoder's kNN graph (n * min(k, n - 1); here a fully connected one on 24 objects), or an edge2node
+    # that names an edge the graph does not have, raises instead of reading the first n * 10 edges / past the message rows
+    nv = 24
+    fc_s, fc_r = torch.where(~torch.eye(nv, dtype=torch.bool))
+    wrong = list(graph_info)
+    wrong[1] = (node_inds[1][fc_s.cuda()], node_inds[1][fc_r.cuda()], torch.argsort(fc_r, stable=True).view(nv, nv - 1).cuda())
+    with pytest.raises(_lib.AetherHipError, match="kNN graph"):
+        model.predict_future(inputs[:, :3].cuda(), masks[:, :3].cuda(), [node_inds], [wrong], burn[:, :3].cuda())
+    wrong = list(graph_info)
+    e2n_bad = graph_info[1][2].clone()
+    e2n_bad[3, 2] = graph_info[1][0].numel() + 5
+    wrong[1] = (graph_info[1][0], graph_info[1][1], e2n_bad)
+    with pytest.raises(ValueError, match="edge2node"):
+        model.predict_future(inputs[:, :3].cuda(), masks[:, :3].cuda(), [node_inds], [wrong], burn[:, :3].cuda())
+    good = model.predict_future(inputs[:, :3].cuda(), masks[:, :3].cuda(), [node_inds], [graph_info], burn[:, :3].cuda(),
+                                uniform=U[:2])
+    assert torch.equal(good, rollout[:, :2])                    # the refused calls queued nothing and touched no state

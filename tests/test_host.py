@@ -213,6 +213,11 @@ def test_host_side_size_functions_of_the_round_3_entries():
     bad = _DynStepConfig(256, 200, 64, 3, 128, 4, 256, 1, 0, 0, 10, 0.5)                # encoder hidden not a multiple of 128
     assert lib.aether_dyn_step_workspace_bytes(C.byref(bad), 40, 24, 240) == 0
     counts = (C.c_int64 * 4)(24, 0, 3, 40)
-    roll = lib.aether_dyn_rollout_workspace_bytes(C.byref(cfg), 40, 4, counts)
+    edges = (C.c_int64 * 4)(240, 0, 6, 400)
+    roll = lib.aether_dyn_rollout_workspace_bytes(C.byref(cfg), 40, 4, counts, edges)
     assert roll >= lib.aether_dyn_step_workspace_bytes(C.byref(cfg), 40, 40, 400)
     assert roll >= need
+    # a step whose graph has another edge count than the encoder's kNN graph (n * min(k, n - 1)) is refused up front
+    # (the rollout used to derive E itself and read only the first n * 10 edges of a longer graph)
+    edges_bad = (C.c_int64 * 4)(240, 0, 6, 40 * 39)
+    assert lib.aether_dyn_rollout_workspace_bytes(C.byref(cfg), 40, 4, counts, edges_bad) == 0
