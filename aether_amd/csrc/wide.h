@@ -25,7 +25,11 @@ constexpr int WG_BM = 128;                    // rows of A (items) per workgroup
 constexpr int WG_BN = 128;                    // rows of B (output features) per workgroup
 constexpr int WG_IMG = 3 * 8 * 64 * 4;        // floats of one split tile image: 3 terms x 8 row blocks x 64 lanes x 16 B
 constexpr int WG_STAGE = 2 * WG_IMG;          // A image | B image
-constexpr size_t WG_LDS_BYTES = (size_t)2 * WG_STAGE * 4;      // double buffered: 96 KB
+// ONE stage in LDS (48 KB), the next k block waits in registers: two workgroups per CU (two waves per SIMD at <= 256
+// registers) instead of one -- with a double-buffered stage (96 KB) a workgroup had the CU to itself and, at K = 128 ..
+// 256 (4 - 8 k blocks), spent most of its time in its own load latencies: 24 us per launch at [48,640 x 128] . [128 x 128]
+// (profiles/r04_wide_*), i.e. 66 TFLOP/s fp32-equivalent.
+constexpr size_t WG_LDS_BYTES = (size_t)WG_STAGE * 4;
 
 struct WGemmArgs {
     const float* A; const float* B;           // [M][lda], [N][ldb]; K columns each, K % 32 == 0, rows 16-byte aligned
@@ -46,7 +50,7 @@ __device__ __forceinline__ f32x4 wide_dsilu4(f32x4 z) {
     return dsilu_from_sigmoid(z, s);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_wgemm(const WGemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,7 +88,7 @@ k_wgemm(const WGemmArgs G) {
     stage(smem);
     lds_barrier();
     for (int kb = 0; kb < nkb; ++kb) {
-        const float* buf = smem + (kb & 1) * WG_STAGE;
+        const float* buf = smem;
         if (kb + 1 < nkb) fetch(kb + 1);                           // in flight under this block's MFMAs
         const bf16x8* xa = reinterpret_cast<const bf16x8*>(buf);
         const bf16x8* wb = reinterpret_cast<const bf16x8*>(buf + WG_IMG);
@@ -112,8 +116,11 @@ k_wgemm(const WGemmArgs G) {
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[ib], acc[fb][ib], 0, 0, 0);
         }
-        if (kb + 1 < nkb) stage(smem + ((kb + 1) & 1) * WG_STAGE);
-        lds_barrier();
+        if (kb + 1 < nkb) {
+            lds_barrier();                                         // every wave has its fragments of this block
+            stage(smem);
+            lds_barrier();
+        }
     }
     // ---- epilogue: acc[fb][ib][r] = C[item 16 (4 wi + ib) + i][feature 16 (4 wf + fb) + 4 q + r]
     const bool use_mask = G.mask != nullptr && (G.maskword == nullptr || *G.maskword != 0);

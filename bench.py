@@ -199,6 +199,132 @@ def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0, sd_trained=None)
     }
 
 
+def _other_configs(dev, budget_s=10.0):
+    """what the driver's one run says about the configurations that are not the headline -- cfg3 forward,
+    hidden_size 128 / 256 at the headline shape (csrc/wide.h), one GPU's share of cfg5 forward (3 steps), the variable-N
+    prediction step (cfg4's model).  Rank 0, after the headline's timed region; bounded: a leg starts only while the block
+    is inside its budget, every leg is guarded (an error is recorded, the headline line is printed regardless)."""
+    import contextlib
+    import io
+    from aether_amd import _lib
+    from aether_amd.nn.state2state.aether import Aether
+    from aether_amd.synthetic import make_batch
+    t_block = time.perf_counter()
+    out = []
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+
+    def timed(fn, n, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    def leg(name, fn):
+        if time.perf_counter() - t_block > budget_s:
+            out.append({"workload": name, "skipped": "block budget spent"})
+            return
+        t0 = time.perf_counter()
+        try:
+            with torch.no_grad():
+                rec = fn()
+            rec = dict({"workload": name}, **rec)
+            _lib.check(_lib.load().aether_check_async_error(), name)
+        except Exception as ex:                                  # recorded; never at the cost of the headline line
+            print(f"other_configs leg {name} failed:", repr(ex), file=sys.stderr)
+            rec = {"workload": name, "error": repr(ex)}
+        rec["leg_seconds"] = round(time.perf_counter() - t0, 2)
+        out.append(rec)
+        torch.cuda.empty_cache()
+
+    def state2state(D, B, N, H, steps, graph):
+        torch.manual_seed(1)
+        with quiet():
+            m = Aether(2 * D, H, 0.0, D, device=dev).eval()
+        inp = make_batch(B, N, D, seed=0, device=dev)
+        E = inp["edges"][0].numel()
+        call = lambda: m(inp["h"], inp["x"], inp["edges"], inp["vel"], inp["edge_attr"], inp["charges"])
+        call()
+        torch.cuda.synchronize()
+        launch = "eager"
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(10):
+                    call()
+            ms = timed(g.replay, max(1, steps // 10)) / 10
+            launch = "hipgraph (10 steps per replay)"
+        else:
+            ms = timed(call, steps)
+        flops = E * (FLOP_PER_EDGE_STEP[D] if H == 64 else 2 * (32 * H + H * H) + 6 * (3 * H * H + H * H))
+        return {"ms_per_step": ms, "value": 4.0 * E / (ms * 1e-3), "unit": "edge-messages/s", "hidden": H, "edges": E,
+                "launch": launch, "edge_mlp_algorithmic_tflops": flops / (ms * 1e-3) / 1e12}
+
+    leg("cfg3 gravitational-3d-N20-B128 forward", lambda: state2state(3, 128, 20, 64, 200, True))
+    leg("electrostatic-2d-N20-B128 forward, hidden_size 128 (csrc/wide.h)", lambda: state2state(2, 128, 20, 128, 30, False))
+    leg("electrostatic-2d-N20-B128 forward, hidden_size 256 (csrc/wide.h)", lambda: state2state(2, 128, 20, 256, 20, False))
+
+    def dyn_step():
+        from aether_amd.knn import get_knn_graph_info
+        from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+        mp = {"input_size": 4, "gpu": True, "decoder_hidden": 256, "num_edge_types": 4, "skip_first": True, "decoder_dropout": 0.0,
+              "pos_representation": "cart", "no_encoder_bn": False, "encoder_dropout": 0.0, "encoder_hidden": 256,
+              "encoder_rnn_hidden": 64, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 128,
+              "prior_num_layers": 3, "prior_hidden_size": 128, "encoder_normalize_mode": "normalize_all", "train_data_len": 50,
+              "field_hidden": 256, "gumbel_temp": 0.5}               # scripts/ind_aether.sh sizes
+        torch.manual_seed(1)
+        with quiet():
+            model = AetherDynamicVars(mp, device=dev).eval()
+        N, T = 20, 26
+        g = torch.Generator().manual_seed(N)
+        inputs = torch.randn(1, T, N, 4, generator=g).to(dev)
+        masks = torch.ones(1, T, N, device=dev)
+        burn = torch.ones(1, T, N, device=dev)
+        burn[:, 10:] = 0
+        node_inds, graph_info = [[]], [[]]
+        for t in range(T):
+            send, recv = get_knn_graph_info(inputs[0, t], masks[0, t], N)
+            graph_info[0].append((send, recv, torch.argsort(recv, stable=True).view(-1, 10)))
+            node_inds[0].append(torch.arange(N, device=dev))
+        fn = lambda: model.predict_future(inputs, masks, node_inds, graph_info, burn)
+        ms = timed(fn, 3, warm=1) / (T - 1)
+        return {"ms_per_step": ms, "value": 1e3 / ms, "unit": "prediction steps/s (one scene)", "objects": N, "edges": 10 * N,
+                "launch": "aether_dyn_rollout (one library call for the loop)"}
+
+    leg("inD-sized variable-N prediction step, 20 objects, kNN k=10 (cfg4's model, one scene)", dyn_step)
+
+    def cfg5_shard():
+        # one GPU's share of BASELINE config 5 (32 graphs of 1,024 bodies, 33.5 M edges), inputs drawn on the device
+        from aether_amd.edges import get_edges, prepare_edge_attr
+        B, N, D = 32, 1024, 2
+        torch.manual_seed(1)
+        with quiet():
+            m = Aether(2 * D, 64, 0.0, D, device=dev).eval()
+        gen = torch.Generator(device=dev).manual_seed(5)
+        x = torch.randn(B * N, D, generator=gen, device=dev) * (N / 5.0) ** (1.0 / 3.0)
+        v = torch.randn(B * N, D, generator=gen, device=dev)
+        v = v * 0.5 / v.norm(dim=-1, keepdim=True)
+        q = torch.randint(0, 2, (B * N, 1), generator=gen, device=dev).float() * 2.0 - 1.0
+        edges = get_edges(B, N, device=dev)
+        ea = prepare_edge_attr(x, edges, q[edges[0]] * q[edges[1]])
+        E = edges[0].numel()
+        call = lambda: m(None, x, edges, v, ea, q)
+        ms = timed(call, 3, warm=1)
+        return {"ms_per_step": ms, "value": 4.0 * E / (ms * 1e-3), "unit": "edge-messages/s", "edges": E, "launch": "eager",
+                "hbm_frac_of_8TBps_at_1560B_per_edge_step": 1560.0 * E / (ms * 1e-3) / 8e12}
+
+    leg("cfg5 shard synthetic-2d-N1024-B32 forward (33.5 M edges, streamed path)", cfg5_shard)
+    return {"budget_s": budget_s, "block_seconds": round(time.perf_counter() - t_block, 2), "legs": out}
+
+
 def _seq2seq_traffic(workload):
     """HBM bytes per launch of the filter GEMM from the committed PMC passes (profiles/traffic.json), or None."""
     try:
@@ -349,6 +475,8 @@ def main():
                     help="testing only: all ranks use cuda:0 (with --backend gloo) to rehearse the N > 1 path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step (fwd+bwd+opt) figure")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the bounded block of non-headline configurations (cfg3, wide hidden, cfg5 shard, variable-N step)")
     ap.add_argument("--streamed", action="store_true", help="force the layer-by-layer kernels")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to aether_set_option")
     ap.add_argument("--dims", type=int, default=WORKLOAD["D"], help="2 (headline) or 3 (cfg3)")
@@ -685,6 +813,7 @@ def main():
 
     # ---- training step: forward + HIP backward + gradient all-reduce (N > 1) + AdamW ----------------
     train = None
+    train_failed_here = 0
     if not args.no_train and args.chunks == 1:        # (config 5 on fewer than 8 ranks: forward figure only)
         # The whole leg runs inside a function: whatever goes wrong in it (a collective that fails on every rank, a capture
         # that is refused) must not cost the run its headline line -- the forward figure above is already measured.
@@ -793,6 +922,7 @@ def main():
         except Exception as ex:
             print("training leg failed:", repr(ex), file=sys.stderr)
             train = {"error": repr(ex)}
+            train_failed_here = 1
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
@@ -849,6 +979,9 @@ def main():
             "step_algorithmic_tflops": step_flops * world / (dt / args.steps) / 1e12,
             "roofline": roof, "roofline_other": other, "kernels": kernels, "rollout": roll, "train": train, "ranks_seen": ranks_seen,
         }
+        if world == 1 and (B, N, D) == (128, 20, 2) and not args.no_other_configs and not args.streamed:
+            del out                                    # the headline's buffers are no longer needed
+            line["other_configs"] = _other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             sd_tr = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if train is not None else None
             line["cpu_baseline"] = _cpu_baseline(sd0, host, model, dev, sd_trained=sd_tr)
@@ -856,8 +989,20 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+    # a leg that failed is in the line as {"error": ...}; the run still says so with its exit code -- after the
+    # headline line is out.  With N > 1 every rank learns of a failure anywhere before leaving (nobody waits in a
+    # collective for a rank that raised).
+    failed = 0
+    if rank == 0:
+        legs = [roll, train] + (line.get("other_configs") or {}).get("legs", [])
+        failed = int(any(isinstance(x, dict) and "error" in x for x in legs))
     if world > 1:
+        f = torch.tensor([float(failed or train_failed_here)], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        failed = int(f.item() > 0)
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
