@@ -155,6 +155,13 @@ SIGNATURES = {
     "aether_dyn_rollout_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aether_dyn_rollout": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 15 + [C.c_void_p, C.c_size_t,
                                                                                                C.c_void_p]),
+    "aether_dyn_step_batched_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aether_dyn_step_batched": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 12 +
+                                [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aether_dyn_rollout_batched_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                               C.c_void_p]),
+    "aether_dyn_rollout_batched": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 +
+                                   [C.c_void_p] * 3 + [C.c_void_p] * 5 + [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "aether_sim_charged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_double, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),

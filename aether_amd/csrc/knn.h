@@ -20,8 +20,10 @@ constexpr int KNN_MAX_OBJECTS = 8192;          // positions + masks + compact in
 // part: LDS scratch of blockDim.x ints.  Per-thread chunk sums, an inclusive scan across each wave's lanes (shuffles), the
 // (at most 16) wave totals added by every thread: no serial pass of one thread over blockDim.x LDS words (that pass alone
 // took 5-7 us per call, four calls per variable-N prediction step).
-__device__ inline int block_exclusive_scan(int* val, int n, int* part) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ inline int block_exclusive_scan(int* val, int n, int* part, const int nt_fixed = 0 /* the workgroup's thread
+        count when the caller knows it: blockDim.x is an implicit (hidden) kernel argument, which by-value-struct kernels of
+        captured steps must not consume (tools/isa_check.py rule R4) */) {
+    const int tid = threadIdx.x, nt = nt_fixed > 0 ? nt_fixed : (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, n_waves = (nt + 63) >> 6;
     const int chunk = (n + nt - 1) / nt;
     const int beg = min(tid * chunk, n), end = min(beg + chunk, n);

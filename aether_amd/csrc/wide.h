@@ -160,10 +160,11 @@ constexpr int WPREP_MAX_TASKS = 32;
 struct WPrepBatch { WPrepTask t[WPREP_MAX_TASKS]; int n_tasks; };
 
 __global__ void __launch_bounds__(256)
-k_wide_prep(const WPrepBatch batch) {
+k_wide_prep(const WPrepBatch batch, const int n_blocks_x /* = gridDim.x, explicit: a by-value struct kernel that may sit in a
+            captured training step consumes no hidden kernel arguments (tools/isa_check.py rule R4) */) {
     const WPrepTask T = batch.t[blockIdx.y];
     const int total = T.dst_rows * T.dst_ld;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += n_blocks_x * 256) {
         const int a = idx / T.dst_ld, b = idx - a * T.dst_ld;
         const int r = T.transpose ? b : a, c = T.transpose ? a : b;
         T.dst[idx] = (r < T.rows && c < T.cols) ? T.src[(size_t)r * T.src_ld + T.col0 + c] : 0.0f;

@@ -403,9 +403,97 @@ class AetherDynamicVars(nn.Module):
         return preds.unsqueeze(0)
 
     @torch.no_grad()
+    def _predict_future_rollout_batched(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
+        """``predict_future`` of B scenes as ONE library call (``aether_dyn_rollout_batched``): per step the burn-in mix and
+        ``aether_dyn_step_batched`` over the present objects of all scenes, queued without a host round trip.  The
+        per-scene index arrays of a step are concatenated in scene order (scene-local numbering, as the single-scene call
+        takes them); the time axis comes first in what the library sees."""
+        if not inputs.is_cuda:
+            raise _lib.AetherHipError("aether_amd AetherDynamicVars runs on an MI355X only; got a CPU tensor "
+                                      "(there is no CPU fallback)")
+        if self.encoder.training:
+            raise _lib.AetherHipError("the prior step uses BatchNorm running statistics: call .eval() first")
+        lib = _lib.load()
+        dev = inputs.device
+        B, T, Nmax = int(inputs.size(0)), int(inputs.size(1)), int(inputs.size(2))
+        n_steps, K = T - 1, self.num_edge_types
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        i64 = lambda t: t.to(device=dev, dtype=torch.int64)
+        x = f32(inputs).transpose(0, 1).contiguous()                                   # [T][B][Nmax][4]
+        m = f32(masks)[:, :n_steps].transpose(0, 1).contiguous()                       # [n_steps][B][Nmax]
+        burn = f32(burn_in_masks)[:, :n_steps].transpose(0, 1).contiguous()
+        if m.shape[0] < n_steps or burn.shape[0] < n_steps:
+            raise ValueError("masks / burn_in_masks must cover every step")
+        n_host = (C.c_int64 * (n_steps * B))()
+        e_host = (C.c_int64 * (n_steps * B))()
+        deg = (C.c_int * (n_steps * B))()
+        ptrs = {k: (C.c_void_p * n_steps)() for k in ("ni", "gs", "gr", "e2n", "u")}
+        keep, e2n_max = [], []
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        for t in range(n_steps):
+            ni_l, gs_l, gr_l, e2n_l, u_l, bounds = [], [], [], [], [], []
+            for b in range(B):
+                n_b = int(node_inds[b][t].numel())
+                n_host[t * B + b] = n_b
+                if n_b < 2:
+                    continue                                   # empty scene (0); a single object is refused by the library
+                gs, gr, e2n = (i64(g) for g in graph_info[b][t])
+                E = int(gs.numel())
+                if gr.numel() != E or e2n.ndim != 2 or e2n.shape[0] != n_b:
+                    raise ValueError(f"graph_info of scene {b}, step {t} does not match its present objects")
+                e_host[t * B + b] = E
+                deg[t * B + b] = int(e2n.shape[1])
+                bounds.append((E, int(e2n.numel())))
+                if uniform is not None:
+                    u = f32(uniform[t][b]).reshape(-1, K)
+                    if u.shape[0] != E:
+                        raise ValueError(f"uniform of scene {b}, step {t} must be [E, K]")
+                    u_l.append(u)
+                ni_l.append(i64(node_inds[b][t])); gs_l.append(gs); gr_l.append(gr); e2n_l.append(e2n.reshape(-1))
+            cat = lambda l: torch.cat(l).contiguous() if l else empty
+            E_t = sum(int(g.numel()) for g in gs_l)
+            u_t = torch.cat(u_l).contiguous() if uniform is not None and u_l else torch.rand(max(E_t, 1), K, device=dev)
+            step = dict(ni=cat(ni_l), gs=cat(gs_l), gr=cat(gr_l), e2n=cat(e2n_l), u=u_t)
+            keep.append(step)
+            if step["e2n"].numel():        # edge2node names edges of its own scene's graph: one comparison per step
+                bound = torch.repeat_interleave(torch.tensor([e for e, _ in bounds], device=dev),
+                                                torch.tensor([c for _, c in bounds], device=dev), output_size=step["e2n"].numel())
+                e2n_max.append((t, ((step["e2n"] >= bound) | (step["e2n"] < 0)).any()))
+            for k in ptrs:
+                ptrs[k][t] = step[k].data_ptr()
+        if e2n_max:                                                # (one device round trip for all steps)
+            flags = torch.stack([f for _, f in e2n_max]).cpu().tolist()
+            for (t, _), bad in zip(e2n_max, flags):
+                if bad:
+                    raise ValueError(f"graph_info of step {t}: an edge2node entry names an edge its scene's graph does not have")
+        cfg = self._step_config()
+        need = lib.aether_dyn_rollout_batched_workspace_bytes(C.byref(cfg), B, Nmax, n_steps, n_host, e_host, deg)
+        if need == 0:
+            raise _lib.AetherHipError("aether_dyn_rollout_batched_workspace_bytes failed: " + lib.aether_last_error().decode())
+        ws = self.__dict__.get("_step_ws")
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self.__dict__["_step_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        prior_h, prior_c = (f32(s)[0].clone() for s in self.encoder.get_initial_hidden(inputs))
+        dec = f32(self.decoder.get_initial_hidden(inputs)).clone()                       # [B][Nmax][hd]
+        preds = torch.empty(n_steps, B, Nmax, 4, dtype=torch.float32, device=dev)
+        fs, ps_e, ps_d = self._field_struct(), self.encoder._param_struct()[0], self.decoder._param_struct()
+        st = lib.aether_dyn_rollout_batched(C.byref(fs), C.byref(ps_e), C.byref(ps_d), C.byref(cfg), B, Nmax, n_steps,
+                                            x.data_ptr(), m.data_ptr(), burn.data_ptr(), n_host, e_host, deg, ptrs["ni"],
+                                            ptrs["gs"], ptrs["gr"], ptrs["e2n"], ptrs["u"], prior_h.data_ptr(),
+                                            prior_c.data_ptr(), dec.data_ptr(), preds.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "aether_dyn_rollout_batched")
+        del keep
+        return preds.transpose(0, 1).contiguous()
+
+    @torch.no_grad()
     def predict_future_batched(self, inputs, masks, node_inds, graph_info, burn_in_masks, uniform=None):
         """``predict_future`` for B scenes at once: per time step one field query, one kNN + prior step, one sampling pass
-        and one decoder step over the present objects of ALL scenes (BASELINE config 4: 64 scenes)."""
+        and one decoder step over the present objects of ALL scenes (BASELINE config 4: 64 scenes).  Default: the whole
+        loop is ONE library call (``aether_dyn_rollout_batched``, up to 256 scenes); ``one_call_step = False`` keeps the
+        staged calls with torch glue of round 2 (same stage kernels: bit-identical)."""
+        if self.one_call_step and inputs.size(1) > 1 and inputs.size(0) <= 256:
+            return self._predict_future_rollout_batched(inputs, masks, node_inds, graph_info, burn_in_masks, uniform)
         B, n_steps = inputs.size(0), inputs.size(1) - 1
         prior_state = self.encoder.get_initial_hidden(inputs)
         dec_state = self.decoder.get_initial_hidden(inputs)

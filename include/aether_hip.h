@@ -774,6 +774,39 @@ int aether_dyn_rollout(const AetherDynFieldQueryParams* field_params, const Aeth
                        float* decoder_hidden, float* predictions, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same step and loop for B scenes per call (round 4; BASELINE config 4 is batch = 64; the reference's models raise on
+ * batch > 1, aether_dynamicvars.py:588-591).  The present objects of all scenes are numbered consecutively, scene-major;
+ * every stage runs once over all of them (same stage kernels as the single-scene call).  HOST arrays of length n_scenes:
+ * n_present (0, or 2 .. n_objects_max per scene), n_edges (= n_present * min(knn_k, n_present - 1) per scene), in_degree
+ * (1 .. 255).  Device arrays: state [B][n_max][4], mask [B][n_max], decoder_hidden [B][n_max][hd], prediction [B][n_max][4],
+ * prior_h / prior_c [B * n_max (n_max - 1)][R] (scene b's slots from b * n_max (n_max - 1) on); node_inds (or NULL),
+ * graph_send, graph_recv, edge2node, uniform: the scenes' arrays CONCATENATED in scene order, indices scene-local exactly
+ * as the single-scene call takes them.  n_scenes <= 256.  A scene whose mask disagrees with its n_present poisons the
+ * step's outputs with NaN (async error word).  aether_dyn_rollout_batched: every per-step tensor TIME-MAJOR -- inputs
+ * [n_steps + 1][B][n_max][4], masks / burn_in_masks [n_steps][B][n_max], predictions [n_steps][B][n_max][4], host size arrays
+ * [n_steps][B], per-step device pointers as in aether_dyn_rollout; everything is validated before the first launch.
+ */
+size_t aether_dyn_step_batched_workspace_bytes(const AetherDynStepConfig* config, int n_scenes, int n_objects_max,
+                                               const int64_t* n_present, const int64_t* n_edges, const int* in_degree);
+int aether_dyn_step_batched(const AetherDynFieldQueryParams* field_params, const AetherDynPriorParams* prior_params,
+                            const AetherDynDecoderParams* decoder_params, const AetherDynStepConfig* config, int n_scenes,
+                            int n_objects_max, const int64_t* n_present, const int64_t* n_edges, const int* in_degree,
+                            const float* state, const float* mask, const int64_t* node_inds, const int64_t* graph_send,
+                            const int64_t* graph_recv, const int64_t* edge2node, float* prior_h, float* prior_c,
+                            float* decoder_hidden, const float* uniform, float* prediction, float* edge_types,
+                            void* workspace, size_t workspace_bytes, void* stream);
+size_t aether_dyn_rollout_batched_workspace_bytes(const AetherDynStepConfig* config, int n_scenes, int n_objects_max, int n_steps,
+                                                  const int64_t* n_present, const int64_t* n_edges, const int* in_degree);
+int aether_dyn_rollout_batched(const AetherDynFieldQueryParams* field_params, const AetherDynPriorParams* prior_params,
+                               const AetherDynDecoderParams* decoder_params, const AetherDynStepConfig* config, int n_scenes,
+                               int n_objects_max, int n_steps, const float* inputs, const float* masks,
+                               const float* burn_in_masks, const int64_t* n_present, const int64_t* n_edges,
+                               const int* in_degree, const int64_t* const* node_inds, const int64_t* const* graph_send,
+                               const int64_t* const* graph_recv, const int64_t* const* edge2node, const float* const* uniform,
+                               float* prior_h, float* prior_c, float* decoder_hidden, float* predictions, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+/*
  * The rest of the runner's training step (experiments/lorentz/main.py:86,164,289-292): nn.MSELoss with the seed of its
  * backward, and optim.AdamW over every parameter tensor -- one launch each (torch: 4 + 3).
  *

@@ -241,6 +241,78 @@ def test_predict_future_batched_scenes_vs_oracle_per_scene():
                                uniform=[[cu(u) for u in U[t]] for t in range(T - 1)])
     assert got.shape == want.shape
     assert scale_rel_err(got.cpu(), want) <= 2 * TOL
+    # round 4: `got` came from ONE library call for the whole loop (aether_dyn_rollout_batched).  The staged path of round 2
+    # (three library calls + torch glue per step) runs the same stage kernels on the same concatenated rows: identical bits;
+    # scene by scene through the single-scene call the stages see other sizes (other k-splits of the filter GEMM): tolerance
+    gi_c = [[tuple(cu(x) for x in gi) for gi in gi_b] for gi_b in graph_info]
+    ni_c = [[cu(n) for n in ni_b] for ni_b in node_inds]
+    u_c = [[cu(u) for u in U[t]] for t in range(T - 1)]
+    model.one_call_step = False
+    try:
+        staged = model.predict_future(inputs.cuda(), masks.cuda(), ni_c, gi_c, burn.cuda(), uniform=u_c)
+    finally:
+        model.one_call_step = True
+    assert torch.equal(got, staged)
+    again = model.predict_future(inputs.cuda(), masks.cuda(), ni_c, gi_c, burn.cuda(), uniform=u_c)
+    assert torch.equal(got, again)
+    for b in (0, 4):
+        one = model.predict_future(inputs[b:b + 1].cuda(), masks[b:b + 1].cuda(), [ni_c[b]], [gi_c[b]], burn[b:b + 1].cuda(),
+                                   uniform=[u_c[t][b] for t in range(T - 1)])
+        assert scale_rel_err(got[b:b + 1].cpu(), one.cpu()) <= 2 * TOL, b
+    # a scene with a single present object is refused before anything is queued, as the single-scene call refuses it
+    bad_ni = [list(n) for n in ni_c]
+    bad_ni[1][0] = ni_c[1][0][:1]
+    with pytest.raises(_lib.AetherHipError, match="one present object"):
+        model.predict_future(inputs.cuda(), masks.cuda(), bad_ni, gi_c, burn.cuda(), uniform=u_c)
+
+
+def test_predict_future_64_scenes_one_call():
+    """BASELINE config 4's batch: 64 inD-sized scenes (up to 40 objects, kNN k = 10) through ONE library call for the loop;
+    equal to the staged batched path bit for bit, every scene within tolerance of its own single-scene call."""
+    from aether_amd.nn.dynamicvars.aether_dynamicvars import AetherDynamicVars
+    import sys, os
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_golden_dynamicvars import MODEL_PARAMS, perturb_bn_
+    params = dict(MODEL_PARAMS, decoder_hidden=256, encoder_hidden=256, num_edge_types=4, pos_representation="cart",
+                  field_hidden=128, encoder_rnn_hidden=64)
+    torch.manual_seed(41)
+    model = AetherDynamicVars(params, device=None).eval()
+    perturb_bn_(model)
+    model = model.cuda()
+    g = torch.Generator().manual_seed(42)
+    B, T, N = 64, 4, 40
+    inputs = torch.randn(B, T, N, 4, generator=g).cuda()
+    masks = torch.zeros(B, T, N)
+    for b in range(B):
+        c = int(torch.randint(2, N + 1, (1,), generator=g))
+        masks[b, :, torch.randperm(N, generator=g)[:c]] = 1
+    masks = masks.cuda()
+    burn = torch.ones(B, T, N).cuda()
+    burn[:, 2:] = 0
+    node_inds, graph_info, U = [], [], [[None] * B for _ in range(T - 1)]
+    for b in range(B):
+        ni_b, gi_b = [], []
+        for step in range(T):
+            nv = int(masks[b, step].sum())
+            send, recv = get_knn_graph_info(inputs[b, step], masks[b, step], nv)
+            gi_b.append((send, recv, torch.argsort(recv, stable=True).view(-1, min(10, nv - 1))))
+            ni_b.append(masks[b, step].nonzero()[:, -1])
+            if step < T - 1:
+                U[step][b] = torch.rand(send.numel(), 4, generator=g).cuda()
+        node_inds.append(ni_b); graph_info.append(gi_b)
+    got = model.predict_future(inputs, masks, node_inds, graph_info, burn, uniform=U)
+    assert got.shape == (B, T - 1, N, 4) and torch.isfinite(got).all()
+    model.one_call_step = False
+    try:
+        staged = model.predict_future(inputs, masks, node_inds, graph_info, burn, uniform=U)
+    finally:
+        model.one_call_step = True
+    assert torch.equal(got, staged)
+    for b in (0, 17, 63):
+        one = model.predict_future(inputs[b:b + 1], masks[b:b + 1], [node_inds[b]], [graph_info[b]], burn[b:b + 1],
+                                   uniform=[U[t][b] for t in range(T - 1)])
+        assert scale_rel_err(got[b:b + 1].cpu(), one.cpu()) <= 2 * TOL, b
 
 
 def test_decoder_and_encoder_two_objects():

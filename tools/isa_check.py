@@ -80,7 +80,7 @@ def kernel_notes(path: str):
     return out
 
 
-R4_KERNELS = ("k_s2s_filter_split_types", "k_s2s_filter_bimg_types", "k_dyn_filter_combine")
+R4_KERNELS = ("k_s2s_filter_split_types", "k_s2s_filter_bimg_types", "k_dyn_filter_combine", "k_dynb_", "k_wgemm", "k_wide_prep")
 
 
 def check_hidden_args(path: str):
