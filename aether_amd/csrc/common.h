@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 #include "../../include/aether_hip.h"
 
 namespace {
@@ -176,6 +177,78 @@ __device__ __forceinline__ void gemm_split(const float* __restrict__ img, const 
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[mb], 0, 0, 0);
         }
     }
+}
+
+// The TRANSPOSED product from the same split image (round 4): acc[ob] += W^T[16 ob + i'][m] * act[item][m], i.e.
+// out[k] = sum_m W[m][k] act[m] for the backward's W2^T dpre2 / W_e^T G, without a second (transposed) copy of the weights.
+// `img` is the image gemm_split reads (MBN = 4 row blocks of W, KBN k blocks); the contraction now runs over W's ROWS, 32 per
+// block (act = 4 accumulator-layout blocks), the outputs are W's columns, OB = 2 KBN blocks of 16.
+// The A fragment a lane needs -- 8 values of ONE column from 8 different rows -- lies in 8 different fragments of the image:
+// ds_read_b64_tr_b16 gathers it.  Per group of 16 lanes (lanes 16 g .. 16 g + 15; g = this lane's q, which selects rows
+// 4 g .. 4 g + 3 of a 16-row block) the instruction reads 4 rows x 16 columns of bf16 and returns them column-major: lane
+// 4 r + p of the group supplies the address of row r, columns 4 p .. 4 p + 3 (8 bytes: one half-fragment of the image,
+// lane slot (4 g + r) + 16 p, half = ob & 1); lane c receives column c of the four rows.  Two reads (row blocks 2 mp and
+// 2 mp + 1) make the 8-element fragment in gemm_split's k order.  Addresses of the four p lanes are 256 bytes apart: a
+// 4-way bank conflict per read (16 instead of 4 LDS cycles) -- 48 reads per 64 x 64 product, ~770 LDS cycles per tile,
+// against 1,300 cycles of vector-ALU time the fp32 MFMA form of the same product holds (64 x v_mfma_f32_16x16x4_f32).
+// EXEC must be all ones (the gather crosses lanes).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// the six transposed reads of block BLK = (mp, ob): rows 32 mp .. of W (two 16-row blocks), columns 16 ob .. of W
+template <int KBN, int BLK>
+__device__ __forceinline__ void split_T_issue(unsigned base, u32x2 (&lo)[3], u32x2 (&hi)[3]) {
+    constexpr int TERM_BYTES = 4 * KBN * 64 * 16, OB = 2 * KBN, mp = BLK / OB, ob = BLK % OB;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        // fragment (mb, kb) of term t starts at ((mb KBN + kb) 64) 16 bytes; kb = ob >> 1, half = ob & 1
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=v"(lo[t]), "=v"(hi[t])
+                     : "v"(base), "n"(t * TERM_BYTES + (((2 * mp) * KBN + (ob >> 1)) * 64) * 16 + (ob & 1) * 8),
+                       "n"(t * TERM_BYTES + (((2 * mp + 1) * KBN + (ob >> 1)) * 64) * 16 + (ob & 1) * 8)
+                     : "memory");
+}
+template <bool LAST>
+__device__ __forceinline__ void split_T_consume(u32x2 (&lo)[3], u32x2 (&hi)[3], const bf16x8 xh, const bf16x8 xm, const bf16x8 xl,
+                                                f32x4& acc) {
+    // LDS returns in order: lgkmcnt(6) leaves exactly the next block's six reads outstanding
+    if constexpr (LAST)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]));
+    bf16x8 w[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const u32x4 v = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+        w[t] = __builtin_bit_cast(bf16x8, v);
+    }
+    const bf16x8 wh = w[0], wm = w[1], wl = w[2];
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);
+}
+template <int KBN, int BLK>
+__device__ __forceinline__ void split_T_step(unsigned base, u32x2 (&lo)[2][3], u32x2 (&hi)[2][3], const bf16x8 (&xh)[2],
+                                             const bf16x8 (&xm)[2], const bf16x8 (&xl)[2], f32x4 (&acc)[2 * KBN]) {
+    constexpr int OB = 2 * KBN, NBLK = 2 * OB, mp = BLK / OB, ob = BLK % OB;
+    if constexpr (BLK + 1 < NBLK) split_T_issue<KBN, BLK + 1>(base, lo[(BLK + 1) & 1], hi[(BLK + 1) & 1]);
+    split_T_consume<BLK + 1 == NBLK>(lo[BLK & 1], hi[BLK & 1], xh[mp], xm[mp], xl[mp], acc[ob]);
+    if constexpr (BLK + 1 < NBLK) split_T_step<KBN, BLK + 1>(base, lo, hi, xh, xm, xl, acc);
+}
+template <int KBN>
+__device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, const f32x4 (&act)[4], f32x4 (&acc)[2 * KBN],
+                                             int lane) {
+    const int g = lane >> 4, r = (lane & 15) >> 2, p = lane & 3;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)img + ((4 * g + r) + 16 * p) * 16;
+    bf16x8 xh[2], xm[2], xl[2];
+    split8(act[0], act[1], xh[0], xm[0], xl[0]);
+    split8(act[2], act[3], xh[1], xm[1], xl[1]);
+    // software pipeline over the blocks (mp, ob): the six reads of block n + 1 are in flight while block n's six MFMAs issue
+    u32x2 lo[2][3], hi[2][3];
+    split_T_issue<KBN, 0>(base, lo[0], hi[0]);
+    split_T_step<KBN, 0>(base, lo, hi, xh, xm, xl, acc);
 }
 
 // Cooperative copy of W[rows][cols] (global, row stride src_ld) into LDS [rows][ldw], zero padded.

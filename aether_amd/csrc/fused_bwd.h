@@ -59,6 +59,10 @@ struct FbLds {                                // offsets in floats
     static constexpr int DXS = STG;                                // [32][LDW]  dx  (own slots)   } node phase only:
     static constexpr int DPU = DXS + FUSED_MAX_NODES * LDW;        // [32][LDU]  dpre_u            } alias the staging
     static constexpr int TOTAL = STG + STG_SIZE;
+    // round 4: G of a tile gets staging rows of its own (d2, h, e_prev and G of the round's four tiles stay staged until every
+    // wave has added its row quarter of both products): [4 waves][16][FB_SA] in what used to hold W2^T (no longer staged)
+    static constexpr int STG_G = W2T;
+    static_assert(4 * 16 * FB_SA <= WEND - W2T, "G staging fits the former transposed-image region");
     // per-wave dumps of the incidence sums alias the (then dead) weight images: [4 waves][32][LDST] each
     static constexpr int DUMP_S = 0;
     static constexpr int DUMP_R = 4 * FUSED_MAX_NODES * LDST;
@@ -123,6 +127,32 @@ __device__ __forceinline__ void fb_outer16(const float* __restrict__ sa, const f
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma16(av[mb], bv[nb], acc[mb][nb]);
+    }
+}
+
+// Row-partitioned form (round 4): the wave with index w owns the rows m = 4 i' + w of the product (a quarter, interleaved)
+// for EVERY tile of the workgroup -- acc[nb] += sum_k X[k][4 i' + w] * Y[k][NB i + nb] -- so the four waves' accumulators are
+// disjoint pieces of the workgroup's sum: no cross-wave reduction, 32 accumulator registers instead of 128.
+// `colsum` (optional): += sum_k X[k][4 i' + w] in every column -- the bias gradient of the rows this wave owns, as one more
+// MFMA per k step against a column of ones (no per-lane sums, no cross-lane reduction at the end of the layer).
+template <int NB, bool COLSUM>
+__device__ __forceinline__ void fb_outer16_q(const float* __restrict__ sa, const float* __restrict__ sb, f32x4 (&acc)[NB],
+                                             f32x4& colsum, int i, int q, int w) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float av = sa[(4 * s4 + q) * FB_SA + 4 * i + w];
+        if constexpr (COLSUM) colsum = mfma16(av, 1.0f, colsum);
+        float bv[NB];
+        if constexpr (NB == 4) {
+            const f32x4 b4 = ld4(sb + (4 * s4 + q) * FB_SA + 4 * i);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bv[nb] = b4[nb];
+        } else {
+            const f32x2 b2 = *reinterpret_cast<const f32x2*>(sb + (4 * s4 + q) * FB_SA + 2 * i);
+            bv[0] = b2[0]; bv[1] = b2[1];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(av, bv[nb], acc[nb]);
     }
 }
 
@@ -195,8 +225,6 @@ k_fused_bwd(FbArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wE = smem + L::WE;
     float* w2 = smem + L::W2;
-    float* w2t = smem + L::W2T;
-    float* wEt = smem + L::WET;
     float* bias = smem + L::BIAS;
     float* psb = smem + L::PSB;
     float* prb = smem + L::PRB;
@@ -273,25 +301,34 @@ k_fused_bwd(FbArgs A) {
     // on nothing the kernel computes: requested for layer l - 1 as soon as layer l's accumulators have been dumped, they
     // arrive under the reduction phases instead of costing the next node phase a memory round trip.
     f32x4 nw3f[2][4], nw4f[2][4], nw3tf[8], nb3v[2];
-    auto issue_node_frags = [&](const int l) {
+    // part 0: W3 + b3, part 1: W4^T, part 2: W3^T (8 KB per wave each); part < 0: all three.  In parts they are issued one per
+    // round of tiles: 25 loads in one go stood a wave ~2 us in its memory instructions (every workgroup asks at the same time)
+    auto issue_node_frags = [&](const int l, const int part) {
         const FbLayer Ln = A.layer[l - 1];
         int tid_o = threadIdx.x;
         asm volatile("" : "+v"(tid_o));
         const int ln = tid_o & 63, wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), ii = ln & 15, qq = ln >> 4;
+        if (part < 0 || part == 0) {
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-            const int mb = 2 * wv + mm;
-            nb3v[mm] = ld4(Ln.upd_b0 + 16 * mb + 4 * qq);
+            for (int mm = 0; mm < 2; ++mm) {
+                const int mb = 2 * wv + mm;
+                nb3v[mm] = ld4(Ln.upd_b0 + 16 * mb + 4 * qq);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                nw3f[mm][a] = ld4(Ln.upd_w0 + (size_t)(16 * mb + ii) * H + 16 * a + 4 * qq);
-                nw4f[mm][a] = ld4(Ln.w4t + (size_t)(16 * mb + ii) * H + 16 * a + 4 * qq);
+                for (int a = 0; a < 4; ++a) nw3f[mm][a] = ld4(Ln.upd_w0 + (size_t)(16 * mb + ii) * H + 16 * a + 4 * qq);
             }
         }
+        if (part < 0 || part == 1) {
 #pragma unroll
-        for (int a = 0; a < 8; ++a) nw3tf[a] = ld4(Ln.w3t + (size_t)(16 * wv + ii) * (2 * H) + 16 * a + 4 * qq);
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) nw4f[mm][a] = ld4(Ln.w4t + (size_t)(16 * (2 * wv + mm) + ii) * H + 16 * a + 4 * qq);
+        }
+        if (part < 0 || part == 2) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) nw3tf[a] = ld4(Ln.w3t + (size_t)(16 * wv + ii) * (2 * H) + 16 * a + 4 * qq);
+        }
     };
-    issue_node_frags(4);
+    issue_node_frags(4, -1);
 
     // ================================================================ one layer of the backward
     auto layer = [&](auto first_tag, const int l) {
@@ -308,6 +345,7 @@ k_fused_bwd(FbArgs A) {
         float* sa = smem + L::STG + wave * (3 * 16 * FB_SA);
         float* sb = sa + 16 * FB_SA;
         float* sc = sb + 16 * FB_SA;
+        float* sd = smem + L::STG_G + wave * (16 * FB_SA);
         // ------------------------------------------------------------ node update backward (locs.py:240-241)
         // x_l = n + W4 silu(W3 n + b3) + b4:  dpre_u = (W4^T dx) * silu'(pre_u),  dn = dx + W3^T dpre_u
         {
@@ -315,13 +353,11 @@ k_fused_bwd(FbArgs A) {
             // whose data is needed first, then the node-phase weight fragments.  One memory round trip for all of it.
             if constexpr (FIRST) {
                 fb_stage_image<12>(wE, Lp.img_e, wave, lane);              // W1 padded to K = 32: 3 terms x 4 fragments
-                fb_stage_frags<2, 4>(wEt, Lp.w0t, H, wave, lane);
             } else {
                 fb_stage_image<24>(wE, Lp.img_e, wave, lane);
-                fb_stage_frags<4, 4>(wEt, Lp.w0t + 2 * H * H, H, wave, lane);
             }
             fb_stage_image<24>(w2, Lp.img_2, wave, lane);
-            fb_stage_frags<4, 4>(w2t, Lp.w2t, H, wave, lane);
+            // (round 4: no transposed copies -- W2^T dpre2 and W_e^T G read these two images transposed, gemm_split_T)
             f32x4 pv[2][2];
             float bv0 = 0.0f, bv1 = 0.0f;
             if constexpr (FIRST) {
@@ -402,18 +438,16 @@ k_fused_bwd(FbArgs A) {
         FB_STAMP(1 + 8 * (4 - l));
 
         // ------------------------------------------------------------ edge tiles, last tile first
-        f32x4 aw2[4][4], awe[4][NBE];          // dW2 += dpre2 (x) h;  dW_e += G (x) e_prev   (dW1 += G (x) features)
+        // dW2 += dpre2 (x) h;  dW_e += G (x) e_prev   (dW1 += G (x) features): this wave's row quarter (m = 4 i' + wave) over ALL
+        // tiles of the workgroup (fb_outer16_q) -- final for the workgroup, written out without a cross-wave reduction
+        f32x4 aw2[4], awe[NBE];
         f32x4 dps[2][4], dpr[2][4];            // sum of G over out-edges (visible slots) / in-edges (own slots)
-        f32x4 db2[4], db1[4];                  // per-lane column sums (edge i of every tile): reduced over lanes at the end
+        f32x4 db2 = f32x4{0.f, 0.f, 0.f, 0.f}, db1 = db2;      // bias gradients of this wave's rows (fb_outer16_q's column sums)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int nbx = 0; nbx < 4; ++nbx) aw2[nbx] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int nbx = 0; nbx < 4; ++nbx) aw2[mb][nbx] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int nbx = 0; nbx < NBE; ++nbx) awe[mb][nbx] = f32x4{0.f, 0.f, 0.f, 0.f};
-            db2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            db1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int nbx = 0; nbx < NBE; ++nbx) awe[nbx] = f32x4{0.f, 0.f, 0.f, 0.f};
+
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
@@ -469,6 +503,10 @@ k_fused_bwd(FbArgs A) {
             for (int r = ROUNDS - 1; r >= 0; --r)
                 if (!have && NWV * r + wave < n_tiles) { load_ep(r, epn); have = true; }
         }
+        // The NEXT layer's node-phase weight fragments (100 KB per workgroup) are requested during the tile phase, a third per
+        // round (below): they arrive under the 28 us of edge tiles.  Requested at the end of the layer (round 3) they met every
+        // other workgroup's -- all 256 run their layers in step -- and the wave stood 3-4 us in its memory instructions; the
+        // row partition of the weight-gradient accumulators (96 registers less) makes room for them during the tiles.
         bool need_publish = !FIRST && split;
 #pragma unroll
         for (int r = ROUNDS - 1; r >= 0; --r) {
@@ -476,6 +514,10 @@ k_fused_bwd(FbArgs A) {
             if (need_publish && tile < n_tiles && 16 * (tile + 1) <= na) {         // no partner sender from here on
                 publish();
                 need_publish = false;
+            }
+            if (l > 1) {           // (rounds: ROUNDS - 1 .. 0 -> parts 0 ..; with fewer than three rounds the rest follows the loop)
+                const int part = ROUNDS - 1 - r;
+                if (part < 3) issue_node_frags(l - 1, part);
             }
             if (tile < n_tiles) {
                 FB_WSTAMP(20 * (4 - l) + 4 * r);
@@ -533,33 +575,23 @@ k_fused_bwd(FbArgs A) {
                     }
                     d2[mb] = dev * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
                     dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    db2[mb] += d2[mb];
                     st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
                 }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(93);
-                fb_gemm<4, 4>(w2t, d2, dh, lane);
+                gemm_split_T<2>(w2, d2, dh, lane);              // W2^T dpre2 on the bf16 pipe, from the forward's image
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(94);
-                // ---- dW2 += dpre2 (x) h
-                __builtin_amdgcn_wave_barrier();
-                fb_outer16<4>(sa, sb, aw2, i, q);
-                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(95);
-                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     g[mb] = dh[mb] * ds1[mb];
-                    st4(sa + i * FB_SA + 16 * mb + 4 * q, g[mb]);
-                    if constexpr (FIRST) db1[mb] += g[mb];
+                    st4(sd + i * FB_SA + 16 * mb + 4 * q, g[mb]);
                 }
                 __builtin_amdgcn_wave_barrier();
-                // ---- dW_e += G (x) e_prev (layer 1: dW1 += G (x) features), incidence sums of G
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(96);
-                fb_outer16<NBE>(sa, sc, awe, i, q);
-                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(97);
                 if constexpr (!FIRST) {
                     // out[node][h] += sum_edge Inc[node][edge] * G[edge][h]: A = the lane's incidence bits, B = G staged
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        const float* grow = sa + (4 * s4 + q) * FB_SA + i;
+                        const float* grow = sd + (4 * s4 + q) * FB_SA + i;
                         float gv[4];
 #pragma unroll
                         for (int nbx = 0; nbx < 4; ++nbx) gv[nbx] = grow[16 * nbx];
@@ -583,13 +615,13 @@ k_fused_bwd(FbArgs A) {
                 // ---- gradient into this layer's edge input
                 if constexpr (FIRST) {
                     f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                    fb_gemm<2, 4>(wEt, g, da, lane);
+                    gemm_split_T<1>(wE, g, da, lane);                      // W1^T G
                     if (ok) { st4(A.DA + kc * FPAD + 4 * q, da[0]); st4(A.DA + kc * FPAD + 16 + 4 * q, da[1]); }
                 } else {
                     f32x4 dep[4];
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    fb_gemm<4, 4>(wEt, g, dep, lane);
+                    gemm_split_T<2>(wE, g, dep, lane);                     // W_e^T G
                     if constexpr (DE_REGS) {
 #pragma unroll
                         for (int mb = 0; mb < 4; ++mb) de[r][mb] = dep[mb];
@@ -599,8 +631,27 @@ k_fused_bwd(FbArgs A) {
                     }
                 }
             }
+            // ---- the round's four tiles are staged (d2 | h | e_prev per wave, G beside them): every wave adds its row quarter
+            // of both weight-gradient products over all of them (workgroup-uniform conditions: every wave takes the barriers)
+            if (NWV * r < n_tiles) {
+                lds_barrier();
+#pragma unroll
+                for (int t = 0; t < NWV; ++t) {
+                    if (NWV * r + t < n_tiles) {
+                        const float* ta = smem + L::STG + t * (3 * 16 * FB_SA);
+                        const float* td = smem + L::STG_G + t * (16 * FB_SA);
+                        fb_outer16_q<4, true>(ta, ta + 16 * FB_SA, aw2, db2, i, q, wave);               // dW2 += dpre2 (x) h, db2
+                        fb_outer16_q<NBE, FIRST>(td, ta + 2 * 16 * FB_SA, awe, db1, i, q, wave);     // dW_e += G (x) e_prev
+                    }
+                }
+                lds_barrier();         // staging rows are free for the next round (and for publish)
+            }
         }
         if (need_publish) publish();
+        if (l > 1) {
+#pragma unroll
+            for (int part = ROUNDS; part < 3; ++part) issue_node_frags(l - 1, part);
+        }
         FB_WSTAMP(20 * (4 - l) + 16);
 
         // ------------------------------------------------------------ reductions over the workgroup
@@ -669,69 +720,40 @@ k_fused_bwd(FbArgs A) {
             lds_barrier();
         }
         FB_STAMP(3 + 8 * (4 - l));
-        // (2) edge-level weight gradients: waves 0, 1 write, waves 2, 3 add, everyone writes the partial out
-        {
-            float* red = smem + (wave & 1) * (2 * H * H);              // [dW2 64 x 64 | dW_e 64 x 64 (dW1: 64 x 32)]
-            auto dump = [&](bool add) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const int mrow = 4 * (4 * q + r4) + mb;
-                        f32x4 v = f32x4{aw2[mb][0][r4], aw2[mb][1][r4], aw2[mb][2][r4], aw2[mb][3][r4]};
-                        float* d = red + mrow * H + 4 * i;
-                        if (add) v += ld4(d);
-                        st4(d, v);
-                        if constexpr (FIRST) {
-                            f32x2 v2 = f32x2{awe[mb][0][r4], awe[mb][1][r4]};
-                            f32x2* d2p = reinterpret_cast<f32x2*>(red + H * H + mrow * FPAD + 2 * i);
-                            if (add) v2 += *d2p;
-                            *d2p = v2;
-                        } else {
-                            f32x4 ve = f32x4{awe[mb][0][r4], awe[mb][1][r4], awe[mb][2][r4], awe[mb][3][r4]};
-                            float* de2 = red + H * H + mrow * H + 4 * i;
-                            if (add) ve += ld4(de2);
-                            st4(de2, ve);
-                        }
-                    }
-            };
-            // bias sums: lanes i = 0..15 of a q group hold the 16 edges of a tile position: add them up (DPP row
-            // reduction), then the four waves in order through LDS words behind the matrices
-            float* bred = smem + 2 * (2 * H * H);                     // [4 waves][128]
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    float s2 = db2[mb][r4], s1 = db1[mb][r4];
-#pragma unroll
-                    for (int o = 8; o >= 1; o >>= 1) { s2 += __shfl_xor(s2, o, 16); s1 += __shfl_xor(s1, o, 16); }
-                    if (i == 0) {
-                        bred[wave * 2 * H + 16 * mb + 4 * q + r4] = s2;
-                        bred[wave * 2 * H + H + 16 * mb + 4 * q + r4] = s1;
-                    }
-                }
-            if (wave < 2) dump(false);
-            lds_barrier();
-            if (wave >= 2) dump(true);
-            if (l > 1) issue_node_frags(l - 1);      // the accumulators are dead: their registers take the next fragments
-            lds_barrier();
-            float* dst = A.partial + ((size_t)blockIdx.x * 4 + (l - 1)) * FB_PART;
-            for (int f = tid; f < 2 * H * H / 4; f += FB_THREADS)
-                st4(dst + 4 * f, ld4(smem + 4 * f) + ld4(smem + 2 * H * H + 4 * f));
-            if (tid < 2 * H)
-                dst[2 * H * H + tid] = ((bred[tid] + bred[2 * H + tid]) + bred[4 * H + tid]) + bred[6 * H + tid];
-        }
-        static_assert(2 * (2 * H * H) + 4 * 2 * H <= L::WEND + 2 * H, "reduction buffers fit the weight images (+ bias)");
-        FB_STAMP(4 + 8 * (4 - l));
-        // (3) dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed): rows 16 * wave ..
+        // (2) + (3).  Order = what the in-order memory counter wants (loads and stores share vmcnt): first every LOAD the rest
+        // of the layer and the next node phase need, then the partial's stores (fire and forget: a wait for the loads above
+        // leaves them outstanding), then the dx GEMM.
+        f32x4 wsf[4], wrf[4];
         if constexpr (!FIRST) {
             const float* w1t = Lp.w0t;                    // [192][64]: W_s^T | W_r^T | W_e^T
-            f32x4 wsf[4], wrf[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 wsf[a] = ld4(w1t + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
                 wrf[a] = ld4(w1t + (size_t)H * H + (size_t)(16 * wave + i) * H + 16 * a + 4 * q);
             }
+        }
+        // (2) edge-level weight gradients: every wave holds a row quarter (rows m = 4 i' + wave) of the workgroup's two sums and
+        // of the bias sums -- straight to the partial, no reduction over the waves (round 3: two LDS passes per layer)
+        {
+            float* dst = A.partial + ((size_t)blockIdx.x * 4 + (l - 1)) * FB_PART;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int mrow = 4 * (4 * q + r4) + wave;
+                st4(dst + mrow * H + 4 * i, f32x4{aw2[0][r4], aw2[1][r4], aw2[2][r4], aw2[3][r4]});
+                if constexpr (FIRST) {
+                    *reinterpret_cast<f32x2*>(dst + H * H + mrow * FPAD + 2 * i) = f32x2{awe[0][r4], awe[1][r4]};
+                } else {
+                    st4(dst + H * H + mrow * H + 4 * i, f32x4{awe[0][r4], awe[1][r4], awe[2][r4], awe[3][r4]});
+                }
+                if (i == 0) {                             // (every column of the ones product holds the sum)
+                    dst[2 * H * H + mrow] = db2[r4];
+                    dst[2 * H * H + H + mrow] = FIRST ? db1[r4] : 0.0f;
+                }
+            }
+        }
+        FB_STAMP(4 + 8 * (4 - l));
+        // (3) dx_{l-1} = dn_l + W_s^T dP_s + W_r^T dP_r   (locs.py:233 split, transposed): rows 16 * wave ..
+        if constexpr (!FIRST) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if (t >= nbk) continue;
