@@ -862,15 +862,28 @@ def main():
             if world > 1:
                 from aether_amd.parallel import attach_data_parallel
                 attach_data_parallel(model)
-            opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12)     # main.py:86,164
             tgt = inp["target"]
+            if args.big:
+                # config-5 shard: the library's own loss and optimizer (one launch each), launched eagerly -- at ~85 ms per
+                # step launch gaps are nothing, and a captured step would hold a second 120 GB workspace in the graph's pool
+                from aether_amd.optim import FusedAdamW, mse_loss_grad
+                opt = FusedAdamW(model.parameters(), lr=5e-4, weight_decay=1e-12)      # main.py:86,164
 
-            def tstep():
-                opt.zero_grad(set_to_none=True)
-                o = call()
-                loss = torch.nn.functional.mse_loss(o, tgt)
-                loss.backward()
-                opt.step()
+                def tstep():
+                    opt.zero_grad(set_to_none=True)
+                    o = call()
+                    _loss, grad = mse_loss_grad(o, tgt)
+                    o.backward(grad)
+                    opt.step()
+            else:
+                opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-12)     # main.py:86,164
+
+                def tstep():
+                    opt.zero_grad(set_to_none=True)
+                    o = call()
+                    loss = torch.nn.functional.mse_loss(o, tgt)
+                    loss.backward()
+                    opt.step()
             tsteps = 3 if args.big else max(10, args.steps // 4)
             for _ in range(1 if args.big else 5):
                 tstep()
@@ -932,9 +945,11 @@ def main():
                         "in_graph": bool(gstep is not None and gstep.collective_in_graph), "ranks_seen": ranks_seen}
             train = {"ms_per_step": 1e3 * tdt / tsteps, "steps": tsteps, "collective": coll,
                      "value": 4.0 * E * world / (tdt / tsteps), "unit": "edge-messages/s",
-                     "includes": ("forward + MSE loss + HIP backward + " if gstep is not None else "forward + torch MSE loss + HIP backward + ")
+                     "includes": ("forward + MSE loss (aether_mse_loss_grad) + HIP backward + " if (gstep is not None or args.big)
+                                  else "forward + torch MSE loss + HIP backward + ")
                                  + ((("RCCL" if coll["backend"] == "nccl" else coll["backend"]) + " grad all-reduce + ") if world > 1 else "")
-                                 + ("AdamW (aether_adamw_step), " if gstep is not None else "torch AdamW, ") + train_launch + " launches"}
+                                 + ("AdamW (aether_adamw_step), " if (gstep is not None or args.big) else "torch AdamW, ")
+                                 + train_launch + " launches"}
             if rank == 0:       # per-kernel breakdown of one training step (rank-local: no collective in here)
                 saved_group, model.dp_group = model.dp_group, None       # (GraphedTrainStep already detached it)
                 lib = _lib.load()
