@@ -1,6 +1,7 @@
-"""world_size = 2 (gloo, CPU) coverage of the data-parallel path: graph sharding, parameter broadcast
-and the flat-buffer gradient all-reduce.  The local step on CPU is the oracle (test infrastructure);
-the product's HIP step is exercised by the -m gpu tests."""
+"""world_size = 2 (gloo) coverage of the data-parallel path: graph sharding, parameter broadcast and the flat-buffer
+gradient all-reduce.  Without a GPU the local step is the oracle (test infrastructure: this container has none); on a box
+with a GPU the same two ranks ALSO run the product's HIP step (the module under attach_data_parallel) and compare its
+all-reduced gradients with the full-batch reference."""
 import os
 import socket
 import sys
@@ -72,6 +73,19 @@ def _worker(rank, world, port, q):
     torch.nn.functional.mse_loss(of, full["target"]).backward()
     want = torch.cat([sdf[k].grad.reshape(-1) for k in sd])
     err = float((flat - want).abs().max() / want.abs().max())
+    if torch.cuda.is_available():
+        # the product's step on this rank's shard: all-reduce + mean happen inside the module's backward
+        from aether_amd.nn.state2state.aether import Aether
+        from aether_amd.parallel import attach_data_parallel
+        dev = torch.device("cuda", 0)
+        m = Aether(2 * D, 64, 0.0, D, device=dev)
+        m.load_state_dict(sd)
+        attach_data_parallel(m)
+        dv = lambda t: t.to(dev)
+        o = m(None, dv(full["x"][sl]), [dv(e) for e in edges], dv(full["vel"][sl]), dv(ea), dv(q_))
+        torch.nn.functional.mse_loss(o, dv(full["target"][sl])).backward()
+        got = torch.cat([p.grad.reshape(-1) for _, p in m.named_parameters()]).cpu()
+        err = max(err, float((got - want).abs().max() / want.abs().max()) / 5.0)      # (HIP gradients: 5e-5 bar)
     q.put((rank, err))
     dist.barrier()
     dist.destroy_process_group()

@@ -42,6 +42,8 @@ def _worker(rank, world, port, q, variant):
         m = DynamicFieldAether(2 * D, 64, 0.0, D, device=dev)
     elif variant == "narrow":                            # hidden_size 32: the zero-padded 64-wide engine
         m = Aether(2 * D, 32, 0.0, D, device=dev)
+    elif variant in ("wide", "wide_padded"):             # hidden_size 128 (csrc/wide.h) / 96 (zero-padded on it)
+        m = Aether(2 * D, 128 if variant == "wide" else 96, 0.0, D, device=dev)
     else:
         m = Aether(2 * D, 64, 0.0, D, device=dev)
         if rank == 0:
@@ -68,7 +70,7 @@ def _worker(rank, world, port, q, variant):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("variant", ["aether", "dynamic_field", "narrow"])
+@pytest.mark.parametrize("variant", ["aether", "dynamic_field", "narrow", "wide", "wide_padded"])
 def test_two_ranks_on_one_gpu_match_single_process_gradients(variant):
     from aether_amd.nn.state2state.aether import Aether
     from aether_amd.synthetic import make_batch
@@ -90,8 +92,8 @@ def test_two_ranks_on_one_gpu_match_single_process_gradients(variant):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in res[0][5].items()})      # rank 0's broadcast weights
         assert all((res[0][5][k] == res[1][5][k]).all() for k in res[0][5])
         extra = (N,)
-    elif variant == "narrow":
-        m = Aether(2 * D, 32, 0.0, D, device="cuda")
+    elif variant in ("narrow", "wide", "wide_padded"):
+        m = Aether(2 * D, {"narrow": 32, "wide": 128, "wide_padded": 96}[variant], 0.0, D, device="cuda")
         m.load_state_dict({k: torch.from_numpy(v) for k, v in res[0][5].items()})
         assert all((res[0][5][k] == res[1][5][k]).all() for k in res[0][5])
         extra = ()
