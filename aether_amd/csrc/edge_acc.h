@@ -274,4 +274,221 @@ k_edge_acc_reduce(const float* __restrict__ partial, int n_wgs, EdgeAccOut O) {
     }
 }
 
+
+// ------------------------------------------------------------------ round 4: two waves per SIMD
+// kb_edge_acc runs ONE wave per SIMD (450 VGPR + 194 AGPR: two 64 x 64 accumulators, four split weight images' worth of
+// LDS): a tile is a dependent chain of ~7 us with the matrix pipe 18 % and the vector ALU 50 % busy, and nobody to fill
+// the gaps.  kb_edge_acc8 is the same arithmetic with what round 4 learnt in k_fused_bwd:
+//   * the transposed products (W2^T dpre2, W_in^T G) read the forward's split images transposed (gemm_split_T): two images
+//     in LDS instead of four;
+//   * the weight-gradient accumulators are partitioned by output rows: a workgroup works in ROUNDS of eight tiles (one per
+//     wave); after a round's tiles are staged, wave w adds the rows 4 i' + (w & 3) of the product over the four tiles
+//     4 (w >> 2) .. of the round -- 16 accumulator registers per product instead of 64, nothing to reduce over the waves
+//     but the two tile halves, which go out as two partials per workgroup;
+//   * bias sums ride along as one more MFMA per k step against a column of ones.
+// 8 waves per workgroup, one workgroup per CU, <= 256 registers: two waves per SIMD.
+constexpr int EA8_WAVES = 8;
+constexpr int EA8_STG = 2 * 16 * FB_SA;              // staging floats per wave: one operand pair at a time
+
+template <bool FIRST>
+__global__ void __launch_bounds__(64 * EA8_WAVES)
+kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, const float* __restrict__ Ps,
+             const float* __restrict__ Pr, const float* __restrict__ e_prev, const float* __restrict__ feat,
+             const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
+             const float* __restrict__ DN, float* __restrict__ DE, int have_de, float* __restrict__ G,
+             float* __restrict__ DA, float* __restrict__ partial /* [n_wgs][2][FB_PART] */,
+             const float* __restrict__ img_in /*split image of W_e (FIRST: of W1, K padded to 32)*/,
+             const float* __restrict__ img_2 /*split image of W2*/, int64_t n_edges, int n_wgs) {
+    constexpr int NBE = FIRST ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wi = smem;                  // split image of W_in (FIRST: half of it is used)
+    float* w2 = wi + SPLIT_WIMG;       // split image of W2
+    float* stg = w2 + SPLIT_WIMG;      // [8 waves][2][16][FB_SA]
+    for (int idx = threadIdx.x; idx < (FIRST ? SPLIT_WIMG / 2 : SPLIT_WIMG) / 4; idx += 64 * EA8_WAVES) st4(wi + 4 * idx, ld4(img_in + 4 * idx));
+    for (int idx = threadIdx.x; idx < SPLIT_WIMG / 4; idx += 64 * EA8_WAVES) st4(w2 + 4 * idx, ld4(img_2 + 4 * idx));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    float* sa = stg + wave * EA8_STG;   // dpre2, then G
+    float* sb = sa + 16 * FB_SA;        // h, then e_prev / features
+    const int wq = wave & 3, whalf = wave >> 2;          // accumulator rows 4 i' + wq, tiles 4 whalf .. of a round
+    const int64_t tiles = (n_edges + 15) >> 4;
+    const int64_t stride = (int64_t)n_wgs * EA8_WAVES;
+    f32x4 accW2[4], accWe[NBE], bs2 = f32x4{0.f, 0.f, 0.f, 0.f}, bs1 = bs2;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) accW2[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NBE; ++b) accWe[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto clampk = [&](int64_t tt) { const int64_t k = 16 * tt + i; return k < n_edges ? k : n_edges - 1; };
+    // the HBM stream of the next round (e_prev / features and the incoming message gradient) is requested a round ahead;
+    // the gathered rows (P_s, P_r, dn: L2 hits) when the tile starts -- the SIMD's other wave covers that round trip
+    f32x4 nbop[4], ndev[4];
+    int64_t t0 = (int64_t)blockIdx.x * EA8_WAVES;
+    {
+        const int64_t k0 = clampk(t0 + wave < tiles ? t0 + wave : tiles - 1);
+        if (FIRST) { nbop[0] = ld4(feat + k0 * FPAD + 4 * q); nbop[1] = ld4(feat + k0 * FPAD + 16 + 4 * q); }
+        else load_tile64(nbop, e_prev, k0, H, q);
+        if (have_de) load_tile64(ndev, DE, k0, H, q);
+    }
+    for (; t0 < tiles; t0 += stride) {                   // rounds: workgroup-uniform
+        const int64_t t = t0 + wave;
+        const bool active = t < tiles;                   // wave-uniform
+        f32x4 g[4], bop[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { g[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; bop[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (active) {
+            const int64_t k = 16 * t + i;
+            const bool ok = k < n_edges;
+            const int64_t kc = ok ? k : n_edges - 1;
+            const int32_t s = send_s[kc], r = recv_s[kc];
+            const int deg = rowptr[r + 1] - rowptr[r];
+            f32x4 p1[4], dnv[4], dev[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) { bop[mb] = nbop[mb]; dev[mb] = ndev[mb]; }
+            if (FIRST) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(b_in + 16 * mb + 4 * q);
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    p1[mb] = ld4(Ps + (int64_t)s * H + 16 * mb + 4 * q) + ld4(Pr + (int64_t)r * H + 16 * mb + 4 * q);
+            }
+            load_tile64(dnv, DN, r, H, q);
+            {   // next round's stream
+                const int64_t tn = t + stride < tiles ? t + stride : t;
+                const int64_t kn = clampk(tn);
+                if (FIRST) { nbop[0] = ld4(feat + kn * FPAD + 4 * q); nbop[1] = ld4(feat + kn * FPAD + 16 + 4 * q); }
+                else load_tile64(nbop, e_prev, kn, H, q);
+                if (have_de) load_tile64(ndev, DE, kn, H, q);
+            }
+            const float inv = own_reg(1.0f / (float)(deg > 1 ? deg : 1));
+            // ---- forward recompute: pre1, h = silu(pre1), pre2
+            f32x4 p2[4], h[4], sg1[4];
+            if (FIRST) {
+                f32x4 b2[2] = {bop[0], bop[1]};
+                gemm_split<4, 1>(wi, b2, p1, lane);
+            } else {
+                gemm_split<4, 2>(wi, bop, p1, lane);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                sg1[mb] = sigmoid4(p1[mb]);
+                h[mb] = p1[mb] * sg1[mb];
+                p2[mb] = ld4(b2g + 16 * mb + 4 * q);
+            }
+            gemm_split<4, 2>(w2, h, p2, lane);
+            // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
+            f32x4 d2[4], dh[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x4 de = dnv[mb] * inv;
+                if (have_de) de += dev[mb];
+                d2[mb] = de * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
+                if (!ok) d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};             // rows past the end contribute nothing to the products
+                dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
+                st4(sb + i * FB_SA + 16 * mb + 4 * q, h[mb]);
+            }
+            gemm_split_T<2>(w2, d2, dh, lane);                          // W2^T dpre2 from the forward's image
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu_from_sigmoid(p1[mb], sg1[mb]);
+            if (FIRST) {
+                f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                gemm_split_T<1>(wi, g, da, lane);                       // W1^T G
+                if (ok) { st4(DA + k * FPAD + 4 * q, da[0]); st4(DA + k * FPAD + 16 + 4 * q, da[1]); }
+            } else {
+                f32x4 dep[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_split_T<2>(wi, g, dep, lane);                      // W_e^T G
+                if (ok) store_tile64(DE, k, H, q, dep);
+            }
+            if (ok) store_tile64(G, k, H, q, g);
+            if (!ok) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) bop[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // ---- dW2 += dpre2 (x) h, db2: the round's tiles are staged; this wave's row quarter over its four tiles
+        lds_barrier();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            if (t0 + 4 * whalf + tt < tiles) {
+                const float* ta = stg + (4 * whalf + tt) * EA8_STG;
+                fb_outer16_q<4, true>(ta, ta + 16 * FB_SA, accW2, bs2, i, q, wq);
+            }
+        }
+        lds_barrier();
+        // ---- dW_e += G (x) e_prev (layer 1: dW1 += G (x) features, db1)
+        if (active) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                st4(sa + i * FB_SA + 16 * mb + 4 * q, g[mb]);          // (g of a row past the end is 0: dh = W2^T 0)
+                if (!FIRST || mb < 2) st4(sb + i * FB_SA + 16 * mb + 4 * q, bop[mb]);
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            if (t0 + 4 * whalf + tt < tiles) {
+                const float* ta = stg + (4 * whalf + tt) * EA8_STG;
+                fb_outer16_q<NBE, FIRST>(ta, ta + 16 * FB_SA, accWe, bs1, i, q, wq);
+            }
+        }
+        lds_barrier();
+    }
+    // ---- two partials per workgroup (tile halves 0 / 1), each wave its row quarter: [dW2 64 x 64 | dW_e 64 x 64 (64 x 32) | db2 | db1]
+    float* dst = partial + ((size_t)blockIdx.x * 2 + whalf) * FB_PART;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int mrow = 4 * (4 * q + r4) + wq;
+        st4(dst + mrow * H + 4 * i, f32x4{accW2[0][r4], accW2[1][r4], accW2[2][r4], accW2[3][r4]});
+        if constexpr (FIRST) {
+            *reinterpret_cast<f32x2*>(dst + H * H + mrow * FPAD + 2 * i) = f32x2{accWe[0][r4], accWe[1][r4]};
+        } else {
+            st4(dst + H * H + mrow * H + 4 * i, f32x4{accWe[0][r4], accWe[1][r4], accWe[2][r4], accWe[3][r4]});
+        }
+        if (i == 0) {
+            dst[2 * H * H + mrow] = bs2[r4];
+            dst[2 * H * H + H + mrow] = FIRST ? bs1[r4] : 0.0f;
+        }
+    }
+}
+
+// Sum of kb_edge_acc8's partials ([n_parts][FB_PART], part order = workgroup order, fixed 16-group tree) into the gradient
+// tensors.  Element e < H*H: dW2[m][n]; < 2 H*H: dW_e (layer 1: [64][FPAD] rows, columns < f1); then db2, db1.
+__global__ void __launch_bounds__(1024)
+k_edge_acc8_reduce(const float* __restrict__ partial, int n_parts, EdgeAccOut O) {
+    const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + t;
+    const bool valid = e < FB_PART;
+    const int per = (n_parts + 15) / 16;
+    const int w0 = grp * per, w1 = w0 + per < n_parts ? w0 + per : n_parts;
+    float s = 0.0f;
+    if (valid)
+        for (int w = w0; w < w1; ++w) s += partial[(size_t)w * FB_PART + e];
+    __shared__ float red[16][64];
+    red[grp][t] = s;
+    __syncthreads();
+    if (grp != 0 || !valid) return;
+    float tot = red[0][t];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) tot += red[g][t];
+    if (e < H * H) {
+        O.w2[e] = tot;
+    } else if (e < 2 * H * H) {
+        const int o = e - H * H;
+        if (O.nb_e == 2) {                               // layer 1: [64][FPAD]
+            const int mrow = o / FPAD, c = o % FPAD;
+            if (o < H * FPAD && c < O.ncols) O.we[(size_t)mrow * O.ldwe + c] = tot;
+        } else {
+            O.we[(size_t)(o >> 6) * O.ldwe + (o & 63)] = tot;
+        }
+    } else if (e < 2 * H * H + H) {
+        O.b2[e - 2 * H * H] = tot;
+    } else if (O.b1 != nullptr) {
+        O.b1[e - 2 * H * H - H] = tot;
+    }
+}
+
 }  // namespace

@@ -13,6 +13,7 @@ from aether_amd.synthetic import make_batch
 from oracle import aether_oracle as O
 
 pytestmark = pytest.mark.gpu
+DEFAULT_EDGE_ACC = 1          # aether_set_option("edge_acc"): the library's default
 GTOL = 5e-5     # gradients: sums over thousands of edges in a different (fixed) order than autograd
 
 
@@ -134,20 +135,21 @@ def test_edge_level_weight_gradients_accumulated_in_the_edge_kernel(D):
         res = {}
         try:
             _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 0), "set_option")
-            for acc in (1, 0, 1):
+            for acc in (2, 1, 0, 1, 2):        # 2: kb_edge_acc8 (round 4, two waves per SIMD), 1: kb_edge_acc, 0: row tensors
                 _lib.check(lib.aether_set_option(b"edge_acc", acc), "set_option")
                 _, g = _loss_backward(m, inp)
-                if acc == 1 and 1 in res:
+                if acc in res:
                     for k in g:
-                        assert torch.equal(g[k], res[1][k]), k            # same bits on a second run
+                        assert torch.equal(g[k], res[acc][k]), (acc, k)   # same bits on a second run
                 res[acc] = g
         finally:
             _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 1 << 20), "set_option")
-            _lib.check(lib.aether_set_option(b"edge_acc", 1), "set_option")
-        for k in res[1]:
-            assert torch.isfinite(res[1][k]).all(), k
-            assert scale_rel_err(res[1][k], sdg[k].grad) <= GTOL, (B, N, k)
-            assert scale_rel_err(res[1][k], res[0][k]) <= GTOL, (B, N, k)
+            _lib.check(lib.aether_set_option(b"edge_acc", DEFAULT_EDGE_ACC), "set_option")
+        for acc in (1, 2):
+            for k in res[acc]:
+                assert torch.isfinite(res[acc][k]).all(), k
+                assert scale_rel_err(res[acc][k], sdg[k].grad) <= GTOL, (acc, B, N, k)
+                assert scale_rel_err(res[acc][k], res[0][k]) <= GTOL, (acc, B, N, k)
 
 
 def test_backward_is_deterministic_and_optimizer_step_runs():
