@@ -686,28 +686,37 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         if (E > 0) {
             const size_t lds = (size_t)(4 * H * LDW) * 4;
             ProfScope* pse = new ProfScope(KB_EDGE, st);
-            if (acc_path && g_edge_acc == 2) {
-                // round 4: eight waves per workgroup (two per SIMD), transposed products from the forward's images,
-                // accumulators partitioned by output rows (edge_acc.h, kb_edge_acc8)
-                const size_t lds_8 = (size_t)(2 * SPLIT_WIMG + EA8_WAVES * EA8_STG) * 4;
-                const unsigned g8 = (unsigned)((etile + EA8_WAVES - 1) / EA8_WAVES < 256 ? (etile + EA8_WAVES - 1) / EA8_WAVES : 256);
+            if (acc_path && g_edge_acc >= 2) {
+                // round 4: two waves per SIMD, transposed products from the forward's images, accumulators partitioned by
+                // output rows (edge_acc.h, kb_edge_acc8): 2 = one workgroup of eight waves per CU, 3 = two of four
                 EdgeAccOut O{};
                 O.w2 = gw2; O.b2 = gb2;
-                if (l == 1) {
-                    if (optin(reinterpret_cast<const void*>(kb_edge_acc8<true>), lds_8)) return AETHER_EHIP;
-                    kb_edge_acc8<true><<<dim3(g8), dim3(64 * EA8_WAVES), lds_8, st>>>(
-                        P.l1_msg_b0, b2, nullptr, nullptr, nullptr, wp(W.feat), send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), 1, bG,
-                        wp(W.DA), partial, wp(W.wimg) + fused_wimg_offset(1, 0), wp(W.wimg) + fused_wimg_offset(1, 1), E, (int)g8);
-                    O.we = Gr.l1_msg_w0; O.ldwe = F1; O.ncols = F1; O.b1 = Gr.l1_msg_b0; O.nb_e = 2;
-                } else {
-                    if (optin(reinterpret_cast<const void*>(kb_edge_acc8<false>), lds_8)) return AETHER_EHIP;
-                    kb_edge_acc8<false><<<dim3(g8), dim3(64 * EA8_WAVES), lds_8, st>>>(
-                        nullptr, b2, wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), nullptr, send_s, recv_s, rowptr, wp(W.DN),
-                        wp(W.DE), l < 4 ? 1 : 0, bG, nullptr, partial, wp(W.wimg) + fused_wimg_offset(l, 0),
-                        wp(W.wimg) + fused_wimg_offset(l, 1), E, (int)g8);
-                    O.we = Gr.ln_msg_w0[l - 2] + 2 * H; O.ldwe = 3 * H; O.ncols = H; O.b1 = nullptr; O.nb_e = 4;
-                }
-                k_edge_acc8_reduce<<<dim3((FB_PART + 63) / 64), dim3(1024), 0, st>>>(partial, 2 * (int)g8, O);
+                int n_parts = 0;
+                auto launch8 = [&](auto nw_tag) -> bool {
+                    constexpr int NW = decltype(nw_tag)::value;
+                    const size_t lds_8 = (size_t)(2 * SPLIT_WIMG + NW * EaStg<NW == 4>::WAVE) * 4;
+                    const int64_t want = (etile + NW - 1) / NW, cap = 256 * (8 / NW);
+                    const unsigned g8 = (unsigned)(want < cap ? want : cap);
+                    n_parts = (int)g8 * (NW / 4);
+                    if (l == 1) {
+                        if (optin(reinterpret_cast<const void*>(kb_edge_acc8<true, NW>), lds_8)) return false;
+                        kb_edge_acc8<true, NW><<<dim3(g8), dim3(64 * NW), lds_8, st>>>(
+                            P.l1_msg_b0, b2, nullptr, nullptr, nullptr, wp(W.feat), send_s, recv_s, rowptr, wp(W.DN), wp(W.DE), 1, bG,
+                            wp(W.DA), partial, wp(W.wimg) + fused_wimg_offset(1, 0), wp(W.wimg) + fused_wimg_offset(1, 1), E, (int)g8);
+                    } else {
+                        if (optin(reinterpret_cast<const void*>(kb_edge_acc8<false, NW>), lds_8)) return false;
+                        kb_edge_acc8<false, NW><<<dim3(g8), dim3(64 * NW), lds_8, st>>>(
+                            nullptr, b2, wp(W.ps[l - 2]), wp(W.pr[l - 2]), wp(W.e[l - 2]), nullptr, send_s, recv_s, rowptr, wp(W.DN),
+                            wp(W.DE), l < 4 ? 1 : 0, bG, nullptr, partial, wp(W.wimg) + fused_wimg_offset(l, 0),
+                            wp(W.wimg) + fused_wimg_offset(l, 1), E, (int)g8);
+                    }
+                    return true;
+                };
+                const bool ok8 = g_edge_acc == 2 ? launch8(std::integral_constant<int, 8>{}) : launch8(std::integral_constant<int, 4>{});
+                if (!ok8) return AETHER_EHIP;
+                if (l == 1) { O.we = Gr.l1_msg_w0; O.ldwe = F1; O.ncols = F1; O.b1 = Gr.l1_msg_b0; O.nb_e = 2; }
+                else { O.we = Gr.ln_msg_w0[l - 2] + 2 * H; O.ldwe = 3 * H; O.ncols = H; O.b1 = nullptr; O.nb_e = 4; }
+                k_edge_acc8_reduce<<<dim3((FB_PART + 63) / 64), dim3(1024), 0, st>>>(partial, n_parts, O);
             } else if (acc_path) {
                 // large graphs: the two edge-level products of the layer accumulate inside the edge kernel (edge_acc.h)
                 const size_t lds_a = (size_t)(4 * SPLIT_WIMG + 4 * EA_STG) * 4;      // four split images + a staging pair per wave
@@ -972,7 +981,7 @@ int aether_set_option(const char* name, int value) {
         return AETHER_OK;
     }
     if (!strcmp(name, "edge_acc")) {                // changes aether_workspace_bytes(): set before sizing workspaces
-        g_edge_acc = value < 0 ? 0 : (value > 2 ? 2 : value);      // 0: row tensors + k_outer, 1: kb_edge_acc (round 3), 2: kb_edge_acc8
+        g_edge_acc = value < 0 ? 0 : (value > 3 ? 3 : value);      // 0: row tensors + k_outer, 1: kb_edge_acc (round 3), 2 / 3: kb_edge_acc8<8 / 4 waves>
         return AETHER_OK;
     }
     if (!strcmp(name, "outer_defer_max_edges")) {   // changes aether_workspace_bytes(): set before sizing workspaces

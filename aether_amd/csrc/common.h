@@ -202,7 +202,7 @@ __device__ __forceinline__ void split_T_issue(unsigned base, u32x2 (&lo)[3], u32
     for (int t = 0; t < 3; ++t)
         // fragment (mb, kb) of term t starts at ((mb KBN + kb) 64) 16 bytes; kb = ob >> 1, half = ob & 1
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                     : "=v"(lo[t]), "=v"(hi[t])
+                     : "=&v"(lo[t]), "=&v"(hi[t])     // early clobber: the first read's data may land before the second one issues
                      : "v"(base), "n"(t * TERM_BYTES + (((2 * mp) * KBN + (ob >> 1)) * 64) * 16 + (ob & 1) * 8),
                        "n"(t * TERM_BYTES + (((2 * mp + 1) * KBN + (ob >> 1)) * 64) * 16 + (ob & 1) * 8)
                      : "memory");

@@ -287,11 +287,52 @@ k_edge_acc_reduce(const float* __restrict__ partial, int n_wgs, EdgeAccOut O) {
 //     but the two tile halves, which go out as two partials per workgroup;
 //   * bias sums ride along as one more MFMA per k step against a column of ones.
 // 8 waves per workgroup, one workgroup per CU, <= 256 registers: two waves per SIMD.
+//
+// NW = 4 (option edge_acc = 3): the same kernel as TWO workgroups of four waves per CU.  Eight waves of one workgroup take
+// their barriers together, so a SIMD's two waves are always in the SAME phase (both in their bf16 GEMMs, then both in
+// their fp32 products): nothing overlaps.  Two independent workgroups drift apart.  Two of them fit the CU's LDS only
+// without the staging rows' padding (2 x 24 KB images + 4 x 8 KB = 80 KB): rows of 64 floats, 16-byte chunk c of row r
+// stored at chunk c ^ r (EaStg<true>) -- the 16-byte row writes and the k-step reads stay conflict-free.
 constexpr int EA8_WAVES = 8;
-constexpr int EA8_STG = 2 * 16 * FB_SA;              // staging floats per wave: one operand pair at a time
+template <bool SW> struct EaStg {
+    static constexpr int LD = SW ? H : FB_SA;
+    static constexpr int WAVE = 2 * 16 * LD;          // staging floats per wave: one operand pair at a time
+    // float offset of (row, col): col a multiple of 4 (16-byte access), of 2 (8-byte, `sub` = col & 3) or any (4-byte)
+    static __device__ __forceinline__ int at(int row, int col) {
+        if constexpr (SW) return row * H + ((((col >> 2) ^ row) & 15) << 2) + (col & 3);
+        else return row * FB_SA + col;
+    }
+};
 
-template <bool FIRST>
-__global__ void __launch_bounds__(64 * EA8_WAVES)
+// fb_outer16_q over staging rows addressed through EaStg<SW>
+template <int NB, bool COLSUM, bool SW>
+__device__ __forceinline__ void ea_outer16_q(const float* __restrict__ sa, const float* __restrict__ sb, f32x4 (&acc)[NB],
+                                             f32x4& colsum, int i, int q, int w) {
+    if constexpr (!SW) {
+        fb_outer16_q<NB, COLSUM>(sa, sb, acc, colsum, i, q, w);
+    } else {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = 4 * s4 + q;
+            const float av = sa[EaStg<true>::at(k, 4 * i + w)];
+            if constexpr (COLSUM) colsum = mfma16(av, 1.0f, colsum);
+            float bv[NB];
+            if constexpr (NB == 4) {
+                const f32x4 b4 = ld4(sb + EaStg<true>::at(k, 4 * i));
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bv[nb] = b4[nb];
+            } else {
+                const f32x2 b2 = *reinterpret_cast<const f32x2*>(sb + EaStg<true>::at(k, 2 * i));
+                bv[0] = b2[0]; bv[1] = b2[1];
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(av, bv[nb], acc[nb]);
+        }
+    }
+}
+
+template <bool FIRST, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, const float* __restrict__ Ps,
              const float* __restrict__ Pr, const float* __restrict__ e_prev, const float* __restrict__ feat,
              const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
@@ -303,17 +344,21 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wi = smem;                  // split image of W_in (FIRST: half of it is used)
     float* w2 = wi + SPLIT_WIMG;       // split image of W2
-    float* stg = w2 + SPLIT_WIMG;      // [8 waves][2][16][FB_SA]
-    for (int idx = threadIdx.x; idx < (FIRST ? SPLIT_WIMG / 2 : SPLIT_WIMG) / 4; idx += 64 * EA8_WAVES) st4(wi + 4 * idx, ld4(img_in + 4 * idx));
-    for (int idx = threadIdx.x; idx < SPLIT_WIMG / 4; idx += 64 * EA8_WAVES) st4(w2 + 4 * idx, ld4(img_2 + 4 * idx));
+    float* stg = w2 + SPLIT_WIMG;      // [NW waves][2][16][LD]
+    constexpr bool SW = NW == 4;
+    using S = EaStg<SW>;
+    constexpr int EA8_STG = S::WAVE;
+    static_assert(NW == 4 || NW == 8, "one or two groups of four row quarters");
+    for (int idx = threadIdx.x; idx < (FIRST ? SPLIT_WIMG / 2 : SPLIT_WIMG) / 4; idx += 64 * NW) st4(wi + 4 * idx, ld4(img_in + 4 * idx));
+    for (int idx = threadIdx.x; idx < SPLIT_WIMG / 4; idx += 64 * NW) st4(w2 + 4 * idx, ld4(img_2 + 4 * idx));
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
     float* sa = stg + wave * EA8_STG;   // dpre2, then G
-    float* sb = sa + 16 * FB_SA;        // h, then e_prev / features
+    float* sb = sa + 16 * S::LD;        // h, then e_prev / features
     const int wq = wave & 3, whalf = wave >> 2;          // accumulator rows 4 i' + wq, tiles 4 whalf .. of a round
     const int64_t tiles = (n_edges + 15) >> 4;
-    const int64_t stride = (int64_t)n_wgs * EA8_WAVES;
+    const int64_t stride = (int64_t)n_wgs * NW;
     f32x4 accW2[4], accWe[NBE], bs2 = f32x4{0.f, 0.f, 0.f, 0.f}, bs1 = bs2;
 #pragma unroll
     for (int b = 0; b < 4; ++b) accW2[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -323,7 +368,7 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
     // the HBM stream of the next round (e_prev / features and the incoming message gradient) is requested a round ahead;
     // the gathered rows (P_s, P_r, dn: L2 hits) when the tile starts -- the SIMD's other wave covers that round trip
     f32x4 nbop[4], ndev[4];
-    int64_t t0 = (int64_t)blockIdx.x * EA8_WAVES;
+    int64_t t0 = (int64_t)blockIdx.x * NW;
     {
         const int64_t k0 = clampk(t0 + wave < tiles ? t0 + wave : tiles - 1);
         if (FIRST) { nbop[0] = ld4(feat + k0 * FPAD + 4 * q); nbop[1] = ld4(feat + k0 * FPAD + 16 + 4 * q); }
@@ -386,8 +431,8 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
                 d2[mb] = de * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
                 if (!ok) d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};             // rows past the end contribute nothing to the products
                 dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
-                st4(sb + i * FB_SA + 16 * mb + 4 * q, h[mb]);
+                st4(sa + S::at(i, 16 * mb + 4 * q), d2[mb]);
+                st4(sb + S::at(i, 16 * mb + 4 * q), h[mb]);
             }
             gemm_split_T<2>(w2, d2, dh, lane);                          // W2^T dpre2 from the forward's image
 #pragma unroll
@@ -415,7 +460,7 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
         for (int tt = 0; tt < 4; ++tt) {
             if (t0 + 4 * whalf + tt < tiles) {
                 const float* ta = stg + (4 * whalf + tt) * EA8_STG;
-                fb_outer16_q<4, true>(ta, ta + 16 * FB_SA, accW2, bs2, i, q, wq);
+                ea_outer16_q<4, true, SW>(ta, ta + 16 * S::LD, accW2, bs2, i, q, wq);
             }
         }
         lds_barrier();
@@ -423,8 +468,8 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
         if (active) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                st4(sa + i * FB_SA + 16 * mb + 4 * q, g[mb]);          // (g of a row past the end is 0: dh = W2^T 0)
-                if (!FIRST || mb < 2) st4(sb + i * FB_SA + 16 * mb + 4 * q, bop[mb]);
+                st4(sa + S::at(i, 16 * mb + 4 * q), g[mb]);            // (g of a row past the end is 0: dh = W2^T 0)
+                if (!FIRST || mb < 2) st4(sb + S::at(i, 16 * mb + 4 * q), bop[mb]);
             }
         }
         lds_barrier();
@@ -432,13 +477,13 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
         for (int tt = 0; tt < 4; ++tt) {
             if (t0 + 4 * whalf + tt < tiles) {
                 const float* ta = stg + (4 * whalf + tt) * EA8_STG;
-                fb_outer16_q<NBE, FIRST>(ta, ta + 16 * FB_SA, accWe, bs1, i, q, wq);
+                ea_outer16_q<NBE, FIRST, SW>(ta, ta + 16 * S::LD, accWe, bs1, i, q, wq);
             }
         }
         lds_barrier();
     }
     // ---- two partials per workgroup (tile halves 0 / 1), each wave its row quarter: [dW2 64 x 64 | dW_e 64 x 64 (64 x 32) | db2 | db1]
-    float* dst = partial + ((size_t)blockIdx.x * 2 + whalf) * FB_PART;
+    float* dst = partial + ((size_t)blockIdx.x * (NW / 4) + whalf) * FB_PART;
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         const int mrow = 4 * (4 * q + r4) + wq;

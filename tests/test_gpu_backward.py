@@ -135,7 +135,8 @@ def test_edge_level_weight_gradients_accumulated_in_the_edge_kernel(D):
         res = {}
         try:
             _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 0), "set_option")
-            for acc in (2, 1, 0, 1, 2):        # 2: kb_edge_acc8 (round 4, two waves per SIMD), 1: kb_edge_acc, 0: row tensors
+            # 3 / 2: kb_edge_acc8 (round 4, two waves per SIMD: two workgroups of four / one of eight), 1: kb_edge_acc, 0: row tensors
+            for acc in (3, 2, 1, 0, 1, 2, 3):
                 _lib.check(lib.aether_set_option(b"edge_acc", acc), "set_option")
                 _, g = _loss_backward(m, inp)
                 if acc in res:
@@ -145,7 +146,7 @@ def test_edge_level_weight_gradients_accumulated_in_the_edge_kernel(D):
         finally:
             _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 1 << 20), "set_option")
             _lib.check(lib.aether_set_option(b"edge_acc", DEFAULT_EDGE_ACC), "set_option")
-        for acc in (1, 2):
+        for acc in (1, 2, 3):
             for k in res[acc]:
                 assert torch.isfinite(res[acc][k]).all(), k
                 assert scale_rel_err(res[acc][k], sdg[k].grad) <= GTOL, (acc, B, N, k)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the config-5 shard's training steps.   usage: tools/cfg5_train_prof.sh [edge_acc option 0|1|2]
+# rocprofv3 kernel stats of the config-5 shard's training steps.   usage: tools/cfg5_train_prof.sh [edge_acc option 0|1|2|3]
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 acc=${1:-2}
 out=$root/gpurun_out/cfg5train_$acc

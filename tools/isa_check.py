@@ -24,6 +24,13 @@ Scans the gfx950 disassembly of every kernel.
       of a 480-byte kernarg segment) on a 2-D grid; as a graph node replayed back to back it ended in a GPU memory access
       fault (20 of 20 runs).  With the workgroup count as an explicit argument the same reproducer passes.
 
+  R5  (FAILS the check) an instruction that names the destination of a `ds_read_b64_tr_b16` still in flight (issued from inline
+      asm, waited for by a hand-placed s_waitcnt).  Round 4's gemm_split_T issued two reads per asm statement with plain "=v"
+      outputs: in k_fused_bwd<3> the compiler gave the first read's destination the register of the address (its last use),
+      so the second read took its address from a register the first read was about to overwrite -- right whenever the second
+      read issued before the first one's data landed, i.e. nearly always: one test failure in three full runs.  The outputs
+      are early-clobber now; this rule keeps it that way.
+
 Usage: isa_check.py [libaether_hip.so | file.s] [--all] [--kernel SUBSTR]
 """
 from __future__ import annotations
@@ -169,6 +176,42 @@ def check_kernel(body):
     return dict(bf16=bf16, r1=r1, r2=r2, r3=r3, agpr_loads=n_agpr_loads)
 
 
+_LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+
+
+def check_async_lds_dest(body):
+    """Rule R5 -> [(instruction, (first, last))]: an instruction that names a register a `ds_read_b64_tr_b16` (issued from
+    inline asm, waited for by a hand-written `s_waitcnt lgkmcnt(n)`) has not yet delivered.  The compiler believes an asm
+    statement's outputs are ready when the statement ends: it may hand the same register to a later operand of that statement
+    (outputs that are not early-clobber: the address of the statement's second read) or copy it before the wait.  Either
+    reads or overwrites a register with a load still in flight -- works until the load happens to land first.
+    Linear scan; LDS and scalar-memory operations are taken to complete in order (true for LDS alone)."""
+    outstanding, viol = [], []
+    for ins in body:
+        op = ins.split()[0]
+        if op == "s_waitcnt":
+            m = _LGKM.search(ins)
+            if m:
+                n = int(m.group(1))
+                outstanding = outstanding[len(outstanding) - n:] if n else []
+            continue
+        live = [d for d in outstanding if d]
+        if live:
+            for tok in operands(ins):
+                r = regs(tok)
+                hit = next((d for d in live if r and r[0] == "v" and not (r[2] < d[0] or d[1] < r[1])), None)
+                if hit:
+                    viol.append((ins, hit))
+                    break
+        if op.startswith(("ds_", "s_load", "s_buffer_load")):
+            d = None
+            if op.startswith("ds_read_b64_tr"):
+                r = regs(operands(ins)[0])
+                d = (r[1], r[2])
+            outstanding.append(d)
+    return viol
+
+
 def main(argv):
     path = next((a for a in argv if not a.startswith("--")), DEFAULT_LIB)
     show_all = "--all" in argv
@@ -181,7 +224,12 @@ def main(argv):
             continue
         n += 1
         res = check_kernel(body)
-        flagged = bool(res["r3"])
+        r5 = check_async_lds_dest(body)
+        flagged = bool(res["r3"]) or bool(r5)
+        if r5:
+            print(f"FAIL {name}: R5(register of a transposed LDS read in flight is named before its wait)={len(r5)}")
+            for ins, d in r5[:3]:
+                print(f"     R5: {ins}   (v[{d[0]}:{d[1]}] in flight)")
         if flagged or (show_all and (res["r1"] or res["r2"] or res["agpr_loads"])):
             print(f"{'FAIL' if flagged else 'note'} {name}: R3(packed fp32 op_sel on src0/src1)={len(res['r3'])} "
                   f"bf16_mfma={res['bf16']} agpr_loads={res['agpr_loads']} R1(load->SrcC)={len(res['r1'])} "
