@@ -44,7 +44,7 @@ def gumbel_softmax_hard(logits, uniform, tau):
 
 
 def filter_image(cache, name, w, n_features, hidden):
-    """bf16 x 3 image of a filter bank ``w`` [n_features * hidden, hidden] for the matrix cores
+    """Two-piece fp16 image of a filter bank ``w`` [n_features * hidden, hidden] for the matrix cores
     (``aether_s2s_filter_prepare``), kept in ``cache[name]`` and rebuilt -- into the same buffer, which captured graphs
     point at -- whenever the weight tensor moved or was written to."""
     key = (w.data_ptr(), w._version, str(w.device))

@@ -416,8 +416,10 @@ typedef struct AetherS2SPriorParams {
                                  step then builds the image in its workspace on every call (reads all of filt_w2) */
 } AetherS2SPriorParams;
 /*
- * The filter GEMM (anisotropic_filter.py:34-40) runs as bf16 x 3 matrix-core terms (fp32-equivalent); its
- * weight operand is a re-ordered three-piece image of filt_w2 (6 bytes per weight).  Prepare it once per weight version:
+ * The filter GEMM (anisotropic_filter.py:34-40) runs on the matrix cores as three fp16 terms on operands split into two
+ * fp16 pieces each, scaled by exact powers of two (22 significand bits: fp32-equivalent at the 1e-5 bar); its
+ * weight operand is a re-ordered two-piece image of filt_w2 (4 bytes per weight + a 256-byte trailer holding max |filt_w2|,
+ * from which the scale is derived).  Prepare it once per weight version (three small launches on `stream`):
  *   image : device buffer of aether_s2s_filter_image_bytes(n_features, hidden) bytes, 16-byte aligned
  */
 size_t aether_s2s_filter_image_bytes(int n_features, int hidden);

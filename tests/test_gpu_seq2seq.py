@@ -279,7 +279,7 @@ def test_prior_step_variants_vs_oracle(D, layers, rep):
 
 @pytest.mark.parametrize("D,N,B,H", [(2, 3, 5, 128), (3, 7, 9, 256), (2, 12, 5, 512)])
 def test_filter_gemm_split_counts_and_ragged_tiles_vs_oracle(D, N, B, H):
-    """The bf16 x 3 filter GEMM (csrc/s2s_filter.h) at edge counts that are not multiples of its 16-edge fragment blocks or
+    """The split-fp16 filter GEMM (csrc/s2s_filter.h) at edge counts that are not multiples of its 16-edge fragment blocks or
     256-edge tiles (30, 378, 660 edges), for every k-split count the hidden size allows (1, 2, 4, 8: one plane per split,
     added in order), with the weight image prepared by the module and, through the C ABI directly, built per call
     (filt_image = NULL)."""
@@ -322,8 +322,44 @@ def test_filter_gemm_split_counts_and_ragged_tiles_vs_oracle(D, N, B, H):
         lib.aether_set_option(b"filter_splits", 0)
 
 
+@pytest.mark.parametrize("log2_scale", [20, -20])
+def test_filter_gemm_is_indifferent_to_the_magnitude_of_its_weights(log2_scale):
+    """The filter GEMM splits its operands into fp16 pieces (round 4); fp16 spans 2^-24 .. 65,504, so weights of 1e-8 or
+    5e4 would be flushed / overflow unscaled.  The image and the hidden rows carry exact power-of-two scales instead
+    (csrc/s2s_filter.h).  Here the filter bank, its bias and res1 (added to the filter's node sums) are multiplied by
+    2^+-20 and every layer that reads the filter's output by 2^-+20: the same function of the inputs up to fp32 rounding --
+    held to the oracle's result for the UNSCALED weights at the usual tolerance."""
+    from aether_amd.nn.seq2seq.encoder import Encoder
+    D, N, B, H, R = 2, 6, 5, 128, 32
+    params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
+              "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "input_size": 2 * D, "encoder_mlp_num_layers": 1,
+              "encoder_mlp_hidden": 32, "prior_num_layers": 1, "prior_hidden_size": 48, "use_3d": False,
+              "pos_representation": "polar"}
+    torch.manual_seed(55)
+    enc = Encoder(params, device="cuda").eval()
+    g = torch.Generator().manual_seed(56)
+    E = N * (N - 1)
+    x = torch.randn(B, N, 2 * D, generator=g)
+    f = torch.randn(B, N, D, generator=g) * 0.3
+    st = (torch.randn(B, E, R, generator=g) * 0.3, torch.randn(B, E, R, generator=g) * 0.3)
+    sd = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    want_l, (want_h, want_c) = S.prior_step(sd, x, st, f, False, "polar", 1)
+    up, down = 2.0 ** log2_scale, 2.0 ** -log2_scale
+    with torch.no_grad():
+        enc.edge_filter.edge_filter[2].weight.mul_(up)
+        enc.edge_filter.edge_filter[2].bias.mul_(up)
+        enc.res1.weight.mul_(up)
+        enc.res1.bias.mul_(up)
+        enc.mlp3.model[0].weight.mul_(down)                 # reads edge2node(filter output) + res1
+        enc.mlp4.model[0].weight[:, 2 * H:].mul_(down)      # reads the filter output (the edge third of [send | recv | edge])
+    got_l, (got_h, got_c) = enc.single_step_forward(x.cuda(), (st[0].cuda(), st[1].cuda()), f.cuda())
+    for got, want in ((got_l, want_l), (got_h, want_h), (got_c, want_c)):
+        assert torch.isfinite(got).all()
+        assert scale_rel_err(got.cpu(), want) <= TOL, log2_scale
+
+
 def test_filter_image_follows_weight_updates():
-    """The cached bf16 x 3 image of the filter bank is rebuilt when the weight tensor is written to (in place)."""
+    """The cached two-piece fp16 image of the filter bank is rebuilt when the weight tensor is written to (in place)."""
     from aether_amd.nn.seq2seq.encoder import Encoder
     D, N, B, H, R = 2, 4, 3, 128, 32
     params = {"num_vars": N, "num_edge_types": 2, "encoder_dropout": 0.0, "encoder_hidden": H,
