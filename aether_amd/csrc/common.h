@@ -96,19 +96,33 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ w, int ldw,
     }
 }
 
-// ------------------------------------------------------------------ fp32 contraction as six bf16 MFMA terms
+// ------------------------------------------------------------------ fp32 contractions on the matrix pipe: split operands
 // v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and on the vector ALUs: 32 cycles for 2,048 FLOP,
-// and every VALU instruction next to it costs matrix time.  v_mfma_f32_16x16x32_bf16 does 16,384 FLOP in 16 cycles on
-// the matrix pipe proper.  An fp32 operand x splits exactly into three bf16 pieces, x = hi + mid + lo + r with
-// |r| <= 2^-24 |x| (each piece: round-to-nearest of what the pieces before it left), and
-//     w * x = hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid   + terms <= 2^-22 |w x| relative to each other's sum,
-// each product of two bf16 being exact in fp32 and the MFMA accumulating in fp32.  Measured on the MI355X against an fp64
-// evaluation of the edge MLP (tools/micro/split_tile.hip): 2.3e-7 scale-relative vs 2.9e-7 for the fp32 MFMA chain --
-// the same fp32-level result, for 6 x 16 cycles per 32-deep k block instead of 8 x 32 (1.75 x on the tile's MLP).
-constexpr int SPLIT_WIMG = 3 * 4 * 2 * 64 * 4;          // floats of the split image of a 64 x 64 matrix (3 terms x 8 KB)
+// and every VALU instruction next to it costs matrix time.  The 16-bit MFMAs (v_mfma_f32_16x16x32_{bf16,f16}) do 16,384
+// FLOP in 16 cycles on the matrix pipe proper, accumulating in fp32; products of two 16-bit pieces are exact in fp32.
+//
+// Rounds 1-3 (still: csrc/wide.h, the seq2seq dense layers): three bf16 pieces per operand, x = hi + mid + lo + r with
+// |r| <= 2^-24 |x|, and SIX terms  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (the rest <= 2^-22 relative).
+//
+// Round 4 (the hidden-64 kernels: gemm_split / gemm_split_T below): two fp16 pieces, x = hi + lo with hi = fp16(x),
+// lo = fp16(x - hi) -- 22 significand bits -- and THREE terms  hi*hi + hi*lo + lo*hi  (lo*lo <= 2^-22 relative): half the
+// MFMAs and 2.5 instead of 5 vector instructions per split value, for an error of 2^-22 instead of 2^-24 per product
+// (parity bar: 1e-5 = 2^-16.6).  fp16 has a narrow exponent range (normal from 2^-14, top 65,504); it is handled so:
+//   * weights are split as they are: a weight's lo piece is a subnormal below |w| = 2^-3 (absolute error <= 2^-25 there),
+//     which the fp16 MFMA reads exactly; |w| >= 65,504 cannot be represented (outputs come out non-finite, not wrong);
+//   * activations / gradients are checked per wave and GEMM: the wave's max |x| (7 DPP steps + a read-lane) decides between
+//     the plain path (2^-6 <= max < 2^15: every value's error is <= 2^-22 of the wave's maximum) and a path that multiplies
+//     operand and accumulator by an exact power of two first (max -> 2^13..2^14) and the accumulator back after.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- three bf16 pieces (wide.h, s2s_step.h)
 __device__ __forceinline__ void split_bf16x3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
     const float r1 = x - (float)h;
@@ -120,8 +134,7 @@ __device__ __forceinline__ void split_bf16x3(float x, __bf16& h, __bf16& m, __bf
 // of the natural one; weight images (stage_split_*) are written in the same order.
 // Written on pairs: the two conversions of a pair are one v_cvt_pk_bf16_f32, the two subtractions one v_pk_add_f32
 // (the library is built without the SLP vectoriser, build.py, so packed math is whatever the sources spell out).
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+__device__ __forceinline__ void split8_bf3(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const f32x2 x = p < 2 ? f32x2{v0[2 * p], v0[2 * p + 1]} : f32x2{v1[2 * p - 4], v1[2 * p - 3]};
@@ -135,11 +148,11 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& h
         lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
     }
 }
-// Weight image for split GEMMs: [term 3][row block mb][k block kb][lane 64] fragments of 8 bf16 (16 bytes); lane (m, q)
+// bf16 x 3 weight image: [term 3][row block mb][k block kb][lane 64] fragments of 8 bf16 (16 bytes); lane (m, q)
 // of fragment (mb, kb) holds W[16 mb + m][32 kb + 4 q + j] (j < 4) | W[16 mb + m][32 kb + 16 + 4 q + j].
 // `v` = W[row][col .. col + 3] (col a multiple of 4): one half-fragment (8 bytes) per term.
 template <int MBN, int KBN>
-__device__ __forceinline__ void stage_split4(float* img, int row, int col, const f32x4 v) {
+__device__ __forceinline__ void stage_split4_bf3(float* img, int row, int col, const f32x4 v) {
     const int mb = row >> 4, m = row & 15, kb = col >> 5, c5 = col & 31, half = c5 >> 4, qq = (c5 & 15) >> 2;
     bf16x4 h, md, l;
 #pragma unroll
@@ -154,28 +167,109 @@ __device__ __forceinline__ void stage_split4(float* img, int row, int col, const
     *reinterpret_cast<bf16x4*>(img + (TERM + frag) * 4 + half * 2) = md;
     *reinterpret_cast<bf16x4*>(img + (2 * TERM + frag) * 4 + half * 2) = l;
 }
+
+// ---- two fp16 pieces (the hidden-64 kernels)
+constexpr int SPLIT_WIMG = 2 * 4 * 2 * 64 * 4;          // floats of the split image of a 64 x 64 matrix (2 terms x 8 KB)
+__device__ __forceinline__ void split_f16x2(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
+}
+// The lane's B fragment of one 32-deep k block from two accumulator-layout blocks (element order as split8_bf3), on pairs:
+// v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 -- five instructions per two values.
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x2 x = p < 2 ? f32x2{v0[2 * p], v0[2 * p + 1]} : f32x2{v1[2 * p - 4], v1[2 * p - 3]};
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 r = x - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+        lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
+    }
+}
+// fp16 x 2 weight image: [term 2][row block mb][k block kb][lane 64] fragments of 8 fp16 (16 bytes); lane (m, q) of
+// fragment (mb, kb) holds W[16 mb + m][32 kb + 4 q + j] (j < 4) | W[16 mb + m][32 kb + 16 + 4 q + j].
+// `v` = W[row][col .. col + 3] (col a multiple of 4): one half-fragment (8 bytes) per term.
+template <int MBN, int KBN>
+__device__ __forceinline__ void stage_split4(float* img, int row, int col, const f32x4 v) {
+    const int mb = row >> 4, m = row & 15, kb = col >> 5, c5 = col & 31, half = c5 >> 4, qq = (c5 & 15) >> 2;
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        _Float16 a, b;
+        split_f16x2(v[j], a, b);
+        h[j] = a; l[j] = b;
+    }
+    const int frag = (mb * KBN + kb) * 64 + m + 16 * qq;
+    constexpr int TERM = MBN * KBN * 64;                        // fragments per term
+    *reinterpret_cast<f16x4*>(img + (frag) * 4 + half * 2) = h;
+    *reinterpret_cast<f16x4*>(img + (TERM + frag) * 4 + half * 2) = l;
+}
+
+// Biased fp32 exponent field of the wave's maximum of m (m >= 0 in every lane): row_shr 1, 2, 4, 8 leave a row's maximum in
+// its lane 15, row_bcast 15 / 31 carry it on to lane 63 (out-of-range source lanes read 0, the identity); read-lane 63.
+__device__ __forceinline__ unsigned wave_max_exponent(float m) {
+    int v = __float_as_int(m);                                  // non-negative floats order like their bit patterns
+#define AETHER_DPP_MAX(CTRL) { const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); v = o > v ? o : v; }
+    AETHER_DPP_MAX(0x111) AETHER_DPP_MAX(0x112) AETHER_DPP_MAX(0x114) AETHER_DPP_MAX(0x118) AETHER_DPP_MAX(0x142) AETHER_DPP_MAX(0x143)
+#undef AETHER_DPP_MAX
+    return ((unsigned)__builtin_amdgcn_readlane(v, 63) >> 23) & 255u;
+}
+// What a GEMM's activation operand needs before it is split into fp16 pieces: nothing (biased exponent of the wave's maximum
+// in [121, 141], i.e. 2^-6 <= max < 2^15; or 0: all zeros), or a power-of-two scale that puts the maximum into 2^13..2^14
+// (exponent clamped to +-40).  Wave-uniform.
+struct SplitScale { bool on; float s, inv_s; };
+template <int N>
+__device__ __forceinline__ SplitScale split_scale_of(const f32x4 (&act)[N]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int b = 0; b < N; ++b) m = fmaxf(fmaxf(m, fmaxf(fabsf(act[b][0]), fabsf(act[b][1]))), fmaxf(fabsf(act[b][2]), fabsf(act[b][3])));
+    const unsigned E = wave_max_exponent(m);
+    SplitScale r;
+    r.on = !(E == 0u || E - 121u <= 20u);
+    int sh = 140 - (int)E;                                      // max (2^(E-127) ..) -> 2^13 ..
+    sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
+    r.s = __int_as_float((127 + sh) << 23);
+    r.inv_s = __int_as_float((127 - sh) << 23);
+    return r;
+}
+
+template <int MBN, int KBN>
+__device__ __forceinline__ void gemm_split_core(const f16x8* __restrict__ w, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN], int lane) {
+    constexpr int TERM = MBN * KBN * 64;
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+        f16x8 xh, xl;
+        split8(act[2 * kb], act[2 * kb + 1], xh, xl);
+#pragma unroll
+        for (int mb = 0; mb < MBN; ++mb) {
+            const int frag = (mb * KBN + kb) * 64 + lane;
+            const f16x8 wh = w[frag], wl = w[TERM + frag];
+            // small terms first
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[mb], 0, 0, 0);
+        }
+    }
+}
 // acc[mb] += W[16 mb + i][k] * act[item][k] over KBN 32-deep k blocks; act = 2 KBN accumulator-layout blocks.
 template <int MBN, int KBN>
 __device__ __forceinline__ void gemm_split(const float* __restrict__ img, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN],
                                            int lane) {
-    constexpr int TERM = MBN * KBN * 64;
-    const bf16x8* w = reinterpret_cast<const bf16x8*>(img);
+    const SplitScale sc = split_scale_of(act);
+    f32x4 x[2 * KBN];
 #pragma unroll
-    for (int kb = 0; kb < KBN; ++kb) {
-        bf16x8 xh, xm, xl;
-        split8(act[2 * kb], act[2 * kb + 1], xh, xm, xl);
+    for (int b = 0; b < 2 * KBN; ++b) x[b] = act[b];
+    if (sc.on) {                                                // (wave-uniform)
 #pragma unroll
-        for (int mb = 0; mb < MBN; ++mb) {
-            const int frag = (mb * KBN + kb) * 64 + lane;
-            const bf16x8 wh = w[frag], wm = w[TERM + frag], wl = w[2 * TERM + frag];
-            // small terms first
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[mb], 0, 0, 0);
-        }
+        for (int b = 0; b < 2 * KBN; ++b) x[b] = x[b] * sc.s;
+#pragma unroll
+        for (int mb = 0; mb < MBN; ++mb) acc[mb] = acc[mb] * sc.s;
+    }
+    gemm_split_core<MBN, KBN>(reinterpret_cast<const f16x8*>(img), x, acc, lane);
+    if (sc.on) {
+#pragma unroll
+        for (int mb = 0; mb < MBN; ++mb) acc[mb] = acc[mb] * sc.inv_s;
     }
 }
 
@@ -185,21 +279,18 @@ __device__ __forceinline__ void gemm_split(const float* __restrict__ img, const 
 // block (act = 4 accumulator-layout blocks), the outputs are W's columns, OB = 2 KBN blocks of 16.
 // The A fragment a lane needs -- 8 values of ONE column from 8 different rows -- lies in 8 different fragments of the image:
 // ds_read_b64_tr_b16 gathers it.  Per group of 16 lanes (lanes 16 g .. 16 g + 15; g = this lane's q, which selects rows
-// 4 g .. 4 g + 3 of a 16-row block) the instruction reads 4 rows x 16 columns of bf16 and returns them column-major: lane
-// 4 r + p of the group supplies the address of row r, columns 4 p .. 4 p + 3 (8 bytes: one half-fragment of the image,
+// 4 g .. 4 g + 3 of a 16-row block) the instruction reads 4 rows x 16 columns of 16-bit values and returns them column-major:
+// lane 4 r + p of the group supplies the address of row r, columns 4 p .. 4 p + 3 (8 bytes: one half-fragment of the image,
 // lane slot (4 g + r) + 16 p, half = ob & 1); lane c receives column c of the four rows.  Two reads (row blocks 2 mp and
 // 2 mp + 1) make the 8-element fragment in gemm_split's k order.  Addresses of the four p lanes are 256 bytes apart: a
-// 4-way bank conflict per read (16 instead of 4 LDS cycles) -- 48 reads per 64 x 64 product, ~770 LDS cycles per tile,
-// against 1,300 cycles of vector-ALU time the fp32 MFMA form of the same product holds (64 x v_mfma_f32_16x16x4_f32).
+// 4-way bank conflict per read (16 instead of 4 LDS cycles) -- 32 reads per 64 x 64 product.
 // EXEC must be all ones (the gather crosses lanes).
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// the six transposed reads of block BLK = (mp, ob): rows 32 mp .. of W (two 16-row blocks), columns 16 ob .. of W
+// the four transposed reads of block BLK = (mp, ob): rows 32 mp .. of W (two 16-row blocks), columns 16 ob .. of W
 template <int KBN, int BLK>
-__device__ __forceinline__ void split_T_issue(unsigned base, u32x2 (&lo)[3], u32x2 (&hi)[3]) {
+__device__ __forceinline__ void split_T_issue(unsigned base, u32x2 (&lo)[2], u32x2 (&hi)[2]) {
     constexpr int TERM_BYTES = 4 * KBN * 64 * 16, OB = 2 * KBN, mp = BLK / OB, ob = BLK % OB;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 2; ++t)
         // fragment (mb, kb) of term t starts at ((mb KBN + kb) 64) 16 bytes; kb = ob >> 1, half = ob & 1
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                      : "=&v"(lo[t]), "=&v"(hi[t])     // early clobber: the first read's data may land before the second one issues
@@ -208,47 +299,57 @@ __device__ __forceinline__ void split_T_issue(unsigned base, u32x2 (&lo)[3], u32
                      : "memory");
 }
 template <bool LAST>
-__device__ __forceinline__ void split_T_consume(u32x2 (&lo)[3], u32x2 (&hi)[3], const bf16x8 xh, const bf16x8 xm, const bf16x8 xl,
-                                                f32x4& acc) {
-    // LDS returns in order: lgkmcnt(6) leaves exactly the next block's six reads outstanding
+__device__ __forceinline__ void split_T_consume(u32x2 (&lo)[2], u32x2 (&hi)[2], const f16x8 xh, const f16x8 xl, f32x4& acc) {
+    // LDS returns in order: lgkmcnt(4) leaves exactly the next block's four reads outstanding
     if constexpr (LAST)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]));
     else
-        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]));
-    bf16x8 w[3];
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]));
+    f16x8 w[2];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < 2; ++t) {
         const u32x4 v = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
-        w[t] = __builtin_bit_cast(bf16x8, v);
+        w[t] = __builtin_bit_cast(f16x8, v);
     }
-    const bf16x8 wh = w[0], wm = w[1], wl = w[2];
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);
+    const f16x8 wh = w[0], wl = w[1];
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);
 }
 template <int KBN, int BLK>
-__device__ __forceinline__ void split_T_step(unsigned base, u32x2 (&lo)[2][3], u32x2 (&hi)[2][3], const bf16x8 (&xh)[2],
-                                             const bf16x8 (&xm)[2], const bf16x8 (&xl)[2], f32x4 (&acc)[2 * KBN]) {
+__device__ __forceinline__ void split_T_step(unsigned base, u32x2 (&lo)[2][2], u32x2 (&hi)[2][2], const f16x8 (&xh)[2],
+                                             const f16x8 (&xl)[2], f32x4 (&acc)[2 * KBN]) {
     constexpr int OB = 2 * KBN, NBLK = 2 * OB, mp = BLK / OB, ob = BLK % OB;
     if constexpr (BLK + 1 < NBLK) split_T_issue<KBN, BLK + 1>(base, lo[(BLK + 1) & 1], hi[(BLK + 1) & 1]);
-    split_T_consume<BLK + 1 == NBLK>(lo[BLK & 1], hi[BLK & 1], xh[mp], xm[mp], xl[mp], acc[ob]);
-    if constexpr (BLK + 1 < NBLK) split_T_step<KBN, BLK + 1>(base, lo, hi, xh, xm, xl, acc);
+    split_T_consume<BLK + 1 == NBLK>(lo[BLK & 1], hi[BLK & 1], xh[mp], xl[mp], acc[ob]);
+    if constexpr (BLK + 1 < NBLK) split_T_step<KBN, BLK + 1>(base, lo, hi, xh, xl, acc);
 }
 template <int KBN>
 __device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, const f32x4 (&act)[4], f32x4 (&acc)[2 * KBN],
                                              int lane) {
     const int g = lane >> 4, r = (lane & 15) >> 2, p = lane & 3;
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)img + ((4 * g + r) + 16 * p) * 16;
-    bf16x8 xh[2], xm[2], xl[2];
-    split8(act[0], act[1], xh[0], xm[0], xl[0]);
-    split8(act[2], act[3], xh[1], xm[1], xl[1]);
-    // software pipeline over the blocks (mp, ob): the six reads of block n + 1 are in flight while block n's six MFMAs issue
-    u32x2 lo[2][3], hi[2][3];
+    const SplitScale sc = split_scale_of(act);
+    f32x4 x[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x[b] = act[b];
+    if (sc.on) {                                                // (wave-uniform; gradients are usually far below 2^-6)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x[b] = x[b] * sc.s;
+#pragma unroll
+        for (int ob = 0; ob < 2 * KBN; ++ob) acc[ob] = acc[ob] * sc.s;
+    }
+    f16x8 xh[2], xl[2];
+    split8(x[0], x[1], xh[0], xl[0]);
+    split8(x[2], x[3], xh[1], xl[1]);
+    // software pipeline over the blocks (mp, ob): the four reads of block n + 1 are in flight while block n's three MFMAs issue
+    u32x2 lo[2][2], hi[2][2];
     split_T_issue<KBN, 0>(base, lo[0], hi[0]);
-    split_T_step<KBN, 0>(base, lo, hi, xh, xm, xl, acc);
+    split_T_step<KBN, 0>(base, lo, hi, xh, xl, acc);
+    if (sc.on) {
+#pragma unroll
+        for (int ob = 0; ob < 2 * KBN; ++ob) acc[ob] = acc[ob] * sc.inv_s;
+    }
 }
 
 // Cooperative copy of W[rows][cols] (global, row stride src_ld) into LDS [rows][ldw], zero padded.

@@ -31,7 +31,7 @@ constexpr int LDU = 2 * H + 8;               // padded LDS row for the 128-wide 
 // weight images (3 x 8 KB each instead of 18 KB of padded fp32) fit every variant since the layer-1 features of the
 // 17-24 tile one are built two rounds at a time.
 template <int ROUNDS> constexpr bool fused_split_gemm() { return true; }
-constexpr int FUSED_WIMG = SPLIT_WIMG;                   // floats of a split image of a 64 x 64 matrix (24 KB)
+constexpr int FUSED_WIMG = SPLIT_WIMG;                   // floats of a split image of a 64 x 64 matrix (16 KB)
 template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
     static constexpr int WSZ = fused_split_gemm<ROUNDS>() ? FUSED_WIMG : H * LDW;
     static constexpr int WA = 0;                                   // W_e  (layer 1: W1): [64][LDW] fp32 (ld LDF) | split image
@@ -344,7 +344,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     auto dma_images = [&](int layer_) {
         const float* ga = dbg.wimg + fused_wimg_offset(layer_, 0);
         const float* gb = dbg.wimg + fused_wimg_offset(layer_, 1);
-        const int na_frag = layer_ == 1 ? 12 : 24, total = na_frag + 24;      // 1 KiB fragments: 3 terms x 4 (x 2)
+        const int na_frag = layer_ == 1 ? 8 : 16, total = na_frag + 16;       // 1 KiB fragments: 2 terms x 4 (x 2)
         for (int f = wave; f < total; f += NW) {
             const float* src = f < na_frag ? ga + f * 256 : gb + (f - na_frag) * 256;
             float* dst = f < na_frag ? wA + f * 256 : wB + (f - na_frag) * 256;

@@ -42,12 +42,12 @@ struct FbLds {                                // offsets in floats
     // (mb, a) is W[16 mb + i][16 a + 4 q .. + 3].  One fragment = 1 KiB contiguous = one LDS-DMA wave instruction with
     // per-lane source addresses (fb_stage_frags), and the fragment reads are lane-linear: no padding, no conflicts.
     // W_e and W2 -- the two recompute GEMMs of a tile -- are the forward's split (3 x bf16) images, copied as they lie
-    // in the workspace (k_prepare_weights; common.h gemm_split): 24 KB each instead of 16.
+    // in the workspace (k_prepare_weights; common.h gemm_split): 16 KB each.
     static constexpr int WE = 0;                                   // W_e   split image (layer 1: W1, K = 32: half of it)
     static constexpr int W2 = WE + SPLIT_WIMG;                     // W2    split image
-    static constexpr int W2T = W2 + SPLIT_WIMG;                    // W2^T  fp32 fragments
-    static constexpr int WET = W2T + H * H;                        // W_e^T (layer 1: W1^T, 32 rows: 8 fragments)
-    static constexpr int WEND = WET + H * H;                       // (the images' region also holds the dumps below)
+    static constexpr int W2T = W2 + SPLIT_WIMG;                    // G staging of the tile rounds (rounds 1-3: W2^T, W_e^T fragments)
+    static constexpr int WEND = 2 * 4 * FUSED_MAX_NODES * LDST;    // the region of images + G staging also holds the dumps below
+    static_assert(WEND >= W2T + 4 * 16 * FB_SA, "images + G staging inside the dump region");
     static_assert(2 * 4 * FUSED_MAX_NODES * LDST <= WEND, "per-wave dumps alias the weight images");
     static constexpr int BIAS = WEND;                              // [64] b2 | [64] b1 (layer 1)
     static constexpr int PSB = BIAS + 2 * H;                       // [32][LDW]  P_s (visible slots) -> total dP_s
@@ -68,7 +68,6 @@ struct FbLds {                                // offsets in floats
     static constexpr int DUMP_R = 4 * FUSED_MAX_NODES * LDST;
     static_assert(DPU + FUSED_MAX_NODES * LDU <= TOTAL, "node-phase buffers alias the staging");
     static_assert(DUMP_R + 4 * FUSED_MAX_NODES * LDST <= WEND, "dumps alias the weight images");
-    static_assert(2 * 2 * H * H <= WEND, "weight-gradient reduction aliases the weight images");
     static_assert(TOTAL * 4 <= 160 * 1024, "LDS budget");
 };
 
@@ -352,11 +351,11 @@ k_fused_bwd(FbArgs A) {
             // Issue order = wait order (vmcnt counts in order): LDS-DMA of the edge weights, then the small row loads
             // whose data is needed first, then the node-phase weight fragments.  One memory round trip for all of it.
             if constexpr (FIRST) {
-                fb_stage_image<12>(wE, Lp.img_e, wave, lane);              // W1 padded to K = 32: 3 terms x 4 fragments
+                fb_stage_image<8>(wE, Lp.img_e, wave, lane);               // W1 padded to K = 32: 2 terms x 4 fragments
             } else {
-                fb_stage_image<24>(wE, Lp.img_e, wave, lane);
+                fb_stage_image<16>(wE, Lp.img_e, wave, lane);
             }
-            fb_stage_image<24>(w2, Lp.img_2, wave, lane);
+            fb_stage_image<16>(w2, Lp.img_2, wave, lane);
             // (round 4: no transposed copies -- W2^T dpre2 and W_e^T G read these two images transposed, gemm_split_T)
             f32x4 pv[2][2];
             float bv0 = 0.0f, bv1 = 0.0f;

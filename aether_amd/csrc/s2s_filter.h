@@ -31,8 +31,6 @@
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int FILT_STAGE = 2 * 4 * 2 * 64;      // f16x8 fragments of one step: 2 k blocks x 4 row blocks x 2 pieces (16 KB)
 constexpr int FILT_NST = 3;                     // ring slots: a step is requested FILT_NST iterations before it is multiplied
 constexpr int FILT_TRAILER = 64;                // floats behind the image's fragments: [0] = max |L2| (scale derived from it)
@@ -56,10 +54,6 @@ __device__ __forceinline__ float fp16_scale_for(float maxabs) {
     int s = 14 - e;
     s = s > 40 ? 40 : (s < -40 ? -40 : s);
     return ldexpf(1.0f, s);
-}
-__device__ __forceinline__ void split_f16x2(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
 }
 
 // max |x| of a tensor in two launches (weight preparation: once per weight version; no atomics, nothing to initialise):

@@ -293,7 +293,7 @@ k_s2s_gemm_split(const S2SJobs jobs) {
         bf16x8 xh[NB], xm[NB], xl[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            split8(xa[nb][0], xa[nb][1], xh[nb], xm[nb], xl[nb]);   // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
+            split8_bf3(xa[nb][0], xa[nb][1], xh[nb], xm[nb], xl[nb]);   // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
         lds_barrier();                                        // fragments visible to every wave; slot (s - 1) % NST is free
         if (s + 1 < S) xload(s + 1);                          // X first, then the DMA (see the vmcnt above)
         if (s + 2 < S) dma(s + 2);

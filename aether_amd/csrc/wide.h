@@ -11,7 +11,7 @@
 // pre-activation, a dropout mask) so that no elementwise pass over an [E, hidden] tensor is left between the GEMMs.
 // Arithmetic is the library's: fp32 operands split into three bf16 pieces, six bf16 MFMA terms per product, fp32
 // accumulation (common.h, gemm_split: fp32-equivalent).  Operands are split once per tile while they are staged into
-// LDS, in the fragment order stage_split4 defines, and re-read by the four waves of the workgroup (2 x 2 wave tiles of
+// LDS, in the fragment order stage_split4_bf3 defines, and re-read by the four waves of the workgroup (2 x 2 wave tiles of
 // 64 x 64).  The backward's data gradients are the same kernel on transposed weight copies (k_wide_prep), its weight
 // gradients the generic outer-product kernel of backward.h (k_outer: 64 x 64 pieces, fixed-order partial sums).
 // Everything that is not a GEMM (frames, edge features, segmented mean, the last D-row Linear, field net) is either the
@@ -75,8 +75,8 @@ k_wgemm(const WGemmArgs G) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = tid + 256 * j, r = f >> 3, c = (f & 7) * 4;
-            stage_split4<8, 1>(buf, r, c, va[j]);
-            stage_split4<8, 1>(buf + WG_IMG, r, c, vb[j]);
+            stage_split4_bf3<8, 1>(buf, r, c, va[j]);
+            stage_split4_bf3<8, 1>(buf + WG_IMG, r, c, vb[j]);
         }
     };
     f32x4 acc[4][4];

@@ -177,3 +177,27 @@ def test_bad_edge_index_is_rejected():
     inp["edges"] = bad
     with pytest.raises(_lib.AetherHipError):
         _run(m, inp)
+
+
+@pytest.mark.parametrize("path", ["fused", "streamed"])
+@pytest.mark.parametrize("scale", [1e-5, 3e-3, 2e2, 3e4])
+def test_inputs_at_extreme_magnitudes(scale, path):
+    """The edge MLP's GEMMs split their operands into fp16 pieces (round 4, common.h gemm_split): a wave whose activations
+    lie outside 2^-6 .. 2^15 takes the path that rescales operand and accumulator by an exact power of two.  Positions and
+    velocities multiplied by 1e-5 .. 3e4 put the layer-1 edge features (and what follows) far outside fp16's own range;
+    the result is held to the oracle's fp64 evaluation of the same inputs at the usual tolerance."""
+    D = 2
+    inp = make_batch(16, 20, D, seed=131)
+    inp["x"] = inp["x"] * scale
+    inp["vel"] = inp["vel"] * scale
+    rows, cols = inp["edges"]
+    inp["edge_attr"] = prepare_edge_attr(inp["x"], inp["edges"], inp["charges"][rows] * inp["charges"][cols])
+    sd = load_state_dict(D)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want = O.aether_forward(sd64, inp["x"].double(), inp["vel"].double(), inp["edges"], inp["edge_attr"].double(),
+                            inp["charges"].double())
+    want32 = O.aether_forward(sd, inp["x"], inp["vel"], inp["edges"], inp["edge_attr"], inp["charges"])
+    out, _ = _run(_model(D, path), inp)
+    assert torch.isfinite(out).all()
+    err, floor = scale_rel_err(out.cpu().double(), want), scale_rel_err(want32.double(), want)
+    assert err <= max(TOL, 4.0 * floor), (scale, err, floor)
