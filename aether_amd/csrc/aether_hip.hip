@@ -414,7 +414,7 @@ int prepare_weights(const AetherParams& P, char* ws, bool split_images, bool tra
     TransposeBatch TB;
     TB.n_tasks = 0;
     if (transposes) (void)transposed_weights<D>(P, reinterpret_cast<float*>(ws + W.wt), TB);
-    const int sb = split_images ? 8 : 0;
+    const int sb = split_images ? FUSED_SPLIT_BLOCKS : 0;
     k_prepare_weights<<<dim3((unsigned)(sb + 2 * TB.n_tasks)), dim3(512), 0, st>>>(P, F1, reinterpret_cast<float*>(ws + W.wimg),
                                                                                     TB, sb);
     HIP_OK(hipGetLastError());

@@ -224,13 +224,21 @@ __device__ __forceinline__ SplitScale split_scale_of(const f32x4 (&act)[N]) {
     float m = 0.0f;
 #pragma unroll
     for (int b = 0; b < N; ++b) m = fmaxf(fmaxf(m, fmaxf(fabsf(act[b][0]), fabsf(act[b][1]))), fmaxf(fabsf(act[b][2]), fabsf(act[b][3])));
-    const unsigned E = wave_max_exponent(m);
+    // The common case costs two compares: no lane at or above 2^15, some lane at or above 2^-6 (or nothing but zeros).  Only
+    // the other case needs the maximum itself (the DPP reduction).
+    const bool big = __builtin_amdgcn_ballot_w64(m >= 32768.0f) != 0ull;
+    const bool some = __builtin_amdgcn_ballot_w64(m >= 0.015625f) != 0ull;
+    const bool any = __builtin_amdgcn_ballot_w64(m > 0.0f) != 0ull;
     SplitScale r;
-    r.on = !(E == 0u || E - 121u <= 20u);
-    int sh = 140 - (int)E;                                      // max (2^(E-127) ..) -> 2^13 ..
-    sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
-    r.s = __int_as_float((127 + sh) << 23);
-    r.inv_s = __int_as_float((127 - sh) << 23);
+    r.on = big || (any && !some);
+    r.s = 1.0f; r.inv_s = 1.0f;
+    if (r.on) {
+        const unsigned E = wave_max_exponent(m);
+        int sh = 140 - (int)E;                                  // max (2^(E-127) ..) -> 2^13 ..
+        sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
+        r.s = __int_as_float((127 + sh) << 23);
+        r.inv_s = __int_as_float((127 - sh) << 23);
+    }
     return r;
 }
 
@@ -270,6 +278,43 @@ __device__ __forceinline__ void gemm_split(const float* __restrict__ img, const 
     if (sc.on) {
 #pragma unroll
         for (int mb = 0; mb < MBN; ++mb) acc[mb] = acc[mb] * sc.inv_s;
+    }
+}
+
+// The same product with the weight fragments of ONE 16-row block held in registers (k_fused's node phase: a wave owns a row
+// block of W3 / W4 / W_s / W_r and applies it to one or two node tiles): wh / wl = the image's fragments (mb, kb = 0 .. KBN).
+template <int KBN>
+__device__ __forceinline__ f32x4 gemm_split_regs(const f16x8 (&wh)[KBN], const f16x8 (&wl)[KBN], const f32x4 (&act)[2 * KBN], f32x4 acc) {
+    const SplitScale sc = split_scale_of(act);
+    f32x4 x[2 * KBN];
+#pragma unroll
+    for (int b = 0; b < 2 * KBN; ++b) x[b] = act[b];
+    if (sc.on) {                                                // (wave-uniform)
+#pragma unroll
+        for (int b = 0; b < 2 * KBN; ++b) x[b] = x[b] * sc.s;
+        acc = acc * sc.s;
+    }
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+        f16x8 xh, xl;
+        split8(x[2 * kb], x[2 * kb + 1], xh, xl);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[kb], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kb], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kb], xh, acc, 0, 0, 0);
+    }
+    if (sc.on) acc = acc * sc.inv_s;
+    return acc;
+}
+// the lane's fragments (mb, kb = 0 .. KBN) of both terms from an image of MBN row blocks in global memory
+template <int MBN, int KBN>
+__device__ __forceinline__ void load_split_frags(const float* __restrict__ img, int mb, int lane, f16x8 (&wh)[KBN], f16x8 (&wl)[KBN]) {
+    // wave-uniform row block -> scalar base + one 32-bit lane offset (no 64-bit address pair per fragment)
+    const f16x8* w = reinterpret_cast<const f16x8*>(img) + __builtin_amdgcn_readfirstlane(mb) * (KBN * 64);
+    constexpr int TERM = MBN * KBN * 64;
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+        wh[kb] = w[kb * 64 + lane];
+        wl[kb] = w[TERM + kb * 64 + lane];
     }
 }
 
@@ -324,6 +369,7 @@ __device__ __forceinline__ void split_T_step(unsigned base, u32x2 (&lo)[2][2], u
     split_T_consume<BLK + 1 == NBLK>(lo[BLK & 1], hi[BLK & 1], xh[mp], xl[mp], acc[ob]);
     if constexpr (BLK + 1 < NBLK) split_T_step<KBN, BLK + 1>(base, lo, hi, xh, xl, acc);
 }
+// (every caller passes zero accumulators: they are not rescaled on the way in)
 template <int KBN>
 __device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, const f32x4 (&act)[4], f32x4 (&acc)[2 * KBN],
                                              int lane) {
@@ -336,8 +382,6 @@ __device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, cons
     if (sc.on) {                                                // (wave-uniform; gradients are usually far below 2^-6)
 #pragma unroll
         for (int b = 0; b < 4; ++b) x[b] = x[b] * sc.s;
-#pragma unroll
-        for (int ob = 0; ob < 2 * KBN; ++ob) acc[ob] = acc[ob] * sc.s;
     }
     f16x8 xh[2], xl[2];
     split8(x[0], x[1], xh[0], xl[0]);

@@ -78,10 +78,50 @@ template <int NW, int ROUNDS> struct FusedLds {          // offsets in floats
 // Split (3 x bf16) images of the edge-MLP weights in global memory, in the exact order the kernel keeps them in LDS
 // (stage_split4): per layer l = 1..4 image A (layer 1: W1 padded to K = 32, FUSED_WIMG / 2 floats; layers 2-4: W_e)
 // and image B (W2).  k_prepare_weights (aether_hip.hip) writes them once per weight version; k_fused copies them with LDS-DMA.
-constexpr int FUSED_WIMG_SET = 8 * FUSED_WIMG;           // floats reserved (layer 1's image A uses half of its slot)
+// Round 4: the node phase's weights as split images too (its GEMMs moved from the fp32 MFMA to the matrix pipe): per layer
+// W3 [128][64] (stage_split4<8, 2>), W4 [64][128] (<4, 4>), and the NEXT layer's W_s, W_r (<4, 2> each; layer 4: out_w0, out_w3).
+constexpr int FUSED_NIMG_W3 = 2 * 8 * 2 * 64 * 4, FUSED_NIMG_W4 = 2 * 4 * 4 * 64 * 4, FUSED_NIMG_WS = 2 * 4 * 2 * 64 * 4;
+constexpr int FUSED_NIMG_LAYER = FUSED_NIMG_W3 + FUSED_NIMG_W4 + 2 * FUSED_NIMG_WS;
+constexpr int FUSED_WIMG_SET = 8 * FUSED_WIMG + 4 * FUSED_NIMG_LAYER;      // floats reserved (layer 1's image A uses half of its slot)
+constexpr int FUSED_SPLIT_BLOCKS = 8 + 4 * 6;            // blocks of k_prepare_weights that write images (512 threads each)
 __device__ __host__ constexpr int fused_wimg_offset(int layer, int which) { return ((layer - 1) * 2 + which) * FUSED_WIMG; }
+// which: 0 W3, 1 W4, 2 W_s (next layer / out_w0), 3 W_r (next layer / out_w3)
+__device__ __host__ constexpr int fused_nimg_offset(int layer, int which) {
+    return 8 * FUSED_WIMG + (layer - 1) * FUSED_NIMG_LAYER +
+           (which == 0 ? 0 : which == 1 ? FUSED_NIMG_W3 : which == 2 ? FUSED_NIMG_W3 + FUSED_NIMG_W4 : FUSED_NIMG_W3 + FUSED_NIMG_W4 + FUSED_NIMG_WS);
+}
 
 __device__ __forceinline__ void split_weights_block(const AetherParams& P, int f1, float* __restrict__ wimg, int block, int tid) {
+    if (block >= 8) {                                     // node-phase images: six blocks per layer
+        const int nbk = block - 8, layer = nbk / 6 + 1, part = nbk % 6;
+        if (part < 2) {                                   // W3 rows 64 part ..: 1,024 float4
+            const float* w3 = layer == 1 ? P.l1_upd_w0 : P.ln_upd_w0[layer - 2];
+            float* img = wimg + fused_nimg_offset(layer, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + 512 * j, rr = 64 * part + (idx >> 4), cc = (idx & 15) * 4;
+                stage_split4<8, 2>(img, rr, cc, ld4(w3 + (size_t)rr * H + cc));
+            }
+        } else if (part < 4) {                            // W4 [64][128], rows 32 (part - 2) ..
+            const float* w4 = layer == 1 ? P.l1_upd_w2 : P.ln_upd_w2[layer - 2];
+            float* img = wimg + fused_nimg_offset(layer, 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + 512 * j, rr = 32 * (part - 2) + (idx >> 5), cc = (idx & 31) * 4;
+                stage_split4<4, 4>(img, rr, cc, ld4(w4 + (size_t)rr * (2 * H) + cc));
+            }
+        } else {                                          // W_s / W_r of the next layer (layer 4: out_w0 / out_w3)
+            const float* src = layer < 4 ? P.ln_msg_w0[layer - 1] + (part == 4 ? 0 : H) : (part == 4 ? P.out_w0 : P.out_w3);
+            const int ld = layer < 4 ? 3 * H : H;
+            float* img = wimg + fused_nimg_offset(layer, part - 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + 512 * j, rr = idx >> 4, cc = (idx & 15) * 4;
+                stage_split4<4, 2>(img, rr, cc, ld4(src + (size_t)rr * ld + cc));
+            }
+        }
+        return;
+    }
     const int layer = block / 2 + 1, which = block & 1;
     float* img = wimg + fused_wimg_offset(layer, which);
     if (which == 0 && layer == 1) {                       // W1 [64][f1] -> K padded to 32: one float4 per thread
@@ -608,7 +648,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         adeg = (float)(deg > 1 ? deg : 1);
     }
 
-    f32x4 wsv[4], wrv[4];        // next layer's W_s / W_r fragments; after layer 4: out_w0 / out_w3
+    // next layer's W_s / W_r fragments (after layer 4: out_w0 / out_w3): fp16 x 2 pieces of the wave's row block, k blocks 0, 1
+    f16x8 wsh[2], wsl[2], wrh[2], wrl[2];
 #pragma unroll 1
     for (int layer = 1; layer <= 4; ++layer) {
         // ------------------------------------------------------------ edge tiles (locs.py:227-238)
@@ -633,7 +674,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         // stream in under the tile's MFMAs: next layer's edge weights (W_e = W1[:, 128:192], W2: they
         // go to LDS once every wave has left the edge tiles), then W3 / W4 / next-layer W_s, W_r fragments.
         constexpr int STG = SPLITG ? 1 : (H * H / 4 + THREADS - 1) / THREADS;      // float4 per thread per staged matrix
-        f32x4 w3v[4], w4v[8], stA[STG], stB[STG];
+        f16x8 w3h[2], w3l[2], w4h[4], w4l[4];              // the wave's row block of W3 (k = 64) and of W4 (k = 128), split pieces
+        f32x4 stA[STG], stB[STG];
         float b2n = 0.0f;
         // layer 4 has no next edge layer: wsv / wrv carry the out-MLP fragments (out_w0, out_w3) instead
         // part 0: staged matrices; 1: W3; 2, 3: W4 halves; 4: W_s / W_r.  A wave spreads the parts over
@@ -653,29 +695,21 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
                 if (tid < H) b2n = P.ln_msg_b2[layer - 1][tid];
             }
-            if (part == 1 && act3) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) w3v[a] = ld4(w3 + (16 * mb2 + i) * H + 16 * a + 4 * q);
-            }
+            // (round 4: fragments of the prepared fp16 x 2 images, fused_nimg_offset -- same bytes per weight as fp32)
+            if (part == 1 && act3) load_split_frags<8, 2>(dbg.wimg + fused_nimg_offset(layer, 0), mb2, lane, w3h, w3l);
             if ((part == 2 || part == 3) && act3 && 16 * tn3 < n) {
+                const f16x8* w = reinterpret_cast<const f16x8*>(dbg.wimg + fused_nimg_offset(layer, 1)) +
+                                 __builtin_amdgcn_readfirstlane(mb3) * (4 * 64);
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    w4v[4 * (part - 2) + a] = ld4(w4 + (16 * mb3 + i) * (2 * H) + 16 * (4 * (part - 2) + a) + 4 * q);
-            }
-            if (part == 4 && layer < 4) {
-                const float* w1n = P.ln_msg_w0[layer - 1];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (do_s) wsv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + 16 * a + 4 * q);
-                    if (do_r) wrv[a] = ld4(w1n + (16 * mb3 + i) * (3 * H) + H + 16 * a + 4 * q);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int kb = 2 * (part - 2) + kk;
+                    w4h[kb] = w[kb * 64 + lane];
+                    w4l[kb] = w[4 * 4 * 64 + kb * 64 + lane];
                 }
             }
-            if (part == 4 && layer == 4 && act3) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    wsv[a] = ld4(P.out_w0 + (16 * mb3 + i) * H + 16 * a + 4 * q);
-                    wrv[a] = ld4(P.out_w3 + (16 * mb3 + i) * H + 16 * a + 4 * q);
-                }
+            if (part == 4 && (layer < 4 ? true : act3)) {
+                if (layer == 4 || do_s) load_split_frags<4, 2>(dbg.wimg + fused_nimg_offset(layer, 2), mb3, lane, wsh, wsl);
+                if (layer == 4 || do_r) load_split_frags<4, 2>(dbg.wimg + fused_nimg_offset(layer, 3), mb3, lane, wrh, wrl);
             }
         };
         // Split mode, layers 2-4: the partner workgroup's P_s rows are in flight when the edge phase starts.  The
@@ -869,13 +903,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
                 if (16 * tn < n) {
-                    f32x4 acc = bv;
+                    f32x4 nv[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const f32x4 nv = ld4(nbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) acc = mfma16(w3v[a][b], nv[b], acc);
-                    }
+                    for (int a = 0; a < 4; ++a) nv[a] = ld4(nbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
+                    const f32x4 acc = gemm_split_regs<2>(w3h, w3l, nv, bv);
                     st4(ubuf + (16 * tn + i) * LDU + 16 * mb2 + 4 * q, silu4(acc));
                 }
             }
@@ -888,10 +919,12 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             const float* ubuf = smem + L::UBUF;
             f32x4 acc = ld4(b4 + 16 * mb3 + 4 * q);
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const f32x4 uv = ld4(ubuf + (16 * tn3 + i) * LDU + 16 * a + 4 * q);
+            for (int hk = 0; hk < 2; ++hk) {                   // k halves of 64 (each with its own range check): fewer live registers
+                f32x4 uv[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc = mfma16(w4v[a][b], uv[b], acc);
+                for (int a = 0; a < 4; ++a) uv[a] = ld4(ubuf + (16 * tn3 + i) * LDU + 16 * (4 * hk + a) + 4 * q);
+                const f16x8 wh2[2] = {w4h[2 * hk], w4h[2 * hk + 1]}, wl2[2] = {w4l[2 * hk], w4l[2 * hk + 1]};
+                acc = gemm_split_regs<2>(wh2, wl2, uv, acc);
             }
             acc += ld4(nbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q);
             st4(xbuf + (16 * tn3 + i) * LDW + 16 * mb3 + 4 * q, acc);
@@ -908,11 +941,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
 #pragma unroll
                 for (int a = 0; a < 4; ++a) xv[a] = ld4(xbuf + (16 * tn4 + i) * LDW + 16 * a + 4 * q);
                 if (do_s) {
-                    f32x4 accs = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) accs = mfma16(wsv[a][b], xv[a][b], accs);
+                    const f32x4 accs = gemm_split_regs<2>(wsh, wsl, xv, f32x4{0.f, 0.f, 0.f, 0.f});
                     if (16 * tn4 + i < n) {      // sender rows live in the visible numbering
                         st4(psb + (off + 16 * tn4 + i) * LDW + 16 * mb3 + 4 * q, accs);
                         float* gps = dbg.ps[layer - 1] + (int64_t)(nb + 16 * tn4 + i) * H + 16 * mb3 + 4 * q;
@@ -932,11 +961,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                     }
                 }
                 if (do_r) {
-                    f32x4 accr = ld4(b1n + 16 * mb3 + 4 * q);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) accr = mfma16(wrv[a][b], xv[a][b], accr);
+                    const f32x4 accr = gemm_split_regs<2>(wrh, wrl, xv, ld4(b1n + 16 * mb3 + 4 * q));
                     st4(prb + (16 * tn4 + i) * LDW + 16 * mb3 + 4 * q, accr);
                     if (keep && 16 * tn4 + i < n)
                         st4(dbg.pr[layer - 1] + (int64_t)(nb + 16 * tn4 + i) * H + 16 * mb3 + 4 * q, accr);
@@ -971,13 +996,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             for (int a = 0; a < 4; ++a) w6v[a] = ld4(P.out_w6 + (i < D ? i : D - 1) * H + 16 * a + 4 * q);
         }
         if (act) {
-            f32x4 acc = ld4(P.out_b0 + 16 * mb + 4 * q);
+            f32x4 xv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const f32x4 xv = ld4(xbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc = mfma16(wsv[a][b], xv[b], acc);
-            }
+            for (int a = 0; a < 4; ++a) xv[a] = ld4(xbuf + (16 * tn + i) * LDW + 16 * a + 4 * q);
+            const f32x4 acc = gemm_split_regs<2>(wsh, wsl, xv, ld4(P.out_b0 + 16 * mb + 4 * q));
             f32x4 v = silu4(acc);
             if constexpr (KEEP) {
                 if (dbg.step.drop1 != nullptr && 16 * tn + i < n)
@@ -990,13 +1012,10 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         }
         lds_barrier();
         if (act) {
-            f32x4 acc = ld4(P.out_b3 + 16 * mb + 4 * q);
+            f32x4 xv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const f32x4 xv = ld4(o1 + (16 * tn + i) * LDW + 16 * a + 4 * q);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc = mfma16(wrv[a][b], xv[b], acc);
-            }
+            for (int a = 0; a < 4; ++a) xv[a] = ld4(o1 + (16 * tn + i) * LDW + 16 * a + 4 * q);
+            const f32x4 acc = gemm_split_regs<2>(wrh, wrl, xv, ld4(P.out_b3 + 16 * mb + 4 * q));
             f32x4 v = silu4(acc);
             if constexpr (KEEP) {
                 if (dbg.step.drop2 != nullptr && 16 * tn + i < n)
