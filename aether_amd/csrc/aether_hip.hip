@@ -269,7 +269,7 @@ constexpr int OUTER_MAX_CHUNKS = 256;      // workgroups (= partials) per task
 // Up to this many edges the backward keeps the operands of every layer's weight gradients alive and
 // multiplies all of them in one launch at the end (12 more [E, 64] buffers: 3 KiB per edge).
 int64_t g_outer_defer_max_edges = 1 << 20;      // aether_set_option("outer_defer_max_edges", n)
-int g_edge_acc = 1;                             // aether_set_option("edge_acc", 0|1): above that threshold, the edge-level weight
+int g_edge_acc = 3;                             // aether_set_option("edge_acc", 0..3; 3 = kb_edge_acc8<4 waves>, two workgroups per CU): above that threshold, the edge-level weight
                                                 // gradients are accumulated inside the edge kernel (edge_acc.h)
 int g_outer_tiles_per_wave = 0;                 // aether_set_option("outer_tiles_per_wave", n): 16-row tiles per wave of k_outer (0: by task size)
 int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
@@ -686,7 +686,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
         if (E > 0) {
             const size_t lds = (size_t)(4 * H * LDW) * 4;
             ProfScope* pse = new ProfScope(KB_EDGE, st);
-            if (acc_path && g_edge_acc >= 2) {
+            if (acc_path && g_edge_acc >= 2 && (size_t)512 * FB_PART <= W.partial_cap * (size_t)OUTER_PART) {       // (<= 512 partials)
                 // round 4: two waves per SIMD, transposed products from the forward's images, accumulators partitioned by
                 // output rows (edge_acc.h, kb_edge_acc8): 2 = one workgroup of eight waves per CU, 3 = two of four
                 EdgeAccOut O{};

@@ -13,7 +13,7 @@ from aether_amd.synthetic import make_batch
 from oracle import aether_oracle as O
 
 pytestmark = pytest.mark.gpu
-DEFAULT_EDGE_ACC = 1          # aether_set_option("edge_acc"): the library's default
+DEFAULT_EDGE_ACC = 3          # aether_set_option("edge_acc"): the library's default
 GTOL = 5e-5     # gradients: sums over thousands of edges in a different (fixed) order than autograd
 
 
@@ -112,7 +112,7 @@ def test_per_layer_weight_gradient_launches_match_deferred(D):
         _, per_layer = _loss_backward(m, inp)
     finally:
         _lib.check(lib.aether_set_option(b"outer_defer_max_edges", 1 << 20), "set_option")
-        _lib.check(lib.aether_set_option(b"edge_acc", 1), "set_option")
+        _lib.check(lib.aether_set_option(b"edge_acc", DEFAULT_EDGE_ACC), "set_option")
         _lib.check(lib.aether_set_option(b"fused_backward", 1), "set_option")
     for k in deferred:
         assert torch.equal(deferred[k], per_layer[k]), k
