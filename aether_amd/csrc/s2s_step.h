@@ -185,42 +185,47 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Large dense layers (>= 16 K rows) on the bf16 pipe: the job-table GEMM as six bf16 MFMA terms on 3-way split operands
-// (common.h: fp32-equivalent).  Weights come as prepared images (the plan), the activation rows are split in registers.
-//   image of W [M][K] (row stride ldw): [k block K/32][row block M/16][piece 3][lane (i, q)] = W[16 mb + i][32 a + 8 q .. + 8)
+// Large dense layers (>= 2 K rows) on the matrix pipe: the job-table GEMM as THREE fp16 MFMA terms on operands split into two
+// fp16 pieces (common.h; rounds 2-3: six bf16 terms on three pieces).  Weights come as prepared images (the plan), the
+// activation rows are split in registers.
+//   image of W [M][K] (row stride ldw): [k block K/32][row block M/16][piece 2][lane (i, q)] = W[16 mb + i][32 a + 8 q .. + 8)
+// fp16's exponent range: the activations of a wave (16 NB rows) carry ONE power-of-two scale s that only ever shrinks while
+// the K loop runs -- the first k step sets it from the wave's maximum (max -> 2^13..2^14), a later step whose scaled values
+// would reach 2^15 lowers it and multiplies the accumulators by the ratio (exact); the epilogue divides by the final s.
+// Every value is thus represented to 2^-22 of the largest value its wave has seen.  Weights are split as they are
+// (|w| < 65,504; a lo piece below |w| = 2^-3 is a subnormal: absolute error <= 2^-25).
 __global__ void __launch_bounds__(256)
-k_s2s_gemm_image(const float* __restrict__ W, int M, int K, int ldw, bf16x8* __restrict__ img) {
+k_s2s_gemm_image(const float* __restrict__ W, int M, int K, int ldw, f16x8* __restrict__ img) {
     const int oct = K >> 3;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;         // (row, k octet)
     if (idx >= (int64_t)M * oct) return;
     const int m = (int)(idx / oct), o = (int)(idx - (int64_t)m * oct);
     const f32x4 v0 = ld4(W + (size_t)m * ldw + 8 * o), v1 = ld4(W + (size_t)m * ldw + 8 * o + 4);
-    bf16x8 hi, mid, lo;
+    f16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        __bf16 a, b, d;
-        split_bf16x3(j < 4 ? v0[j] : v1[j - 4], a, b, d);
-        hi[j] = a; mid[j] = b; lo[j] = d;
+        _Float16 a, b;
+        split_f16x2(j < 4 ? v0[j] : v1[j - 4], a, b);
+        hi[j] = a; lo[j] = b;
     }
     const int a32 = o >> 2, q = o & 3, mb = m >> 4, i = m & 15;
-    const size_t frag = ((size_t)a32 * (M >> 4) + mb) * 3;
+    const size_t frag = ((size_t)a32 * (M >> 4) + mb) * 2;
     img[(frag + 0) * 64 + i + 16 * q] = hi;
-    img[(frag + 1) * 64 + i + 16 * q] = mid;
-    img[(frag + 2) * 64 + i + 16 * q] = lo;
+    img[(frag + 1) * 64 + i + 16 * q] = lo;
 }
 
 // Workgroup = 4 waves on a 128 (m) x 128 (rows n) tile; a wave owns 128 m x 32 rows (8 x 2 accumulator blocks).  Per
-// 32-wide k step the 24 KB of weight fragments (128 m x 32 k x 3 pieces, contiguous in the image) arrive by LDS-DMA two
+// 32-wide k step the 16 KB of weight fragments (128 m x 32 k x 2 pieces, contiguous in the image) arrive by LDS-DMA two
 // steps ahead in a three-slot ring (one barrier per step); the wave's row blocks of X (lane: row i, eight consecutive k)
-// are requested one step ahead, split into three bf16 pieces in registers (8 NB values per lane) and feed 8 x NB x 6 MFMAs.
-// Epilogue and job table as k_s2s_linear_jobs.  Needs M % 128 == 0, K % 32 == 0 (both segments).
-constexpr int GS_STAGE = 8 * 3 * 64;             // bf16x8 fragments per k step (24 KB)
+// are requested one step ahead, scaled and split into two fp16 pieces in registers (8 NB values per lane) and feed
+// 8 x NB x 3 MFMAs.  Epilogue and job table as k_s2s_linear_jobs.  Needs M % 128 == 0, K % 32 == 0 (both segments).
+constexpr int GS_STAGE = 8 * 2 * 64;             // f16x8 fragments per k step (16 KB)
 constexpr int GS_NST = 3;
 template <int NB>          // row blocks of 16 per wave: 2 (128-row tiles) from 16 K rows on, 1 (64-row tiles) for 2 K - 16 K rows
 __global__ void __launch_bounds__(256, 2)
 k_s2s_gemm_split(const S2SJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
-    bf16x8* ring = reinterpret_cast<bf16x8*>(gs_smem);
+    f16x8* ring = reinterpret_cast<f16x8*>(gs_smem);
     int ji = 0;
 #pragma unroll
     for (int t = 1; t < S2S_MAX_JOBS; ++t)
@@ -238,8 +243,8 @@ k_s2s_gemm_split(const S2SJobs jobs) {
     if ((int64_t)bx * (64 * NB) >= N) return;                // the whole workgroup
     const int s1 = J.K >> 5, s2 = J.W2img != nullptr ? J.K2 >> 5 : 0, S = s1 + s2;
     const int n_mb = M >> 4;
-    const bf16x8* img1 = reinterpret_cast<const bf16x8*>(J.Wimg);
-    const bf16x8* img2 = reinterpret_cast<const bf16x8*>(J.W2img);
+    const f16x8* img1 = reinterpret_cast<const f16x8*>(J.Wimg);
+    const f16x8* img2 = reinterpret_cast<const f16x8*>(J.W2img);
     // rows of X for the wave's two blocks (clamped; gathered through xidx)
     const float* xr1[NB];
     const float* xr2[NB];
@@ -252,11 +257,11 @@ k_s2s_gemm_split(const S2SJobs jobs) {
         xr2[nb] = s2 ? J.X2 + (size_t)n * J.ldx2 + 8 * q : xr1[nb];
     }
     auto dma = [&](int s) {                                   // weight fragments of step s -> slot s % NST
-        const bf16x8* src = (s < s1 ? img1 + ((size_t)s * n_mb + (m0 >> 4)) * 3 * 64
-                                    : img2 + ((size_t)(s - s1) * n_mb + (m0 >> 4)) * 3 * 64) + lane;
-        bf16x8* dst = ring + (s % GS_NST) * GS_STAGE;
+        const f16x8* src = (s < s1 ? img1 + ((size_t)s * n_mb + (m0 >> 4)) * 2 * 64
+                                    : img2 + ((size_t)(s - s1) * n_mb + (m0 >> 4)) * 2 * 64) + lane;
+        f16x8* dst = ring + (s % GS_NST) * GS_STAGE;
 #pragma unroll
-        for (int f = 0; f < 6; ++f) {
+        for (int f = 0; f < 4; ++f) {
             const int fr = wave + 4 * f;
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + fr * 64),
                                              (__attribute__((address_space(3))) void*)(dst + fr * 64), 16, 0, 0);
@@ -286,28 +291,60 @@ k_s2s_gemm_split(const S2SJobs jobs) {
     xload(0);
     dma(0);
     if (S > 1) dma(1);
-    for (int s = 0; s < S; ++s) {
-        // X of this step and the fragments of this step have landed; the six DMA loads of step s + 1 may be in flight
-        if (s + 1 < S) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bf16x8 xh[NB], xm[NB], xl[NB];
+    float xs = 0.0f;                                          // the wave's activation scale (0: not set yet); accumulators hold xs x sums
+    f16x8 xh[NB], xl[NB];
+    // X of a step -> range check, scale, split.  Done for step s + 1 at the END of step s (under the matrix pipe's drain) so
+    // that the dependent chain max -> compare -> branch -> multiply -> convert is off the step's critical path.
+    auto prepare_x = [&]() {
+        float m = 0.0f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            split8_bf3(xa[nb][0], xa[nb][1], xh[nb], xm[nb], xl[nb]);   // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(xa[nb][hh][0]), fabsf(xa[nb][hh][1]))), fmaxf(fabsf(xa[nb][hh][2]), fabsf(xa[nb][hh][3])));
+        // the first step sets the scale; a step that would reach 2^15 lowers it (wave-uniform, rare)
+        const bool redo = xs == 0.0f || __builtin_amdgcn_ballot_w64(m * xs >= 32768.0f) != 0ull;
+        if (redo) {
+            const unsigned E = wave_max_exponent(m);
+            int sh = 140 - (int)E;                                // max (2^(E-127) ..) -> 2^13 ..
+            sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
+            float ns = __int_as_float((127 + sh) << 23);
+            float ratio = ns;                                     // first time: the accumulators hold the bias
+            if (xs != 0.0f) {
+                ns = ns < xs ? ns : xs;                           // only ever down
+                ratio = ns / xs;                                  // (powers of two: exact)
+            }
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = acc[mb][nb] * ratio;
+            xs = ns;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            split8(xa[nb][0] * xs, xa[nb][1] * xs, xh[nb], xl[nb]);    // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
+    };
+    // X(0) has landed (the DMA loads of steps 0 and 1 were issued behind it: vmcnt counts in order)
+    if (S > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    prepare_x();
+    for (int s = 0; s < S; ++s) {
+        // the fragments of this step have landed; the four DMA loads of step s + 1 may be in flight
+        if (s + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();                                        // fragments visible to every wave; slot (s - 1) % NST is free
-        if (s + 1 < S) xload(s + 1);                          // X first, then the DMA (see the vmcnt above)
+        if (s + 1 < S) xload(s + 1);                          // X first, then the DMA (see the vmcnt below)
         if (s + 2 < S) dma(s + 2);
         else if (s + 1 < S) asm volatile("" ::: "memory");
-        const bf16x8* st = ring + (s % GS_NST) * GS_STAGE + lane;
+        const f16x8* st = ring + (s % GS_NST) * GS_STAGE + lane;
         const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
-        // fragments of row block mb + 1 are requested before the MFMAs of row block mb (LDS returns in order: lgkmcnt(3)
-        // leaves exactly the newer three outstanding)
-        bf16x8 w[2][3];
+        // fragments of row block mb + 1 are requested before the MFMAs of row block mb (LDS returns in order: lgkmcnt(2)
+        // leaves exactly the newer two outstanding)
+        f16x8 w[2][2];
 #define GS_READ(buf, mb)                                                                                          \
         do {                                                                                                      \
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[buf][0]) : "v"(base), "n"(((mb) * 3 + 0) * 1024)); \
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[buf][1]) : "v"(base), "n"(((mb) * 3 + 1) * 1024)); \
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[buf][2]) : "v"(base), "n"(((mb) * 3 + 2) * 1024)); \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w[buf][0]) : "v"(base), "n"(((mb) * 2 + 0) * 1024)); \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w[buf][1]) : "v"(base), "n"(((mb) * 2 + 1) * 1024)); \
         } while (0)
         GS_READ(0, 0);
 #pragma unroll
@@ -315,26 +352,27 @@ k_s2s_gemm_split(const S2SJobs jobs) {
             const int cur = mb & 1;
             if (mb < 7) {
                 if (cur == 0) GS_READ(1, mb + 1); else GS_READ(0, mb + 1);
-                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w[cur][0]), "+v"(w[cur][1]), "+v"(w[cur][2]));
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w[cur][0]), "+v"(w[cur][1]));
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[cur][0]), "+v"(w[cur][1]), "+v"(w[cur][2]));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[cur][0]), "+v"(w[cur][1]));
             }
-            const bf16x8 wh = w[cur][0], wm = w[cur][1], wl = w[cur][2];
+            const f16x8 wh = w[cur][0], wl = w[cur][1];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[nb], acc[mb][nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[nb], acc[mb][nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[nb], acc[mb][nb], 0, 0, 0);
         }
 #undef GS_READ
+        if (s + 1 < S) {
+            // X of step s + 1 has landed (the DMA of step s + 2, issued behind it, may be in flight)
+            if (s + 2 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prepare_x();
+        }
     }
+    const float inv_xs = xs != 0.0f ? 1.0f / xs : 1.0f;      // (a power of two: exact)
     const int act = J.act;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -348,7 +386,7 @@ k_s2s_gemm_split(const S2SJobs jobs) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             const int m = m0 + 16 * mb + 4 * q;
-            f32x4 v = acc[mb][nb];
+            f32x4 v = acc[mb][nb] * inv_xs;
             if (g1 != nullptr) v += ld4(g1 + m) + ld4(g2 + m);
             if (act == 1) v = silu4(v);
             else if (act == 2) {
