@@ -208,13 +208,14 @@ __device__ __forceinline__ void stage_split4(float* img, int row, int col, const
 
 // Biased fp32 exponent field of the wave's maximum of m (m >= 0 in every lane): row_shr 1, 2, 4, 8 leave a row's maximum in
 // its lane 15, row_bcast 15 / 31 carry it on to lane 63 (out-of-range source lanes read 0, the identity); read-lane 63.
-__device__ __forceinline__ unsigned wave_max_exponent(float m) {
+__device__ __forceinline__ unsigned wave_max_bits(float m) {     // bit pattern of the wave's maximum (m >= 0 in every lane)
     int v = __float_as_int(m);                                  // non-negative floats order like their bit patterns
 #define AETHER_DPP_MAX(CTRL) { const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); v = o > v ? o : v; }
     AETHER_DPP_MAX(0x111) AETHER_DPP_MAX(0x112) AETHER_DPP_MAX(0x114) AETHER_DPP_MAX(0x118) AETHER_DPP_MAX(0x142) AETHER_DPP_MAX(0x143)
 #undef AETHER_DPP_MAX
-    return ((unsigned)__builtin_amdgcn_readlane(v, 63) >> 23) & 255u;
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ unsigned wave_max_exponent(float m) { return (wave_max_bits(m) >> 23) & 255u; }
 // What a GEMM's activation operand needs before it is split into fp16 pieces: nothing (biased exponent of the wave's maximum
 // in [121, 141], i.e. 2^-6 <= max < 2^15; or 0: all zeros), or a power-of-two scale that puts the maximum into 2^13..2^14
 // (exponent clamped to +-40).  Wave-uniform.

@@ -9,9 +9,9 @@
 //
 // with the epilogues a layer needs (bias, up to two row-gathered addends, SiLU or the product with SiLU' of a saved
 // pre-activation, a dropout mask) so that no elementwise pass over an [E, hidden] tensor is left between the GEMMs.
-// Arithmetic is the library's: fp32 operands split into three bf16 pieces, six bf16 MFMA terms per product, fp32
-// accumulation (common.h, gemm_split: fp32-equivalent).  Operands are split once per tile while they are staged into
-// LDS, in the fragment order stage_split4_bf3 defines, and re-read by the four waves of the workgroup (2 x 2 wave tiles of
+// Arithmetic is the library's: fp32 operands split into two fp16 pieces, three MFMA terms per product, fp32 accumulation
+// (common.h, gemm_split; k_wgemm below for how the A operand's range is handled).  Operands are split once per tile while
+// they are staged into LDS, in the fragment order stage_split4 defines, and re-read by the four waves (2 x 2 wave tiles of
 // 64 x 64).  The backward's data gradients are the same kernel on transposed weight copies (k_wide_prep), its weight
 // gradients the generic outer-product kernel of backward.h (k_outer: 64 x 64 pieces, fixed-order partial sums).
 // Everything that is not a GEMM (frames, edge features, segmented mean, the last D-row Linear, field net) is either the
@@ -23,13 +23,12 @@ namespace {
 
 constexpr int WG_BM = 128;                    // rows of A (items) per workgroup
 constexpr int WG_BN = 128;                    // rows of B (output features) per workgroup
-constexpr int WG_IMG = 3 * 8 * 64 * 4;        // floats of one split tile image: 3 terms x 8 row blocks x 64 lanes x 16 B
+constexpr int WG_IMG = 2 * 8 * 64 * 4;        // floats of one split tile image: 2 terms x 8 row blocks x 64 lanes x 16 B
 constexpr int WG_STAGE = 2 * WG_IMG;          // A image | B image
-// ONE stage in LDS (48 KB), the next k block waits in registers: two workgroups per CU (two waves per SIMD at <= 256
-// registers) instead of one -- with a double-buffered stage (96 KB) a workgroup had the CU to itself and, at K = 128 ..
-// 256 (4 - 8 k blocks), spent most of its time in its own load latencies: 24 us per launch at [48,640 x 128] . [128 x 128]
-// (profiles/r04_wide_*), i.e. 66 TFLOP/s fp32-equivalent.
-constexpr size_t WG_LDS_BYTES = (size_t)WG_STAGE * 4;
+// ONE stage in LDS (32 KB + a few words), the next k block waits in registers: two workgroups per CU (two waves per SIMD at
+// <= 256 registers) instead of one -- with a double-buffered stage a workgroup had the CU to itself and, at K = 128 .. 256
+// (4 - 8 k blocks), spent most of its time in its own load latencies (HISTORY R4).
+constexpr size_t WG_LDS_BYTES = (size_t)WG_STAGE * 4 + 16;
 
 struct WGemmArgs {
     const float* A; const float* B;           // [M][lda], [N][ldb]; K columns each, K % 32 == 0, rows 16-byte aligned
@@ -50,9 +49,17 @@ __device__ __forceinline__ f32x4 wide_dsilu4(f32x4 z) {
     return dsilu_from_sigmoid(z, s);
 }
 
+// Round 4 (second half): two fp16 pieces per operand, three MFMA terms (common.h; was three bf16 pieces, six terms).  The B
+// operand (weights, |w| < 65,504) is split as it is.  The A operand (activations forward, gradients backward: any magnitude)
+// carries ONE power-of-two scale per workgroup that only ever shrinks along K: every thread leaves the maximum of the values
+// it fetched for the next k block in an LDS word (ds_max on the bit patterns of non-negative floats) in front of the barrier
+// the loop takes anyway; behind it everybody derives the same scale -- the first k block sets it (maximum -> 2^13 .. 2^14), a
+// later block that would reach 2^15 lowers it and every wave multiplies its accumulators by the ratio (exact).  The epilogue
+// divides by the final scale.
 __global__ void __launch_bounds__(256, 2)
 k_wgemm(const WGemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* smax = reinterpret_cast<unsigned*>(smem + WG_STAGE);    // [2]: maxima of the k blocks, alternating
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int wi = wave & 1, wf = wave >> 1;                      // the wave's 64 x 64 quadrant: items, features
@@ -71,57 +78,84 @@ k_wgemm(const WGemmArgs G) {
             vb[j] = n < G.N ? ld4(G.B + (size_t)n * G.ldb + 32 * kb + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto stage = [&](float* buf) {
+    auto publish_max = [&](int kb) {                               // this thread's part of |A| of block kb -> smax[kb & 1]
+        float m = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = tid + 256 * j, r = f >> 3, c = (f & 7) * 4;
-            stage_split4_bf3<8, 1>(buf, r, c, va[j]);
-            stage_split4_bf3<8, 1>(buf + WG_IMG, r, c, vb[j]);
-        }
+        for (int j = 0; j < 4; ++j)
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(va[j][0]), fabsf(va[j][1]))), fmaxf(fabsf(va[j][2]), fabsf(va[j][3])));
+        const unsigned wm = wave_max_bits(m);                      // one LDS atomic per wave, not per lane
+        if (lane == 0) atomicMax(smax + (kb & 1), wm);
     };
     f32x4 acc[4][4];
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float xs = 0.0f;                                               // the workgroup's A scale (0: not set yet)
+    // scale of block kb from the published maximum (workgroup-uniform), accumulators follow; then split + stage
+    auto stage = [&](float* buf, int kb) {
+        const unsigned mb = smax[kb & 1];
+        const unsigned E = (mb >> 23) & 255u;
+        if (xs == 0.0f || __uint_as_float(mb) * xs >= 32768.0f) {
+            int sh = 140 - (int)E;                                 // max (2^(E-127) ..) -> 2^13 ..
+            sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
+            float ns = __int_as_float((127 + sh) << 23);
+            if (xs != 0.0f) {
+                ns = ns < xs ? ns : xs;                            // only ever down
+                const float ratio = ns / xs;                       // (powers of two: exact)
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = acc[fb][ib] * ratio;
+            }
+            xs = ns;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j, r = f >> 3, c = (f & 7) * 4;
+            stage_split4<8, 1>(buf, r, c, va[j] * xs);
+            stage_split4<8, 1>(buf + WG_IMG, r, c, vb[j]);
+        }
+    };
+    if (tid < 2) smax[tid] = 0u;
     fetch(0);
-    stage(smem);
+    lds_barrier();                                                 // smax cleared
+    publish_max(0);
+    lds_barrier();
+    stage(smem, 0);
     lds_barrier();
     for (int kb = 0; kb < nkb; ++kb) {
         const float* buf = smem;
+        if (tid == 0) smax[kb & 1] = 0u;                           // block kb's word (read by everybody before the last barrier) is block kb + 2's: two barriers before anybody publishes into it
         if (kb + 1 < nkb) fetch(kb + 1);                           // in flight under this block's MFMAs
-        const bf16x8* xa = reinterpret_cast<const bf16x8*>(buf);
-        const bf16x8* wb = reinterpret_cast<const bf16x8*>(buf + WG_IMG);
-        bf16x8 xh[4], xm[4], xl[4];
+        const f16x8* xa = reinterpret_cast<const f16x8*>(buf);
+        const f16x8* wb = reinterpret_cast<const f16x8*>(buf + WG_IMG);
+        f16x8 xh[4], xl[4];
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
             const int frag = (4 * wi + ib) * 64 + lane;
-            xh[ib] = xa[frag]; xm[ib] = xa[512 + frag]; xl[ib] = xa[1024 + frag];
+            xh[ib] = xa[frag]; xl[ib] = xa[512 + frag];
         }
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
             const int frag = (4 * wf + fb) * 64 + lane;
-            const bf16x8 wh = wb[frag], wm = wb[512 + frag], wl = wb[1024 + frag];
+            const f16x8 wh = wb[frag], wl = wb[512 + frag];
             // small terms first; the four item blocks between two terms of one accumulator hide the MFMA latency
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[ib], acc[fb][ib], 0, 0, 0);
+            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[ib], acc[fb][ib], 0, 0, 0);
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[ib], acc[fb][ib], 0, 0, 0);
+            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[ib], acc[fb][ib], 0, 0, 0);
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[ib], acc[fb][ib], 0, 0, 0);
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[ib], acc[fb][ib], 0, 0, 0);
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[ib], acc[fb][ib], 0, 0, 0);
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[ib], acc[fb][ib], 0, 0, 0);
+            for (int ib = 0; ib < 4; ++ib) acc[fb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ib], acc[fb][ib], 0, 0, 0);
         }
         if (kb + 1 < nkb) {
-            lds_barrier();                                         // every wave has its fragments of this block
-            stage(smem);
+            publish_max(kb + 1);
+            lds_barrier();                                         // every wave has its fragments of this block; the maximum is complete
+            stage(smem, kb + 1);
             lds_barrier();
         }
     }
+    const float inv_xs = xs != 0.0f ? 1.0f / xs : 1.0f;            // (a power of two: exact)
     // ---- epilogue: acc[fb][ib][r] = C[item 16 (4 wi + ib) + i][feature 16 (4 wf + fb) + 4 q + r]
     const bool use_mask = G.mask != nullptr && (G.maskword == nullptr || *G.maskword != 0);
 #pragma unroll
@@ -134,7 +168,7 @@ k_wgemm(const WGemmArgs G) {
         for (int ib = 0; ib < 4; ++ib) {
             const int64_t row = m0 + 16 * (4 * wi + ib) + i;
             if (row >= G.M) continue;
-            f32x4 v = acc[fb][ib] + bv;
+            f32x4 v = acc[fb][ib] * inv_xs + bv;
             if (G.add1 != nullptr) {
                 const int64_t r1 = G.idx1 != nullptr ? (int64_t)G.idx1[row] : row;
                 v += ld4(G.add1 + r1 * G.ldadd + n);
