@@ -955,7 +955,7 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
 // =================================================================== C ABI
 extern "C" {
 
-const char* aether_version(void) { return "aether_hip 0.6 (gfx950; state2state fused + streamed + fused backward, loss + AdamW, seq2seq fused step + split-bf16 GEMMs, variable-N steps, kNN, simulators)"; }
+const char* aether_version(void) { return "aether_hip 0.7 (gfx950; state2state fused + streamed + wide + fused backward, loss + AdamW, seq2seq fused step, variable-N steps, kNN, simulators; dense layers as split-fp16 matrix-core GEMMs)"; }
 const char* aether_last_error(void) { return g_err; }
 
 #include "host_seq2seq.inc"

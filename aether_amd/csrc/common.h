@@ -101,10 +101,11 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ w, int ldw,
 // and every VALU instruction next to it costs matrix time.  The 16-bit MFMAs (v_mfma_f32_16x16x32_{bf16,f16}) do 16,384
 // FLOP in 16 cycles on the matrix pipe proper, accumulating in fp32; products of two 16-bit pieces are exact in fp32.
 //
-// Rounds 1-3 (still: csrc/wide.h, the seq2seq dense layers): three bf16 pieces per operand, x = hi + mid + lo + r with
-// |r| <= 2^-24 |x|, and SIX terms  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (the rest <= 2^-22 relative).
+// Rounds 1-3: three bf16 pieces per operand, x = hi + mid + lo + r with |r| <= 2^-24 |x|, and SIX terms
+// hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (the rest <= 2^-22 relative).
 //
-// Round 4 (the hidden-64 kernels: gemm_split / gemm_split_T below): two fp16 pieces, x = hi + lo with hi = fp16(x),
+// Round 4 (every split GEMM of the library: gemm_split / gemm_split_T below, k_wgemm, k_s2s_gemm_split, k_s2s_filter_split):
+// two fp16 pieces, x = hi + lo with hi = fp16(x),
 // lo = fp16(x - hi) -- 22 significand bits -- and THREE terms  hi*hi + hi*lo + lo*hi  (lo*lo <= 2^-22 relative): half the
 // MFMAs and 2.5 instead of 5 vector instructions per split value, for an error of 2^-22 instead of 2^-24 per product
 // (parity bar: 1e-5 = 2^-16.6).  fp16 has a narrow exponent range (normal from 2^-14, top 65,504); it is handled so:
@@ -112,69 +113,23 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ w, int ldw,
 //     which the fp16 MFMA reads exactly; |w| >= 65,504 cannot be represented (outputs come out non-finite, not wrong);
 //   * activations / gradients are checked per wave and GEMM: the wave's max |x| (7 DPP steps + a read-lane) decides between
 //     the plain path (2^-6 <= max < 2^15: every value's error is <= 2^-22 of the wave's maximum) and a path that multiplies
-//     operand and accumulator by an exact power of two first (max -> 2^13..2^14) and the accumulator back after.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+//     operand and accumulator by an exact power of two first (max -> 2^13..2^14) and the accumulator back after;
+//   * the streaming GEMMs (k_wgemm, k_s2s_gemm_split) keep one such scale per wave / workgroup that only shrinks along K.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// ---- three bf16 pieces (wide.h, s2s_step.h)
-__device__ __forceinline__ void split_bf16x3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
-// The lane's B fragment of one 32-deep k block from two accumulator-layout blocks: element j < 4 is hidden unit
-// 32 kb + 4 q + j, element j >= 4 is 32 kb + 16 + 4 q + (j - 4).  The k order inside a block is thus a permutation
-// of the natural one; weight images (stage_split_*) are written in the same order.
-// Written on pairs: the two conversions of a pair are one v_cvt_pk_bf16_f32, the two subtractions one v_pk_add_f32
-// (the library is built without the SLP vectoriser, build.py, so packed math is whatever the sources spell out).
-__device__ __forceinline__ void split8_bf3(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const f32x2 x = p < 2 ? f32x2{v0[2 * p], v0[2 * p + 1]} : f32x2{v1[2 * p - 4], v1[2 * p - 3]};
-        const bf16x2 h = __builtin_convertvector(x, bf16x2);
-        const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
-        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
-        const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
-        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
-        hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
-        mid[2 * p] = m[0]; mid[2 * p + 1] = m[1];
-        lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
-    }
-}
-// bf16 x 3 weight image: [term 3][row block mb][k block kb][lane 64] fragments of 8 bf16 (16 bytes); lane (m, q)
-// of fragment (mb, kb) holds W[16 mb + m][32 kb + 4 q + j] (j < 4) | W[16 mb + m][32 kb + 16 + 4 q + j].
-// `v` = W[row][col .. col + 3] (col a multiple of 4): one half-fragment (8 bytes) per term.
-template <int MBN, int KBN>
-__device__ __forceinline__ void stage_split4_bf3(float* img, int row, int col, const f32x4 v) {
-    const int mb = row >> 4, m = row & 15, kb = col >> 5, c5 = col & 31, half = c5 >> 4, qq = (c5 & 15) >> 2;
-    bf16x4 h, md, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __bf16 a, b, c;
-        split_bf16x3(v[j], a, b, c);
-        h[j] = a; md[j] = b; l[j] = c;
-    }
-    const int frag = (mb * KBN + kb) * 64 + m + 16 * qq;
-    constexpr int TERM = MBN * KBN * 64;                        // fragments per term
-    *reinterpret_cast<bf16x4*>(img + (frag) * 4 + half * 2) = h;
-    *reinterpret_cast<bf16x4*>(img + (TERM + frag) * 4 + half * 2) = md;
-    *reinterpret_cast<bf16x4*>(img + (2 * TERM + frag) * 4 + half * 2) = l;
-}
-
-// ---- two fp16 pieces (the hidden-64 kernels)
+// ---- two fp16 pieces
 constexpr int SPLIT_WIMG = 2 * 4 * 2 * 64 * 4;          // floats of the split image of a 64 x 64 matrix (2 terms x 8 KB)
 __device__ __forceinline__ void split_f16x2(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x;
     l = (_Float16)(x - (float)h);
 }
-// The lane's B fragment of one 32-deep k block from two accumulator-layout blocks (element order as split8_bf3), on pairs:
+// The lane's B fragment of one 32-deep k block from two accumulator-layout blocks: element j < 4 is hidden unit
+// 32 kb + 4 q + j, element j >= 4 is 32 kb + 16 + 4 q + (j - 4) -- a permutation of the natural k order; weight images
+// (stage_split4) are written in the same order.  On pairs (the library is built without the SLP vectoriser, build.py):
 // v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 -- five instructions per two values.
 __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, f16x8& hi, f16x8& lo) {
 #pragma unroll

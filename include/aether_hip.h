@@ -78,8 +78,10 @@ typedef struct AetherGraphInfo {
  * workspace may be re-purposed freely.  Consequence: two launches that use the SAME graph buffer must not run
  * concurrently (different streams); build a second graph view for that. */
 #define AETHER_FLAG_WORKSPACE_REUSED 8
-/* The fused kernel multiplies the edge MLPs as six bf16 matrix-core terms on operands split into three bf16 pieces each
- * (fp32-equivalent result, see csrc/common.h); the weights' pieces are prepared by a small kernel in front of every call
+/* The fused kernel multiplies its 64 x 64 layers (edge MLPs, node update, out MLP) as three fp16 matrix-core terms on
+ * operands split into two fp16 pieces each, with exact power-of-two rescaling where a wave's activations leave fp16's
+ * comfortable range (22 significand bits; parity 1e-5, measured 4e-8: csrc/common.h).  Weights must be below 65,504 in
+ * magnitude (beyond: non-finite outputs).  The weights' pieces are prepared by a small kernel in front of every call
  * (workspace region).  Set this flag when `workspace` still holds the pieces written by an earlier call with the SAME
  * parameter values (inference loops, rollouts): that kernel is then skipped.  Never set it after the weights changed. */
 #define AETHER_FLAG_WEIGHTS_PREPARED 16
@@ -274,7 +276,7 @@ int aether_dynamic_field_backward_inputs(const AetherDynFieldParams* params, con
  * [64]-sized dimension of AetherParams above becomes [hidden], [128] becomes [2 hidden], [192] becomes [3 hidden].
  * The calls below are the calls above with the width as an argument:
  *   hidden == 64        : exactly the functions above (fused / streamed 64-wide kernels);
- *   hidden == 64 m > 64 : layer-by-layer on one generic split-bf16 MFMA GEMM kernel with fused epilogues (csrc/wide.h);
+ *   hidden == 64 m > 64 : layer-by-layer on one generic split-operand (2 x fp16) MFMA GEMM kernel with fused epilogues (csrc/wide.h);
  *   other widths        : not accepted here -- zero-pad the parameters to the next multiple of 64 (padded channels stay
  *                         exactly zero through SiLU, the mean and the residuals; the Python module does this).
  * `field` (forward) / `grad_field` (backward) may be NULL (the built-in field net) or the external field of
@@ -463,7 +465,7 @@ int aether_s2s_mlp_head(const float* const* w, const float* const* b, int layers
  * layers that are independent of each other share a launch, the gate pre-activations are K-concatenated products, the
  * local frames are built once for prior and decoder, and everything derived from the weights alone comes from a PLAN:
  *   aether_s2s_plan_build : filter image, padded input layers, BatchNorm affines, concatenated gate weights / summed gate
- *                           biases, summed LSTM biases, bf16 x 3 images of the dense layers (used from 2 K rows on; `field` may be
+ *                           biases, summed LSTM biases, two-piece fp16 images of the dense layers (used from 2 K rows on; `field` may be
  *                           NULL when every step will be given ext_field, otherwise pass the field net the steps will use) -> plan (device, 256-byte aligned, aether_s2s_plan_bytes); rebuild after the weights change
  *   aether_s2s_step       : inputs [n_nodes][2D], decoder_hidden_in [n_nodes][hd], h0 / c0 [n_edges][rnn], uniform
  *                           [n_edges][K] (the U(0,1) draw of gumbel_softmax) -> outputs, decoder_hidden_out, h1, c1 and,
