@@ -202,7 +202,7 @@ def _cpu_baseline(sd, inp, model=None, dev=None, budget_s=15.0, sd_trained=None)
 def _other_configs(dev, budget_s=10.0):
     """what the driver's one run says about the configurations that are not the headline -- cfg3 forward,
     hidden_size 128 / 256 at the headline shape (csrc/wide.h), one GPU's share of cfg5 forward (3 steps), the variable-N
-    prediction step (cfg4's model).  Rank 0, after the headline's timed region; bounded: a leg starts only while the block
+    prediction step (cfg4's model), the seq2seq model's prediction step (round 4).  Rank 0, after the headline's timed region; bounded: a leg starts only while the block
     is inside its budget, every leg is guarded (an error is recorded, the headline line is printed regardless)."""
     import contextlib
     import io
@@ -339,6 +339,30 @@ def _other_configs(dev, budget_s=10.0):
                 "launch": "aether_dyn_rollout_batched (one library call for the loop, host-side list handling included)"}
 
     leg("BASELINE cfg4: 64 inD-sized scenes per variable-N prediction step (2..40 objects, kNN k=10)", dyn_step_64)
+
+    def s2s_step(D, N, B, hd, T, reps):
+        # the seq2seq model's autoregressive prediction step: device-side rollout, ONE library call for T steps
+        from aether_amd.nn.seq2seq.aether import Aether as S2SAether
+        H, R = 512, 128
+        params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": hd, "num_edge_types": 2,
+                  "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3, "encoder_dropout": 0.0, "encoder_hidden": H,
+                  "encoder_rnn_hidden": R, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 256,
+                  "prior_num_layers": 3, "prior_hidden_size": 256, "pos_representation": "polar" if D == 2 else "cart",
+                  "gumbel_temp": 0.5, "rff_std": 1.0}
+        torch.manual_seed(0)
+        with quiet():
+            m = S2SAether(params, device=dev).eval()
+        E = N * (N - 1)
+        x = torch.randn(B, N, 2 * D, device=dev)
+        dh = torch.zeros(B, N, hd, device=dev)
+        ps = (torch.zeros(B, E, R, device=dev), torch.zeros(B, E, R, device=dev))
+        U = torch.rand(T, B, E, 2, device=dev)
+        ms = timed(lambda: m.predict_from_state(x, dh, ps, T, uniform=U), reps, warm=2) / T
+        return {"ms_per_step": ms, "value": B * E / (ms * 1e-3), "unit": "edge-steps/s", "edges": B * E, "encoder_hidden": H,
+                "decoder_hidden": hd, "launch": "aether_s2s_rollout (one library call for the loop)"}
+
+    leg("seq2seq prediction step, gravitational-3d N=5 B=128 (the reference's own size)", lambda: s2s_step(3, 5, 128, 256, 20, 3))
+    leg("seq2seq prediction step, 2-d N=20 B=128", lambda: s2s_step(2, 20, 128, 512, 10, 2))
 
     def cfg5_shard():
         # one GPU's share of BASELINE config 5 (32 graphs of 1,024 bodies, 33.5 M edges), inputs drawn on the device
