@@ -30,6 +30,10 @@ struct S2SJob {
     int64_t N;
     int M, K, ldw, ldx, ldy, sstride, act, accumulate, K2, ldw2, ldx2;
     int wg0, gx;                                 // first workgroup of the job, workgroups along n
+    // act == 5 (k_s2s_gemm_split only): the rows of W are the LSTM's gates interleaved by unit (image row 4 u + g = gate g of
+    // unit u: k_s2s_gemm_image with gate_units = R, bias permuted alike), so a lane's four accumulator rows are (i, f, g, o) of
+    // ONE unit: the cell update runs in the epilogue -- c1 = sig(f) c0 + sig(i) tanh(g), h1 = sig(o) tanh(c1) -- and Y is not written
+    const float* cell_c0; float* cell_h1; float* cell_c1;       // [N][M / 4]
 };
 struct S2SJobs { int n; S2SJob j[S2S_MAX_JOBS]; };
 
@@ -194,13 +198,15 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
 // would reach 2^15 lowers it and multiplies the accumulators by the ratio (exact); the epilogue divides by the final s.
 // Every value is thus represented to 2^-22 of the largest value its wave has seen.  Weights are split as they are
 // (|w| < 65,504; a lo piece below |w| = 2^-3 is a subnormal: absolute error <= 2^-25).
+// gate_units > 0: image row 4 u + g is row g * gate_units + u of W (the four gates of an LSTM unit side by side)
 __global__ void __launch_bounds__(256)
-k_s2s_gemm_image(const float* __restrict__ W, int M, int K, int ldw, f16x8* __restrict__ img) {
+k_s2s_gemm_image(const float* __restrict__ W, int M, int K, int ldw, f16x8* __restrict__ img, int gate_units) {
     const int oct = K >> 3;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;         // (row, k octet)
     if (idx >= (int64_t)M * oct) return;
     const int m = (int)(idx / oct), o = (int)(idx - (int64_t)m * oct);
-    const f32x4 v0 = ld4(W + (size_t)m * ldw + 8 * o), v1 = ld4(W + (size_t)m * ldw + 8 * o + 4);
+    const int ms = gate_units > 0 ? (m & 3) * gate_units + (m >> 2) : m; // source row
+    const f32x4 v0 = ld4(W + (size_t)ms * ldw + 8 * o), v1 = ld4(W + (size_t)ms * ldw + 8 * o + 4);
     f16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -383,6 +389,20 @@ k_s2s_gemm_split(const S2SJobs jobs) {
         const float* g1 = J.g1 != nullptr ? J.g1 + (size_t)J.i1[nsrc] * M : nullptr;
         const float* g2 = J.g2 != nullptr ? J.g2 + (size_t)J.i2[nsrc] * M : nullptr;
         const float sc = J.scale != nullptr ? J.scale[(size_t)n * J.sstride] : 1.0f;
+        if (act == 5) {                                       // LSTM cell on the gate pre-activations (rows interleaved by unit)
+            const int Ru = M >> 2;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                const int u = ((m0 + 16 * mb) >> 2) + q;      // rows 4 u .. 4 u + 3
+                const f32x4 v = acc[mb][nb] * inv_xs;
+                const float ig = 1.0f / (1.0f + expf(-v[0])), fg = 1.0f / (1.0f + expf(-v[1]));
+                const float gg = tanhf(v[2]), og = 1.0f / (1.0f + expf(-v[3]));
+                const float cn = fg * J.cell_c0[(size_t)n * Ru + u] + ig * gg;
+                J.cell_c1[(size_t)n * Ru + u] = cn;
+                J.cell_h1[(size_t)n * Ru + u] = og * tanhf(cn);
+            }
+            continue;
+        }
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             const int m = m0 + 16 * mb + 4 * q;
@@ -724,6 +744,15 @@ k_s2s_segment_mean2(const float* __restrict__ M1, const float* __restrict__ M2, 
         const float cnt = (float)(end - beg > 1 ? end - beg : 1);
         st4(out + (size_t)n * ldo + c, s / cnt);
     }
+}
+
+// out[4 u + g] = a[g R + u] + b[g R + u]: the summed LSTM biases with the gates interleaved by unit (S2SJob act 5)
+__global__ void __launch_bounds__(256)
+k_s2s_lstm_bias_interleave(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int R) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= 4 * R) return;
+    const int src = (m & 3) * R + (m >> 2);
+    out[m] = a[src] + b[src];
 }
 
 // Plan helpers: dst[r][0 .. ld) = [a[r][0..ca) zero-padded to cap | b[r][0..cb) | c[r][0..cc)] (nullptr parts are skipped)
