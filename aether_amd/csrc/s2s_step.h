@@ -193,10 +193,10 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
 // fp16 pieces (common.h; rounds 2-3: six bf16 terms on three pieces).  Weights come as prepared images (the plan), the
 // activation rows are split in registers.
 //   image of W [M][K] (row stride ldw): [k block K/32][row block M/16][piece 2][lane (i, q)] = W[16 mb + i][32 a + 8 q .. + 8)
-// fp16's exponent range: the activations of a wave (16 NB rows) carry ONE power-of-two scale s that only ever shrinks while
-// the K loop runs -- the first k step sets it from the wave's maximum (max -> 2^13..2^14), a later step whose scaled values
-// would reach 2^15 lowers it and multiplies the accumulators by the ratio (exact); the epilogue divides by the final s.
-// Every value is thus represented to 2^-22 of the largest value its wave has seen.  Weights are split as they are
+// fp16's exponent range: every ROW of activations carries a power-of-two scale s that only ever shrinks while the K loop
+// runs -- the first k step sets it from the row's maximum (max -> 2^13..2^14), a later step whose scaled values would reach
+// 2^15 lowers it and multiplies the row's accumulators by the ratio (exact); the epilogue divides by the final s.  Every
+// value is thus represented to 2^-22 of the largest value its row has shown so far.  Weights are split as they are
 // (|w| < 65,504; a lo piece below |w| = 2^-3 is a subnormal: absolute error <= 2^-25).
 // gate_units > 0: image row 4 u + g is row g * gate_units + u of W (the four gates of an LSTM unit side by side)
 __global__ void __launch_bounds__(256)
@@ -297,38 +297,51 @@ k_s2s_gemm_split(const S2SJobs jobs) {
     xload(0);
     dma(0);
     if (S > 1) dma(1);
-    float xs = 0.0f;                                          // the wave's activation scale (0: not set yet); accumulators hold xs x sums
+    // Activation scale: ONE power of two per ROW of X (lane (i, q) holds eight k of row 16 nb + i: the four q lanes of a row
+    // agree on its maximum through two cross-lane exchanges), 0 = not set yet; the accumulators of a row hold xs x sums.
+    // Per row, not per wave: the rows a wave works on may be gathered through per-type lists whose order differs from run to
+    // run (atomic appends) -- a scale shared by whichever rows meet in a wave made the result depend on that order (found by
+    // tools/s2s_soak.py: 1-ulp differences between runs).
+    float xs[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xs[nb] = 0.0f;
     f16x8 xh[NB], xl[NB];
     // X of a step -> range check, scale, split.  Done for step s + 1 at the END of step s (under the matrix pipe's drain) so
     // that the dependent chain max -> compare -> branch -> multiply -> convert is off the step's critical path.
     auto prepare_x = [&]() {
-        float m = 0.0f;
+        float m[NB];
+        bool redo_lane = false;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb) {
+            float v = 0.0f;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
-                m = fmaxf(fmaxf(m, fmaxf(fabsf(xa[nb][hh][0]), fabsf(xa[nb][hh][1]))), fmaxf(fabsf(xa[nb][hh][2]), fabsf(xa[nb][hh][3])));
-        // the first step sets the scale; a step that would reach 2^15 lowers it (wave-uniform, rare)
-        const bool redo = xs == 0.0f || __builtin_amdgcn_ballot_w64(m * xs >= 32768.0f) != 0ull;
-        if (redo) {
-            const unsigned E = wave_max_exponent(m);
-            int sh = 140 - (int)E;                                // max (2^(E-127) ..) -> 2^13 ..
-            sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
-            float ns = __int_as_float((127 + sh) << 23);
-            float ratio = ns;                                     // first time: the accumulators hold the bias
-            if (xs != 0.0f) {
-                ns = ns < xs ? ns : xs;                           // only ever down
-                ratio = ns / xs;                                  // (powers of two: exact)
+                v = fmaxf(fmaxf(v, fmaxf(fabsf(xa[nb][hh][0]), fabsf(xa[nb][hh][1]))), fmaxf(fabsf(xa[nb][hh][2]), fabsf(xa[nb][hh][3])));
+            v = fmaxf(v, __shfl_xor(v, 16));
+            v = fmaxf(v, __shfl_xor(v, 32));                      // the row's maximum over this step's 32 k, in all four q lanes
+            m[nb] = v;
+            redo_lane = redo_lane || xs[nb] == 0.0f || v * xs[nb] >= 32768.0f;
+        }
+        // the first step sets the scales; a row that would reach 2^15 lowers its own (wave-uniform branch, rare)
+        if (__builtin_amdgcn_ballot_w64(redo_lane) != 0ull) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const unsigned E = (__float_as_uint(m[nb]) >> 23) & 255u;
+                int sh = 140 - (int)E;                            // max (2^(E-127) ..) -> 2^13 ..
+                sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
+                float ns = __int_as_float((127 + sh) << 23);
+                float ratio;
+                if (xs[nb] == 0.0f) ratio = ns;                   // first time: the accumulators hold the bias
+                else if (m[nb] * xs[nb] >= 32768.0f) { ns = ns < xs[nb] ? ns : xs[nb]; ratio = ns / xs[nb]; }    // (powers of two: exact)
+                else { ns = xs[nb]; ratio = 1.0f; }
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = acc[mb][nb] * ratio;
+                xs[nb] = ns;
             }
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = acc[mb][nb] * ratio;
-            xs = ns;
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            split8(xa[nb][0] * xs, xa[nb][1] * xs, xh[nb], xl[nb]);    // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
+            split8(xa[nb][0] * xs[nb], xa[nb][1] * xs[nb], xh[nb], xl[nb]);    // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
     };
     // X(0) has landed (the DMA loads of steps 0 and 1 were issued behind it: vmcnt counts in order)
     if (S > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -378,7 +391,9 @@ k_s2s_gemm_split(const S2SJobs jobs) {
             prepare_x();
         }
     }
-    const float inv_xs = xs != 0.0f ? 1.0f / xs : 1.0f;      // (a power of two: exact)
+    float inv_xs[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) inv_xs[nb] = xs[nb] != 0.0f ? 1.0f / xs[nb] : 1.0f;      // (powers of two: exact)
     const int act = J.act;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -394,7 +409,7 @@ k_s2s_gemm_split(const S2SJobs jobs) {
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
                 const int u = ((m0 + 16 * mb) >> 2) + q;      // rows 4 u .. 4 u + 3
-                const f32x4 v = acc[mb][nb] * inv_xs;
+                const f32x4 v = acc[mb][nb] * inv_xs[nb];
                 const float ig = 1.0f / (1.0f + expf(-v[0])), fg = 1.0f / (1.0f + expf(-v[1]));
                 const float gg = tanhf(v[2]), og = 1.0f / (1.0f + expf(-v[3]));
                 const float cn = fg * J.cell_c0[(size_t)n * Ru + u] + ig * gg;
@@ -406,7 +421,7 @@ k_s2s_gemm_split(const S2SJobs jobs) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             const int m = m0 + 16 * mb + 4 * q;
-            f32x4 v = acc[mb][nb] * inv_xs;
+            f32x4 v = acc[mb][nb] * inv_xs[nb];
             if (g1 != nullptr) v += ld4(g1 + m) + ld4(g2 + m);
             if (act == 1) v = silu4(v);
             else if (act == 2) {

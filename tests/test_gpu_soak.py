@@ -60,3 +60,29 @@ def test_streamed_edge_kernels_are_bit_stable_on_a_dense_graph():
     for _ in range(6):
         for x, y in zip(first, run()):
             assert torch.equal(x, y)
+
+
+def test_seq2seq_step_is_bit_stable_when_the_type_lists_change_order():
+    """The decoder's message layers gather their rows through per-type edge lists that the sampling kernel fills with atomic
+    appends: their order differs from run to run.  Every row's arithmetic has to be its own -- round 4's first fp16 form of
+    k_s2s_gemm_split shared one operand scale between the rows of a wave and came out 1 ulp different in 186 of 200 runs at
+    this size (48,640 edges: the 128-row tiles), caught by tools/s2s_soak.py; the scale is per row now."""
+    from aether_amd.nn.seq2seq.aether import Aether as S2SAether
+    D, N, B, hd = 2, 20, 128, 512
+    params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": hd, "num_edge_types": 2,
+              "skip_first": False, "decoder_dropout": 0.0, "use_3d": False, "encoder_dropout": 0.0, "encoder_hidden": 512,
+              "encoder_rnn_hidden": 128, "encoder_rnn_type": "lstm", "encoder_mlp_num_layers": 3, "encoder_mlp_hidden": 256,
+              "prior_num_layers": 3, "prior_hidden_size": 256, "pos_representation": "polar", "gumbel_temp": 0.5, "rff_std": 1.0}
+    torch.manual_seed(0)
+    m = S2SAether(params, device="cuda").eval()
+    E = N * (N - 1)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, N, 2 * D, generator=g).cuda()
+    dh = (torch.randn(B, N, hd, generator=g) * 0.3).cuda()
+    ps = ((torch.randn(B, E, 128, generator=g) * 0.3).cuda(), (torch.randn(B, E, 128, generator=g) * 0.3).cuda())
+    u = torch.rand(B, E, 2, generator=g).cuda()
+    flat = lambda o: [o[0], o[1], o[2][0], o[2][1], o[3]]
+    first = flat(m._fused_step(x, dh, ps, u))
+    for _ in range(25):
+        for a, b in zip(flat(m._fused_step(x, dh, ps, u)), first):
+            assert torch.equal(a, b)
