@@ -198,28 +198,30 @@ __device__ __forceinline__ SplitScale split_scale_of(const f32x4 (&act)[N]) {
     return r;
 }
 
+// (xh / xl: the operand's pieces, kept for callers that stage them: fused_bwd.h)
 template <int MBN, int KBN>
-__device__ __forceinline__ void gemm_split_core(const f16x8* __restrict__ w, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN], int lane) {
+__device__ __forceinline__ void gemm_split_core(const f16x8* __restrict__ w, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN], int lane,
+                                                f16x8 (&xh)[KBN], f16x8 (&xl)[KBN]) {
     constexpr int TERM = MBN * KBN * 64;
 #pragma unroll
     for (int kb = 0; kb < KBN; ++kb) {
-        f16x8 xh, xl;
-        split8(act[2 * kb], act[2 * kb + 1], xh, xl);
+        split8(act[2 * kb], act[2 * kb + 1], xh[kb], xl[kb]);
 #pragma unroll
         for (int mb = 0; mb < MBN; ++mb) {
             const int frag = (mb * KBN + kb) * 64 + lane;
             const f16x8 wh = w[frag], wl = w[TERM + frag];
             // small terms first
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[kb], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[kb], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[kb], acc[mb], 0, 0, 0);
         }
     }
 }
 // acc[mb] += W[16 mb + i][k] * act[item][k] over KBN 32-deep k blocks; act = 2 KBN accumulator-layout blocks.
+// Returns the scale it applied to the operand (1 on the plain path) and the operand's pieces (of the SCALED values).
 template <int MBN, int KBN>
-__device__ __forceinline__ void gemm_split(const float* __restrict__ img, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN],
-                                           int lane) {
+__device__ __forceinline__ SplitScale gemm_split_keep(const float* __restrict__ img, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN],
+                                                      int lane, f16x8 (&xh)[KBN], f16x8 (&xl)[KBN]) {
     const SplitScale sc = split_scale_of(act);
     f32x4 x[2 * KBN];
 #pragma unroll
@@ -230,11 +232,18 @@ __device__ __forceinline__ void gemm_split(const float* __restrict__ img, const 
 #pragma unroll
         for (int mb = 0; mb < MBN; ++mb) acc[mb] = acc[mb] * sc.s;
     }
-    gemm_split_core<MBN, KBN>(reinterpret_cast<const f16x8*>(img), x, acc, lane);
+    gemm_split_core<MBN, KBN>(reinterpret_cast<const f16x8*>(img), x, acc, lane, xh, xl);
     if (sc.on) {
 #pragma unroll
         for (int mb = 0; mb < MBN; ++mb) acc[mb] = acc[mb] * sc.inv_s;
     }
+    return sc;
+}
+template <int MBN, int KBN>
+__device__ __forceinline__ void gemm_split(const float* __restrict__ img, const f32x4 (&act)[2 * KBN], f32x4 (&acc)[MBN],
+                                           int lane) {
+    f16x8 xh[KBN], xl[KBN];
+    (void)gemm_split_keep<MBN, KBN>(img, act, acc, lane, xh, xl);
 }
 
 // The same product with the weight fragments of ONE 16-row block held in registers (k_fused's node phase: a wave owns a row
@@ -325,10 +334,10 @@ __device__ __forceinline__ void split_T_step(unsigned base, u32x2 (&lo)[2][2], u
     split_T_consume<BLK + 1 == NBLK>(lo[BLK & 1], hi[BLK & 1], xh[mp], xl[mp], acc[ob]);
     if constexpr (BLK + 1 < NBLK) split_T_step<KBN, BLK + 1>(base, lo, hi, xh, xl, acc);
 }
-// (every caller passes zero accumulators: they are not rescaled on the way in)
+// (every caller passes zero accumulators: they are not rescaled on the way in).  Returns the operand's scale and pieces.
 template <int KBN>
-__device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, const f32x4 (&act)[4], f32x4 (&acc)[2 * KBN],
-                                             int lane) {
+__device__ __forceinline__ SplitScale gemm_split_T_keep(const float* __restrict__ img, const f32x4 (&act)[4], f32x4 (&acc)[2 * KBN],
+                                                        int lane, f16x8 (&xh)[2], f16x8 (&xl)[2]) {
     const int g = lane >> 4, r = (lane & 15) >> 2, p = lane & 3;
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)img + ((4 * g + r) + 16 * p) * 16;
     const SplitScale sc = split_scale_of(act);
@@ -339,7 +348,6 @@ __device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, cons
 #pragma unroll
         for (int b = 0; b < 4; ++b) x[b] = x[b] * sc.s;
     }
-    f16x8 xh[2], xl[2];
     split8(x[0], x[1], xh[0], xl[0]);
     split8(x[2], x[3], xh[1], xl[1]);
     // software pipeline over the blocks (mp, ob): the four reads of block n + 1 are in flight while block n's three MFMAs issue
@@ -350,6 +358,13 @@ __device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, cons
 #pragma unroll
         for (int ob = 0; ob < 2 * KBN; ++ob) acc[ob] = acc[ob] * sc.inv_s;
     }
+    return sc;
+}
+template <int KBN>
+__device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, const f32x4 (&act)[4], f32x4 (&acc)[2 * KBN],
+                                             int lane) {
+    f16x8 xh[2], xl[2];
+    (void)gemm_split_T_keep<KBN>(img, act, acc, lane, xh, xl);
 }
 
 // Cooperative copy of W[rows][cols] (global, row stride src_ld) into LDS [rows][ldw], zero padded.

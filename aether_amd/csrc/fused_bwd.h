@@ -58,7 +58,8 @@ struct FbLds {                                // offsets in floats
     static constexpr int STG_SIZE = 4 * 3 * 16 * FB_SA;
     static constexpr int DXS = STG;                                // [32][LDW]  dx  (own slots)   } node phase only:
     static constexpr int DPU = DXS + FUSED_MAX_NODES * LDW;        // [32][LDU]  dpre_u            } alias the staging
-    static constexpr int TOTAL = STG + STG_SIZE;
+    static constexpr int SCL = STG + STG_SIZE;                      // [4 waves][4]: 1/(s_d2 s_h), 1/(s_G s_ep), 1/s_d2, 1/s_G of the round's tiles
+    static constexpr int TOTAL = SCL + 16;
     // round 4: G of a tile gets staging rows of its own (d2, h, e_prev and G of the round's four tiles stay staged until every
     // wave has added its row quarter of both products): [4 waves][16][FB_SA] in what used to hold W2^T (no longer staged)
     static constexpr int STG_G = W2T;
@@ -153,6 +154,78 @@ __device__ __forceinline__ void fb_outer16_q(const float* __restrict__ sa, const
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(av, bv[nb], acc[nb]);
     }
+}
+
+// ------------------------------------------------------------------ round 4 (second half): the staged tiles as fp16 pieces
+// A staged tensor of a tile ([16 edges][64 features]) lies in LDS as the two fp16 pieces the tile's GEMMs split it into
+// anyway (gemm_split_keep / gemm_split_T_keep: pieces of the SCALED values, the wave's power-of-two scale beside them):
+// [piece 2][16 rows][FB_RH halves] -- 4,352 bytes, exactly what the fp32 rows [16][FB_SA] took.  The weight-gradient and
+// incidence products read them TRANSPOSED (ds_read_b64_tr_b16: lane (c, q) of a 16-lane group gets rows 4 q .. 4 q + 3 of
+// column c) as A / B fragments of v_mfma_f32_16x16x32_f16 with K = the tile's 16 edges in k slots 8 q + j, j < 4 (slots
+// j >= 4 are zero), three terms per product (two where one operand is a 0/1 matrix), and add tmp x 1 / (s_x s_y) to the
+// fp32 accumulators: ~1/3 of the matrix time of the fp32 MFMA form (16 x 32 cycles per 16 x 64 product and tile), which
+// ran on the vector ALU.
+constexpr int FB_RH = 2 * FB_SA;              // bytes of a staged row: 64 halves + 4 halves of padding (136)
+constexpr int FB_PLANE = 16 * FB_RH;          // bytes of one piece of a tile
+static_assert(2 * FB_PLANE == 16 * FB_SA * 4, "the two pieces take the room of the fp32 rows");
+template <int KBN>
+__device__ __forceinline__ void fb_stage_pieces(float* arr, int i, int q, const f16x8 (&xh)[KBN], const f16x8 (&xl)[KBN]) {
+    char* row = reinterpret_cast<char*>(arr) + i * FB_RH + 8 * q;
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+        const u32x4 h = __builtin_bit_cast(u32x4, xh[kb]), l = __builtin_bit_cast(u32x4, xl[kb]);
+        // elements j < 4: features 32 kb + 4 q + j; j >= 4: 32 kb + 16 + 4 q + (j - 4)
+        *reinterpret_cast<u32x2*>(row + 64 * kb) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(row + 64 * kb + 32) = u32x2{h[2], h[3]};
+        *reinterpret_cast<u32x2*>(row + FB_PLANE + 64 * kb) = u32x2{l[0], l[1]};
+        *reinterpret_cast<u32x2*>(row + FB_PLANE + 64 * kb + 32) = u32x2{l[2], l[3]};
+    }
+}
+// the lane's part of a transposed 4 x 16 read: rows 4 q + r, 8-byte column group p (lane = 16 q + 4 r + p)
+__device__ __forceinline__ unsigned fb_tr_lane_offset(int lane) {
+    const int q = lane >> 4, c = lane & 15;
+    return (unsigned)((4 * q + (c >> 2)) * FB_RH + 8 * (c & 3));
+}
+__device__ __forceinline__ unsigned fb_lds_addr(const float* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ f16x8 fb_frag(const u32x2 v) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], 0u, 0u}); }
+#define FB_TR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off) : "memory")
+// acc[nb] += c_xy * sum_k X[k][m0 + 4 q + r] Y[k][16 nb + i] over the 16 staged rows; colsum += c_x * sum_k X[k][m0 + 4 q + r]
+// xa / ya: LDS byte addresses of the arrays' hi planes + the lane's offset (xa also + 2 m0)
+template <int NB, bool COLSUM>
+__device__ __forceinline__ void fb_outer16_h(unsigned xa, unsigned ya, f32x4 (&acc)[NB], f32x4& colsum, float c_xy, float c_x) {
+    u32x2 xr[2], yr[NB][2];
+    FB_TR(xr[0], xa, 0); FB_TR(xr[1], xa, FB_PLANE);
+    FB_TR(yr[0][0], ya, 0); FB_TR(yr[0][1], ya, FB_PLANE);
+    FB_TR(yr[1][0], ya, 32); FB_TR(yr[1][1], ya, FB_PLANE + 32);
+    if constexpr (NB == 4) {
+        FB_TR(yr[2][0], ya, 64); FB_TR(yr[2][1], ya, FB_PLANE + 64);
+        FB_TR(yr[3][0], ya, 96); FB_TR(yr[3][1], ya, FB_PLANE + 96);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(yr[0][0]), "+v"(yr[0][1]), "+v"(yr[1][0]), "+v"(yr[1][1]),
+                                              "+v"(yr[2][0]), "+v"(yr[2][1]), "+v"(yr[3][0]), "+v"(yr[3][1]));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(yr[0][0]), "+v"(yr[0][1]), "+v"(yr[1][0]), "+v"(yr[1][1]));
+    }
+    const f16x8 xh = fb_frag(xr[0]), xl = fb_frag(xr[1]);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const f16x8 yh = fb_frag(yr[nb][0]), yl = fb_frag(yr[nb][1]);
+        f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yh, zero, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yl, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, t, 0, 0, 0);
+        acc[nb] = acc[nb] + t * c_xy;
+    }
+    if constexpr (COLSUM) {
+        const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{0x3C003C00u, 0x3C003C00u, 0u, 0u});       // 1.0 in the four live k slots
+        f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ones, zero, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, ones, t, 0, 0, 0);
+        colsum = colsum + t * c_x;
+    }
+}
+// 0 / 1 fragment of four incidence bits (bit j: k slot j): fp16 1.0 = 0x3C00
+__device__ __forceinline__ f16x8 fb_inc_frag(unsigned nib) {
+    const unsigned lo = ((nib & 1u) | ((nib & 2u) << 15)) * 0x3C00u, hi = (((nib >> 2) & 1u) | ((nib & 8u) << 13)) * 0x3C00u;
+    return __builtin_bit_cast(f16x8, u32x4{lo, hi, 0u, 0u});
 }
 
 // acc[mb] += W[16 mb + i][k] * act[item][k] with W as a fragment-ordered LDS image of KB k blocks per row block.
@@ -252,7 +325,7 @@ k_fused_bwd(FbArgs A) {
 
     // ---------------------------------------------------------------- per-tile structure (rounds r: tile 4r + wave)
     int ke[ROUNDS], sl[ROUNDS], rl[ROUNDS];
-    unsigned inc[ROUNDS];                    // bits 0-7: sender incidence (s4 + 4 * node block), 8-15: receiver incidence
+    unsigned inc[ROUNDS];                    // bits 0-7: sender incidence (edge 4 q + j: bit j + 4 * node block), 8-15: receiver incidence
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const int local = 16 * (NWV * r + wave) + i;
@@ -263,14 +336,14 @@ k_fused_bwd(FbArgs A) {
         rl[r] = m > 0 ? A.recv_s[k] - nb : 0;
         unsigned bits = 0;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int e_lane = (lane & 48) + 4 * s4 + q;            // lane of this 16-group that holds edge 4 s4 + q
+        for (int j = 0; j < 4; ++j) {
+            const int e_lane = (lane & 48) + 4 * q + j;             // lane of this 16-group that holds edge 4 q + j (k slot 8 q + j)
             const int es = __shfl(sl[r], e_lane), er = __shfl(rl[r], e_lane), ek = __shfl(ke[r], e_lane);
             if (ek >= 0) {
 #pragma unroll
                 for (int b2 = 0; b2 < 2; ++b2) {
-                    if (es == 16 * b2 + i) bits |= 1u << (s4 + 4 * b2);
-                    if (er == 16 * b2 + i) bits |= 1u << (8 + s4 + 4 * b2);
+                    if (es == 16 * b2 + i) bits |= 1u << (j + 4 * b2);
+                    if (er == 16 * b2 + i) bits |= 1u << (8 + j + 4 * b2);
                 }
             }
         }
@@ -535,20 +608,22 @@ k_fused_bwd(FbArgs A) {
 #pragma unroll
                 for (int mb = 0; mb < (FIRST ? 2 : 4); ++mb) ep[mb] = epn[mb] * vm;
                 if (r > 0) load_ep(r > 0 ? r - 1 : 0, epn);      // tile r exists, so does tile r - 1
+                // (each operand's fp16 pieces go to the wave's staging rows as its GEMM makes them: fb_stage_pieces)
+                SplitScale s_ep;
                 if constexpr (FIRST) {
-                    st4(sc + i * FB_SA + 4 * q, ep[0]);
-                    st4(sc + i * FB_SA + 16 + 4 * q, ep[1]);
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) p1[mb] = ld4(bias + H + 16 * mb + 4 * q);
                     f32x4 b2[2] = {ep[0], ep[1]};
-                    gemm_split<4, 1>(wE, b2, p1, lane);
+                    f16x8 ph[1], pl[1];
+                    s_ep = gemm_split_keep<4, 1>(wE, b2, p1, lane, ph, pl);
+                    fb_stage_pieces<1>(sc, i, q, ph, pl);
                 } else {
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        st4(sc + i * FB_SA + 16 * mb + 4 * q, ep[mb]);
+                    for (int mb = 0; mb < 4; ++mb)
                         p1[mb] = ld4(psb + slr * LDW + 16 * mb + 4 * q) + ld4(prb + rlr * LDW + 16 * mb + 4 * q);
-                    }
-                    gemm_split<4, 2>(wE, ep, p1, lane);
+                    f16x8 ph[2], pl[2];
+                    s_ep = gemm_split_keep<4, 2>(wE, ep, p1, lane, ph, pl);
+                    fb_stage_pieces<2>(sc, i, q, ph, pl);
                 }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(90);
 #pragma unroll
@@ -556,11 +631,15 @@ k_fused_bwd(FbArgs A) {
                     const f32x4 sg = sigmoid4(p1[mb]);
                     hh[mb] = p1[mb] * sg;
                     ds1[mb] = dsilu_from_sigmoid(p1[mb], sg);
-                    st4(sb + i * FB_SA + 16 * mb + 4 * q, hh[mb]);
                     p2[mb] = ld4(bias + 16 * mb + 4 * q);
                 }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(91);
-                gemm_split<4, 2>(w2, hh, p2, lane);
+                SplitScale s_h;
+                {
+                    f16x8 ph[2], pl[2];
+                    s_h = gemm_split_keep<4, 2>(w2, hh, p2, lane, ph, pl);
+                    fb_stage_pieces<2>(sb, i, q, ph, pl);
+                }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(92);
                 // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
                 f32x4 d2[4], dh[4], g[4];
@@ -574,53 +653,32 @@ k_fused_bwd(FbArgs A) {
                     }
                     d2[mb] = dev * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
                     dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    st4(sa + i * FB_SA + 16 * mb + 4 * q, d2[mb]);
                 }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(93);
-                gemm_split_T<2>(w2, d2, dh, lane);              // W2^T dpre2 on the bf16 pipe, from the forward's image
+                SplitScale s_d2;
+                {
+                    f16x8 ph[2], pl[2];
+                    s_d2 = gemm_split_T_keep<2>(w2, d2, dh, lane, ph, pl);       // W2^T dpre2 on the matrix pipe, from the forward's image
+                    fb_stage_pieces<2>(sa, i, q, ph, pl);
+                }
                 if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(94);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    g[mb] = dh[mb] * ds1[mb];
-                    st4(sd + i * FB_SA + 16 * mb + 4 * q, g[mb]);
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(96);
-                if constexpr (!FIRST) {
-                    // out[node][h] += sum_edge Inc[node][edge] * G[edge][h]: A = the lane's incidence bits, B = G staged
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const float* grow = sd + (4 * s4 + q) * FB_SA + i;
-                        float gv[4];
-#pragma unroll
-                        for (int nbx = 0; nbx < 4; ++nbx) gv[nbx] = grow[16 * nbx];
-#pragma unroll
-                        for (int b2 = 0; b2 < 2; ++b2) {
-                            if (b2 == 0 || nv > 16) {
-                                const float sv = (incr >> (s4 + 4 * b2)) & 1u ? 1.0f : 0.0f;
-#pragma unroll
-                                for (int nbx = 0; nbx < 4; ++nbx) dps[b2][nbx] = mfma16(sv, gv[nbx], dps[b2][nbx]);
-                            }
-                            if (b2 == 0 || n > 16) {
-                                const float rv = (incr >> (8 + s4 + 4 * b2)) & 1u ? 1.0f : 0.0f;
-#pragma unroll
-                                for (int nbx = 0; nbx < 4; ++nbx) dpr[b2][nbx] = mfma16(rv, gv[nbx], dpr[b2][nbx]);
-                            }
-                        }
-                    }
-                }
-                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(98);
-                __builtin_amdgcn_wave_barrier();
-                // ---- gradient into this layer's edge input
+                for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * ds1[mb];
+                // ---- gradient into this layer's edge input (its GEMM also makes G's pieces for the staging rows)
+                SplitScale s_g;
                 if constexpr (FIRST) {
                     f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                    gemm_split_T<1>(wE, g, da, lane);                      // W1^T G
+                    f16x8 ph[2], pl[2];
+                    s_g = gemm_split_T_keep<1>(wE, g, da, lane, ph, pl);            // W1^T G
+                    fb_stage_pieces<2>(sd, i, q, ph, pl);
                     if (ok) { st4(A.DA + kc * FPAD + 4 * q, da[0]); st4(A.DA + kc * FPAD + 16 + 4 * q, da[1]); }
                 } else {
                     f32x4 dep[4];
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    gemm_split_T<2>(wE, g, dep, lane);                     // W_e^T G
+                    f16x8 ph[2], pl[2];
+                    s_g = gemm_split_T_keep<2>(wE, g, dep, lane, ph, pl);           // W_e^T G
+                    fb_stage_pieces<2>(sd, i, q, ph, pl);
                     if constexpr (DE_REGS) {
 #pragma unroll
                         for (int mb = 0; mb < 4; ++mb) de[r][mb] = dep[mb];
@@ -629,6 +687,48 @@ k_fused_bwd(FbArgs A) {
                         for (int mb = 0; mb < 4; ++mb) st4(A.DE + kc * H + 16 * mb + 4 * q, dep[mb]);
                     }
                 }
+                if (lane == 0) {                               // this tile's scales for the round's products
+                    float* scl = smem + L::SCL + 4 * wave;
+                    scl[0] = s_d2.inv_s * s_h.inv_s; scl[1] = s_g.inv_s * s_ep.inv_s; scl[2] = s_d2.inv_s; scl[3] = s_g.inv_s;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(96);
+                if constexpr (!FIRST) {
+                    // out[node][h] += sum_edge Inc[node][edge] * G[edge][h]: A = the lane's incidence bits as 0 / 1 fp16, B = G's
+                    // staged pieces read transposed; two terms (A is exact), then the tile's 1 / s_G
+                    const unsigned ga = fb_lds_addr(sd) + fb_tr_lane_offset(lane);
+                    u32x2 gr[4][2];
+                    FB_TR(gr[0][0], ga, 0); FB_TR(gr[0][1], ga, FB_PLANE);
+                    FB_TR(gr[1][0], ga, 32); FB_TR(gr[1][1], ga, FB_PLANE + 32);
+                    FB_TR(gr[2][0], ga, 64); FB_TR(gr[2][1], ga, FB_PLANE + 64);
+                    FB_TR(gr[3][0], ga, 96); FB_TR(gr[3][1], ga, FB_PLANE + 96);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gr[0][0]), "+v"(gr[0][1]), "+v"(gr[1][0]), "+v"(gr[1][1]), "+v"(gr[2][0]),
+                                                          "+v"(gr[2][1]), "+v"(gr[3][0]), "+v"(gr[3][1]));
+                    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const float cg = s_g.inv_s;
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        if (b2 == 0 || nv > 16) {
+                            const f16x8 sv = fb_inc_frag((incr >> (4 * b2)) & 15u);
+#pragma unroll
+                            for (int nbx = 0; nbx < 4; ++nbx) {
+                                f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(sv, fb_frag(gr[nbx][1]), zero, 0, 0, 0);
+                                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(sv, fb_frag(gr[nbx][0]), t, 0, 0, 0);
+                                dps[b2][nbx] = dps[b2][nbx] + t * cg;
+                            }
+                        }
+                        if (b2 == 0 || n > 16) {
+                            const f16x8 rv = fb_inc_frag((incr >> (8 + 4 * b2)) & 15u);
+#pragma unroll
+                            for (int nbx = 0; nbx < 4; ++nbx) {
+                                f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(rv, fb_frag(gr[nbx][1]), zero, 0, 0, 0);
+                                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(rv, fb_frag(gr[nbx][0]), t, 0, 0, 0);
+                                dpr[b2][nbx] = dpr[b2][nbx] + t * cg;
+                            }
+                        }
+                    }
+                }
+                if (l == 3 && r == ROUNDS - 1) FB_WSTAMP(98);
             }
             // ---- the round's four tiles are staged (d2 | h | e_prev per wave, G beside them): every wave adds its row quarter
             // of both weight-gradient products over all of them (workgroup-uniform conditions: every wave takes the barriers)
@@ -639,8 +739,10 @@ k_fused_bwd(FbArgs A) {
                     if (NWV * r + t < n_tiles) {
                         const float* ta = smem + L::STG + t * (3 * 16 * FB_SA);
                         const float* td = smem + L::STG_G + t * (16 * FB_SA);
-                        fb_outer16_q<4, true>(ta, ta + 16 * FB_SA, aw2, db2, i, q, wave);               // dW2 += dpre2 (x) h, db2
-                        fb_outer16_q<NBE, FIRST>(td, ta + 2 * 16 * FB_SA, awe, db1, i, q, wave);     // dW_e += G (x) e_prev
+                        const float* scl = smem + L::SCL + 4 * t;
+                        const unsigned lo_ = fb_tr_lane_offset(lane), xo = lo_ + 32u * (unsigned)wave;      // rows m = 16 wave ..
+                        fb_outer16_h<4, true>(fb_lds_addr(ta) + xo, fb_lds_addr(ta + 16 * FB_SA) + lo_, aw2, db2, scl[0], scl[2]);            // dW2 += dpre2 (x) h, db2
+                        fb_outer16_h<NBE, FIRST>(fb_lds_addr(td) + xo, fb_lds_addr(ta + 2 * 16 * FB_SA) + lo_, awe, db1, scl[1], scl[3]);     // dW_e += G (x) e_prev
                     }
                 }
                 lds_barrier();         // staging rows are free for the next round (and for publish)
@@ -737,12 +839,15 @@ k_fused_bwd(FbArgs A) {
             float* dst = A.partial + ((size_t)blockIdx.x * 4 + (l - 1)) * FB_PART;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int mrow = 4 * (4 * q + r4) + wave;
-                st4(dst + mrow * H + 4 * i, f32x4{aw2[0][r4], aw2[1][r4], aw2[2][r4], aw2[3][r4]});
+                const int mrow = 16 * wave + 4 * q + r4;       // accumulator block nb holds columns 16 nb + i
+#pragma unroll
+                for (int nbx = 0; nbx < 4; ++nbx) dst[mrow * H + 16 * nbx + i] = aw2[nbx][r4];
                 if constexpr (FIRST) {
-                    *reinterpret_cast<f32x2*>(dst + H * H + mrow * FPAD + 2 * i) = f32x2{awe[0][r4], awe[1][r4]};
+                    dst[H * H + mrow * FPAD + i] = awe[0][r4];
+                    dst[H * H + mrow * FPAD + 16 + i] = awe[1][r4];
                 } else {
-                    st4(dst + H * H + mrow * H + 4 * i, f32x4{awe[0][r4], awe[1][r4], awe[2][r4], awe[3][r4]});
+#pragma unroll
+                    for (int nbx = 0; nbx < 4; ++nbx) dst[H * H + mrow * H + 16 * nbx + i] = awe[nbx][r4];
                 }
                 if (i == 0) {                             // (every column of the ones product holds the sum)
                     dst[2 * H * H + mrow] = db2[r4];
