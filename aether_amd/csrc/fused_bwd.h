@@ -190,26 +190,43 @@ __device__ __forceinline__ unsigned fb_lds_addr(const float* p) { return (unsign
 __device__ __forceinline__ f16x8 fb_frag(const u32x2 v) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], 0u, 0u}); }
 #define FB_TR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off) : "memory")
 // acc[nb] += c_xy * sum_k X[k][m0 + 4 q + r] Y[k][16 nb + i] over the 16 staged rows; colsum += c_x * sum_k X[k][m0 + 4 q + r]
-// xa / ya: LDS byte addresses of the arrays' hi planes + the lane's offset (xa also + 2 m0)
-template <int NB, bool COLSUM>
-__device__ __forceinline__ void fb_outer16_h(unsigned xa, unsigned ya, f32x4 (&acc)[NB], f32x4& colsum, float c_xy, float c_x) {
-    u32x2 xr[2], yr[NB][2];
-    FB_TR(xr[0], xa, 0); FB_TR(xr[1], xa, FB_PLANE);
-    FB_TR(yr[0][0], ya, 0); FB_TR(yr[0][1], ya, FB_PLANE);
-    FB_TR(yr[1][0], ya, 32); FB_TR(yr[1][1], ya, FB_PLANE + 32);
+// xa / ya: LDS byte addresses of the arrays' hi planes + the lane's offset (xa also + 2 m0).  In two halves -- the reads, and
+// the wait + MFMAs -- so that the caller can have the next product's reads in flight: LATER = reads issued after this
+// product's (LDS returns in order).
+template <int NB> struct FbOuterRegs { u32x2 xr[2], yr[NB][2]; };
+template <int NB>
+__device__ __forceinline__ void fb_outer16_issue(unsigned xa, unsigned ya, FbOuterRegs<NB>& R) {
+    FB_TR(R.xr[0], xa, 0); FB_TR(R.xr[1], xa, FB_PLANE);
+    FB_TR(R.yr[0][0], ya, 0); FB_TR(R.yr[0][1], ya, FB_PLANE);
+    FB_TR(R.yr[1][0], ya, 32); FB_TR(R.yr[1][1], ya, FB_PLANE + 32);
     if constexpr (NB == 4) {
-        FB_TR(yr[2][0], ya, 64); FB_TR(yr[2][1], ya, FB_PLANE + 64);
-        FB_TR(yr[3][0], ya, 96); FB_TR(yr[3][1], ya, FB_PLANE + 96);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(yr[0][0]), "+v"(yr[0][1]), "+v"(yr[1][0]), "+v"(yr[1][1]),
-                                              "+v"(yr[2][0]), "+v"(yr[2][1]), "+v"(yr[3][0]), "+v"(yr[3][1]));
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(yr[0][0]), "+v"(yr[0][1]), "+v"(yr[1][0]), "+v"(yr[1][1]));
+        FB_TR(R.yr[2][0], ya, 64); FB_TR(R.yr[2][1], ya, FB_PLANE + 64);
+        FB_TR(R.yr[3][0], ya, 96); FB_TR(R.yr[3][1], ya, FB_PLANE + 96);
     }
-    const f16x8 xh = fb_frag(xr[0]), xl = fb_frag(xr[1]);
+}
+template <int NB, bool COLSUM, int LATER>
+__device__ __forceinline__ void fb_outer16_consume(FbOuterRegs<NB>& R, f32x4 (&acc)[NB], f32x4& colsum, float c_xy, float c_x) {
+    static_assert(LATER == 0 || LATER == 6 || LATER == 10, "reads of the product issued behind this one");
+    if constexpr (NB == 4) {
+        if constexpr (LATER == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.xr[0]), "+v"(R.xr[1]), "+v"(R.yr[0][0]), "+v"(R.yr[0][1]), "+v"(R.yr[1][0]), "+v"(R.yr[1][1]),
+                                                  "+v"(R.yr[2][0]), "+v"(R.yr[2][1]), "+v"(R.yr[3][0]), "+v"(R.yr[3][1]) :: "memory");
+        else if constexpr (LATER == 6)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(R.xr[0]), "+v"(R.xr[1]), "+v"(R.yr[0][0]), "+v"(R.yr[0][1]), "+v"(R.yr[1][0]), "+v"(R.yr[1][1]),
+                                                  "+v"(R.yr[2][0]), "+v"(R.yr[2][1]), "+v"(R.yr[3][0]), "+v"(R.yr[3][1]) :: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(R.xr[0]), "+v"(R.xr[1]), "+v"(R.yr[0][0]), "+v"(R.yr[0][1]), "+v"(R.yr[1][0]), "+v"(R.yr[1][1]),
+                                                   "+v"(R.yr[2][0]), "+v"(R.yr[2][1]), "+v"(R.yr[3][0]), "+v"(R.yr[3][1]) :: "memory");
+    } else {
+        static_assert(LATER == 0, "the narrow product is the second of its tile");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.xr[0]), "+v"(R.xr[1]), "+v"(R.yr[0][0]), "+v"(R.yr[0][1]), "+v"(R.yr[1][0]), "+v"(R.yr[1][1]) :: "memory");
+    }
+    const f16x8 xh = fb_frag(R.xr[0]), xl = fb_frag(R.xr[1]);
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    c_xy = own_reg(c_xy); c_x = own_reg(c_x);                  // (broadcast operands of packed fp32 math: rule R3)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const f16x8 yh = fb_frag(yr[nb][0]), yl = fb_frag(yr[nb][1]);
+        const f16x8 yh = fb_frag(R.yr[nb][0]), yl = fb_frag(R.yr[nb][1]);
         f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yh, zero, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yl, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, t, 0, 0, 0);
@@ -705,7 +722,7 @@ k_fused_bwd(FbArgs A) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gr[0][0]), "+v"(gr[0][1]), "+v"(gr[1][0]), "+v"(gr[1][1]), "+v"(gr[2][0]),
                                                           "+v"(gr[2][1]), "+v"(gr[3][0]), "+v"(gr[3][1]));
                     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const float cg = s_g.inv_s;
+                    const float cg = own_reg(s_g.inv_s);                       // (broadcast operand of packed fp32 math: rule R3)
 #pragma unroll
                     for (int b2 = 0; b2 < 2; ++b2) {
                         if (b2 == 0 || nv > 16) {
@@ -741,8 +758,13 @@ k_fused_bwd(FbArgs A) {
                         const float* td = smem + L::STG_G + t * (16 * FB_SA);
                         const float* scl = smem + L::SCL + 4 * t;
                         const unsigned lo_ = fb_tr_lane_offset(lane), xo = lo_ + 32u * (unsigned)wave;      // rows m = 16 wave ..
-                        fb_outer16_h<4, true>(fb_lds_addr(ta) + xo, fb_lds_addr(ta + 16 * FB_SA) + lo_, aw2, db2, scl[0], scl[2]);            // dW2 += dpre2 (x) h, db2
-                        fb_outer16_h<NBE, FIRST>(fb_lds_addr(td) + xo, fb_lds_addr(ta + 2 * 16 * FB_SA) + lo_, awe, db1, scl[1], scl[3]);     // dW_e += G (x) e_prev
+                        const float c0 = scl[0], c1 = scl[1], c2 = scl[2], c3 = scl[3];
+                        FbOuterRegs<4> R2;
+                        FbOuterRegs<NBE> Re;
+                        fb_outer16_issue<4>(fb_lds_addr(ta) + xo, fb_lds_addr(ta + 16 * FB_SA) + lo_, R2);                  // both products' reads in flight
+                        fb_outer16_issue<NBE>(fb_lds_addr(td) + xo, fb_lds_addr(ta + 2 * 16 * FB_SA) + lo_, Re);
+                        fb_outer16_consume<4, true, 2 + 2 * NBE>(R2, aw2, db2, c0, c2);                                   // dW2 += dpre2 (x) h, db2
+                        fb_outer16_consume<NBE, FIRST, 0>(Re, awe, db1, c1, c3);                                          // dW_e += G (x) e_prev
                     }
                 }
                 lds_barrier();         // staging rows are free for the next round (and for publish)
