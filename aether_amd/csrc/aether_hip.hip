@@ -694,7 +694,7 @@ int backward_impl(const AetherParams& P, const AetherParams& Gr, int64_t Nn, int
                 int n_parts = 0;
                 auto launch8 = [&](auto nw_tag) -> bool {
                     constexpr int NW = decltype(nw_tag)::value;
-                    const size_t lds_8 = (size_t)(2 * SPLIT_WIMG + NW * EaStg<NW == 4>::WAVE) * 4;
+                    const size_t lds_8 = ea8_lds_bytes(NW);
                     const int64_t want = (etile + NW - 1) / NW, cap = 256 * (8 / NW);
                     const unsigned g8 = (unsigned)(want < cap ? want : cap);
                     n_parts = (int)g8 * (NW / 4);

@@ -282,55 +282,22 @@ k_edge_acc_reduce(const float* __restrict__ partial, int n_wgs, EdgeAccOut O) {
 //   * the transposed products (W2^T dpre2, W_in^T G) read the forward's split images transposed (gemm_split_T): two images
 //     in LDS instead of four;
 //   * the weight-gradient accumulators are partitioned by output rows: a workgroup works in ROUNDS of eight tiles (one per
-//     wave); after a round's tiles are staged, wave w adds the rows 4 i' + (w & 3) of the product over the four tiles
+//     wave); after a round's tiles are staged, wave w adds the rows 16 (w & 3) .. of the product over the four tiles
 //     4 (w >> 2) .. of the round -- 16 accumulator registers per product instead of 64, nothing to reduce over the waves
 //     but the two tile halves, which go out as two partials per workgroup;
 //   * bias sums ride along as one more MFMA per k step against a column of ones.
 // 8 waves per workgroup, one workgroup per CU, <= 256 registers: two waves per SIMD.
 //
-// NW = 4 (option edge_acc = 3): the same kernel as TWO workgroups of four waves per CU.  Eight waves of one workgroup take
-// their barriers together, so a SIMD's two waves are always in the SAME phase (both in their bf16 GEMMs, then both in
-// their fp32 products): nothing overlaps.  Two independent workgroups drift apart.  Two of them fit the CU's LDS only
-// without the staging rows' padding (2 x 24 KB images + 4 x 8 KB = 80 KB): rows of 64 floats, 16-byte chunk c of row r
-// stored at chunk c ^ r (EaStg<true>) -- the 16-byte row writes and the k-step reads stay conflict-free.
+// NW = 4 (option edge_acc = 3, the default): the same kernel as TWO workgroups of four waves per CU.  Eight waves of one
+// workgroup take their barriers together, so a SIMD's two waves are always in the SAME phase (both in their GEMMs, then both
+// in their weight-gradient products): nothing overlaps.  Two independent workgroups drift apart.
+// Round 4, second half: the staged tensors are the fp16 pieces their GEMMs make (fused_bwd.h: fb_stage_pieces), the
+// weight-gradient products run on the 16-bit matrix pipe from transposed reads with per-tile power-of-two scales
+// (fb_outer16_issue / fb_outer16_consume) instead of fp32 MFMAs on the vector ALU: 12.2 -> 11.4 ms per launch at the
+// 33.5 M-edge shard.  LDS per workgroup: 2 x 16 KB images + 4 x 8.5 KB staging = 67 KB.
 constexpr int EA8_WAVES = 8;
-template <bool SW> struct EaStg {
-    static constexpr int LD = SW ? H : FB_SA;
-    static constexpr int WAVE = 2 * 16 * LD;          // staging floats per wave: one operand pair at a time
-    // float offset of (row, col): col a multiple of 4 (16-byte access), of 2 (8-byte, `sub` = col & 3) or any (4-byte)
-    static __device__ __forceinline__ int at(int row, int col) {
-        if constexpr (SW) return row * H + ((((col >> 2) ^ row) & 15) << 2) + (col & 3);
-        else return row * FB_SA + col;
-    }
-};
-
-// fb_outer16_q over staging rows addressed through EaStg<SW>
-template <int NB, bool COLSUM, bool SW>
-__device__ __forceinline__ void ea_outer16_q(const float* __restrict__ sa, const float* __restrict__ sb, f32x4 (&acc)[NB],
-                                             f32x4& colsum, int i, int q, int w) {
-    if constexpr (!SW) {
-        fb_outer16_q<NB, COLSUM>(sa, sb, acc, colsum, i, q, w);
-    } else {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int k = 4 * s4 + q;
-            const float av = sa[EaStg<true>::at(k, 4 * i + w)];
-            if constexpr (COLSUM) colsum = mfma16(av, 1.0f, colsum);
-            float bv[NB];
-            if constexpr (NB == 4) {
-                const f32x4 b4 = ld4(sb + EaStg<true>::at(k, 4 * i));
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) bv[nb] = b4[nb];
-            } else {
-                const f32x2 b2 = *reinterpret_cast<const f32x2*>(sb + EaStg<true>::at(k, 2 * i));
-                bv[0] = b2[0]; bv[1] = b2[1];
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(av, bv[nb], acc[nb]);
-        }
-    }
-}
-
+constexpr int EA8_WAVE_STG = 2 * 16 * FB_SA;     // staging floats per wave: one operand pair at a time, as fp16 pieces
+__host__ __device__ constexpr size_t ea8_lds_bytes(int nw) { return (size_t)(2 * SPLIT_WIMG + nw * EA8_WAVE_STG + 2 * nw) * 4; }
 template <bool FIRST, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, const float* __restrict__ Ps,
@@ -344,10 +311,9 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wi = smem;                  // split image of W_in (FIRST: half of it is used)
     float* w2 = wi + SPLIT_WIMG;       // split image of W2
-    float* stg = w2 + SPLIT_WIMG;      // [NW waves][2][16][LD]
-    constexpr bool SW = NW == 4;
-    using S = EaStg<SW>;
-    constexpr int EA8_STG = S::WAVE;
+    float* stg = w2 + SPLIT_WIMG;      // [NW waves][2 arrays][2 fp16 pieces][16][FB_RH bytes] (fused_bwd.h: fb_stage_pieces)
+    constexpr int EA8_STG = EA8_WAVE_STG;
+    float* scl = stg + NW * EA8_STG;   // [NW][2]: the staged pair's 1 / (s_x s_y), 1 / s_x
     static_assert(NW == 4 || NW == 8, "one or two groups of four row quarters");
     for (int idx = threadIdx.x; idx < (FIRST ? SPLIT_WIMG / 2 : SPLIT_WIMG) / 4; idx += 64 * NW) st4(wi + 4 * idx, ld4(img_in + 4 * idx));
     for (int idx = threadIdx.x; idx < SPLIT_WIMG / 4; idx += 64 * NW) st4(w2 + 4 * idx, ld4(img_2 + 4 * idx));
@@ -355,8 +321,8 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
     float* sa = stg + wave * EA8_STG;   // dpre2, then G
-    float* sb = sa + 16 * S::LD;        // h, then e_prev / features
-    const int wq = wave & 3, whalf = wave >> 2;          // accumulator rows 4 i' + wq, tiles 4 whalf .. of a round
+    float* sb = sa + 16 * FB_SA;        // h, then e_prev / features
+    const int wq = wave & 3, whalf = wave >> 2;          // accumulator rows 16 wq .., tiles 4 whalf .. of a round
     const int64_t tiles = (n_edges + 15) >> 4;
     const int64_t stride = (int64_t)n_wgs * NW;
     f32x4 accW2[4], accWe[NBE], bs2 = f32x4{0.f, 0.f, 0.f, 0.f}, bs1 = bs2;
@@ -379,6 +345,7 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
         const int64_t t = t0 + wave;
         const bool active = t < tiles;                   // wave-uniform
         f32x4 g[4], bop[4];
+        SplitScale s_ep{false, 1.0f, 1.0f}, s_g{false, 1.0f, 1.0f};
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) { g[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; bop[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (active) {
@@ -411,9 +378,11 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
             f32x4 p2[4], h[4], sg1[4];
             if (FIRST) {
                 f32x4 b2[2] = {bop[0], bop[1]};
-                gemm_split<4, 1>(wi, b2, p1, lane);
+                f16x8 ph[1], pl[1];
+                s_ep = gemm_split_keep<4, 1>(wi, b2, p1, lane, ph, pl);
             } else {
-                gemm_split<4, 2>(wi, bop, p1, lane);
+                f16x8 ph[2], pl[2];
+                s_ep = gemm_split_keep<4, 2>(wi, bop, p1, lane, ph, pl);
             }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -421,7 +390,12 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
                 h[mb] = p1[mb] * sg1[mb];
                 p2[mb] = ld4(b2g + 16 * mb + 4 * q);
             }
-            gemm_split<4, 2>(w2, h, p2, lane);
+            SplitScale s_h;
+            {   // h's pieces go to the staging rows as its GEMM makes them
+                f16x8 ph[2], pl[2];
+                s_h = gemm_split_keep<4, 2>(w2, h, p2, lane, ph, pl);
+                fb_stage_pieces<2>(sb, i, q, ph, pl);
+            }
             // ---- de = dn[recv] / deg (+ gradient through the next layer's edge input); back through both Linears
             f32x4 d2[4], dh[4];
 #pragma unroll
@@ -431,21 +405,26 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
                 d2[mb] = de * dsilu_from_sigmoid(p2[mb], sigmoid4(p2[mb]));
                 if (!ok) d2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};             // rows past the end contribute nothing to the products
                 dh[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                st4(sa + S::at(i, 16 * mb + 4 * q), d2[mb]);
-                st4(sb + S::at(i, 16 * mb + 4 * q), h[mb]);
             }
-            gemm_split_T<2>(w2, d2, dh, lane);                          // W2^T dpre2 from the forward's image
+            {
+                f16x8 ph[2], pl[2];
+                const SplitScale s_d2 = gemm_split_T_keep<2>(w2, d2, dh, lane, ph, pl);        // W2^T dpre2 from the forward's image
+                fb_stage_pieces<2>(sa, i, q, ph, pl);
+                if (lane == 0) { scl[2 * wave] = s_d2.inv_s * s_h.inv_s; scl[2 * wave + 1] = s_d2.inv_s; }
+            }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) g[mb] = dh[mb] * dsilu_from_sigmoid(p1[mb], sg1[mb]);
             if (FIRST) {
                 f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                gemm_split_T<1>(wi, g, da, lane);                       // W1^T G
+                f16x8 ph[2], pl[2];
+                s_g = gemm_split_T_keep<1>(wi, g, da, lane, ph, pl);    // W1^T G
                 if (ok) { st4(DA + k * FPAD + 4 * q, da[0]); st4(DA + k * FPAD + 16 + 4 * q, da[1]); }
             } else {
                 f32x4 dep[4];
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) dep[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_split_T<2>(wi, g, dep, lane);                      // W_e^T G
+                f16x8 ph[2], pl[2];
+                s_g = gemm_split_T_keep<2>(wi, g, dep, lane, ph, pl);   // W_e^T G
                 if (ok) store_tile64(DE, k, H, q, dep);
             }
             if (ok) store_tile64(G, k, H, q, g);
@@ -460,24 +439,41 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
         for (int tt = 0; tt < 4; ++tt) {
             if (t0 + 4 * whalf + tt < tiles) {
                 const float* ta = stg + (4 * whalf + tt) * EA8_STG;
-                ea_outer16_q<4, true, SW>(ta, ta + 16 * S::LD, accW2, bs2, i, q, wq);
+                const float c0 = scl[2 * (4 * whalf + tt)], c1 = scl[2 * (4 * whalf + tt) + 1];
+                const unsigned lo_ = fb_tr_lane_offset(lane);
+                FbOuterRegs<4> R;
+                fb_outer16_issue<4>(fb_lds_addr(ta) + lo_ + 32u * (unsigned)wq, fb_lds_addr(ta + 16 * FB_SA) + lo_, R);
+                fb_outer16_consume<4, true, 0>(R, accW2, bs2, c0, c1);
             }
         }
         lds_barrier();
         // ---- dW_e += G (x) e_prev (layer 1: dW1 += G (x) features, db1)
-        if (active) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                st4(sa + S::at(i, 16 * mb + 4 * q), g[mb]);            // (g of a row past the end is 0: dh = W2^T 0)
-                if (!FIRST || mb < 2) st4(sb + S::at(i, 16 * mb + 4 * q), bop[mb]);
+        if (active) {                      // (the pieces are made again from the live tiles, with the scales their GEMMs used: 40 vector
+                                           //  instructions per tensor against 32 registers held across the first product)
+            f16x8 ph[2], pl[2];
+            split8(g[0] * s_g.s, g[1] * s_g.s, ph[0], pl[0]);          // (g of a row past the end is 0: dh = W2^T 0)
+            split8(g[2] * s_g.s, g[3] * s_g.s, ph[1], pl[1]);
+            fb_stage_pieces<2>(sa, i, q, ph, pl);
+            split8(bop[0] * s_ep.s, bop[1] * s_ep.s, ph[0], pl[0]);
+            if constexpr (FIRST) {
+                const f16x8 h1[1] = {ph[0]}, l1[1] = {pl[0]};
+                fb_stage_pieces<1>(sb, i, q, h1, l1);
+            } else {
+                split8(bop[2] * s_ep.s, bop[3] * s_ep.s, ph[1], pl[1]);
+                fb_stage_pieces<2>(sb, i, q, ph, pl);
             }
+            if (lane == 0) { scl[2 * wave] = s_g.inv_s * s_ep.inv_s; scl[2 * wave + 1] = s_g.inv_s; }
         }
         lds_barrier();
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             if (t0 + 4 * whalf + tt < tiles) {
                 const float* ta = stg + (4 * whalf + tt) * EA8_STG;
-                ea_outer16_q<NBE, FIRST, SW>(ta, ta + 16 * S::LD, accWe, bs1, i, q, wq);
+                const float c0 = scl[2 * (4 * whalf + tt)], c1 = scl[2 * (4 * whalf + tt) + 1];
+                const unsigned lo_ = fb_tr_lane_offset(lane);
+                FbOuterRegs<NBE> R;
+                fb_outer16_issue<NBE>(fb_lds_addr(ta) + lo_ + 32u * (unsigned)wq, fb_lds_addr(ta + 16 * FB_SA) + lo_, R);
+                fb_outer16_consume<NBE, FIRST, 0>(R, accWe, bs1, c0, c1);
             }
         }
         lds_barrier();
@@ -486,12 +482,15 @@ kb_edge_acc8(const float* __restrict__ b_in, const float* __restrict__ b2g, cons
     float* dst = partial + ((size_t)blockIdx.x * (NW / 4) + whalf) * FB_PART;
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
-        const int mrow = 4 * (4 * q + r4) + wq;
-        st4(dst + mrow * H + 4 * i, f32x4{accW2[0][r4], accW2[1][r4], accW2[2][r4], accW2[3][r4]});
+        const int mrow = 16 * wq + 4 * q + r4;           // accumulator block nb holds columns 16 nb + i
+#pragma unroll
+        for (int nbx = 0; nbx < 4; ++nbx) dst[mrow * H + 16 * nbx + i] = accW2[nbx][r4];
         if constexpr (FIRST) {
-            *reinterpret_cast<f32x2*>(dst + H * H + mrow * FPAD + 2 * i) = f32x2{accWe[0][r4], accWe[1][r4]};
+            dst[H * H + mrow * FPAD + i] = accWe[0][r4];
+            dst[H * H + mrow * FPAD + 16 + i] = accWe[1][r4];
         } else {
-            st4(dst + H * H + mrow * H + 4 * i, f32x4{accWe[0][r4], accWe[1][r4], accWe[2][r4], accWe[3][r4]});
+#pragma unroll
+            for (int nbx = 0; nbx < 4; ++nbx) dst[H * H + mrow * H + 16 * nbx + i] = accWe[nbx][r4];
         }
         if (i == 0) {
             dst[2 * H * H + mrow] = bs2[r4];
