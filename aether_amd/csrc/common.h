@@ -367,6 +367,80 @@ __device__ __forceinline__ void gemm_split_T(const float* __restrict__ img, cons
     (void)gemm_split_T_keep<KBN>(img, act, acc, lane, xh, xl);
 }
 
+// The product on operand pieces that exist already (k_fused keeps a message tile as its pieces: they serve the receiver sums
+// of this layer and the first GEMM of the next): sc = the scale the pieces were made with.
+template <int MBN, int KBN>
+__device__ __forceinline__ void gemm_split_pieces(const float* __restrict__ img, const f16x8 (&xh)[KBN], const f16x8 (&xl)[KBN],
+                                                  const SplitScale sc, f32x4 (&acc)[MBN], int lane) {
+    constexpr int TERM = MBN * KBN * 64;
+    const f16x8* w = reinterpret_cast<const f16x8*>(img);
+    if (sc.on) {                                                // (wave-uniform)
+#pragma unroll
+        for (int mb = 0; mb < MBN; ++mb) acc[mb] = acc[mb] * own_reg(sc.s);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb)
+#pragma unroll
+        for (int mb = 0; mb < MBN; ++mb) {
+            const int frag = (mb * KBN + kb) * 64 + lane;
+            const f16x8 wh = w[frag], wl = w[TERM + frag];
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[kb], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[kb], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[kb], acc[mb], 0, 0, 0);
+        }
+    if (sc.on) {
+#pragma unroll
+        for (int mb = 0; mb < MBN; ++mb) acc[mb] = acc[mb] * own_reg(sc.inv_s);
+    }
+}
+// the pieces of an operand tile (accumulator layout, 2 KBN blocks) and the scale they carry
+template <int KBN>
+__device__ __forceinline__ SplitScale split_tile(const f32x4 (&act)[2 * KBN], f16x8 (&xh)[KBN], f16x8 (&xl)[KBN]) {
+    const SplitScale sc = split_scale_of(act);
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+        if (sc.on) split8(act[2 * kb] * own_reg(sc.s), act[2 * kb + 1] * own_reg(sc.s), xh[kb], xl[kb]);
+        else split8(act[2 * kb], act[2 * kb + 1], xh[kb], xl[kb]);
+    }
+    return sc;
+}
+
+// ------------------------------------------------------------------ staged tiles as fp16 pieces, read transposed (round 4)
+// A staged tensor of a tile ([16 rows][64 features]) lies in LDS as the two fp16 pieces its GEMM splits it into anyway:
+// [piece 2][16 rows][FB_RH bytes] -- 4,352 bytes, what fp32 rows [16][LDST] take.  Products over the tile's 16 rows read the
+// pieces TRANSPOSED (ds_read_b64_tr_b16: lane (c, q) of a 16-lane group gets rows 4 q .. 4 q + 3 of column c) as A / B
+// fragments of v_mfma_f32_16x16x32_f16 with K = the 16 rows in k slots 8 q + j, j < 4 (slots j >= 4 are zero).
+constexpr int FB_RH = 2 * LDST;                // bytes of a staged row: 64 halves + 4 halves of padding (136)
+constexpr int FB_PLANE = 16 * FB_RH;          // bytes of one piece of a tile
+static_assert(2 * FB_PLANE == 16 * LDST * 4, "the two pieces take the room of the fp32 rows");
+template <int KBN>
+__device__ __forceinline__ void fb_stage_pieces(float* arr, int i, int q, const f16x8 (&xh)[KBN], const f16x8 (&xl)[KBN]) {
+    char* row = reinterpret_cast<char*>(arr) + i * FB_RH + 8 * q;
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+        const u32x4 h = __builtin_bit_cast(u32x4, xh[kb]), l = __builtin_bit_cast(u32x4, xl[kb]);
+        // elements j < 4: features 32 kb + 4 q + j; j >= 4: 32 kb + 16 + 4 q + (j - 4)
+        *reinterpret_cast<u32x2*>(row + 64 * kb) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(row + 64 * kb + 32) = u32x2{h[2], h[3]};
+        *reinterpret_cast<u32x2*>(row + FB_PLANE + 64 * kb) = u32x2{l[0], l[1]};
+        *reinterpret_cast<u32x2*>(row + FB_PLANE + 64 * kb + 32) = u32x2{l[2], l[3]};
+    }
+}
+// the lane's part of a transposed 4 x 16 read: rows 4 q + r, 8-byte column group p (lane = 16 q + 4 r + p)
+__device__ __forceinline__ unsigned fb_tr_lane_offset(int lane) {
+    const int q = lane >> 4, c = lane & 15;
+    return (unsigned)((4 * q + (c >> 2)) * FB_RH + 8 * (c & 3));
+}
+__device__ __forceinline__ unsigned fb_lds_addr(const float* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ f16x8 fb_frag(const u32x2 v) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], 0u, 0u}); }
+#define FB_TR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off) : "memory")
+// 0 / 1 fragment of four incidence bits (bit j: k slot j): fp16 1.0 = 0x3C00
+__device__ __forceinline__ f16x8 fb_inc_frag(unsigned nib) {
+    const unsigned lo = ((nib & 1u) | ((nib & 2u) << 15)) * 0x3C00u, hi = (((nib >> 2) & 1u) | ((nib & 8u) << 13)) * 0x3C00u;
+    return __builtin_bit_cast(f16x8, u32x4{lo, hi, 0u, 0u});
+}
+
+
 // Cooperative copy of W[rows][cols] (global, row stride src_ld) into LDS [rows][ldw], zero padded.
 __device__ __forceinline__ void stage_weight(float* lds, const float* __restrict__ w, int rows,
                                              int cols, int src_ld, int ldw) {

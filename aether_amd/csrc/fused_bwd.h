@@ -165,30 +165,7 @@ __device__ __forceinline__ void fb_outer16_q(const float* __restrict__ sa, const
 // j >= 4 are zero), three terms per product (two where one operand is a 0/1 matrix), and add tmp x 1 / (s_x s_y) to the
 // fp32 accumulators: ~1/3 of the matrix time of the fp32 MFMA form (16 x 32 cycles per 16 x 64 product and tile), which
 // ran on the vector ALU.
-constexpr int FB_RH = 2 * FB_SA;              // bytes of a staged row: 64 halves + 4 halves of padding (136)
-constexpr int FB_PLANE = 16 * FB_RH;          // bytes of one piece of a tile
-static_assert(2 * FB_PLANE == 16 * FB_SA * 4, "the two pieces take the room of the fp32 rows");
-template <int KBN>
-__device__ __forceinline__ void fb_stage_pieces(float* arr, int i, int q, const f16x8 (&xh)[KBN], const f16x8 (&xl)[KBN]) {
-    char* row = reinterpret_cast<char*>(arr) + i * FB_RH + 8 * q;
-#pragma unroll
-    for (int kb = 0; kb < KBN; ++kb) {
-        const u32x4 h = __builtin_bit_cast(u32x4, xh[kb]), l = __builtin_bit_cast(u32x4, xl[kb]);
-        // elements j < 4: features 32 kb + 4 q + j; j >= 4: 32 kb + 16 + 4 q + (j - 4)
-        *reinterpret_cast<u32x2*>(row + 64 * kb) = u32x2{h[0], h[1]};
-        *reinterpret_cast<u32x2*>(row + 64 * kb + 32) = u32x2{h[2], h[3]};
-        *reinterpret_cast<u32x2*>(row + FB_PLANE + 64 * kb) = u32x2{l[0], l[1]};
-        *reinterpret_cast<u32x2*>(row + FB_PLANE + 64 * kb + 32) = u32x2{l[2], l[3]};
-    }
-}
-// the lane's part of a transposed 4 x 16 read: rows 4 q + r, 8-byte column group p (lane = 16 q + 4 r + p)
-__device__ __forceinline__ unsigned fb_tr_lane_offset(int lane) {
-    const int q = lane >> 4, c = lane & 15;
-    return (unsigned)((4 * q + (c >> 2)) * FB_RH + 8 * (c & 3));
-}
-__device__ __forceinline__ unsigned fb_lds_addr(const float* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
-__device__ __forceinline__ f16x8 fb_frag(const u32x2 v) { return __builtin_bit_cast(f16x8, u32x4{v[0], v[1], 0u, 0u}); }
-#define FB_TR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off) : "memory")
+// (FB_RH, FB_PLANE, fb_stage_pieces, fb_tr_lane_offset, fb_lds_addr, fb_frag, FB_TR, fb_inc_frag: common.h -- fused.h uses them too)
 // acc[nb] += c_xy * sum_k X[k][m0 + 4 q + r] Y[k][16 nb + i] over the 16 staged rows; colsum += c_x * sum_k X[k][m0 + 4 q + r]
 // xa / ya: LDS byte addresses of the arrays' hi planes + the lane's offset (xa also + 2 m0).  In two halves -- the reads, and
 // the wait + MFMAs -- so that the caller can have the next product's reads in flight: LATER = reads issued after this
@@ -239,12 +216,6 @@ __device__ __forceinline__ void fb_outer16_consume(FbOuterRegs<NB>& R, f32x4 (&a
         colsum = colsum + t * c_x;
     }
 }
-// 0 / 1 fragment of four incidence bits (bit j: k slot j): fp16 1.0 = 0x3C00
-__device__ __forceinline__ f16x8 fb_inc_frag(unsigned nib) {
-    const unsigned lo = ((nib & 1u) | ((nib & 2u) << 15)) * 0x3C00u, hi = (((nib >> 2) & 1u) | ((nib & 8u) << 13)) * 0x3C00u;
-    return __builtin_bit_cast(f16x8, u32x4{lo, hi, 0u, 0u});
-}
-
 // acc[mb] += W[16 mb + i][k] * act[item][k] with W as a fragment-ordered LDS image of KB k blocks per row block.
 template <int MB, int KB>
 __device__ __forceinline__ void fb_gemm(const float* __restrict__ img, const f32x4 (&bop)[KB], f32x4 (&acc)[MB], int lane) {
