@@ -1003,7 +1003,7 @@ int aether_set_option(const char* name, int value) {
         g_linear_kwaves = value;
         return AETHER_OK;
     }
-    if (!strcmp(name, "gemm_split")) { g_gemm_split = value != 0; return AETHER_OK; }
+    if (!strcmp(name, "gemm_split")) { g_gemm_split = value; return AETHER_OK; }
     if (!strcmp(name, "dyn_filter_v1")) {
         if (value < 0 || value > 2) return fail(AETHER_EINVAL, "set_option: dyn_filter_v1 must be 0, 1 or 2");
         g_dyn_filter_v1 = value;

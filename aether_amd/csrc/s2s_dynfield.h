@@ -22,9 +22,9 @@ k_s2s_gru_gate(const float* __restrict__ gi, int64_t gi_stride, const float* __r
     const int c = (int)(idx - s * H);
     const float* a = gi + s * gi_stride;
     const float* b = gh + s * 3 * H;
-    const float r = 1.0f / (1.0f + expf(-(a[c] + b[c])));
-    const float z = 1.0f / (1.0f + expf(-(a[H + c] + b[H + c])));
-    const float n = tanhf(a[2 * H + c] + r * b[2 * H + c]);
+    const float r = sigmoid1(a[c] + b[c]);
+    const float z = sigmoid1(a[H + c] + b[H + c]);
+    const float n = tanh1(a[2 * H + c] + r * b[2 * H + c]);
     h[idx] = (1.0f - z) * n + z * h[idx];
 }
 

@@ -138,7 +138,7 @@ __device__ __forceinline__ void filter_bimg_body(const float* __restrict__ pos, 
         float sv = b1[k];
 #pragma unroll
         for (int p = 0; p < P; ++p) sv = fmaf(W1[k * P + p], pe[p], sv);
-        return sv > 0.0f ? sv : (relu ? 0.0f : expm1f(sv));
+        return relu ? fmaxf(sv, 0.0f) : elu1(sv);
     };
     // the thread's values: octets og, og + 16, .. (h <= 1024: at most 8 of them stay in registers; beyond, recomputed)
     constexpr int KEEP = 8;

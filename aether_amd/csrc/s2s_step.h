@@ -165,10 +165,10 @@ k_s2s_linear_jobs(const S2SJobs jobs) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
             } else if (act == 3) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = tanh1(v[r]);
             } else if (act == 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = elu1(v[r]);
             }
             if (J.post_scale != nullptr) {
 #pragma unroll
@@ -220,16 +220,301 @@ k_s2s_gemm_image(const float* __restrict__ W, int M, int K, int ldw, f16x8* __re
     img[(frag + 1) * 64 + i + 16 * q] = lo;
 }
 
-// Workgroup = 4 waves on a 128 (m) x 128 (rows n) tile; a wave owns 128 m x 32 rows (8 x 2 accumulator blocks).  Per
-// 32-wide k step the 16 KB of weight fragments (128 m x 32 k x 2 pieces, contiguous in the image) arrive by LDS-DMA two
-// steps ahead in a three-slot ring (one barrier per step); the wave's row blocks of X (lane: row i, eight consecutive k)
-// are requested one step ahead, scaled and split into two fp16 pieces in registers (8 NB values per lane) and feed
-// 8 x NB x 3 MFMAs.  Epilogue and job table as k_s2s_linear_jobs.  Needs M % 128 == 0, K % 32 == 0 (both segments).
-constexpr int GS_STAGE = 8 * 2 * 64;             // f16x8 fragments per k step (16 KB)
-constexpr int GS_NST = 3;
+// Workgroup = 4 waves (one per SIMD, one workgroup per CU) on a 128 (m) x 64 NB (rows n) tile; a wave owns 128 m x 16 NB rows
+// (8 x NB accumulator blocks).  Per 32-wide k step BOTH operands arrive by LDS-DMA in a four-slot ring, requested three steps
+// before they are multiplied: the 16 KB of weight fragments (128 m x 32 k x 2 pieces, contiguous in the image; every wave
+// reads all of them: one barrier per step) and the wave's own 16 NB rows of X (fp32, 2 KB per row block; read by the wave
+// that asked for them: no barrier).  Rounds 2 - 4 (first half) loaded X into registers ONE step ahead: every step then waited
+// out a memory round trip (2.2 us per step against 0.35 us of MFMAs: 28 % of the matrix pipe at 48,640 rows, and 24 us for
+// a 2,560-row layer whose 160 workgroups each walk 16 dependent steps).
+// X in LDS: one DMA instruction moves 16 rows x 64 bytes -- lane L asks for row L & 15, 16-byte chunk L >> 4 of the half row
+// and lands at byte 16 L: [chunk 4][row 16] x 16 B, so the read back (lane (i, q): chunks 2 q, 2 q + 1 of row i) is
+// consecutive over i.  The rows are scaled and split into two fp16 pieces for step s + 1 UNDER step s's MFMAs: row maxima
+// and a speculative split with the current scales sit in the middle of the MFMA stream; only a row whose scale has to
+// shrink (first step; rare afterwards) pays for a second split behind it.
+// Epilogue and job table as k_s2s_linear_jobs.  Needs M % 128 == 0, K % 32 == 0 (both segments).
+constexpr int GS_STAGE = 8 * 2 * 64;             // f16x8 weight fragments per k step (16 KB)
+constexpr int GS_NST = 4;
+constexpr int GS_XBLK = 2048;                    // bytes of one row block of X per step: 16 rows x 32 k x 4 B
+__host__ __device__ constexpr size_t gs_lds_bytes(int nb) { return (size_t)GS_NST * (GS_STAGE * 16 + 4 * nb * GS_XBLK); }
+template <int NB>          // row blocks of 16 per wave: 2 (128-row tiles) once those fill the chip twice over, else 1 (64-row tiles)
+__global__ void __launch_bounds__(256, 2)      // (2: 256 registers a lane, all of them VGPRs -- at 1 the accumulators moved to AGPRs and
+                                              // every step copied the 64 of them out and back around the rescale branch)
+k_s2s_gemm_split(const S2SJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
+    f16x8* ring = reinterpret_cast<f16x8*>(gs_smem);
+    constexpr int XSTAGE = 4 * NB * GS_XBLK;                  // bytes of X per slot
+    constexpr int NDMA = 4 + 2 * NB;                          // DMA instructions per wave and step
+    int ji = 0;
+#pragma unroll
+    for (int t = 1; t < S2S_MAX_JOBS; ++t)
+        if (t < jobs.n && (int)blockIdx.x >= jobs.j[t].wg0) ji = t;
+    const S2SJob& J = jobs.j[ji];
+    // (row tile, column block) of the workgroup: the M / 128 column blocks of a row tile sit in consecutive slots of ONE XCD
+    // (workgroups go round-robin over the 8 XCDs), so that the tile's rows of X come from memory once and from that XCD's L2
+    // for the other column blocks.  The job's grid is padded to 8 x ceil(gx / 8) row tiles; the extra ones leave below.
+    const int local = (int)blockIdx.x - J.wg0, gy = J.M >> 7, slot = local >> 3;
+    const int bx = (local & 7) + 8 * (slot / gy), by = slot % gy;
+    int64_t N = J.N;
+    if (J.n_dev != nullptr) N = *J.n_dev;
+    const int M = J.M, ldy = J.ldy;
+    float* __restrict__ Y = J.Y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = by * 128;
+    const int64_t n0 = (int64_t)bx * (64 * NB) + 16 * NB * wave;
+    if ((int64_t)bx * (64 * NB) >= N) return;                // the whole workgroup
+    const int s1 = J.K >> 5, s2 = J.W2img != nullptr ? J.K2 >> 5 : 0, S = s1 + s2;
+    const int n_mb = M >> 4;
+    const f16x8* img1 = reinterpret_cast<const f16x8*>(J.Wimg);
+    const f16x8* img2 = reinterpret_cast<const f16x8*>(J.W2img);
+    // DMA sources in X: row i of the wave's row blocks (clamped; gathered through xidx), chunk q of a half row
+    const float* xr1[NB];
+    const float* xr2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        int64_t n = n0 + 16 * nb + i;
+        n = n < N ? n : N - 1;
+        if (J.xidx != nullptr) n = J.xidx[n];
+        xr1[nb] = J.X + (size_t)n * J.ldx + 4 * q;
+        xr2[nb] = s2 ? J.X2 + (size_t)n * J.ldx2 + 4 * q : xr1[nb];
+    }
+    unsigned char* xring = gs_smem + (size_t)GS_NST * GS_STAGE * 16 + wave * (NB * GS_XBLK);      // + slot * XSTAGE
+    auto dma = [&](int s) {                                   // both operands of step s -> slot s % NST
+        const int slot = s & (GS_NST - 1);
+        const f16x8* src = (s < s1 ? img1 + ((size_t)s * n_mb + (m0 >> 4)) * 2 * 64
+                                    : img2 + ((size_t)(s - s1) * n_mb + (m0 >> 4)) * 2 * 64) + lane;
+        f16x8* dst = ring + slot * GS_STAGE;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int fr = wave + 4 * f;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + fr * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + fr * 64), 16, 0, 0);
+        }
+        unsigned char* xd = xring + slot * XSTAGE;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float* p = s < s1 ? xr1[nb] + 32 * s : xr2[nb] + 32 * (s - s1);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                __builtin_amdgcn_global_load_lds(p + 16 * hf, (__attribute__((address_space(3))) void*)(xd + nb * GS_XBLK + hf * 1024),
+                                                 16, 0, 0);
+        }
+    };
+    // this lane's two chunks of row i in a row block: half q >> 1, chunks 2 (q & 1) and 2 (q & 1) + 1
+    const unsigned xlane = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)xring + (q >> 1) * 1024 +
+                           (32 * (q & 1) + i) * 16;
+    f32x4 xa[NB][2];                                          // X of the next step: [nb][half of the lane's eight k]
+    auto xread = [&](int s) {
+        const unsigned base = xlane + (s & (GS_NST - 1)) * XSTAGE;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(xa[nb][0]) : "v"(base), "n"(nb * GS_XBLK));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(xa[nb][1]) : "v"(base), "n"(nb * GS_XBLK + 256));
+        }
+    };
+    f32x4 acc[8][NB];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (J.bias != nullptr) b4 = ld4(J.bias + m0 + 16 * mb + 4 * q);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = b4;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // bias / index loads done: the counts below are exact
+    dma(0);
+    if (S > 1) dma(1);
+    if (S > 2) dma(2);
+    // Activation scale: ONE power of two per ROW of X (lane (i, q) holds eight k of row 16 nb + i: the four q lanes of a row
+    // agree on its maximum through two cross-lane exchanges), 0 = not set yet; the accumulators of a row hold xs x sums.
+    // Per row, not per wave: the rows a wave works on may be gathered through per-type lists whose order differs from run to
+    // run (atomic appends) -- a scale shared by whichever rows meet in a wave made the result depend on that order (found by
+    // tools/s2s_soak.py: 1-ulp differences between runs).
+    float xs[NB], xm[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xs[nb] = 0.0f;
+    f16x8 xh[NB], xl[NB], xh_n[NB], xl_n[NB];
+    // row maxima of the step held in xa (bit patterns: non-negative floats order like unsigned integers; the four q lanes of
+    // a row sit in the wave's four rows of 16 lanes: two VALU row swaps, no LDS traffic), and its split with the scales as
+    // they stand
+    auto x_rowmax = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float v = 0.0f;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                v = fmaxf(fmaxf(v, fmaxf(fabsf(xa[nb][hh][0]), fabsf(xa[nb][hh][1]))), fmaxf(fabsf(xa[nb][hh][2]), fabsf(xa[nb][hh][3])));
+            unsigned u = __float_as_uint(v);
+            const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            u = r16[0] > r16[1] ? r16[0] : r16[1];
+            const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            u = r32[0] > r32[1] ? r32[0] : r32[1];
+            xm[nb] = __uint_as_float(u);                          // the row's maximum over this step's 32 k, in all four q lanes
+        }
+    };
+    auto x_split = [&](int nb) {                                  // (natural k order: the halves are 8 q .. + 4, + 4 .. + 8)
+        split8(xa[nb][0] * xs[nb], xa[nb][1] * xs[nb], xh_n[nb], xl_n[nb]);
+    };
+    // behind the step's MFMAs: the first step sets the scales; a row that would reach 2^15 lowers its own and rescales its
+    // accumulators (wave-uniform branch, rare); then the split pieces become the current ones
+    auto x_settle = [&]() {
+        bool redo_lane = false;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) redo_lane = redo_lane || xs[nb] == 0.0f || xm[nb] * xs[nb] >= 32768.0f;
+        if (__builtin_amdgcn_ballot_w64(redo_lane) != 0ull) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const unsigned E = (__float_as_uint(xm[nb]) >> 23) & 255u;
+                int sh = 140 - (int)E;                            // max (2^(E-127) ..) -> 2^13 ..
+                sh = sh > 40 ? 40 : (sh < -40 ? -40 : sh);
+                float ns = __int_as_float((127 + sh) << 23);
+                float ratio;
+                if (xs[nb] == 0.0f) ratio = ns;                   // first time: the accumulators hold the bias
+                else if (xm[nb] * xs[nb] >= 32768.0f) { ns = ns < xs[nb] ? ns : xs[nb]; ratio = ns / xs[nb]; }    // (powers of two: exact)
+                else { ns = xs[nb]; ratio = 1.0f; }
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = acc[mb][nb] * ratio;
+                xs[nb] = ns;
+                split8(xa[nb][0] * ns, xa[nb][1] * ns, xh_n[nb], xl_n[nb]);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { xh[nb] = xh_n[nb]; xl[nb] = xl_n[nb]; }
+    };
+#define GS_XWAIT(cnt)                                                                                             \
+    do {                                                                                                          \
+        if constexpr (NB == 2)                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1])); \
+        else                                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(xa[0][0]), "+v"(xa[0][1]));                       \
+    } while (0)
+#define GS_XTIE()                                                                                                 \
+    do {                                                                                                          \
+        if constexpr (NB == 2) asm volatile("" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1])); \
+        else asm volatile("" : "+v"(xa[0][0]), "+v"(xa[0][1]));                                                 \
+    } while (0)
+    // X(0): the wave's own requests of step 0 have landed (those of steps 1 and 2 may be in flight: vmcnt counts in order)
+    if (S > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xread(0);
+    GS_XWAIT(0);
+    x_rowmax();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) x_split(nb);
+    x_settle();
+    for (int s = 0; s < S; ++s) {
+        // this wave's requests of step s have landed; those of steps s + 1 and s + 2 may be in flight
+        if (s + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                        // weight fragments of step s visible to every wave; slot (s - 1) % NST is free
+        if (s + 3 < S) dma(s + 3);
+        const bool more = s + 1 < S;                          // (uniform)
+        const f16x8* st = ring + (s & (GS_NST - 1)) * GS_STAGE + lane;
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
+        // fragments of row block mb + 1 are requested before the MFMAs of row block mb (LDS returns in order: lgkmcnt(2)
+        // leaves exactly the newer two outstanding)
+        f16x8 w[2][2];
+#define GS_READ(buf, mb)                                                                                          \
+        do {                                                                                                      \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w[buf][0]) : "v"(base), "n"(((mb) * 2 + 0) * 1024)); \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w[buf][1]) : "v"(base), "n"(((mb) * 2 + 1) * 1024)); \
+        } while (0)
+        GS_READ(0, 0);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const int cur = mb & 1;
+            if (mb == 3 && more) {
+                // half way: the wave's X rows of step s + 1 have landed (steps s + 2, s + 3 may be in flight) -> registers;
+                // the reads are older than the two weight reads below, so the wait there covers them
+                if (s + 3 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+                else if (s + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                xread(s + 1);
+            }
+            if (mb < 7) {
+                if (cur == 0) GS_READ(1, mb + 1); else GS_READ(0, mb + 1);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w[cur][0]), "+v"(w[cur][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[cur][0]), "+v"(w[cur][1]));
+            }
+            if (mb == 3 && more) GS_XTIE();
+            const f16x8 wh = w[cur][0], wl = w[cur][1];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[nb], acc[mb][nb], 0, 0, 0);
+            // VALU work of the next step under this step's MFMAs, a piece per row block
+            if (more) {
+                if (mb == 4) x_rowmax();
+                if (mb == 5) x_split(0);
+                if (mb == 6 && NB == 2) x_split(NB - 1);
+            }
+        }
+#undef GS_READ
+        if (more) x_settle();
+    }
+#undef GS_XWAIT
+#undef GS_XTIE
+    float inv_xs[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) inv_xs[nb] = xs[nb] != 0.0f ? 1.0f / xs[nb] : 1.0f;      // (powers of two: exact)
+    const int act = J.act;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        int64_t n = n0 + 16 * nb + i;
+        if (n >= N) continue;
+        const int64_t nsrc = n;
+        if (J.yidx != nullptr) n = J.yidx[n];
+        const float* g1 = J.g1 != nullptr ? J.g1 + (size_t)J.i1[nsrc] * M : nullptr;
+        const float* g2 = J.g2 != nullptr ? J.g2 + (size_t)J.i2[nsrc] * M : nullptr;
+        const float sc = J.scale != nullptr ? J.scale[(size_t)n * J.sstride] : 1.0f;
+        if (act == 5) {                                       // LSTM cell on the gate pre-activations (rows interleaved by unit)
+            const int Ru = M >> 2;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                const int u = ((m0 + 16 * mb) >> 2) + q;      // rows 4 u .. 4 u + 3
+                const f32x4 v = acc[mb][nb] * inv_xs[nb];
+                const float ig = sigmoid1(v[0]), fg = sigmoid1(v[1]);
+                const float gg = tanh1(v[2]), og = sigmoid1(v[3]);
+                const float cn = fg * J.cell_c0[(size_t)n * Ru + u] + ig * gg;
+                J.cell_c1[(size_t)n * Ru + u] = cn;
+                J.cell_h1[(size_t)n * Ru + u] = og * tanh1(cn);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const int m = m0 + 16 * mb + 4 * q;
+            f32x4 v = acc[mb][nb] * inv_xs[nb];
+            if (g1 != nullptr) v += ld4(g1 + m) + ld4(g2 + m);
+            if (act == 1) v = silu4(v);
+            else if (act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            } else if (act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanh1(v[r]);
+            } else if (act == 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = elu1(v[r]);
+            }
+            if (J.post_scale != nullptr) v = v * ld4(J.post_scale + m) + ld4(J.post_shift + m);
+            v = v * sc;
+            if (J.accumulate) v += ld4(Y + (size_t)n * ldy + m);
+            st4(Y + (size_t)n * ldy + m, v);
+        }
+    }
+}
+
+// (A/B: the rounds 2 - 4 structure: X in registers one step ahead, two workgroups per CU)
+constexpr int GS1_NST = 3;
 template <int NB>          // row blocks of 16 per wave: 2 (128-row tiles) from 16 K rows on, 1 (64-row tiles) for 2 K - 16 K rows
 __global__ void __launch_bounds__(256, 2)
-k_s2s_gemm_split(const S2SJobs jobs) {
+k_s2s_gemm_split_r1(const S2SJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
     f16x8* ring = reinterpret_cast<f16x8*>(gs_smem);
     int ji = 0;
@@ -237,7 +522,11 @@ k_s2s_gemm_split(const S2SJobs jobs) {
     for (int t = 1; t < S2S_MAX_JOBS; ++t)
         if (t < jobs.n && (int)blockIdx.x >= jobs.j[t].wg0) ji = t;
     const S2SJob& J = jobs.j[ji];
-    const int local = (int)blockIdx.x - J.wg0, bx = local % J.gx, by = local / J.gx;
+    // (row tile, column block) of the workgroup: the M / 128 column blocks of a row tile sit in consecutive slots of ONE XCD
+    // (workgroups go round-robin over the 8 XCDs), so that the tile's rows of X come from memory once and from that XCD's L2
+    // for the other column blocks.  The job's grid is padded to 8 x ceil(gx / 8) row tiles; the extra ones leave below.
+    const int local = (int)blockIdx.x - J.wg0, gy = J.M >> 7, slot = local >> 3;
+    const int bx = (local & 7) + 8 * (slot / gy), by = slot % gy;
     int64_t N = J.N;
     if (J.n_dev != nullptr) N = *J.n_dev;
     const int M = J.M, ldy = J.ldy;
@@ -265,7 +554,7 @@ k_s2s_gemm_split(const S2SJobs jobs) {
     auto dma = [&](int s) {                                   // weight fragments of step s -> slot s % NST
         const f16x8* src = (s < s1 ? img1 + ((size_t)s * n_mb + (m0 >> 4)) * 2 * 64
                                     : img2 + ((size_t)(s - s1) * n_mb + (m0 >> 4)) * 2 * 64) + lane;
-        f16x8* dst = ring + (s % GS_NST) * GS_STAGE;
+        f16x8* dst = ring + (s % GS1_NST) * GS_STAGE;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int fr = wave + 4 * f;
@@ -355,7 +644,7 @@ k_s2s_gemm_split(const S2SJobs jobs) {
         if (s + 1 < S) xload(s + 1);                          // X first, then the DMA (see the vmcnt below)
         if (s + 2 < S) dma(s + 2);
         else if (s + 1 < S) asm volatile("" ::: "memory");
-        const f16x8* st = ring + (s % GS_NST) * GS_STAGE + lane;
+        const f16x8* st = ring + (s % GS1_NST) * GS_STAGE + lane;
         const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
         // fragments of row block mb + 1 are requested before the MFMAs of row block mb (LDS returns in order: lgkmcnt(2)
         // leaves exactly the newer two outstanding)
@@ -410,11 +699,11 @@ k_s2s_gemm_split(const S2SJobs jobs) {
             for (int mb = 0; mb < 8; ++mb) {
                 const int u = ((m0 + 16 * mb) >> 2) + q;      // rows 4 u .. 4 u + 3
                 const f32x4 v = acc[mb][nb] * inv_xs[nb];
-                const float ig = 1.0f / (1.0f + expf(-v[0])), fg = 1.0f / (1.0f + expf(-v[1]));
-                const float gg = tanhf(v[2]), og = 1.0f / (1.0f + expf(-v[3]));
+                const float ig = sigmoid1(v[0]), fg = sigmoid1(v[1]);
+                const float gg = tanh1(v[2]), og = sigmoid1(v[3]);
                 const float cn = fg * J.cell_c0[(size_t)n * Ru + u] + ig * gg;
                 J.cell_c1[(size_t)n * Ru + u] = cn;
-                J.cell_h1[(size_t)n * Ru + u] = og * tanhf(cn);
+                J.cell_h1[(size_t)n * Ru + u] = og * tanh1(cn);
             }
             continue;
         }
@@ -429,10 +718,10 @@ k_s2s_gemm_split(const S2SJobs jobs) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
             } else if (act == 3) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = tanh1(v[r]);
             } else if (act == 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = elu1(v[r]);
             }
             if (J.post_scale != nullptr) v = v * ld4(J.post_scale + m) + ld4(J.post_shift + m);
             v = v * sc;
@@ -692,7 +981,7 @@ k_s2s_narrow_layers(NarrowLayers L, const float* __restrict__ X, int ldx, int C,
         for (int r = 0; r < 4; ++r) {
             float sv = L.b[g] != nullptr ? L.b[g][m + r] : 0.0f;
             for (int c = 0; c < C; ++c) sv = fmaf(L.W[g][(size_t)(m + r) * C + c], x[c], sv);
-            v[r] = act == 4 ? (sv > 0.0f ? sv : expm1f(sv)) : sv;
+            v[r] = act == 4 ? elu1(sv) : sv;
         }
         st4(L.Y[g] + (size_t)n * M + m, v);
     }
@@ -741,7 +1030,7 @@ k_s2s_pair_tanh_all(const float* __restrict__ A, const float* __restrict__ S, in
     for (int k = k0; k < K; ++k) {
         if (edge_w[e * K + k] == 0.0f) continue;
         const f32x4 v = ld4(A + ((size_t)k * n_nodes + r) * h + c) + ld4(S + ((size_t)k * n_nodes + s) * h + c);
-        st4(T + ((size_t)k * n_edges + e) * h + c, f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])});
+        st4(T + ((size_t)k * n_edges + e) * h + c, f32x4{tanh1(v[0]), tanh1(v[1]), tanh1(v[2]), tanh1(v[3])});
     }
 }
 

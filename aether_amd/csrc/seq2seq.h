@@ -162,11 +162,11 @@ k_s2s_linear(const float* __restrict__ W, const float* __restrict__ bias, const 
             }
             if (ACT == 3) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = tanh1(v[r]);
             }
             if (ACT == 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);     // ELU, alpha = 1
+                for (int r = 0; r < 4; ++r) v[r] = elu1(v[r]);     // ELU, alpha = 1
             }
             if (post_scale != nullptr) {
 #pragma unroll
@@ -387,7 +387,7 @@ k_s2s_pair_tanh(const float* __restrict__ A, const float* __restrict__ S, const 
     const int c = (int)(idx - j * q4) * 4;
     const int64_t e = list[j];
     const f32x4 v = ld4(A + (size_t)recv[e] * h + c) + ld4(S + (size_t)send[e] * h + c);
-    st4(T + (size_t)j * h + c, f32x4{tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])});
+    st4(T + (size_t)j * h + c, f32x4{tanh1(v[0]), tanh1(v[1]), tanh1(v[2]), tanh1(v[3])});
 }
 
 // list = the edges whose weight for type k is not zero (one-hot types: the edges of that type; soft
@@ -452,9 +452,9 @@ k_s2s_gate(const float* __restrict__ rp, const float* __restrict__ ip, const flo
            int64_t count) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= count) return;
-    const float r = 1.0f / (1.0f + expf(-rp[idx]));
-    const float i = 1.0f / (1.0f + expf(-ip[idx]));
-    const float n = tanhf(np_[idx] + r * hh[idx]);
+    const float r = sigmoid1(rp[idx]);
+    const float i = sigmoid1(ip[idx]);
+    const float n = tanh1(np_[idx] + r * hh[idx]);
     hidden_out[idx] = (1.0f - i) * n + i * hidden[idx];
 }
 
@@ -492,7 +492,7 @@ k_s2s_pos_hidden(const float* __restrict__ W1, const float* __restrict__ b1, con
     const int c = (int)(idx - e * h);
     float s = b1[c];
     for (int p = 0; p < P; ++p) s = fmaf(W1[c * P + p], pos[e * P + p], s);
-    hw[idx] = s > 0.0f ? s : (relu ? 0.0f : expm1f(s));
+    hw[idx] = relu ? fmaxf(s, 0.0f) : elu1(s);
 }
 
 // M[e][:] += relu(F[e][:]) * w[e * K]   (present messages of the variable-N decoder, aether_dynamicvars.py:831-835)
@@ -683,7 +683,7 @@ k_s2s_edge_sum_elu(float* __restrict__ T, const float* __restrict__ Ps, const fl
     const int c = (int)(idx - e * q4) * 4;
     f32x4 v = ld4(T + (size_t)e * h + c) + ld4(Ps + (size_t)send[e] * h + c) + ld4(Pr + (size_t)recv[e] * h + c);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);
+    for (int r = 0; r < 4; ++r) v[r] = elu1(v[r]);
     st4(T + (size_t)e * h + c, v);
 }
 
@@ -718,11 +718,11 @@ k_s2s_lstm_cell(const float* __restrict__ gates, const float* __restrict__ c0, f
     const int64_t e = idx / R;
     const int c = (int)(idx - e * R);
     const float* g = gates + (size_t)e * 4 * R;
-    const float ig = 1.0f / (1.0f + expf(-g[c])), fg = 1.0f / (1.0f + expf(-g[R + c]));
-    const float gg = tanhf(g[2 * R + c]), og = 1.0f / (1.0f + expf(-g[3 * R + c]));
+    const float ig = sigmoid1(g[c]), fg = sigmoid1(g[R + c]);
+    const float gg = tanh1(g[2 * R + c]), og = sigmoid1(g[3 * R + c]);
     const float cn = fg * c0[idx] + ig * gg;
     c1[idx] = cn;
-    h1[idx] = og * tanhf(cn);
+    h1[idx] = og * tanh1(cn);
 }
 
 // gumbel_softmax(hard=True) with the uniform draw supplied (nn/utils/model_utils.py:58-118)

@@ -11,7 +11,12 @@ ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--decoder-hidden", type=int, default=256)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--opt", action="append", default=[], help="library option name=value (aether_set_option)")
 a = ap.parse_args()
+from aether_amd import _lib
+for kv in a.opt:
+    k, v = kv.split("=")
+    _lib.check(_lib.load().aether_set_option(k.encode(), int(v)), "set_option " + kv)
 D, N, B, H, R = a.dims, a.nodes, a.batch, 512, 128
 params = {"num_vars": N, "input_size": 2 * D, "gpu": True, "decoder_hidden": a.decoder_hidden, "num_edge_types": 2,
           "skip_first": False, "decoder_dropout": 0.0, "use_3d": D == 3, "encoder_dropout": 0.0, "encoder_hidden": H,
