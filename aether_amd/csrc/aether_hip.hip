@@ -275,7 +275,7 @@ int g_outer_tiles_per_wave = 0;                 // aether_set_option("outer_tile
 int g_linear_small_wgs = 128;                   // aether_set_option("linear_small_wgs", n): below n workgroups, 16 x 32 blocks
 int g_linear_kwaves = 4;                        // aether_set_option("linear_kwaves", 1 | 4): waves of a workgroup that split a small layer's k-groups
 int g_filter_wg_target = 768;                   // aether_set_option("filter_wg_target", n): k-splits of the first-version filter kernel (variable-N steps)
-int g_gemm_split = 1;                           // aether_set_option("gemm_split", 0 | 1): bf16 x 3 GEMM for the >= 16 K-row layers of the fused seq2seq step
+int g_gemm_split = 1;                           // aether_set_option("gemm_split", 0 | 1 | 2 | 3): fp16 x 2 GEMM for the >= 128-workgroup layers of the fused seq2seq step (2 / 3: force a kernel structure)
 int g_dyn_filter_v1 = 0;                        // aether_set_option("dyn_filter_v1", 0 auto | 1 always | 2 never): first-version filter kernel in the variable-N steps
 int g_dyn_filter_v1_edges = 0;                  // auto: below this many edges (measured: no size where the first version wins)
 int g_filter_rsplits = 0;                       // aether_set_option("filter_rsplits", 0 auto | 1 | 3 | 5 | 15): feature split of the 15-feature filter GEMM
@@ -1003,7 +1003,11 @@ int aether_set_option(const char* name, int value) {
         g_linear_kwaves = value;
         return AETHER_OK;
     }
-    if (!strcmp(name, "gemm_split")) { g_gemm_split = value; return AETHER_OK; }
+    if (!strcmp(name, "gemm_split")) {
+        if (value < 0 || value > 3) return fail(AETHER_EINVAL, "set_option: gemm_split must be 0, 1, 2 or 3");
+        g_gemm_split = value;
+        return AETHER_OK;
+    }
     if (!strcmp(name, "dyn_filter_v1")) {
         if (value < 0 || value > 2) return fail(AETHER_EINVAL, "set_option: dyn_filter_v1 must be 0, 1 or 2");
         g_dyn_filter_v1 = value;

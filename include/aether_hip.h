@@ -848,7 +848,11 @@ int aether_adamw_step(const AetherAdamWTensor* tensors, int n_tensors, float* st
  * decoder workspace sizes), "linear_small_wgs" n (dense layers of the seq2seq / variable-N steps whose 64 x 32-per-wave
  * tiling would launch fewer than n workgroups use 16 x 32 blocks per wave instead: four times the waves for the
  * 5-object graphs; default 128), "linear_kwaves" 1|4 (when even those blocks are few, the four waves of a workgroup
- * share one block and split its k-groups, partial sums added in wave order; default 4, 1 turns it off).
+ * share one block and split its k-groups, partial sums added in wave order; default 4, 1 turns it off),
+ * "gemm_split" 0|1|2|3 (dense layers of the fused seq2seq step from 128 workgroups on: 1, the default, multiplies
+ * fp16 x 2 pieces on the 16-bit matrix pipe and picks the kernel structure per launch -- both operands through an
+ * LDS-DMA ring up to 256 workgroups, X rows in registers above; 2 / 3 force the second / the first structure for
+ * every launch; 0 sends these layers through the fp32-MFMA job kernel).
  */
 int aether_set_option(const char* name, int value);
 

@@ -419,14 +419,16 @@ def test_fused_step_equals_the_four_entry_points(D, N, B, K, skip_first, layers)
     assert scale_rel_err(got_x2.cpu(), want_x.cpu()) <= 2e-6
 
 
+@pytest.mark.parametrize("structure", [1, 2, 3])
 @pytest.mark.parametrize("D,he,hd,B", [(2, 128, 128, 44), (3, 128, 128, 44), (2, 512, 256, 44), (2, 512, 256, 110)])
-def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he, hd, B):
-    """From 16 K rows on the edge-level layers of the fused step run as six bf16 MFMA terms on prepared weight images
+def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he, hd, B, structure):
+    """From 2 K rows on, the dense layers of the fused step run as three fp16 MFMA terms on prepared weight images
     (k_s2s_gemm_split); aether_set_option("gemm_split", 0) sends them through the fp32-MFMA job kernel instead: same edge
     samples, outputs equal to fp32 rounding (16,720 edges, ragged last tile, per-type row lists, two-segment LSTM product,
     gather epilogue; 64-row tiles at hidden 128, 128-row tiles for the 512-wide layers; with 110 graphs = 2,200 nodes the
     node-level layers -- field net, mlp3, mlp4 halves, message first layers, K-concatenated gates, output MLP -- take the
-    split path too)."""
+    split path too).  structure 1: the library's choice per launch (both operands through the LDS-DMA ring up to 256
+    workgroups, X in registers above); 2 / 3: either structure for every launch."""
     from aether_amd import _lib
     from aether_amd.nn.seq2seq.aether import Aether
     N, K = 20, 2
@@ -447,8 +449,9 @@ def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he
     try:
         lib.aether_set_option(b"gemm_split", 0)
         want_x, want_dh, (want_h, want_c), want_e = m._fused_step(x, dh, st, u)
-        lib.aether_set_option(b"gemm_split", 1)
+        lib.aether_set_option(b"gemm_split", structure)
         got_x, got_dh, (got_h, got_c), got_e = m._fused_step(x, dh, st, u)
+        again = m._fused_step(x, dh, st, u)
     finally:
         lib.aether_set_option(b"gemm_split", 1)
     assert (got_e == want_e).all(dim=-1).float().mean() > 0.9999          # a sample may sit on the rounding of its logits
@@ -459,7 +462,6 @@ def test_fused_step_large_layers_on_the_bf16_pipe_equal_the_fp32_mfma_path(D, he
         assert scale_rel_err(got[same].cpu(), want[same].cpu()) <= TOL
     # the split path is bit-stable run to run (an inline-asm prefetch of X once raced with a register copy at the loop's
     # back edge: results changed from run to run)
-    again = m._fused_step(x, dh, st, u)
     assert torch.equal(again[0], got_x) and torch.equal(again[2][0], got_h) and torch.equal(again[3], got_e)
 
 
