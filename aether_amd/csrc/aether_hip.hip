@@ -225,7 +225,7 @@ int g_fused_pair_stride = 8;  // aether_set_option("fused_pair_stride", 1|8): di
                               // placement hint only: the hand-off protocol is the cross-XCD one either way)
 
 struct GraphLayout {
-    size_t perm, send_s, recv_s, rowptr, gsel, wgdesc, tdesc, tsel, tdst, lorder, nrange, hflags, sperm, srowptr, keys,
+    size_t perm, send_s, recv_s, rowptr, gsel, wgdesc, tdesc, tsel, tdst, lorder, ledge, nrange, hflags, sperm, srowptr, keys,
         vals, diff, cross, flag, cub, total, cub_bytes;
     int64_t max_wgs, max_tiles;
     GraphLayout(int64_t E, int64_t Nn, bool with_sort_scratch = true) {
@@ -244,6 +244,7 @@ struct GraphLayout {
         tsel = take((size_t)max_tiles * 64 * 4 + 4);
         tdst = take((size_t)max_tiles * 64 * 4 + 4);
         lorder = take(tables ? e4 : 4);         // local edge order of every fused workgroup (FusedWG)
+        ledge = take(tables ? 4 * e4 : 16);     // ... and {sorted position, sender, receiver, original edge} in that order
         nrange = take(tables ? (size_t)Nn * 16 : 4);                 // per node: local index ranges of its two runs
         hflags = take((size_t)(2 * max_wgs + 64) * 4);               // split-mode hand-off flags: forward | backward
         sperm = take(e4);                       // receiver-sorted positions grouped by sender (stable)
@@ -425,14 +426,14 @@ template <int D, int NW, int ROUNDS, bool KEEP>
 int fused_launch(const AetherParams& P, const float* x, const float* vel, const float* charges,
                  const float* ea, const int32_t* perm, const int32_t* send_s, const int32_t* recv_s,
                  const int32_t* rowptr, const FusedWG* wgdesc, const uint32_t* tsel, const uint32_t* tdst,
-                 const int32_t* lorder, const int32_t* nrange, int n_groups, const FusedDebug& dbg, float* out,
+                 const int4* ledge, const int32_t* nrange, int n_groups, const FusedDebug& dbg, float* out,
                  hipStream_t st) {
     auto kern = k_fused<D, NW, ROUNDS, KEEP>;
     constexpr size_t lds = (size_t)FusedLds<NW, ROUNDS>::TOTAL * 4;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return AETHER_EHIP;
     ProfScope ps(K_FUSED, st);
     kern<<<dim3((unsigned)n_groups), dim3(NW * 64), lds, st>>>(P, x, vel, charges, ea, perm, send_s, recv_s,
-                                                              rowptr, wgdesc, tsel, tdst, lorder, nrange, dbg, out);
+                                                              rowptr, wgdesc, tsel, tdst, ledge, nrange, dbg, out);
     return AETHER_OK;
 }
 
@@ -470,10 +471,10 @@ int fused_impl(const AetherParams& P, int64_t Nn, int64_t E, const AetherGraphIn
 #define AETHER_FUSED_CASE(NWV, R)                                                                     \
     rc = keep ? fused_launch<D, NWV, R, true>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),       \
                                               gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,            \
-                                              gp(G.lorder), gp(G.nrange), info.n_groups, dbg, out, st) \
+                                              reinterpret_cast<const int4*>(graph + G.ledge), gp(G.nrange), info.n_groups, dbg, out, st) \
               : fused_launch<D, NWV, R, false>(P, x, vel, charges, ea, gp(G.perm), gp(G.send_s),      \
                                                gp(G.recv_s), gp(G.rowptr), wgd, tsel, tdst,           \
-                                               gp(G.lorder), gp(G.nrange), info.n_groups, dbg, out, st)
+                                               reinterpret_cast<const int4*>(graph + G.ledge), gp(G.nrange), info.n_groups, dbg, out, st)
     if (tiles <= 8) { AETHER_FUSED_CASE(8, 1); }
     else if (tiles <= 16) { AETHER_FUSED_CASE(8, 2); }
     else { AETHER_FUSED_CASE(8, 3); }
@@ -1180,8 +1181,8 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
             std::vector<FusedTile> tiles;
             mgn = 0; mge = 0;
             auto add_wg = [&](int vb, int ve, int nb, int ne, int partner) {
-                FusedWG w = {vb, ve, nb, ne, (int)tiles.size(), partner, 0, 0};
                 const int m = h_rowptr[ne] - h_rowptr[nb];
+                FusedWG w = {vb, ve, nb, ne, (int)tiles.size(), partner, 0, (int)h_rowptr[nb], m, 0, 0, 0};
                 for (int t = 0; t < (m + 15) / 16; ++t) tiles.push_back(FusedTile{(int)wgs.size(), t});
                 if (ne - nb > mgn) mgn = ne - nb;
                 if (m > mge) mge = m;
@@ -1224,8 +1225,8 @@ int aether_graph_build(const int64_t* send, const int64_t* recv, int64_t n_edges
                 HIP_OK(hipMemcpyAsync(g + G.wgdesc, wgs.data(), wgs.size() * sizeof(FusedWG), hipMemcpyHostToDevice, st));
                 HIP_OK(hipMemsetAsync(g + G.hflags, 0, (size_t)(2 * G.max_wgs + 64) * 4, st));
                 k_graph_lorder<<<dim3((unsigned)wgs.size()), dim3(512), 0, st>>>(
-                    (FusedWG*)(g + G.wgdesc), (const int32_t*)(g + G.send_s), rowptr, (int32_t*)(g + G.lorder),
-                    (int32_t*)(g + G.nrange));
+                    (FusedWG*)(g + G.wgdesc), (const int32_t*)(g + G.send_s), recv_s, (const int32_t*)(g + G.perm), rowptr,
+                    (int32_t*)(g + G.lorder), (int4*)(g + G.ledge), (int32_t*)(g + G.nrange));
                 if (!tiles.empty()) {
                     HIP_OK(hipMemcpyAsync(g + G.tdesc, tiles.data(), tiles.size() * sizeof(FusedTile),
                                           hipMemcpyHostToDevice, st));

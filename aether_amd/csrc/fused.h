@@ -187,14 +187,15 @@ constexpr int FUSED_STAMPS = 512;
 // receiver-sorted (unsplit: na = m, the identity).  Tiles of the first run need nothing from the partner, so
 // the forward starts with them while the partner's rows are in flight -- and the backward starts with the
 // second run, whose sender-side sums the partner waits for.
-struct FusedWG { int vb, ve, nb, ne, tile0, partner, na, pad1; };
+struct FusedWG { int vb, ve, nb, ne, tile0, partner, na, eb, m, pad1, pad2, pad3; };   // eb, m: first in-edge (sorted position) and in-edge count of [nb, ne)
 struct FusedTile { int wg, t; };             // workgroup descriptor index, tile index within the workgroup
 
 // Local edge order of every workgroup (one block per workgroup; m <= FUSED_MAX_EDGES <= blockDim.x) and the
 // local index ranges of every own node's in-edges in the two runs: nrange[node] = {a_beg, a_end, b_beg, b_end}.
 __global__ void __launch_bounds__(512)
-k_graph_lorder(FusedWG* __restrict__ wgdesc, const int32_t* __restrict__ send_s, const int32_t* __restrict__ rowptr,
-               int32_t* __restrict__ lorder, int32_t* __restrict__ nrange) {
+k_graph_lorder(FusedWG* __restrict__ wgdesc, const int32_t* __restrict__ send_s, const int32_t* __restrict__ recv_s,
+               const int32_t* __restrict__ perm, const int32_t* __restrict__ rowptr, int32_t* __restrict__ lorder,
+               int4* __restrict__ ledge, int32_t* __restrict__ nrange) {
     __shared__ int wsum[2][8];
     __shared__ int cnt_a[FUSED_MAX_NODES + 1], cnt_b[FUSED_MAX_NODES + 1];
     const FusedWG wg = wgdesc[blockIdx.x];
@@ -215,8 +216,13 @@ k_graph_lorder(FusedWG* __restrict__ wgdesc, const int32_t* __restrict__ send_s,
         if (w < wave) { base_o += wsum[0][w]; base_t += wsum[1][w]; }
         na += wsum[0][w];
     }
-    if (own) lorder[eb + base_o + __popcll(bo & below)] = tid;
-    if (oth) lorder[eb + na + base_t + __popcll(bt & below)] = tid;
+    // ledge: the same order with everything the forward kernel's feature phase looks up per edge in one 16-byte record
+    // {sorted position, sender, receiver, original edge}: one round trip instead of three dependent ones (k_fused, P2)
+    if (valid) {
+        const int pos = own ? base_o + __popcll(bo & below) : na + base_t + __popcll(bt & below);
+        lorder[eb + pos] = tid;
+        ledge[eb + pos] = make_int4(eb + tid, snd, recv_s[eb + tid], perm[eb + tid]);
+    }
     if (tid == 0) wgdesc[blockIdx.x].na = na;
     // per-node run lengths (thread per own node, a handful of edges each), then a serial prefix
     if (tid < n) {
@@ -331,7 +337,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         const int32_t* __restrict__ perm, const int32_t* __restrict__ send_s,
         const int32_t* __restrict__ recv_s, const int32_t* __restrict__ rowptr,
         const FusedWG* __restrict__ wgdesc, const uint32_t* __restrict__ tsel,
-        const uint32_t* __restrict__ tdst, const int32_t* __restrict__ lorder,
+        const uint32_t* __restrict__ tdst, const int4* __restrict__ ledge,
         const int32_t* __restrict__ nrange, FusedDebug dbg, float* __restrict__ out) {
     constexpr bool keep = KEEP;      // inference build carries none of the save-for-backward stores
     using NI = NodeInfo<D>;
@@ -357,8 +363,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     const int vb = wg.vb, nv = wg.ve - wg.vb;            // visible nodes (slots of ninfo / psb)
     const int nb = wg.nb, ne = wg.ne;                    // own nodes (slots of xbuf / nbuf / prb / part)
     const int n = ne - nb, off = nb - vb;
-    const int eb = rowptr[nb], ee = rowptr[ne];
-    const int m = ee - eb;
+    const int eb = wg.eb, m = wg.m;                      // (= rowptr[nb], rowptr[ne] - rowptr[nb]: kept with the descriptor)
     const int n_tiles = (m + 15) >> 4;
     const int na = wg.na;                                // edges [0, na) of the local order have own senders
     volatile int* arrived = reinterpret_cast<volatile int*>(smem + L::ARRIVED);
@@ -407,6 +412,45 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
     }
     if (tid < 2 * H) p0bias = tid < H ? P.l1_msg_b0[tid] : P.l1_msg_b2[tid - H];
     FUSED_STAMP(1);
+
+    // ---------------------------------------------------------------- edge indices of P2, requested during P1
+    // P2 needs, per lane, dependent rounds of global loads before it can read a node record: in rounds 1 - 4 (first half)
+    // row pointers -> local order -> sender / receiver / original edge -> edge attributes, issued in P2 (1.8 us per workgroup).
+    // Now the descriptor carries the row pointers, the graph one 16-byte record per edge in local order (ledge,
+    // k_graph_lorder), and every wave asks for its records and attributes during P1 -- only two of the eight waves work
+    // there (<= 32 visible nodes), behind their own inputs.
+    constexpr int FR = ROUNDS < 2 ? ROUNDS : 2;              // rounds of the first feature pass (lane >> 4)
+    const int f_local = 16 * (NW * (lane >> 4) + wave) + (lane & 15);
+    const bool f_have = lane < 16 * FR && f_local < m;       // this lane builds the features of edge f_local
+    int4 f_e = make_int4(0, 0, 0, 0);                        // {sorted position, sender, receiver, original edge}
+    f32x2 f_ea = {0.0f, 0.0f};                               // its two edge attributes (q_i q_j: the first only)
+    int4 t_e[ROUNDS];                                        // per (round, lane i): the tile's edge i
+    unsigned t_sel[ROUNDS], t_dst[ROUNDS];
+    auto index_stage_a = [&]() {
+        if (f_have) f_e = ledge[eb + f_local];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int tile = NW * r + wave, local = 16 * tile + i;
+            t_e[r] = m > 0 ? ledge[eb + (local < m ? local : 0)] : make_int4(0, vb, nb, 0);
+            const bool have = tile < n_tiles;
+            t_sel[r] = have ? tsel[(size_t)(wg.tile0 + tile) * 64 + lane] : 0u;
+            t_dst[r] = have ? tdst[(size_t)(wg.tile0 + tile) * 64 + lane] : 0xFFFFFFFFu;
+        }
+    };
+    // (returns its result: written through the capture, the two floats were kept in scratch memory -- 8 bytes per thread
+    // stored and re-loaded, + 1 MB of WRITE_SIZE per launch in the first version)
+    auto index_stage_b = [&]() -> f32x2 {
+        f32x2 v = {0.0f, 0.0f};
+        if (f_have) {
+            if (dbg.step.qattr) {          // main.py:243-246: q_i q_j (the distance is computed with the features)
+                v[0] = dbg.step.qattr[f_e.y] * dbg.step.qattr[f_e.z];
+            } else {
+                const float* ea = edge_attr_orig + 2 * (int64_t)f_e.w;
+                v[0] = ea[0]; v[1] = ea[1];
+            }
+        }
+        return v;
+    };
 
     // ---------------------------------------------------------------- P1: field net, frames, x0 on the matrix core
     // aether.py:108-134 (field), geometry.py:7-73 + aether.py:33-50 (frames), locs.py:214-218 (x0).
@@ -459,6 +503,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 for (int s4 = 0; s4 < 2; ++s4)
                     ar[mb][s4] = 4 * s4 + q < 2 * D ? P.l1_res_w[(16 * mb + i) * 3 * D + D + 4 * s4 + q] : 0.0f;
             }
+            index_stage_a();                                    // behind this wave's own inputs (in-order returns: they do not wait for it)
             long ci = (long)(ch + 1.0f);                        // charge_to_index: (q + 1).long(), aether.py:127-129
             ci = ci < 0 ? 0 : (ci > 2 ? 2 : ci);
 #pragma unroll
@@ -473,6 +518,7 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             f32x4 hh[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) hh[mb] = silu4(acc1[mb]);
+            f_ea = index_stage_b();                                    // (the records are back by now; measured: asked for earlier, nothing gained)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -524,6 +570,8 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 }
             }
         } else {
+            index_stage_a();
+            f_ea = index_stage_b();
             // rows of unused node slots are zero
             for (int idx = tid - 64 * vtiles; idx < (FUSED_MAX_NODES - n) * (H / 4); idx += THREADS - 64 * vtiles)
                 st4(xbuf + (n + (idx >> 4)) * LDW + (idx & 15) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -568,9 +616,11 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                 const int local = 16 * (NW * r + wave) + ii;
                 float o[FPAD];
                 if (local < m) {
-                    const int k = eb + lorder[eb + local];       // position in the receiver-sorted edge list
-                    const float* nj = ninfo + (send_s[k] - vb) * 24;
-                    const float* nr = ninfo + (recv_s[k] - vb) * 24;
+                    // position in the receiver-sorted edge list, sender, receiver (first pass: requested during P1)
+                    const int4 le = r0 == 0 ? f_e : ledge[eb + local];
+                    const int k = le.x, ks = le.y, kr = le.z;
+                    const float* nj = ninfo + (ks - vb) * 24;
+                    const float* nr = ninfo + (kr - vb) * 24;
                     float njl[NI::STRIDE], nrl[NI::STRIDE];
 #pragma unroll
                     for (int t = 0; t < NI::STRIDE; ++t) { njl[t] = nj[t]; nrl[t] = nr[t]; }
@@ -582,10 +632,12 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                             const float df = njl[NI::P + d] - nrl[NI::P + d];
                             d2 += df * df;
                         }
-                        eal[0] = dbg.step.qattr[send_s[k]] * dbg.step.qattr[recv_s[k]];
+                        eal[0] = r0 == 0 ? f_ea[0] : dbg.step.qattr[ks] * dbg.step.qattr[kr];
                         eal[1] = sqrtf(d2);
+                    } else if (r0 == 0) {
+                        eal[0] = f_ea[0]; eal[1] = f_ea[1];
                     } else {
-                        const float* ea = edge_attr_orig + 2 * (int64_t)perm[k];
+                        const float* ea = edge_attr_orig + 2 * (int64_t)le.w;
                         eal[0] = ea[0]; eal[1] = ea[1];
                     }
                     edge_features<D>(njl, nrl, eal, o);
@@ -618,15 +670,12 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
         for (int r = 0; r < ROUNDS; ++r) {
             e[r][2] = f32x4{0.f, 0.f, 0.f, 0.f};
             e[r][3] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int tile = NW * r + wave;
-            const int local = 16 * tile + i;
-            const int k = m > 0 ? eb + lorder[eb + (local < m ? local : 0)] : 0;
-            sl[r] = m > 0 ? send_s[k] - vb : 0;
-            rl[r] = m > 0 ? recv_s[k] - nb : 0;
-            if constexpr (KEEP) ke[r] = local < m ? k : -1;
-            const bool have = tile < n_tiles;
-            selbits[r] = have ? tsel[(size_t)(wg.tile0 + tile) * 64 + lane] : 0u;
-            destpack[r] = have ? tdst[(size_t)(wg.tile0 + tile) * 64 + lane] : 0xFFFFFFFFu;
+            const int local = 16 * (NW * r + wave) + i;
+            sl[r] = t_e[r].y - vb;                             // (requested during P1)
+            rl[r] = t_e[r].z - nb;
+            if constexpr (KEEP) ke[r] = local < m ? t_e[r].x : -1;
+            selbits[r] = t_sel[r];
+            destpack[r] = t_dst[r];
         }
         lds_barrier();       // feature scratch (aliases SCRATCH) is dead from here on
     }

@@ -213,15 +213,21 @@ def _other_configs(dev, budget_s=10.0):
     out = []
     quiet = lambda: contextlib.redirect_stdout(io.StringIO())
 
-    def timed(fn, n, warm=3):
+    def timed(fn, n, warm=3, blocks=1):
+        """ms per call; with blocks > 1 the fastest of that many blocks of n calls (the short eager legs: one host hiccup
+        inside a 15 ms window once put 3.2 ms on a 0.73 ms step)"""
         for _ in range(warm):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / n
+        best = None
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / n
+            best = ms if best is None or ms < best else best
+        return best
 
     def leg(name, fn):
         if time.perf_counter() - t_block > budget_s:
@@ -260,13 +266,13 @@ def _other_configs(dev, budget_s=10.0):
             with torch.cuda.graph(g):
                 for _ in range(10):
                     call()
-            ms = timed(g.replay, max(1, steps // 10)) / 10
+            ms = timed(g.replay, max(1, steps // 10), blocks=3) / 10
             launch = "hipgraph (10 steps per replay)"
         else:
-            ms = timed(call, steps)
+            ms = timed(call, steps, blocks=3)
         flops = E * (FLOP_PER_EDGE_STEP[D] if H == 64 else 2 * (32 * H + H * H) + 6 * (3 * H * H + H * H))
         return {"ms_per_step": ms, "value": 4.0 * E / (ms * 1e-3), "unit": "edge-messages/s", "hidden": H, "edges": E,
-                "launch": launch, "edge_mlp_algorithmic_tflops": flops / (ms * 1e-3) / 1e12}
+                "launch": launch, "timing": "fastest of 3 blocks", "edge_mlp_algorithmic_tflops": flops / (ms * 1e-3) / 1e12}
 
     leg("cfg3 gravitational-3d-N20-B128 forward", lambda: state2state(3, 128, 20, 64, 200, True))
     leg("electrostatic-2d-N20-B128 forward, hidden_size 128 (csrc/wide.h)", lambda: state2state(2, 128, 20, 128, 30, False))
