@@ -855,7 +855,7 @@ int backward_fused_impl(const AetherParams& P, const AetherParams& Gr, int64_t N
         FbArgs A;
         A.rowptr = rowptr; A.send_s = gp(G.send_s); A.recv_s = recv_s;
         A.wgdesc = reinterpret_cast<const FusedWG*>(graph + G.wgdesc);
-        A.lorder = gp(G.lorder); A.nrange = gp(G.nrange);
+        A.lorder = gp(G.lorder); A.ledge = reinterpret_cast<const int4*>(graph + G.ledge); A.nrange = gp(G.nrange);
         for (int k = 0; k < 4; ++k) {                           // layer k + 1
             FbLayer& Y = A.layer[k];
             Y.e_prev = k == 0 ? wp(W.feat) : wp(W.e[k - 1]);

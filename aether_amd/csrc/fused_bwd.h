@@ -91,7 +91,7 @@ struct FbLayer {
 struct FbArgs {
     // graph view
     const int32_t* rowptr; const int32_t* send_s; const int32_t* recv_s; const FusedWG* wgdesc;
-    const int32_t* lorder; const int32_t* nrange;
+    const int32_t* lorder; const int4* ledge; const int32_t* nrange;
     FbLayer layer[4];
     const float* msg_b0_1;     // layer 1 only (layers 2-4: b1 sits in P_r)
     int f1;
@@ -301,7 +301,7 @@ k_fused_bwd(FbArgs A) {
     const FusedWG wg = A.wgdesc[blockIdx.x];
     const int vb = wg.vb, nv = wg.ve - wg.vb;
     const int nb = wg.nb, n = wg.ne - wg.nb, off = nb - vb;
-    const int eb = A.rowptr[nb], m = A.rowptr[wg.ne] - eb;
+    const int eb = wg.eb, m = wg.m;                      // (row pointers kept with the descriptor)
     const int n_tiles = (m + 15) >> 4;
     const int na = wg.na;
     const bool split = wg.partner >= 0;
@@ -318,10 +318,12 @@ k_fused_bwd(FbArgs A) {
     for (int r = 0; r < ROUNDS; ++r) {
         const int local = 16 * (NWV * r + wave) + i;
         const bool ok = local < m;
-        const int k = ok ? eb + A.lorder[eb + local] : eb;
-        ke[r] = ok ? k : -1;
-        sl[r] = m > 0 ? A.send_s[k] - vb : 0;
-        rl[r] = m > 0 ? A.recv_s[k] - nb : 0;
+        // one record per edge in local order (fused.h, k_graph_lorder): {sorted position, sender, receiver, original edge};
+        // a padding row borrows the slots of the workgroup's first edge (its contributions are masked by ke < 0)
+        const int4 le = m > 0 ? A.ledge[eb + (ok ? local : 0)] : make_int4(eb, vb, nb, 0);
+        ke[r] = ok ? le.x : -1;
+        sl[r] = le.y - vb;
+        rl[r] = le.z - nb;
         unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
