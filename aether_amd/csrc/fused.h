@@ -641,11 +641,6 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
                         eal[0] = ea[0]; eal[1] = ea[1];
                     }
                     edge_features<D>(njl, nrl, eal, o);
-                    if (keep) {
-#pragma unroll
-                        for (int t = 0; t < FPAD; t += 4)
-                            st4(dbg.feat + (int64_t)k * FPAD + t, f32x4{o[t], o[t + 1], o[t + 2], o[t + 3]});
-                    }
                 } else {
 #pragma unroll
                     for (int t = 0; t < FPAD; ++t) o[t] = 0.0f;
@@ -673,7 +668,15 @@ k_fused(AetherParams P, const float* __restrict__ x, const float* __restrict__ v
             const int local = 16 * (NW * r + wave) + i;
             sl[r] = t_e[r].y - vb;                             // (requested during P1)
             rl[r] = t_e[r].z - nb;
-            if constexpr (KEEP) ke[r] = local < m ? t_e[r].x : -1;
+            if constexpr (KEEP) {
+                ke[r] = local < m ? t_e[r].x : -1;
+                // the saved feature rows, from the B-operand registers: 16 rows x 64 contiguous bytes per store and all 64 lanes
+                // (written by the lane that built the row they went out as eight 16-byte pieces per lane, half the wave idle)
+                if (ke[r] >= 0) {
+                    st4(dbg.feat + (int64_t)ke[r] * FPAD + 4 * q, e[r][0]);
+                    st4(dbg.feat + (int64_t)ke[r] * FPAD + 16 + 4 * q, e[r][1]);
+                }
+            }
             selbits[r] = t_sel[r];
             destpack[r] = t_dst[r];
         }
