@@ -31,6 +31,17 @@ Scans the gfx950 disassembly of every kernel.
       read issued before the first one's data landed, i.e. nearly always: one test failure in three full runs.  The outputs
       are early-clobber now; this rule keeps it that way.
 
+  R6  (FAILS the check, library input only) register placement the compiler chose behind the source's back, found twice in
+      round 4 by their cost, not by a wrong result:
+      (a) the inference instances of k_fused (KEEP = false; one or two tiles per wave -- the three-tile instance spills by
+          design, HISTORY 4.1b) must not touch scratch memory (private segment 0 bytes): two
+          floats assigned through a by-reference lambda capture were kept in scratch -- 8 bytes per thread stored and
+          re-loaded in the feature phase, + 1 MB of WRITE_SIZE per launch;
+      (b) k_s2s_gemm_split / k_s2s_gemm_split_r1 / k_wgemm must contain no v_accvgpr_read / v_accvgpr_write: built for
+          one wave per SIMD (__launch_bounds__(256, 1)) the compiler selects the AGPR form for every MFMA and copied all 64
+          accumulators of a lane out and back around the rarely taken rescale branch in EVERY k step (+ 0.4 ms per seq2seq
+          step at N = 20).
+
 Usage: isa_check.py [libaether_hip.so | file.s] [--all] [--kernel SUBSTR]
 """
 from __future__ import annotations
@@ -82,8 +93,10 @@ def kernel_notes(path: str):
     for blk in txt.split("  - .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk)
         seg = re.search(r"\.kernarg_segment_size:\s+(\d+)", blk)
+        priv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
         if name:
-            out[name.group(1)] = (int(seg.group(1)) if seg else -1, re.findall(r"\.value_kind:\s+(hidden_\w+)", blk))
+            out[name.group(1)] = (int(seg.group(1)) if seg else -1, re.findall(r"\.value_kind:\s+(hidden_\w+)", blk),
+                                  int(priv.group(1)) if priv else 0)
     return out
 
 
@@ -92,7 +105,15 @@ R4_KERNELS = ("k_s2s_filter_split_types", "k_s2s_filter_bimg_types", "k_dyn_filt
 
 def check_hidden_args(path: str):
     """Rule R4 -> [(kernel, hidden kinds)] of the by-value-struct kernels that consume hidden kernel arguments."""
-    return [(n, h) for n, (_, h) in kernel_notes(path).items() if h and any(k in n for k in R4_KERNELS)]
+    return [(n, h) for n, (_, h, _p) in kernel_notes(path).items() if h and any(k in n for k in R4_KERNELS)]
+
+
+R6_NO_AGPR_COPIES = ("k_s2s_gemm_split", "k_wgemm")
+
+
+def check_scratch(path: str):
+    """Rule R6a -> [(kernel, private segment bytes)] of inference k_fused instances that use scratch memory."""
+    return [(n, p) for n, (_, _h, p) in kernel_notes(path).items() if p and re.search(r"7k_fusedILi\dELi\d+ELi[12]ELb0E", n)]
 
 
 def split_kernels(txt: str):
@@ -242,7 +263,15 @@ def main(argv):
                 for mf in res["r2"][:2]:
                     print("     R2:", mf)
         bad += bool(flagged)
+        if any(k in name for k in R6_NO_AGPR_COPIES):
+            copies = sum(1 for ins in body if "v_accvgpr_read" in ins or "v_accvgpr_write" in ins)
+            if copies:
+                print(f"FAIL {name}: R6b(AGPR copies in a kernel that is meant to keep its accumulators in VGPRs)={copies}")
+                bad += 1
     if not path.endswith(".s") and not only:
+        for name, priv in check_scratch(path):
+            print(f"FAIL {name}: R6a(inference k_fused uses {priv} bytes of scratch memory per thread)")
+            bad += 1
         for name, hidden in check_hidden_args(path):
             print(f"FAIL {name}: R4(by-value struct kernel consumes hidden kernel arguments)={sorted(set(hidden))}")
             bad += 1
