@@ -1017,20 +1017,28 @@ __global__ void __launch_bounds__(256)
 k_s2s_pair_tanh_all(const float* __restrict__ A, const float* __restrict__ S, int64_t n_nodes,
                     const int64_t* __restrict__ send, const int64_t* __restrict__ recv, const float* __restrict__ edge_w,
                     int K, int k0, float* __restrict__ T, float* __restrict__ M1, float* __restrict__ M2, int h,
-                    int64_t n_edges) {
+                    int64_t n_edges, int clear_all) {
+    // clear_all = 0 (the fused seq2seq step: hard samples, every edge in at most ONE type's list, whose job writes its row
+    // of M1 / M2 without reading it): only the rows that no type >= k0 will write are cleared -- none without skip_first.
+    // Clearing every row cost 2 x n_edges x h x 4 bytes of writes per step (200 of this kernel's 300 MB at 48,640 x 512)
+    // and the same again as reads in the accumulating epilogues.
     const int q4 = h >> 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_edges * q4) return;
     const int64_t e = idx / q4;
     const int c = (int)(idx - e * q4) * 4;
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    st4(M1 + (size_t)e * h + c, zero);
-    st4(M2 + (size_t)e * h + c, zero);
     const int64_t r = recv[e], s = send[e];
+    bool written = false;
     for (int k = k0; k < K; ++k) {
         if (edge_w[e * K + k] == 0.0f) continue;
+        written = true;
         const f32x4 v = ld4(A + ((size_t)k * n_nodes + r) * h + c) + ld4(S + ((size_t)k * n_nodes + s) * h + c);
         st4(T + ((size_t)k * n_edges + e) * h + c, f32x4{tanh1(v[0]), tanh1(v[1]), tanh1(v[2]), tanh1(v[3])});
+    }
+    if (clear_all || !written) {
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        st4(M1 + (size_t)e * h + c, zero);
+        st4(M2 + (size_t)e * h + c, zero);
     }
 }
 
