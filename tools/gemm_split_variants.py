@@ -2,7 +2,9 @@
 """Timing-only variants of k_s2s_gemm_split (results are garbage): which part of a k step costs what.
 
   gemm_split_variants.py build   -> aether_amd/libaether_gsvar{N}.so from patched scratch copies of csrc/
-  on the GPU box:                   tools/gemm_split_variants_run.sh [rollout args]
+  on the GPU box:                   tools/gemm_split_variants_run.sh [rollout args]      (add  --opt gemm_split=3  to put every
+                                    launch on this kernel: by default launches of > 256 workgroups use k_s2s_gemm_split_r1)
+  results of round 4:               profiles/r04_seq2seq_gemm_split_variants.txt
 
   1: X by LDS-DMA from CONTIGUOUS addresses (1 KB per instruction instead of 16 rows x 64 B)
   2: no X DMA at all   3: no MFMAs   4: no weight DMA   5: no workgroup barrier per step
