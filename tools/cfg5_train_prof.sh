@@ -11,7 +11,7 @@ rm -rf $out/trace
 python3 - <<PY
 import csv,re
 rows=list(csv.DictReader(open("$out/kernel_stats.csv")))
-for r in rows[:14]:
+for r in rows[:24]:
     n=re.sub(r'\(anonymous namespace\)::','',r['Name']); n=re.sub(r'\(.*','',n)[:64]
     print(f"{n:66s} calls={int(r['Calls']):5d} avg={float(r['AverageNs'])/1e3:10.1f}us total={float(r['TotalDurationNs'])/1e6:9.1f}ms")
 PY
